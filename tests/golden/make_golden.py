@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures for the oracle.
+
+Run in the authoring container only (needs /root/reference):
+    python tests/golden/make_golden.py
+
+Outputs (committed, data only):
+  tests/golden/reference_vectors.json  known-answer vectors transcribed (inputs + expected
+        outputs, as data) from the reference's own unit tests; each entry names its source.
+  tests/golden/np_box_golden.npz       outputs of the reference's importable numpy modules
+        (object_detection/utils/np_box_ops.py, np_box_list_ops.py) on seeded random boxes.
+"""
+import builtins
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+VEC = {
+    # object_detection/anchor_generators/grid_anchor_generator_test.py:26-47
+    "anchors_single": dict(
+        scales=[0.5, 1.0, 2.0], aspect_ratios=[0.25, 1.0, 4.0], offset=[7, -3], grid=[1, 1],
+        base=[256, 256], stride=[16, 16],
+        expected=[[-121, -35, 135, 29], [-249, -67, 263, 61], [-505, -131, 519, 125],
+                  [-57, -67, 71, 61], [-121, -131, 135, 125], [-249, -259, 263, 253],
+                  [-25, -131, 39, 125], [-57, -259, 71, 253], [-121, -515, 135, 509]]),
+    # grid_anchor_generator_test.py:49-73
+    "anchors_grid": dict(
+        scales=[0.5, 1.0, 2.0], aspect_ratios=[1.0], offset=[0, 0], grid=[2, 2],
+        base=[10, 10], stride=[19, 19],
+        expected=[[-2.5, -2.5, 2.5, 2.5], [-5., -5., 5., 5.], [-10., -10., 10., 10.],
+                  [-2.5, 16.5, 2.5, 21.5], [-5., 14., 5, 24], [-10., 9., 10, 29],
+                  [16.5, -2.5, 21.5, 2.5], [14., -5., 24, 5], [9., -10., 29, 10],
+                  [16.5, 16.5, 21.5, 21.5], [14., 14., 24, 24], [9., 9., 29, 29]]),
+    # object_detection/box_coders/faster_rcnn_box_coder_test.py:26-91
+    "coder": dict(
+        boxes=[[10.0, 10.0, 20.0, 15.0], [0.2, 0.1, 0.5, 0.4]],
+        anchors=[[15.0, 12.0, 30.0, 18.0], [0.1, 0.0, 0.7, 0.9]],
+        codes_noscale=[[-0.5, -0.416666, -0.405465, -0.182321],
+                       [-0.083333, -0.222222, -0.693147, -1.098612]],
+        scale_factors=[2, 3, 4, 5],
+        codes_scaled=[[-1., -1.25, -1.62186, -0.911608],
+                      [-0.166667, -0.666667, -2.772588, -5.493062]],
+        tiny_box=[[10.0, 10.0, 10.0000001, 20.0]], tiny_anchor=[[15.0, 12.0, 30.0, 18.0]],
+        tiny_codes=[[-0.833333, 0., -21.128731, 0.510826]]),
+    # object_detection/matchers/argmax_matcher_test.py:25-181 ; expected = full match vector
+    "matcher": [
+        dict(sim=[[1., 1, 1, 3, 1], [2, -1, 2, 0, 4], [3, 0, -1, 0, 0]],
+             matched=None, unmatched=None, nlu=True, force=False, expected=[2, 0, 1, 0, 1]),
+        dict(sim=[[1, 1, 1, 3, 1], [2, -1, 2, 0, 4], [3, 0, -1, 0, 0]],
+             matched=3, unmatched=None, nlu=True, force=False, expected=[2, -1, -1, 0, 1]),
+        dict(sim=[[1, 1, 1, 3, 1], [2, -1, 2, 0, 4], [3, 0, -1, 0, 0]],
+             matched=3, unmatched=2, nlu=True, force=False, expected=[2, -1, -2, 0, 1]),
+        dict(sim=[[1, 1, 1, 3, 1], [2, -1, 2, 0, 4], [3, 0, -1, 0, 0]],
+             matched=3, unmatched=2, nlu=False, force=False, expected=[2, -2, -1, 0, 1]),
+        dict(sim=[[1, 1, 1, 3, 1], [-1, 0, -2, -2, -1], [3, 0, -1, 2, 0]],
+             matched=3, unmatched=2, nlu=True, force=False, expected=[2, -1, -1, 0, -1]),
+        dict(sim=[[1, 1, 1, 3, 1], [-1, 0, -2, -2, -1], [3, 0, -1, 2, 0]],
+             matched=3, unmatched=2, nlu=True, force=True, expected=[2, 1, -1, 0, -1]),
+    ],
+    # object_detection/core/box_list_ops_test.py:28-35,64-130,156-236,292-304
+    "box_ops": dict(
+        area_in=[[0.0, 0.0, 10.0, 20.0], [1.0, 2.0, 3.0, 4.0]], area=[200.0, 4.0],
+        window=[0, 0, 9, 14],
+        clip_in=[[5.0, 5.0, 6.0, 6.0], [-1.0, -2.0, 4.0, 5.0], [2.0, 3.0, 5.0, 9.0],
+                 [0.0, 0.0, 9.0, 14.0], [-100.0, -100.0, 300.0, 600.0],
+                 [-10.0, -10.0, -9.0, -9.0]],
+        clip_filtered=[[5.0, 5.0, 6.0, 6.0], [0.0, 0.0, 4.0, 5.0], [2.0, 3.0, 5.0, 9.0],
+                       [0.0, 0.0, 9.0, 14.0], [0.0, 0.0, 9.0, 14.0]],
+        clip_unfiltered=[[5.0, 5.0, 6.0, 6.0], [0.0, 0.0, 4.0, 5.0], [2.0, 3.0, 5.0, 9.0],
+                         [0.0, 0.0, 9.0, 14.0], [0.0, 0.0, 9.0, 14.0], [0.0, 0.0, 0.0, 0.0]],
+        prune_in=[[5.0, 5.0, 6.0, 6.0], [-1.0, -2.0, 4.0, 5.0], [2.0, 3.0, 5.0, 9.0],
+                  [0.0, 0.0, 9.0, 14.0], [-10.0, -10.0, -9.0, -9.0],
+                  [-100.0, -100.0, 300.0, 600.0]],
+        prune_keep=[0, 2, 3],
+        c1=[[4.0, 3.0, 7.0, 5.0], [5.0, 6.0, 10.0, 7.0]],
+        c2=[[3.0, 4.0, 6.0, 8.0], [14.0, 14.0, 15.0, 15.0], [0.0, 0.0, 20.0, 20.0]],
+        intersection=[[2.0, 0.0, 6.0], [1.0, 0.0, 5.0]],
+        iou=[[2.0 / 16.0, 0, 6.0 / 400.0], [1.0 / 16.0, 0.0, 5.0 / 400.0]],
+        ioa_12=[[2.0 / 12.0, 0, 6.0 / 400.0], [1.0 / 12.0, 0.0, 5.0 / 400.0]],
+        ioa_21=[[2.0 / 6.0, 1.0 / 5.0], [0, 0], [6.0 / 6.0, 5.0 / 5.0]],
+        frame_in=[[0.25, 0.5, 0.75, 0.75], [0.5, 0.0, 1.0, 1.0]],
+        frame_window=[0.25, 0.25, 0.75, 0.75],
+        frame_out=[[0, 0.5, 1.0, 1.0], [0.5, -0.5, 1.5, 1.5]]),
+    # box_list_ops_test.py:677-766 (NMS clusters)
+    "nms_clusters": dict(
+        boxes=[[0, 0, 1, 1], [0, 0.1, 1, 1.1], [0, -0.1, 1, 0.9], [0, 10, 1, 11],
+               [0, 10.1, 1, 11.1], [0, 100, 1, 101]],
+        scores=[.9, .75, .6, .95, .5, .3], iou_thresh=.5,
+        cases=[dict(max=3, expected=[[0, 10, 1, 11], [0, 0, 1, 1], [0, 100, 1, 101]]),
+               dict(max=2, expected=[[0, 10, 1, 11], [0, 0, 1, 1]]),
+               dict(max=30, expected=[[0, 10, 1, 11], [0, 0, 1, 1], [0, 100, 1, 101]])],
+        identical=dict(n=10, box=[0, 0, 1, 1], score=.9, max=3, expected=[[0, 0, 1, 1]])),
+    # object_detection/core/post_processing_test.py:42-73 (shared boxes, two classes)
+    "multiclass_nms": dict(
+        boxes=[[[0, 0, 1, 1]], [[0, 0.1, 1, 1.1]], [[0, -0.1, 1, 0.9]], [[0, 10, 1, 11]],
+               [[0, 10.1, 1, 11.1]], [[0, 100, 1, 101]], [[0, 1000, 1, 1002]],
+               [[0, 1000, 1, 1002.1]]],
+        scores=[[.9, 0.01], [.75, 0.05], [.6, 0.01], [.95, 0], [.5, 0.01], [.3, 0.01],
+                [.01, .85], [.01, .5]],
+        score_thresh=0.1, iou_thresh=.5, max_output_size=4,
+        exp_corners=[[0, 10, 1, 11], [0, 0, 1, 1], [0, 1000, 1, 1002], [0, 100, 1, 101]],
+        exp_scores=[.95, .9, .85, .3], exp_classes=[0, 0, 1, 0]),
+    # object_detection/core/losses_test.py:97-119
+    "smooth_l1": dict(
+        pred=[[[2.5, 0, .4, 0], [0, 0, 0, 0], [0, 2.5, 0, .4]],
+              [[3.5, 0, 0, 0], [0, .4, 0, .9], [0, 0, 1.5, 0]]],
+        weights=[[2, 1, 1], [0, 3, 0]], expected_sum=7.695),
+    # losses_test.py:228-284
+    "softmax_ce": dict(
+        pred=[[[-100, 100, -100], [100, -100, -100], [0, 0, -100], [-100, -100, 100]],
+              [[-100, 0, 0], [-100, 100, -100], [-100, 100, -100], [100, -100, -100]]],
+        target=[[[0, 1, 0], [1, 0, 0], [1, 0, 0], [0, 0, 1]],
+                [[0, 0, 1], [0, 1, 0], [0, 1, 0], [1, 0, 0]]],
+        weights=[[1, 1, .5, 1], [1, 1, 1, 0]],
+        expected_sum=-1.5 * math.log(.5),
+        expected_anchorwise=[[0, 0, -0.5 * math.log(.5), 0], [-math.log(.5), 0, 0, 0]]),
+    # object_detection/core/target_assigner_test.py:32-60 (IoA similarity, MeanStddev coder)
+    "assign_agnostic": dict(
+        priors=[[0.5, 0.5, 1.0, 0.8], [0, 0.5, .5, 1.0], [0.0, 0.0, 0.5, 0.5]],
+        boxes=[[0.0, 0.0, 0.5, 0.5], [0.5, 0.5, 0.9, 0.9]], matched=0.5, similarity="ioa",
+        cls_targets=[[1], [0], [1]], cls_weights=[1, 1, 1],
+        reg_targets=[[0, 0, -1, 1], [0, 0, 0, 0], [0, 0, 0, 0]], reg_weights=[1, 0, 1]),
+    # object_detection/meta_architectures/faster_rcnn_meta_arch_test_lib.py:411-461
+    "rpn_postprocess": dict(
+        anchors=[[0, 0, 16, 16], [0, 16, 16, 32], [16, 0, 32, 16], [16, 16, 32, 32]],
+        objectness=[[[-10, 13], [10, -10], [10, -11], [-10, 12]],
+                    [[10, -10], [-10, 13], [-10, 12], [10, -11]]],
+        image_hw=[32, 32], max_proposals=8, iou_thresh=0.7, score_thresh=0.0,
+        expected_boxes_normalized=[
+            [[0, 0, .5, .5], [.5, .5, 1, 1], [0, .5, .5, 1], [.5, 0, 1.0, .5]],
+            [[0, .5, .5, 1], [.5, 0, 1.0, .5], [0, 0, .5, .5], [.5, .5, 1, 1]]],
+        expected_scores=[[1, 1, 0, 0, 0, 0, 0, 0], [1, 1, 0, 0, 0, 0, 0, 0]],
+        expected_num=[4, 4]),
+    # faster_rcnn_meta_arch_test_lib.py:651-730 (test_loss_full). NOTE the fork sets the
+    # RPN SmoothL1 sigma to 3 (faster_rcnn_meta_arch.py:391-392); all of these
+    # expectations are 0 and therefore sigma-independent.
+    "loss_full": dict(
+        anchors=[[0, 0, 16, 16], [0, 16, 16, 32], [16, 0, 32, 16], [16, 16, 32, 32]],
+        objectness=[[[-10, 13], [10, -10], [10, -11], [-10, 12]],
+                    [[10, -10], [-10, 13], [-10, 12], [10, -11]]],
+        image_hw=[32, 32], num_proposals=[6, 6],
+        proposal_boxes=2 * [[[0, 0, 16, 16], [0, 16, 16, 32], [16, 0, 32, 16],
+                             [16, 16, 32, 32], [0, 0, 16, 16], [0, 16, 16, 32]]],
+        class_predictions=[[-10, 10, -10], [10, -10, -10], [10, -10, -10], [-10, -10, 10],
+                           [-10, 10, -10], [10, -10, -10], [10, -10, -10], [-10, 10, -10],
+                           [-10, 10, -10], [10, -10, -10], [10, -10, -10], [-10, 10, -10]],
+        gt_boxes=[[[0, 0, .5, .5], [.5, .5, 1, 1]], [[0, .5, .5, 1], [.5, 0, 1, .5]]],
+        gt_classes=[[[1, 0], [0, 1]], [[1, 0], [1, 0]]],
+        expected=dict(first_stage_localization_loss=0, first_stage_objectness_loss=0,
+                      second_stage_localization_loss=0, second_stage_classification_loss=0)),
+}
+
+
+def main():
+    with open(os.path.join(HERE, "reference_vectors.json"), "w") as f:
+        json.dump(VEC, f, indent=1)
+
+    # --- outputs of the reference's own numpy modules on seeded random boxes
+    builtins.xrange = range                      # py2 idiom in np_box_list_ops.py:240,329,338
+    sys.path.insert(0, REF)
+    from object_detection.utils import np_box_list, np_box_list_ops, np_box_ops
+    rng = np.random.RandomState(20260927)
+
+    def rand_boxes(n, scale=64.0):
+        # float32-representable coordinates on a 1/8 grid so float64 (reference) and
+        # float32 (oracle/device) arithmetic agree closely
+        yx = np.round(rng.uniform(0, scale * 0.8, (n, 2)) * 8) / 8
+        hw = np.round(rng.uniform(1, scale * 0.5, (n, 2)) * 8) / 8
+        return np.concatenate([yx, yx + hw], 1).astype(np.float32)
+
+    out = {}
+    b1, b2 = rand_boxes(37), rand_boxes(211)
+    out["b1"], out["b2"] = b1, b2
+    out["area_b2"] = np_box_ops.area(b2.astype(np.float64))
+    out["intersection"] = np_box_ops.intersection(b1.astype(np.float64), b2.astype(np.float64))
+    out["iou"] = np_box_ops.iou(b1.astype(np.float64), b2.astype(np.float64))
+    out["ioa"] = np_box_ops.ioa(b1.astype(np.float64), b2.astype(np.float64))
+    win = np.array([8.0, 4.0, 48.0, 56.0])
+    bl = np_box_list.BoxList(b2.astype(np.float64))
+    out["window"] = win
+    out["clip"] = np_box_list_ops.clip_to_window(bl, win).get()
+    pruned = np_box_list_ops.prune_outside_window(bl, win)
+    out["prune_boxes"] = pruned[0].get()
+    out["prune_idx"] = pruned[1]
+    out["change_frame"] = np_box_list_ops.change_coordinate_frame(bl, win).get()
+    # greedy NMS, distinct float32-exact scores
+    nb = rand_boxes(400, 48.0)
+    sc = (rng.permutation(400).astype(np.float32) + 1) / 512.0
+    out["nms_boxes"], out["nms_scores"] = nb, sc
+    for thr in (0.3, 0.5, 0.7):
+        bl = np_box_list.BoxList(nb.astype(np.float64))
+        bl.add_field("scores", sc.astype(np.float64))
+        res = np_box_list_ops.non_max_suppression(bl, max_output_size=100, iou_threshold=thr)
+        out["nms_out_%d" % int(thr * 10)] = res.get()
+        out["nms_out_scores_%d" % int(thr * 10)] = res.get_field("scores")
+    np.savez_compressed(os.path.join(HERE, "np_box_golden.npz"), **out)
+    print("wrote", len(VEC), "vector groups and", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,186 @@
+"""Pin the CPU oracle against (a) known-answer vectors transcribed from the reference's
+own unit tests and (b) outputs of the reference's importable numpy box modules.
+CPU only (-m "not gpu")."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import assign as A
+from oracle import boxes as B
+from oracle import frcnn_losses as L
+from oracle import nms as N
+from oracle import ops_torch as T
+
+
+@pytest.fixture(scope="module")
+def vec(golden_dir):
+    with open(os.path.join(golden_dir, "reference_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def npg(golden_dir):
+    return np.load(os.path.join(golden_dir, "np_box_golden.npz"))
+
+
+def test_anchors(vec):
+    for key in ("anchors_single", "anchors_grid"):
+        v = vec[key]
+        a = B.grid_anchors(v["grid"][0], v["grid"][1], v["scales"], v["aspect_ratios"],
+                           v["base"], v["stride"], v["offset"])
+        np.testing.assert_allclose(a, np.array(v["expected"], np.float32), rtol=1e-6, atol=1e-5)
+
+
+def test_box_coder(vec):
+    v = vec["coder"]
+    np.testing.assert_allclose(B.encode(v["boxes"], v["anchors"], None), v["codes_noscale"],
+                               rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(B.encode(v["boxes"], v["anchors"], v["scale_factors"]),
+                               v["codes_scaled"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(B.decode(v["codes_noscale"], v["anchors"], None), v["boxes"],
+                               rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(B.decode(v["codes_scaled"], v["anchors"], v["scale_factors"]),
+                               v["boxes"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(B.encode(v["tiny_box"], v["tiny_anchor"], None), v["tiny_codes"],
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_matcher(vec):
+    for c in vec["matcher"]:
+        m = A.argmax_match(np.array(c["sim"], np.float32), c["matched"], c["unmatched"],
+                           c["nlu"], c["force"])
+        assert m.tolist() == c["expected"], c
+    m = A.argmax_match(np.zeros([0, 5], np.float32), None)
+    assert m.tolist() == [-1] * 5
+
+
+def test_box_ops_known_answers(vec):
+    v = vec["box_ops"]
+    np.testing.assert_allclose(B.area(v["area_in"]), v["area"])
+    c, _ = B.clip_to_window(v["clip_in"], v["window"], True)
+    np.testing.assert_allclose(c, v["clip_filtered"])
+    c, _ = B.clip_to_window(v["clip_in"], v["window"], False)
+    np.testing.assert_allclose(c, v["clip_unfiltered"])
+    _, keep = B.prune_outside_window(v["prune_in"], v["window"])
+    assert keep.tolist() == v["prune_keep"]
+    np.testing.assert_allclose(B.intersection(v["c1"], v["c2"]), v["intersection"])
+    np.testing.assert_allclose(B.iou(v["c1"], v["c2"]), v["iou"], rtol=1e-6)
+    np.testing.assert_allclose(B.ioa(v["c1"], v["c2"]), v["ioa_12"], rtol=1e-6)
+    np.testing.assert_allclose(B.ioa(v["c2"], v["c1"]), v["ioa_21"], rtol=1e-6)
+    np.testing.assert_allclose(B.change_coordinate_frame(v["frame_in"], v["frame_window"]),
+                               v["frame_out"], rtol=1e-6)
+    assert B.iou(v["c1"], np.zeros([0, 4])).shape == (2, 0)
+    assert B.iou(np.zeros([0, 4]), v["c2"]).shape == (0, 3)
+
+
+def test_box_ops_vs_reference_numpy(npg):
+    b1, b2 = npg["b1"], npg["b2"]
+    np.testing.assert_allclose(B.area(b2), npg["area_b2"], rtol=1e-6)
+    np.testing.assert_allclose(B.intersection(b1, b2), npg["intersection"], rtol=1e-6)
+    np.testing.assert_allclose(B.iou(b1, b2), npg["iou"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(B.ioa(b1, b2), npg["ioa"], rtol=2e-6, atol=1e-7)
+    c, _ = B.clip_to_window(b2, npg["window"])
+    np.testing.assert_allclose(c, npg["clip"], rtol=1e-6)
+    pb, pi = B.prune_outside_window(b2, npg["window"])
+    assert pi.tolist() == npg["prune_idx"].tolist()
+    np.testing.assert_allclose(pb, npg["prune_boxes"])
+    np.testing.assert_allclose(B.change_coordinate_frame(b2, npg["window"]),
+                               npg["change_frame"], rtol=1e-5, atol=1e-6)
+
+
+def test_nms_vs_reference_numpy(npg):
+    nb, sc = npg["nms_boxes"], npg["nms_scores"]
+    for thr in (0.3, 0.5, 0.7):
+        idx = N.greedy_nms(nb, sc, 100, thr)
+        np.testing.assert_allclose(nb[idx], npg["nms_out_%d" % int(thr * 10)])
+        np.testing.assert_allclose(sc[idx], npg["nms_out_scores_%d" % int(thr * 10)])
+
+
+def test_nms_known_answers(vec):
+    v = vec["nms_clusters"]
+    for c in v["cases"]:
+        idx = N.greedy_nms(v["boxes"], v["scores"], c["max"], v["iou_thresh"])
+        np.testing.assert_allclose(np.array(v["boxes"], np.float32)[idx], c["expected"])
+    i = v["identical"]
+    idx = N.greedy_nms([i["box"]] * i["n"], [i["score"]] * i["n"], i["max"], v["iou_thresh"])
+    assert len(idx) == 1
+    m = vec["multiclass_nms"]
+    b, s, c = N.multiclass_nms(np.array(m["boxes"], np.float32), np.array(m["scores"], np.float32),
+                               m["score_thresh"], m["iou_thresh"], m["max_output_size"])
+    # the reference test passes max_size_per_class only (max_total_size=0)
+    np.testing.assert_allclose(b, m["exp_corners"])
+    np.testing.assert_allclose(s, m["exp_scores"])
+    np.testing.assert_allclose(c, m["exp_classes"])
+
+
+def test_losses_known_answers(vec):
+    v = vec["smooth_l1"]
+    p = torch.tensor(v["pred"])
+    loss = T.smooth_l1(p, torch.zeros_like(p), torch.tensor(v["weights"], dtype=torch.float32))
+    assert abs(float(loss.sum()) - v["expected_sum"]) < 1e-5
+    v = vec["softmax_ce"]
+    ce = T.softmax_ce(torch.tensor(v["pred"], dtype=torch.float32),
+                      torch.tensor(v["target"], dtype=torch.float32),
+                      torch.tensor(v["weights"], dtype=torch.float32))
+    np.testing.assert_allclose(ce.numpy(), v["expected_anchorwise"], atol=1e-6)
+    assert abs(float(ce.sum()) - v["expected_sum"]) < 1e-5
+
+
+def test_target_assigner_known_answer(vec):
+    v = vec["assign_agnostic"]
+    r = A.assign_targets(v["priors"], v["boxes"], None, [0.0], v["matched"],
+                         coder=B.mean_stddev_encode, similarity=B.ioa)
+    np.testing.assert_allclose(r["cls_targets"], v["cls_targets"])
+    np.testing.assert_allclose(r["cls_weights"], v["cls_weights"])
+    np.testing.assert_allclose(r["reg_targets"], v["reg_targets"], atol=1e-5)
+    np.testing.assert_allclose(r["reg_weights"], v["reg_weights"])
+
+
+def test_rpn_postprocess_known_answer(vec):
+    v = vec["rpn_postprocess"]
+    anchors = np.array(v["anchors"], np.float32)
+    enc = np.zeros([2, 4, 4], np.float32)
+    b, s, _, n = N.rpn_proposals(enc, np.array(v["objectness"], np.float32), anchors,
+                                 v["image_hw"], v["score_thresh"], v["iou_thresh"],
+                                 v["max_proposals"])
+    assert n.tolist() == v["expected_num"]
+    for i in range(2):
+        bn = B.to_normalized(b[i], *v["image_hw"])
+        np.testing.assert_allclose(bn[:4], v["expected_boxes_normalized"][i], atol=1e-6)
+        np.testing.assert_allclose(bn[4:], 0)
+    np.testing.assert_allclose(s, v["expected_scores"], atol=1e-6)
+
+
+def test_meta_arch_loss_full_known_answer(vec):
+    v = vec["loss_full"]
+    anchors = np.array(v["anchors"], np.float32)
+    H, W = v["image_hw"]
+    gt_abs = [B.to_absolute(g, H, W) for g in v["gt_boxes"]]
+    gt_cls_bg = [np.pad(np.array(c, np.float32), [[0, 0], [1, 0]]) for c in v["gt_classes"]]
+    tg = L.rpn_targets(anchors, gt_abs, 256, 0.5, seed=1)
+    out = L.loss_rpn(torch.zeros(2, 4, 4), torch.tensor(v["objectness"], dtype=torch.float32),
+                     tg, 1.0, 1.0)
+    props = np.array(v["proposal_boxes"], np.float32)
+    dt = L.detector_targets(props, gt_abs, gt_cls_bg)
+    out.update(L.loss_box_classifier(torch.zeros(12, 2, 4),
+                                     torch.tensor(v["class_predictions"], dtype=torch.float32),
+                                     v["num_proposals"], dt, 1.0, 1.0))
+    for k, e in v["expected"].items():
+        assert abs(float(out[k]) - e) < 1e-4, (k, float(out[k]))
+
+
+def test_sampler_properties():
+    """object_detection/core/balanced_positive_negative_sampler_test.py:26-64 checks
+    counts only (random shuffle); same properties here."""
+    rng = np.random.RandomState(0)
+    labels = np.arange(300) >= 290                      # 10 positives
+    ind = np.ones(300, bool)
+    prio = A.hash_priority(7, 300)
+    s = A.balanced_subsample(ind, 64, labels, 0.5, prio)
+    assert s.sum() == 64 and (s & labels).sum() == 10 and (s & ~labels).sum() == 54
+    ind2 = rng.rand(300) > 0.5
+    s = A.balanced_subsample(ind2, 64, labels, 0.5, prio)
+    assert not (s & ~ind2).any() and s.sum() == min(64, ind2.sum())
