@@ -1,0 +1,234 @@
+/*
+ * libmtlssl_hip.so — C ABI of the MI355X (gfx950) hot path for the mtl-ssl
+ * Faster R-CNN / R-FCN multi-task detector.
+ *
+ * Boundary rules:
+ *   - plain `extern "C"`; raw DEVICE pointers + integer dims + a hipStream_t passed as void*;
+ *   - every function is asynchronous on the given stream and returns 0 on success or a
+ *     negative MTLSSL_E* code (message via mtlssl_last_error(), thread-local);
+ *   - no ownership transfer: the caller owns every buffer including workspaces;
+ *   - all floats are fp32, all indices int32, all images/feature maps NHWC, all boxes
+ *     [ymin, xmin, ymax, xmax].
+ *
+ * Each entry point names the reference (TensorFlow-graph) code it replaces; paths are
+ * relative to the reference tree (object_detection/... or slim/...).
+ */
+#ifndef MTLSSL_HIP_H_
+#define MTLSSL_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mtlssl_stream_t; /* hipStream_t */
+
+#define MTLSSL_OK 0
+#define MTLSSL_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MTLSSL_ELAUNCH (-2)  /* HIP launch error */
+
+const char* mtlssl_last_error(void);
+int mtlssl_abi_version(void);
+
+/* ------------------------------------------------------------------ convolution family
+ * Replaces slim.conv2d / resnet_utils.conv2d_same (slim/nets/resnet_utils.py:77-122,
+ * slim/nets/resnet_v1.py:107-119) + frozen slim.batch_norm + ReLU, and their TF gradient
+ * kernels. Implicit GEMM on v_mfma_f32_32x32x2_f32. Filter layout HWIO [R,S,C,K] (TF).
+ * Padding is explicit (pad_t/pad_l); out-of-range taps read zero, so TF 'SAME' asymmetry
+ * and conv2d_same's explicit padding are both expressed by the caller's pad/OH/OW choice.
+ */
+typedef struct {
+  int32_t N, H, W, C;        /* input  [N,H,W,C]   */
+  int32_t K, R, S;           /* filter [R,S,C,K]   */
+  int32_t OH, OW;            /* output [N,OH,OW,K] */
+  int32_t stride, dilation;
+  int32_t pad_t, pad_l;
+} mtlssl_conv_desc;
+
+#define MTLSSL_EPI_BIAS 1      /* + bias[k] (folded BN shift or conv bias)                  */
+#define MTLSSL_EPI_RESIDUAL 2  /* + residual[n,oh,ow,k]                                     */
+#define MTLSSL_EPI_RELU 4      /* max(.,0)                                                  */
+#define MTLSSL_EPI_TANH 8      /* tanh(.)  (core/mask_predictor.py:105-119)                 */
+#define MTLSSL_EPI_RELU6 16    /* min(max(.,0),6) (slim/nets/mobilenet_v1.py)               */
+#define MTLSSL_EPI_MASK 32     /* dgrad only: out *= (mask_ref > 0)  (ReLU backward)         */
+#define MTLSSL_EPI_ACCUM 64    /* dgrad only: out += existing contents of the output buffer */
+
+/* y = epilogue(conv(x, w)). */
+int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
+                      const float* bias, const float* residual, float* y, int epilogue,
+                      mtlssl_stream_t stream);
+/* dx = conv_transpose(dy, w); epilogue flags MASK (mask_ref, same shape as dx) / ACCUM /
+ * RESIDUAL (adds `residual`, same shape as dx, before the mask). */
+int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float* w,
+                        const float* residual, const float* mask_ref, float* dx, int epilogue,
+                        mtlssl_stream_t stream);
+/* dw[r,s,c,k] (beta=0: overwrite, beta=1: accumulate) = sum_pixels x*dy, optionally scaled
+ * per output channel by out_scale[k] (frozen-BN fold) and dbias[k] = sum dy (nullable).
+ * workspace: mtlssl_conv2d_wgrad_workspace_bytes(d) bytes. */
+int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d);
+int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,
+                        const float* out_scale, float* dw, float* dbias, float beta,
+                        void* workspace, mtlssl_stream_t stream);
+
+/* slim.max_pool2d (slim/nets/resnet_v1.py:222; resnet_utils.subsample :59-74). */
+int mtlssl_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, int k, int stride,
+                       int pad_t, int pad_l, int OH, int OW, mtlssl_stream_t stream);
+int mtlssl_maxpool_bwd(const float* x, const float* y, const float* dy, float* dx, int N, int H,
+                       int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW,
+                       mtlssl_stream_t stream);
+/* tf.reduce_mean over H,W (core/box_predictor.py:469-471) and its gradient. */
+int mtlssl_spatial_mean_fwd(const float* x, float* y, int N, int HW, int C, mtlssl_stream_t s);
+int mtlssl_spatial_mean_bwd(const float* dy, float* dx, int N, int HW, int C, mtlssl_stream_t s);
+
+/* ------------------------------------------------------------------ detection family */
+
+/* GridAnchorGenerator._generate / tile_anchors
+ * (anchor_generators/grid_anchor_generator.py:96-214). scales/aspect_ratios are HOST arrays. */
+int mtlssl_anchors_generate(float* anchors_out, int grid_h, int grid_w, const float* scales,
+                            int n_scales, const float* aspect_ratios, int n_ratios, float base_h,
+                            float base_w, float stride_y, float stride_x, float offset_y,
+                            float offset_x, mtlssl_stream_t stream);
+
+/* box_list_ops.prune_outside_window (core/box_list_ops.py:140-169): order-preserving
+ * compaction. keep_idx_out[n] int32, count_out[1] int32 (device). */
+int mtlssl_boxes_prune_outside_window(const float* boxes, int n, float win_ymin, float win_xmin,
+                                      float win_ymax, float win_xmax, int32_t* keep_idx_out,
+                                      int32_t* count_out, mtlssl_stream_t stream);
+
+/* tf.gather over rows per batch item (faster_rcnn_meta_arch.py:965-976) and its gradient
+ * (scatter into a zeroed buffer; indices are unique). */
+int mtlssl_gather_rows(const float* src, const int32_t* idx, float* dst, int batch, int n_src,
+                       int n_idx, int row_len, mtlssl_stream_t stream);
+int mtlssl_scatter_rows(const float* src, const int32_t* idx, float* dst, int batch, int n_dst,
+                        int n_idx, int row_len, mtlssl_stream_t stream);
+
+/* FasterRcnnBoxCoder._decode/_encode (box_coders/faster_rcnn_box_coder.py:60-118);
+ * anchors are broadcast over `batch` when anchors_batched == 0. */
+int mtlssl_boxes_decode(const float* rel_codes, const float* anchors, float* boxes_out, int batch,
+                        int n, int anchors_batched, float sy, float sx, float sh, float sw,
+                        mtlssl_stream_t stream);
+int mtlssl_boxes_encode(const float* boxes, const float* anchors, float* codes_out, int n, float sy,
+                        float sx, float sh, float sw, mtlssl_stream_t stream);
+
+/* _postprocess_rpn (faster_rcnn_meta_arch.py:1055-1115) =
+ * decode + softmax fg score + score filter + clip_to_window + greedy NMS + sort + pad.
+ * Outputs: proposals_out [B,max_proposals,4] ABSOLUTE coords zero padded,
+ * scores_out [B,max_proposals], num_out int32[B].
+ * workspace: mtlssl_rpn_proposals_workspace_bytes(B, n). */
+int64_t mtlssl_rpn_proposals_workspace_bytes(int batch, int n);
+int mtlssl_rpn_proposals(const float* rpn_box_encodings, const float* rpn_objectness,
+                         const float* anchors, int batch, int n, float img_h, float img_w,
+                         float score_thresh, float iou_thresh, int max_proposals,
+                         float* proposals_out, float* scores_out, int32_t* num_out,
+                         void* workspace, mtlssl_stream_t stream);
+/* Stand-alone pieces of the above, exposed for parity tests:
+ * greedy NMS of tf.image.non_max_suppression (call site core/post_processing.py:146) on
+ * boxes that are already filtered (finite scores); selected_out[max_out] int32 indices in selection order. */
+int64_t mtlssl_nms_workspace_bytes(int n);
+int mtlssl_nms(const float* boxes, const float* scores, int n, float iou_thresh, int max_out,
+               int32_t* selected_out, int32_t* num_out, void* workspace,
+               mtlssl_stream_t stream);
+
+/* TargetAssigner.assign with IouSimilarity + ArgMaxMatcher
+ * (core/target_assigner.py:99-213, matchers/argmax_matcher.py:102-189,
+ * core/region_similarity_calculator.py:57-74). One call handles a batch:
+ *   anchors [n,4] shared (anchors_batched=0) or [B,n,4];
+ *   gt_boxes [B,max_gt,4] absolute, num_gt int32[B];
+ *   gt_labels [B,max_gt,label_dim] (nullable -> label 1, label_dim must be 1);
+ *   gt_extra  [B,max_gt,extra_dim] (closeness, nullable);
+ *   unmatched_cls_target [label_dim] (device).
+ * Outputs (any nullable): match int32[B,n] in {-2,-1,0..G-1}; cls_targets [B,n,label_dim];
+ * cls_weights [B,n]; reg_targets [B,n,4]; reg_weights [B,n]; extra_targets [B,n,extra_dim].
+ * workspace: mtlssl_assign_targets_workspace_bytes(B, n, max_gt). */
+int64_t mtlssl_assign_targets_workspace_bytes(int batch, int n, int max_gt);
+int mtlssl_assign_targets(const float* anchors, int anchors_batched, int batch, int n,
+                          const float* gt_boxes, const int32_t* num_gt, int max_gt,
+                          const float* gt_labels, int label_dim, const float* gt_extra,
+                          int extra_dim, const float* unmatched_cls_target, float matched_thresh,
+                          float unmatched_thresh, int force_match, int32_t* match_out,
+                          float* cls_targets_out, float* cls_weights_out, float* reg_targets_out,
+                          float* reg_weights_out, float* extra_targets_out, void* workspace,
+                          mtlssl_stream_t stream);
+
+/* BalancedPositiveNegativeSampler.subsample (core/balanced_positive_negative_sampler.py:51-92)
+ * with tf.random_shuffle replaced by counter-hash priorities (seed, stream_id0 + batch index
+ * * stream_stride). indicator/labels/sampled_out are float 0/1 arrays [B,n]. */
+int mtlssl_balanced_sample(const float* indicator, const float* labels, int batch, int n,
+                           int batch_size, float positive_fraction, uint32_t seed,
+                           uint32_t stream_id0, uint32_t stream_stride, float* sampled_out,
+                           mtlssl_stream_t stream);
+
+/* _unpad_proposals_and_sample_box_classifier_batch + _sample_box_classifier_minibatch
+ * (faster_rcnn_meta_arch.py:1134-1216,1268-1302): detector-assign the valid proposals,
+ * balanced-sample, keep order, zero pad to n2. proposals [B,max_p,4] absolute.
+ * Outputs: boxes_abs_out [B,n2,4], boxes_norm_out [B,n2,4], num_out int32[B]. */
+int mtlssl_sample_proposals(const float* proposals, const int32_t* num_proposals, int batch,
+                            int max_p, const float* gt_boxes, const int32_t* num_gt, int max_gt,
+                            const float* gt_labels_bg, int label_dim, int n2,
+                            float balance_fraction, uint32_t seed, uint32_t stream_id0,
+                            uint32_t stream_stride, float img_h, float img_w,
+                            float* boxes_abs_out, float* boxes_norm_out, int32_t* num_out,
+                            mtlssl_stream_t stream);
+
+/* tf.image.crop_and_resize (bilinear, extrapolation 0) fused with the VALID k x k / stride
+ * max-pool that follows it (faster_rcnn_meta_arch.py:1304-1348).
+ * feat [B,H,W,C]; boxes [R,4] normalised; box_ind int32[R];
+ * out [R,PH,PW,C] with PH = (crop-k)/stride+1; argmax_out uint8 [R,PH,PW,C] (nullable; index
+ * of the winning crop sample inside its pool window, needed by the backward). */
+int mtlssl_roi_crop_pool_fwd(const float* feat, int B, int H, int W, int C, const float* boxes,
+                             const int32_t* box_ind, int R, int crop, int pool_k, int pool_stride,
+                             float* out, uint8_t* argmax_out, mtlssl_stream_t stream);
+/* dfeat += scatter(dout) (dfeat must be zeroed or hold an accumulated gradient). */
+int mtlssl_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax, int B, int H, int W, int C,
+                             const float* boxes, const int32_t* box_ind, int R, int crop,
+                             int pool_k, int pool_stride, float* dfeat, mtlssl_stream_t stream);
+
+/* tf.image.resize_images bilinear, align_corners=False (faster_rcnn_meta_arch.py:1870). */
+int mtlssl_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH,
+                               int OW, mtlssl_stream_t stream);
+int mtlssl_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH,
+                               int OW, mtlssl_stream_t stream);
+
+/* ------------------------------------------------------------------ loss family
+ * Fused loss + gradient. Every loss is a weighted sum of per-row terms; `row_loss_out[rows]`
+ * receives the per-row contribution (already multiplied by row_scale) and
+ * mtlssl_reduce_sum folds it deterministically. d* outputs are d(loss)/d(input). */
+
+/* WeightedSmoothL1LocalizationLoss (core/losses.py:169-196):
+ * row term = row_scale[r] * sum_j smoothl1(pred[r,j]-target[r,j]; sigma). */
+int mtlssl_smooth_l1_fwd_bwd(const float* pred, const float* target, const float* row_scale,
+                             int rows, int code_size, float sigma, float* row_loss_out,
+                             float* dpred_out, mtlssl_stream_t stream);
+/* WeightedSoftmaxClassificationLoss(_v2) (core/losses.py:285-352):
+ * row term = row_scale[r] * -(sum_c t[r,c] * log_softmax(x[r,:])[c]) over the class columns
+ * [col0, col0+C) of rows with leading dimension ld_logits / ld_targets.
+ * dlogits (same ld as logits) gets row_scale*(softmax*sum(t) - t) in those columns. */
+int mtlssl_softmax_ce_fwd_bwd(const float* logits, int ld_logits, const float* targets,
+                              int ld_targets, int col0, int C, const float* row_scale, int rows,
+                              float* row_loss_out, float* dlogits_out, mtlssl_stream_t stream);
+/* out[0] = scale * sum(x[0..n)) with a fixed reduction order. */
+int mtlssl_reduce_sum(const float* x, int n, float scale, float* out, mtlssl_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer family
+ * slim.learning.clip_gradient_norms (per-variable tf.clip_by_norm, slim/learning.py:282-301)
+ * + tf.train.MomentumOptimizer (builders/optimizer_builder.py:48-52):
+ *   g <- g * min(1, clip/||g||_2) per variable; acc <- momentum*acc + g; w <- w - lr*acc.
+ * The parameters live in one flat buffer; var_offsets int32[num_vars+1] (device) delimits the
+ * variables (offsets in floats, multiples of 4); max_var_size = largest variable (floats).
+ * norms_ws: float[num_vars] workspace. */
+int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
+                             const int32_t* var_offsets, int num_vars, int64_t total,
+                             int64_t max_var_size, float lr, float momentum, float clip_norm,
+                             float grad_scale, float* norms_ws, mtlssl_stream_t stream);
+
+/* Elementwise helpers used by the graph glue. */
+int mtlssl_axpby(const float* x, float* y, int64_t n, float a, float b, mtlssl_stream_t s); /* y=a*x+b*y */
+int mtlssl_scale_channels(const float* w, const float* scale, float* out, int64_t rows, int K,
+                          mtlssl_stream_t s); /* out[r,k] = w[r,k]*scale[k] (BN fold) */
+int mtlssl_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlssl_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTLSSL_HIP_H_ */

@@ -1,0 +1,542 @@
+// NHWC fp32 convolution family for gfx950 (MI355X) as implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).
+//
+//   forward : Y[m=(n,oh,ow)][k]   = sum_{r,s,c} X[n, oh*st-pt+r*dl, ow*st-pl+s*dl, c] * W[r,s,c,k]
+//   dgrad   : dX[m=(n,ih,iw)][c]  = sum_{r,s,k} dY[n,(ih+pt-r*dl)/st,(iw+pl-s*dl)/st,k] * W[r,s,c,k]
+//   wgrad   : dW[r,s][c][k]       = sum_{p=(n,oh,ow)} X[p shifted by (r,s)][c] * dY[p][k]
+//
+// One kernel template, three gather modes. Block = 256 threads = 4 wavefronts (2x2), block tile
+// BM x BN x 16, wave tile (BM/2) x (BN/2) made of 32x32 MFMA tiles. Operands are staged through
+// LDS in a k-major image sA[16][BM+4], sB[16][BN+4] so that an MFMA fragment read is one
+// conflict-free ds_read_b32 per operand (lane l reads [2*kk + l/32][tile + l%32]); the next
+// K-step's global loads are issued before the current step's MFMAs (register prefetch, double
+// buffered LDS, one barrier per step). Frozen BatchNorm is folded into the weights by the caller,
+// so the epilogue is bias(+residual)(+ReLU) and the backward needs only ReLU masks.
+#include "common.h"
+
+namespace mtlssl {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+constexpr int BK = 16;
+
+struct ConvArgs {
+  const float* a;        // fwd: x     dgrad: dy    wgrad: x
+  const float* b;        // fwd: w     dgrad: w     wgrad: dy
+  float* out;            // fwd: y     dgrad: dx    wgrad: workspace partials
+  const float* bias;     // fwd
+  const float* residual; // fwd / dgrad
+  const float* mask;     // dgrad
+  int N, H, W, C, K, R, S, OH, OW, stride, dil, pt, pl;
+  int M;                 // GEMM rows
+  int NG;                // GEMM cols
+  int epi;
+  int tiles_m, tiles_n;
+  int nsplit;            // wgrad: splits of the pixel range
+  int pix_per_split;     // wgrad
+};
+
+template <int BM, int BN, int MODE>
+__global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave in m / n
+  constexpr bool A_KC = (MODE != MODE_WGRAD);     // A float4 runs along k (else along m)
+  constexpr bool B_KC = (MODE == MODE_DGRAD);     // B float4 runs along k (else along n)
+  constexpr int A_LD = BM / 64, B_LD = BN / 64;   // float4 loads per thread per K-step
+  __shared__ __attribute__((aligned(16))) float sA[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float sB[2][BK * LDB];
+
+  // XCD-aware tile order: the dispatcher places block b on XCD b%8; give each XCD a contiguous
+  // range of tiles (n fastest) so blocks sharing an A row-panel share an L2.
+  int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int lo = lane & 31, hi = lane >> 5;
+
+  // ---- K-loop extent
+  int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps;
+  if constexpr (MODE == MODE_FWD) {
+    ksteps = p.R * p.S * (p.C / BK);
+  } else if constexpr (MODE == MODE_DGRAD) {
+    ksteps = p.R * p.S * (p.K / BK);
+  } else {
+    rs_fixed = blockIdx.y;
+    int split = blockIdx.z;
+    int P = p.N * p.OH * p.OW;
+    pix0 = split * p.pix_per_split;
+    pix1 = min(P, pix0 + p.pix_per_split);
+    ksteps = (max(pix1 - pix0, 0) + BK - 1) / BK;
+  }
+
+  // ---- per-thread gather state for the rows this thread stages
+  // KC loaders: thread -> (row = tid/4 + 64*i, kq = tid%4)   [float4 along k]
+  // MC loaders: thread -> (krow = tid/(B?/4) + pass, col4)   [float4 along m or n]
+  int a_n[A_LD], a_y[A_LD], a_x[A_LD];
+  bool a_ok[A_LD];
+  if constexpr (A_KC) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      int m = m0 + (tid >> 2) + 64 * i;
+      a_ok[i] = m < p.M;
+      int mm = a_ok[i] ? m : 0;
+      if constexpr (MODE == MODE_FWD) {
+        int ow = mm % p.OW, t = mm / p.OW;
+        a_x[i] = ow * p.stride - p.pl;
+        a_y[i] = (t % p.OH) * p.stride - p.pt;
+        a_n[i] = t / p.OH;
+      } else {
+        int iw = mm % p.W, t = mm / p.W;
+        a_x[i] = iw + p.pl;
+        a_y[i] = (t % p.H) + p.pt;
+        a_n[i] = t / p.H;
+      }
+    }
+  }
+
+  float4 ra[A_LD], rb[B_LD];
+
+  auto load_tile = [&](int ks) {
+    if constexpr (MODE == MODE_FWD) {
+      int cpk = p.C / BK;
+      int rs = ks / cpk, c0 = (ks - rs * cpk) * BK;
+      int r = rs / p.S, s = rs - r * p.S;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        int ih = a_y[i] + r * p.dil, iw = a_x[i] + s * p.dil;
+        bool ok = a_ok[i] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        ra[i] = ok ? *reinterpret_cast<const float4*>(
+                         p.a + (((int64_t)a_n[i] * p.H + ih) * p.W + iw) * p.C + c0 + (tid & 3) * 4)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        int u = tid + 256 * i;                 // float4 unit in the [16][BN/4] tile
+        int kr = u / (BN / 4), n4 = u % (BN / 4);
+        rb[i] = *reinterpret_cast<const float4*>(p.b + ((int64_t)ks * BK + kr) * p.K + n0 + n4 * 4);
+      }
+    } else if constexpr (MODE == MODE_DGRAD) {
+      int kpk = p.K / BK;
+      int rs = ks / kpk, k0 = (ks - rs * kpk) * BK;
+      int r = rs / p.S, s = rs - r * p.S;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        int ny = a_y[i] - r * p.dil, nx = a_x[i] - s * p.dil;
+        bool ok = a_ok[i] && ny >= 0 && nx >= 0;
+        int oh = ny, ow = nx;
+        if (p.stride > 1) {
+          ok = ok && (ny % p.stride == 0) && (nx % p.stride == 0);
+          oh = ny / p.stride; ow = nx / p.stride;
+        }
+        ok = ok && oh < p.OH && ow < p.OW;
+        ra[i] = ok ? *reinterpret_cast<const float4*>(
+                         p.a + (((int64_t)a_n[i] * p.OH + oh) * p.OW + ow) * p.K + k0 + (tid & 3) * 4)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        int c = n0 + (tid >> 2) + 64 * i;      // GEMM column = input channel
+        rb[i] = *reinterpret_cast<const float4*>(p.b + ((int64_t)rs * p.C + c) * p.K + k0 + (tid & 3) * 4);
+      }
+    } else {
+      int r = rs_fixed / p.S, s = rs_fixed - r * p.S;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        int u = tid + 256 * i;
+        int kr = u / (BM / 4), m4 = u % (BM / 4);
+        int pix = pix0 + ks * BK + kr;
+        bool ok = pix < pix1;
+        int64_t off = 0;
+        if (ok) {
+          if (p.R == 1 && p.S == 1 && p.stride == 1) {
+            off = (int64_t)pix * p.C;
+          } else {
+            int ow = pix % p.OW, t = pix / p.OW;
+            int oh = t % p.OH, n = t / p.OH;
+            int ih = oh * p.stride - p.pt + r * p.dil, iw = ow * p.stride - p.pl + s * p.dil;
+            ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            off = (((int64_t)n * p.H + ih) * p.W + iw) * p.C;
+          }
+        }
+        ra[i] = ok ? *reinterpret_cast<const float4*>(p.a + off + m0 + m4 * 4)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        int u = tid + 256 * i;
+        int kr = u / (BN / 4), n4 = u % (BN / 4);
+        int pix = pix0 + ks * BK + kr;
+        rb[i] = pix < pix1 ? *reinterpret_cast<const float4*>(p.b + (int64_t)pix * p.K + n0 + n4 * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    float* a = sA[buf];
+    float* b = sB[buf];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      if constexpr (A_KC) {
+        int row = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
+        a[(k + 0) * LDA + row] = ra[i].x; a[(k + 1) * LDA + row] = ra[i].y;
+        a[(k + 2) * LDA + row] = ra[i].z; a[(k + 3) * LDA + row] = ra[i].w;
+      } else {
+        int u = tid + 256 * i;
+        int kr = u / (BM / 4), m4 = u % (BM / 4);
+        *reinterpret_cast<float4*>(a + kr * LDA + m4 * 4) = ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      if constexpr (B_KC) {
+        int row = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
+        b[(k + 0) * LDB + row] = rb[i].x; b[(k + 1) * LDB + row] = rb[i].y;
+        b[(k + 2) * LDB + row] = rb[i].z; b[(k + 3) * LDB + row] = rb[i].w;
+      } else {
+        int u = tid + 256 * i;
+        int kr = u / (BN / 4), n4 = u % (BN / 4);
+        *reinterpret_cast<float4*>(b + kr * LDB + n4 * 4) = rb[i];
+      }
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (ksteps > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < ksteps) load_tile(ks + 1);
+    const float* a = sA[cur] + wr * (BM / 2) + lo;
+    const float* b = sB[cur] + wc * (BN / 2) + lo;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = a[(2 * kk + hi) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = b[(2 * kk + hi) * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (ks + 1 < ksteps) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue. MFMA C/D map: lane l, reg e -> row (e&3) + 8*(e>>2) + 4*(l>>5), col l&31.
+  const int ldo = p.NG;
+  float* outp = p.out;
+  if constexpr (MODE == MODE_WGRAD)
+    outp += ((int64_t)blockIdx.z * (p.R * p.S) + rs_fixed) * (int64_t)p.M * p.NG;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wc * (BN / 2) + j * 32 + lo;
+      float bv = 0.f;
+      if constexpr (MODE == MODE_FWD)
+        if (p.epi & MTLSSL_EPI_BIAS) bv = p.bias[col];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        if (row >= p.M) continue;
+        const int64_t o = (int64_t)row * ldo + col;
+        float v = acc[i][j][e];
+        if constexpr (MODE == MODE_FWD) {
+          v += bv;
+          if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
+          if (p.epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
+          if (p.epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+          if (p.epi & MTLSSL_EPI_TANH) v = tanhf(v);
+        } else if constexpr (MODE == MODE_DGRAD) {
+          if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
+          if (p.epi & MTLSSL_EPI_ACCUM) v += outp[o];
+          if (p.epi & MTLSSL_EPI_MASK) v = p.mask[o] > 0.f ? v : 0.f;
+        }
+        outp[o] = v;
+      }
+    }
+  }
+}
+
+// wgrad split-K fold: dw = beta*dw + scale[k] * sum_split ws[split]; float4 over k.
+__global__ void k_wgrad_reduce(const float* ws, int nsplit, int64_t total4, int K,
+                               const float* scale, float* dw, float beta) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < nsplit; ++k) {
+    float4 v = reinterpret_cast<const float4*>(ws)[(int64_t)k * total4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (scale) {
+    float4 sc = *reinterpret_cast<const float4*>(scale + (i * 4) % K);
+    s.x *= sc.x; s.y *= sc.y; s.z *= sc.z; s.w *= sc.w;
+  }
+  if (beta != 0.f) {
+    float4 d = reinterpret_cast<float4*>(dw)[i];
+    s.x += beta * d.x; s.y += beta * d.y; s.z += beta * d.z; s.w += beta * d.w;
+  }
+  reinterpret_cast<float4*>(dw)[i] = s;
+}
+
+// dbias[k] = sum over rows of dy[row][k]; one block per 64 columns, rows strided over waves.
+__global__ void __launch_bounds__(256) k_colsum(const float* dy, int64_t rows, int K, float* out,
+                                                float beta) {
+  __shared__ float s[4][64];
+  int k = blockIdx.x * 64 + (threadIdx.x & 63);
+  int w = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (k < K)
+    for (int64_t r = w; r < rows; r += 4) acc += dy[r * K + k];
+  s[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && k < K) {
+    float t = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+    out[k] = beta != 0.f ? beta * out[k] + t : t;
+  }
+}
+
+// ------------------------------------------------------------------------------ generic paths
+// Direct convolution for shapes the MFMA path does not take (the 7x7x3 stem, heads with a
+// handful of output channels). One thread per output element group; VALU only. These layers are
+// <1% of the step's FLOPs.
+__global__ void k_conv_direct_fwd(ConvArgs p) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)p.M * p.K;
+  if (i >= total) return;
+  int k = i % p.K;
+  int m = i / p.K;
+  int ow = m % p.OW, t = m / p.OW, oh = t % p.OH, n = t / p.OH;
+  float acc = 0.f;
+  for (int r = 0; r < p.R; ++r) {
+    int ih = oh * p.stride - p.pt + r * p.dil;
+    if (ih < 0 || ih >= p.H) continue;
+    for (int s = 0; s < p.S; ++s) {
+      int iw = ow * p.stride - p.pl + s * p.dil;
+      if (iw < 0 || iw >= p.W) continue;
+      const float* xp = p.a + (((int64_t)n * p.H + ih) * p.W + iw) * p.C;
+      const float* wp = p.b + ((int64_t)(r * p.S + s) * p.C) * p.K + k;
+      for (int c = 0; c < p.C; ++c) acc = fmaf(xp[c], wp[(int64_t)c * p.K], acc);
+    }
+  }
+  if (p.epi & MTLSSL_EPI_BIAS) acc += p.bias[k];
+  if (p.epi & MTLSSL_EPI_RESIDUAL) acc += p.residual[i];
+  if (p.epi & MTLSSL_EPI_RELU) acc = fmaxf(acc, 0.f);
+  if (p.epi & MTLSSL_EPI_RELU6) acc = fminf(fmaxf(acc, 0.f), 6.f);
+  if (p.epi & MTLSSL_EPI_TANH) acc = tanhf(acc);
+  p.out[i] = acc;
+}
+__global__ void k_conv_direct_dgrad(ConvArgs p) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)p.M * p.C;
+  if (i >= total) return;
+  int c = i % p.C;
+  int m = i / p.C;
+  int iw = m % p.W, t = m / p.W, ih = t % p.H, n = t / p.H;
+  float acc = 0.f;
+  for (int r = 0; r < p.R; ++r) {
+    int ny = ih + p.pt - r * p.dil;
+    if (ny < 0 || ny % p.stride) continue;
+    int oh = ny / p.stride;
+    if (oh >= p.OH) continue;
+    for (int s = 0; s < p.S; ++s) {
+      int nx = iw + p.pl - s * p.dil;
+      if (nx < 0 || nx % p.stride) continue;
+      int ow = nx / p.stride;
+      if (ow >= p.OW) continue;
+      const float* gp = p.a + (((int64_t)n * p.OH + oh) * p.OW + ow) * p.K;
+      const float* wp = p.b + ((int64_t)(r * p.S + s) * p.C + c) * p.K;
+      for (int k = 0; k < p.K; ++k) acc = fmaf(gp[k], wp[k], acc);
+    }
+  }
+  if (p.epi & MTLSSL_EPI_RESIDUAL) acc += p.residual[i];
+  if (p.epi & MTLSSL_EPI_ACCUM) acc += p.out[i];
+  if (p.epi & MTLSSL_EPI_MASK) acc = p.mask[i] > 0.f ? acc : 0.f;
+  p.out[i] = acc;
+}
+// wgrad for small layers: one block per (rs, c), threads over k, pixels reduced serially.
+__global__ void k_conv_direct_wgrad(ConvArgs p, const float* scale, float* dw, float beta) {
+  int rs = blockIdx.y, c = blockIdx.x;
+  int r = rs / p.S, s = rs % p.S;
+  int P = p.N * p.OH * p.OW;
+  for (int k = threadIdx.x; k < p.K; k += blockDim.x) {
+    float acc = 0.f;
+    for (int pix = 0; pix < P; ++pix) {
+      int ow = pix % p.OW, t = pix / p.OW, oh = t % p.OH, n = t / p.OH;
+      int ih = oh * p.stride - p.pt + r * p.dil, iw = ow * p.stride - p.pl + s * p.dil;
+      if (ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) continue;
+      acc = fmaf(p.a[(((int64_t)n * p.H + ih) * p.W + iw) * p.C + c], p.b[(int64_t)pix * p.K + k], acc);
+    }
+    if (scale) acc *= scale[k];
+    int64_t o = ((int64_t)rs * p.C + c) * p.K + k;
+    dw[o] = beta != 0.f ? beta * dw[o] + acc : acc;
+  }
+}
+
+static ConvArgs make_args(const mtlssl_conv_desc* d) {
+  ConvArgs p;
+  memset(&p, 0, sizeof(p));
+  p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.K = d->K; p.R = d->R; p.S = d->S;
+  p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.dil = d->dilation; p.pt = d->pad_t;
+  p.pl = d->pad_l;
+  return p;
+}
+
+static int check_desc(const mtlssl_conv_desc* d) {
+  MTLSSL_REQUIRE(d != nullptr, "conv: null descriptor");
+  MTLSSL_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0 &&
+                     d->OH > 0 && d->OW > 0 && d->stride > 0 && d->dilation > 0,
+                 "conv: non-positive dimension");
+  MTLSSL_REQUIRE((int64_t)d->N * d->H * d->W * d->C < (1ll << 31) &&
+                     (int64_t)d->N * d->OH * d->OW * d->K < (1ll << 31),
+                 "conv: tensor exceeds 2^31 elements");
+  return MTLSSL_OK;
+}
+
+// Tile choice: the biggest tile whose grid still fills the 256 CUs without a bad tail.
+// cfg 0: 128x128, 1: 128x64, 2: 64x64.
+static int pick_tile(int64_t M, int64_t NG, int64_t zmul) {
+  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+  int best = 2;
+  double best_cost = 1e30;
+  for (int c = 0; c < 3; ++c) {
+    if (NG % bn[c]) continue;
+    int64_t blocks = cdiv(M, bm[c]) * (NG / bn[c]) * zmul;
+    double per_cu = (double)cdiv(blocks, 256);                 // rounds of work on the busiest CU
+    double work = per_cu * bm[c] * bn[c];                      // ~ MFMA time
+    double eff_penalty = (c == 0 ? 1.0 : (c == 1 ? 1.04 : 1.10));  // smaller tiles: more staging
+    double cost = work * eff_penalty;
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+template <int MODE>
+static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st) {
+  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+  p.tiles_m = (int)cdiv(p.M, bm[cfg]);
+  p.tiles_n = p.NG / bn[cfg];
+  dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
+  switch (cfg) {
+    case 0: hipLaunchKernelGGL((k_conv_mfma<128, 128, MODE>), grid, dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((k_conv_mfma<128, 64, MODE>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_conv_mfma<64, 64, MODE>), grid, dim3(256), 0, st, p); break;
+  }
+}
+
+static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pps) {
+  int64_t P = (int64_t)d->N * d->OH * d->OW;
+  int RS = d->R * d->S;
+  // aim for >= ~3 blocks per CU; each split should still cover >= 256 pixels
+  int c = pick_tile(d->C, d->K, RS);
+  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+  int64_t tiles = cdiv(d->C, bm[c]) * (d->K / bn[c]) * RS;
+  int64_t want = cdiv(768, tiles);
+  int64_t maxs = P / 256 > 0 ? P / 256 : 1;
+  int64_t s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  int64_t per = align_up(cdiv(P, s), BK);
+  *nsplit = (int)cdiv(P, per);
+  *pps = (int)per;
+  *cfg = c;
+}
+
+}  // namespace mtlssl
+
+using namespace mtlssl;
+
+extern "C" {
+
+int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w, const float* bias,
+                      const float* residual, float* y, int epi, mtlssl_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_BIAS) || bias, "conv_fwd: bias pointer required");
+  MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_fwd: residual pointer required");
+  ConvArgs p = make_args(d);
+  p.a = x; p.b = w; p.out = y; p.bias = bias; p.residual = residual; p.epi = epi;
+  p.M = d->N * d->OH * d->OW;
+  p.NG = d->K;
+  if (d->C % BK == 0 && d->K % 64 == 0) {
+    launch_mfma<MODE_FWD>(pick_tile(p.M, p.NG, 1), p, dim3(1, 1, 1), S(stream));
+  } else {
+    int64_t total = (int64_t)p.M * p.K;
+    hipLaunchKernelGGL(k_conv_direct_fwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), p);
+  }
+  return check_launch("conv2d_fwd");
+}
+
+int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float* w,
+                        const float* residual, const float* mask_ref, float* dx, int epi,
+                        mtlssl_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_MASK) || mask_ref, "conv_dgrad: mask_ref pointer required");
+  MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_dgrad: residual pointer required");
+  ConvArgs p = make_args(d);
+  p.a = dy; p.b = w; p.out = dx; p.residual = residual; p.mask = mask_ref; p.epi = epi;
+  p.M = d->N * d->H * d->W;
+  p.NG = d->C;
+  if (d->K % BK == 0 && d->C % 64 == 0) {
+    launch_mfma<MODE_DGRAD>(pick_tile(p.M, p.NG, 1), p, dim3(1, 1, 1), S(stream));
+  } else {
+    int64_t total = (int64_t)p.M * p.C;
+    hipLaunchKernelGGL(k_conv_direct_dgrad, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), p);
+  }
+  return check_launch("conv2d_dgrad");
+}
+
+int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
+  if (!d || d->C % 64 || d->K % 64) return 256;
+  int cfg, ns, pps;
+  wgrad_plan(d, &cfg, &ns, &pps);
+  return align_up((int64_t)ns * d->R * d->S * d->C * d->K * 4, 256);
+}
+
+int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,
+                        const float* out_scale, float* dw, float* dbias, float beta,
+                        void* workspace, mtlssl_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  hipStream_t st = S(stream);
+  ConvArgs p = make_args(d);
+  p.a = x; p.b = dy;
+  int64_t P = (int64_t)d->N * d->OH * d->OW;
+  if (d->C % 64 == 0 && d->K % 64 == 0) {
+    MTLSSL_REQUIRE(workspace != nullptr, "conv_wgrad: workspace required");
+    int cfg, ns, pps;
+    wgrad_plan(d, &cfg, &ns, &pps);
+    p.out = (float*)workspace;
+    p.M = d->C; p.NG = d->K; p.nsplit = ns; p.pix_per_split = pps;
+    launch_mfma<MODE_WGRAD>(cfg, p, dim3(1, d->R * d->S, ns), st);
+    int64_t total4 = (int64_t)d->R * d->S * d->C * d->K / 4;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(total4, 256)), dim3(256), 0, st,
+                       (const float*)workspace, ns, total4, d->K, out_scale, dw, beta);
+  } else {
+    hipLaunchKernelGGL(k_conv_direct_wgrad, dim3(d->C, d->R * d->S), dim3(64), 0, st, p, out_scale,
+                       dw, beta);
+  }
+  if (dbias) hipLaunchKernelGGL(k_colsum, dim3(cdiv(d->K, 64)), dim3(256), 0, st, dy, P, d->K, dbias, beta);
+  return check_launch("conv2d_wgrad");
+}
+
+}  // extern "C"

@@ -1,0 +1,832 @@
+// Detection-side kernels of the mtl-ssl hot path for gfx950 (MI355X): anchors, box coder,
+// IoU + arg-max matching + target assignment, samplers, RPN proposal generation (decode, score,
+// clip, sort, greedy NMS). All HBM/latency-bound integer+float work: coalesced loads, LDS
+// staging of the small operand (GT boxes / score chunks), wave64 reductions. No MFMA here.
+//
+// Built with -ffp-contract=off: every float expression below is evaluated in the same order
+// as oracle/boxes.py so that integer outputs (matches, keep lists, NMS selections) are
+// bit-exact against the CPU oracle.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace mtlssl {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ------------------------------------------------------------------------------ box helpers
+struct Box {
+  float y0, x0, y1, x1;
+};
+__device__ __forceinline__ Box load_box(const float* p) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  return Box{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void store_box(float* p, Box b) {
+  *reinterpret_cast<float4*>(p) = make_float4(b.y0, b.x0, b.y1, b.x1);
+}
+__device__ __forceinline__ float box_area(Box b) { return (b.y1 - b.y0) * (b.x1 - b.x0); }
+
+// box_list_ops.iou (core/box_list_ops.py:203-272): a = row box (groundtruth), b = column box.
+__device__ __forceinline__ float iou_tf(Box a, float area_a, Box b, float area_b) {
+  float ymin = fmaxf(a.y0, b.y0), ymax = fminf(a.y1, b.y1);
+  float h = fmaxf(0.f, ymax - ymin);
+  float xmin = fmaxf(a.x0, b.x0), xmax = fminf(a.x1, b.x1);
+  float w = fmaxf(0.f, xmax - xmin);
+  float inter = h * w;
+  float uni = (area_a + area_b) - inter;
+  return inter == 0.f ? 0.f : inter / uni;
+}
+
+// tf.image.non_max_suppression's IoU test (TF 1.7 non_max_suppression_op.cc).
+__device__ __forceinline__ bool nms_iou_gt(Box a, Box b, float thr) {
+  float ay0 = fminf(a.y0, a.y1), ay1 = fmaxf(a.y0, a.y1), ax0 = fminf(a.x0, a.x1),
+        ax1 = fmaxf(a.x0, a.x1);
+  float by0 = fminf(b.y0, b.y1), by1 = fmaxf(b.y0, b.y1), bx0 = fminf(b.x0, b.x1),
+        bx1 = fmaxf(b.x0, b.x1);
+  float area_a = (ay1 - ay0) * (ax1 - ax0);
+  float area_b = (by1 - by0) * (bx1 - bx0);
+  if (area_a <= 0.f || area_b <= 0.f) return false;
+  float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
+  float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.f);
+  float inter = ih * iw;
+  float iou = inter / ((area_a + area_b) - inter);
+  return iou > thr;
+}
+
+// FasterRcnnBoxCoder (box_coders/faster_rcnn_box_coder.py:60-118).
+__device__ __forceinline__ Box decode_box(float ty, float tx, float th, float tw, Box a, float sy,
+                                          float sx, float sh, float sw) {
+  float ha = a.y1 - a.y0, wa = a.x1 - a.x0;
+  float yca = a.y0 + ha / 2.f, xca = a.x0 + wa / 2.f;
+  ty = ty / sy; tx = tx / sx; th = th / sh; tw = tw / sw;
+  float w = expf(tw) * wa, h = expf(th) * ha;
+  float yc = ty * ha + yca, xc = tx * wa + xca;
+  return Box{yc - h / 2.f, xc - w / 2.f, yc + h / 2.f, xc + w / 2.f};
+}
+__device__ __forceinline__ float4 encode_box(Box b, Box a, float sy, float sx, float sh, float sw) {
+  const float EPS = 1e-8f;
+  float ha = a.y1 - a.y0, wa = a.x1 - a.x0;
+  float yca = a.y0 + ha / 2.f, xca = a.x0 + wa / 2.f;
+  float h = b.y1 - b.y0, w = b.x1 - b.x0;
+  float yc = b.y0 + h / 2.f, xc = b.x0 + w / 2.f;
+  ha += EPS; wa += EPS; h += EPS; w += EPS;
+  float tx = (xc - xca) / wa, ty = (yc - yca) / ha;
+  float tw = logf(w / wa), th = logf(h / ha);
+  return make_float4(ty * sy, tx * sx, th * sh, tw * sw);
+}
+
+// ------------------------------------------------------------------------------ anchors
+struct AnchorSizes {
+  int n;
+  float h[64], w[64];
+};
+__global__ void k_anchors(float* out, int gh, int gw, AnchorSizes sz, float sy, float sx, float oy,
+                          float ox) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)gh * gw * sz.n;
+  if (i >= total) return;
+  int a = i % sz.n;
+  int64_t cell = i / sz.n;
+  int ix = cell % gw, iy = cell / gw;
+  float yc = (float)iy * sy + oy, xc = (float)ix * sx + ox;
+  float h = sz.h[a], w = sz.w[a];
+  store_box(out + i * 4, Box{yc - 0.5f * h, xc - 0.5f * w, yc + 0.5f * h, xc + 0.5f * w});
+}
+
+// ------------------------------------------------------------------------------ prune (compaction)
+__global__ void k_prune(const float* boxes, int n, float wy0, float wx0, float wy1, float wx1,
+                        int32_t* keep, int32_t* count) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int start = 0; start < n; start += blockDim.x) {
+    int i = start + threadIdx.x;
+    bool ok = false;
+    if (i < n) {
+      Box b = load_box(boxes + (int64_t)i * 4);
+      ok = !(b.y0 < wy0 || b.x0 < wx0 || b.y1 > wy1 || b.x1 > wx1);
+    }
+    unsigned long long m = __ballot(ok);
+    int before = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) s_wave[wid] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wid; ++w) off += s_wave[w];
+    if (ok) keep[off + before] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < nw; ++w) t += s_wave[w];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = s_base;
+}
+
+// ------------------------------------------------------------------------------ gather / scatter
+__global__ void k_gather_rows(const float* src, const int32_t* idx, float* dst, int n_src,
+                              int n_idx, int row_len, bool scatter) {
+  int b = blockIdx.y;
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= (int64_t)n_idx * row_len) return;
+  int r = e / row_len, c = e % row_len;
+  int s = idx[r];
+  if (!scatter)
+    dst[((int64_t)b * n_idx + r) * row_len + c] = src[((int64_t)b * n_src + s) * row_len + c];
+  else
+    dst[((int64_t)b * n_src + s) * row_len + c] = src[((int64_t)b * n_idx + r) * row_len + c];
+}
+
+// ------------------------------------------------------------------------------ coder kernels
+__global__ void k_decode(const float* codes, const float* anchors, float* out, int n,
+                         int anchors_batched, float sy, float sx, float sh, float sw) {
+  int b = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t o = ((int64_t)b * n + i) * 4;
+  float4 c = *reinterpret_cast<const float4*>(codes + o);
+  Box a = load_box(anchors + (anchors_batched ? o : (int64_t)i * 4));
+  store_box(out + o, decode_box(c.x, c.y, c.z, c.w, a, sy, sx, sh, sw));
+}
+__global__ void k_encode(const float* boxes, const float* anchors, float* out, int n, float sy,
+                         float sx, float sh, float sw) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Box b = load_box(boxes + (int64_t)i * 4), a = load_box(anchors + (int64_t)i * 4);
+  *reinterpret_cast<float4*>(out + (int64_t)i * 4) = encode_box(b, a, sy, sx, sh, sw);
+}
+
+// ------------------------------------------------------------------------------ RPN proposals
+// Stage 1: decode + fg softmax + score filter + clip_to_window (+ drop area<=0).
+__global__ void k_rpn_decode_score(const float* enc, const float* logits, const float* anchors,
+                                   int n, float H, float W, float score_thresh, float* boxes,
+                                   float* scores, int32_t* nvalid) {
+  int b = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = false;
+  if (i < n) {
+    int64_t o = (int64_t)b * n + i;
+    float4 c = *reinterpret_cast<const float4*>(enc + o * 4);
+    Box a = load_box(anchors + (int64_t)i * 4);
+    Box d = decode_box(c.x, c.y, c.z, c.w, a, 10.f, 10.f, 5.f, 5.f);
+    float2 l = *reinterpret_cast<const float2*>(logits + o * 2);
+    float m = fmaxf(l.x, l.y);
+    float e0 = expf(l.x - m), e1 = expf(l.y - m);
+    float s = e1 / (e0 + e1);
+    valid = s > score_thresh;
+    Box cl{fmaxf(fminf(d.y0, H), 0.f), fmaxf(fminf(d.x0, W), 0.f), fmaxf(fminf(d.y1, H), 0.f),
+           fmaxf(fminf(d.x1, W), 0.f)};
+    valid = valid && (box_area(cl) > 0.f);
+    store_box(boxes + o * 4, cl);
+    scores[o] = valid ? s : -INFINITY;
+  }
+  unsigned long long m = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(nvalid + b, __popcll(m));
+}
+
+// Stage 2: rank sort by (score desc, index asc) via counting, chunked through LDS.
+// Entries with score == -inf are not candidates. Writes sorted boxes/scores/orig index.
+constexpr int RANK_CHUNK = 4096;
+__global__ void __launch_bounds__(256) k_rank_sort(const float* boxes, const float* scores, int n,
+                                                   float* sboxes, float* sscores, int32_t* sidx) {
+  __shared__ float s_sc[RANK_CHUNK];
+  int b = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float* sc = scores + (int64_t)b * n;
+  float si = i < n ? sc[i] : -INFINITY;
+  bool cand = si > -INFINITY;
+  int rank = 0;
+  for (int c0 = 0; c0 < n; c0 += RANK_CHUNK) {
+    int cn = min(RANK_CHUNK, n - c0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cn; j += blockDim.x) s_sc[j] = sc[c0 + j];
+    __syncthreads();
+    if (cand) {
+      // entries before i win ties, entries after lose them
+      int jsplit = min(max(i - c0, 0), cn);
+      int r = 0;
+      for (int j = 0; j < jsplit; ++j) r += (s_sc[j] >= si);
+      for (int j = jsplit; j < cn; ++j) r += (s_sc[j] > si);
+      rank += r;
+    }
+  }
+  if (cand) {
+    int64_t o = (int64_t)b * n + rank;
+    store_box(sboxes + o * 4, load_box(boxes + ((int64_t)b * n + i) * 4));
+    sscores[o] = si;
+    sidx[o] = i;
+  }
+}
+
+// Stage 3: suppression bit matrix over the sorted candidates. mask[b][row][colchunk] bit j set
+// iff IoU(row, colchunk*64+j) > thr and col > row.
+__global__ void __launch_bounds__(64) k_nms_mask(const float* sboxes, const int32_t* nvalid, int n,
+                                                 int nchunks, float thr,
+                                                 unsigned long long* mask) {
+  int b = blockIdx.z;
+  int nv = nvalid ? min(nvalid[b], n) : n;
+  int rc = blockIdx.y, cc = blockIdx.x;
+  if (cc < rc || rc * 64 >= nv || cc * 64 >= nv) return;
+  __shared__ float4 s_col[64];
+  const float* bx = sboxes + (int64_t)b * n * 4;
+  int col = cc * 64 + threadIdx.x;
+  if (col < nv) s_col[threadIdx.x] = *reinterpret_cast<const float4*>(bx + (int64_t)col * 4);
+  __syncthreads();
+  int row = rc * 64 + threadIdx.x;
+  if (row >= nv) return;
+  Box r = load_box(bx + (int64_t)row * 4);
+  int ncol = min(64, nv - cc * 64);
+  unsigned long long bits = 0;
+  for (int j = 0; j < ncol; ++j) {
+    float4 v = s_col[j];
+    int cj = cc * 64 + j;
+    if (cj > row && nms_iou_gt(r, Box{v.x, v.y, v.z, v.w}, thr)) bits |= 1ull << j;
+  }
+  mask[((int64_t)b * n + row) * nchunks + cc] = bits;
+}
+
+// Stage 4: greedy scan, one wave per image. Chunk-wise: resolve the 64 candidates of a chunk in
+// registers against the chunk's diagonal block, then OR the selected rows into the running
+// removed-set held in LDS.
+__global__ void __launch_bounds__(64) k_nms_scan(const unsigned long long* mask,
+                                                 const int32_t* nvalid, int n, int nchunks,
+                                                 int max_out, int32_t* sel_rank, int32_t* num_out) {
+  extern __shared__ unsigned long long s_remv[];
+  int b = blockIdx.x;
+  int lane = threadIdx.x;
+  int nv = nvalid ? min(nvalid[b], n) : n;
+  const unsigned long long* mk = mask + (int64_t)b * n * nchunks;
+  int nch = (nv + 63) / 64;
+  for (int w = lane; w < nch; w += 64) s_remv[w] = 0;
+  __syncthreads();
+  int nsel = 0;
+  for (int c = 0; c < nch && nsel < max_out; ++c) {
+    int row = c * 64 + lane;
+    unsigned long long diag = row < nv ? mk[(int64_t)row * nchunks + c] : 0ull;
+    unsigned long long word = s_remv[c];
+    int ncand = min(64, nv - c * 64);
+    unsigned long long sel = 0;
+    for (int j = 0; j < ncand && nsel < max_out; ++j) {
+      unsigned long long dj = __shfl(diag, j, 64);
+      if (!((word >> j) & 1ull)) {
+        sel |= 1ull << j;
+        word |= dj;
+        ++nsel;
+      }
+    }
+    // record selections (in order) and fold their rows into the removed set
+    int base = nsel - __popcll(sel);
+    if ((sel >> lane) & 1ull) sel_rank[(int64_t)b * max_out + base + __popcll(sel & ((1ull << lane) - 1))] = row;
+    if (nsel < max_out) {
+      unsigned long long rem = sel;
+      while (rem) {
+        int j = __ffsll((long long)rem) - 1;
+        rem &= rem - 1;
+        const unsigned long long* rowp = mk + (int64_t)(c * 64 + j) * nchunks;
+        for (int w = c + 1 + lane; w < nch; w += 64) s_remv[w] |= rowp[w];
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) num_out[b] = nsel;
+}
+
+// Stage 5: emit padded proposals.
+__global__ void k_emit_proposals(const float* sboxes, const float* sscores, const int32_t* sel_rank,
+                                 const int32_t* num, int n, int max_out, float* boxes_out,
+                                 float* scores_out) {
+  int b = blockIdx.y;
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= max_out) return;
+  int64_t o = (int64_t)b * max_out + k;
+  if (k < num[b]) {
+    int r = sel_rank[o];
+    store_box(boxes_out + o * 4, load_box(sboxes + ((int64_t)b * n + r) * 4));
+    scores_out[o] = sscores[(int64_t)b * n + r];
+  } else {
+    store_box(boxes_out + o * 4, Box{0, 0, 0, 0});
+    scores_out[o] = 0.f;
+  }
+}
+__global__ void k_emit_selected(const int32_t* sidx, const int32_t* sel_rank, const int32_t* num,
+                                int max_out, int32_t* selected_out) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= max_out) return;
+  selected_out[k] = k < num[0] ? sidx[sel_rank[k]] : -1;
+}
+
+struct NmsWs {
+  float* boxes;
+  float* scores;
+  float* sboxes;
+  float* sscores;
+  int32_t* sidx;
+  int32_t* nvalid;
+  int32_t* sel_rank;
+  unsigned long long* mask;
+  int nchunks;
+};
+static int64_t nms_ws_layout(int batch, int n, int max_out, char* base, NmsWs* ws) {
+  int nchunks = (n + 63) / 64;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  NmsWs w;
+  w.nchunks = nchunks;
+  w.boxes = (float*)take((int64_t)batch * n * 16);
+  w.scores = (float*)take((int64_t)batch * n * 4);
+  w.sboxes = (float*)take((int64_t)batch * n * 16);
+  w.sscores = (float*)take((int64_t)batch * n * 4);
+  w.sidx = (int32_t*)take((int64_t)batch * n * 4);
+  w.nvalid = (int32_t*)take((int64_t)batch * 4);
+  w.sel_rank = (int32_t*)take((int64_t)batch * max_out * 4);
+  w.mask = (unsigned long long*)take((int64_t)batch * n * nchunks * 8);
+  if (ws) *ws = w;
+  return off;
+}
+
+static int run_nms_sorted(const NmsWs& w, const int32_t* nvalid, int batch, int n, float thr,
+                          int max_out, int32_t* num_out, hipStream_t st) {
+  dim3 g(w.nchunks, w.nchunks, batch);
+  hipLaunchKernelGGL(k_nms_mask, g, dim3(64), 0, st, w.sboxes, nvalid, n, w.nchunks, thr, w.mask);
+  size_t lds = (size_t)w.nchunks * 8;
+  hipLaunchKernelGGL(k_nms_scan, dim3(batch), dim3(64), lds, st, w.mask, nvalid, n, w.nchunks,
+                     max_out, w.sel_rank, num_out);
+  return check_launch("nms");
+}
+
+// ------------------------------------------------------------------------------ target assignment
+constexpr int ASSIGN_BLOCK = 256;
+// Pass A: per-anchor column arg-max + thresholds; per-block row partials for force-match.
+__global__ void __launch_bounds__(ASSIGN_BLOCK)
+    k_match_cols(const float* anchors, int anchors_batched, int n, const float* gt_boxes,
+                 const int32_t* num_gt, int max_gt, float mthr, float uthr, int force,
+                 int32_t* match, float* row_pval, int32_t* row_pidx, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  float4* s_gt = reinterpret_cast<float4*>(s_mem);               // [max_gt]
+  float* s_ga = s_mem + 4 * max_gt;                               // [max_gt]
+  float* s_wv = s_ga + max_gt;                                    // [4][max_gt]
+  int* s_wi = reinterpret_cast<int*>(s_wv + 4 * max_gt);          // [4][max_gt]
+  int b = blockIdx.y;
+  int G = min(num_gt[b], max_gt);
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float4 v = *reinterpret_cast<const float4*>(gt_boxes + ((int64_t)b * max_gt + g) * 4);
+    s_gt[g] = v;
+    s_ga[g] = (v.z - v.x) * (v.w - v.y);
+  }
+  __syncthreads();
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool in = i < n;
+  Box a{0, 0, 0, 0};
+  float aa = 0.f;
+  if (in) {
+    a = load_box(anchors + (anchors_batched ? ((int64_t)b * n + i) : (int64_t)i) * 4);
+    aa = box_area(a);
+  }
+  float best = -INFINITY;
+  int besti = 0;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int g = 0; g < G; ++g) {
+    float4 v = s_gt[g];
+    float q = in ? iou_tf(Box{v.x, v.y, v.z, v.w}, s_ga[g], a, aa) : -1.f;
+    if (q > best) { best = q; besti = g; }
+    if (force) {
+      // wave arg-max over anchors: larger value wins, then smaller anchor index
+      float rv = q;
+      int ri = in ? i : 0x7fffffff;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(rv, o, 64);
+        int oi = __shfl_xor(ri, o, 64);
+        if (ov > rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+      }
+      if (lane == 0) { s_wv[wid * max_gt + g] = rv; s_wi[wid * max_gt + g] = ri; }
+    }
+  }
+  if (in) {
+    int m;
+    if (G == 0) {
+      m = -1;
+    } else {
+      m = besti;
+      bool below = uthr > best;
+      bool between = (best >= uthr) && (mthr > best);
+      if (below) m = -1;
+      if (between) m = -2;
+    }
+    match[(int64_t)b * n + i] = m;
+  }
+  if (force) {
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+      float rv = s_wv[g];
+      int ri = s_wi[g];
+      for (int w = 1; w < ASSIGN_BLOCK / 64; ++w) {
+        float ov = s_wv[w * max_gt + g];
+        int oi = s_wi[w * max_gt + g];
+        if (ov > rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+      }
+      int64_t o = ((int64_t)b * nblocks + blockIdx.x) * max_gt + g;
+      row_pval[o] = rv;
+      row_pidx[o] = ri;
+    }
+  }
+}
+// Pass B: fold the row partials, then apply forced matches (largest row index wins a column).
+__global__ void k_force_match(const float* row_pval, const int32_t* row_pidx, int nblocks,
+                              const int32_t* num_gt, int max_gt, int n, int32_t* match) {
+  extern __shared__ int s_f[];
+  int b = blockIdx.x;
+  int G = min(num_gt[b], max_gt);
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float rv = -INFINITY;
+    int ri = 0x7fffffff;
+    for (int k = 0; k < nblocks; ++k) {
+      int64_t o = ((int64_t)b * nblocks + k) * max_gt + g;
+      float ov = row_pval[o];
+      int oi = row_pidx[o];
+      if (ov > rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+    }
+    s_f[g] = ri;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    int f = s_f[g];
+    bool win = true;
+    for (int h = g + 1; h < G; ++h) win = win && (s_f[h] != f);
+    if (win && f < n) match[(int64_t)b * n + f] = g;
+  }
+}
+// Pass C: targets and weights from the match vector.
+__global__ void k_assign_outputs(const float* anchors, int anchors_batched, int n,
+                                 const float* gt_boxes, int max_gt, const float* gt_labels,
+                                 int label_dim, const float* gt_extra, int extra_dim,
+                                 const float* unmatched, const int32_t* match, float* cls_t,
+                                 float* cls_w, float* reg_t, float* reg_w, float* extra_t) {
+  int b = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t o = (int64_t)b * n + i;
+  int m = match[o];
+  if (reg_w) reg_w[o] = m >= 0 ? 1.f : 0.f;
+  if (cls_w) cls_w[o] = m == -2 ? 0.f : 1.f;
+  if (reg_t) {
+    float4 t = make_float4(0, 0, 0, 0);
+    if (m >= 0) {
+      Box g = load_box(gt_boxes + ((int64_t)b * max_gt + m) * 4);
+      Box a = load_box(anchors + (anchors_batched ? o : (int64_t)i) * 4);
+      t = encode_box(g, a, 10.f, 10.f, 5.f, 5.f);
+    }
+    *reinterpret_cast<float4*>(reg_t + o * 4) = t;
+  }
+  if (cls_t) {
+    for (int c = 0; c < label_dim; ++c) {
+      float v;
+      if (m >= 0) v = gt_labels ? gt_labels[((int64_t)b * max_gt + m) * label_dim + c] : 1.f;
+      else v = unmatched ? unmatched[c] : 0.f;
+      cls_t[o * label_dim + c] = v;
+    }
+  }
+  if (extra_t) {
+    for (int c = 0; c < extra_dim; ++c)
+      extra_t[o * extra_dim + c] = m >= 0 ? gt_extra[((int64_t)b * max_gt + m) * extra_dim + c] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------ samplers
+__device__ __host__ __forceinline__ uint32_t sampler_priority(uint32_t seed, uint32_t stream,
+                                                              uint32_t i) {
+  uint32_t x = i + 0x9E3779B9u * seed + 0x85EBCA6Bu * stream;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+constexpr int SAMP_CHUNK = 4096;
+__global__ void __launch_bounds__(256)
+    k_balanced_sample(const float* indicator, const float* labels, int n, int batch_size,
+                      int max_pos, uint32_t seed, uint32_t stream0, uint32_t stream_stride,
+                      float* sampled) {
+  __shared__ uint32_t s_pr[SAMP_CHUNK];
+  __shared__ unsigned char s_cl[SAMP_CHUNK];
+  __shared__ int s_cnt[4];
+  int b = blockIdx.y;
+  uint32_t stream = stream0 + stream_stride * (uint32_t)b;
+  const float* ind = indicator + (int64_t)b * n;
+  const float* lab = labels + (int64_t)b * n;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int mycl = 0;
+  uint32_t pi = 0;
+  if (i < n) {
+    bool id = ind[i] != 0.f, lb = lab[i] != 0.f;
+    mycl = id ? (lb ? 1 : 2) : 0;
+    pi = sampler_priority(seed, stream, (uint32_t)i);
+  }
+  int rank = 0, npos = 0;
+  for (int c0 = 0; c0 < n; c0 += SAMP_CHUNK) {
+    int cn = min(SAMP_CHUNK, n - c0);
+    __syncthreads();
+    int lp = 0;
+    for (int j = threadIdx.x; j < cn; j += blockDim.x) {
+      bool id = ind[c0 + j] != 0.f, lb = lab[c0 + j] != 0.f;
+      unsigned char cl = id ? (lb ? 1 : 2) : 0;
+      s_cl[j] = cl;
+      s_pr[j] = sampler_priority(seed, stream, (uint32_t)(c0 + j));
+      lp += cl == 1;
+    }
+    lp = wave_sum_i(lp);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = lp;
+    __syncthreads();
+    npos += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (mycl) {
+      int r = 0;
+      for (int j = 0; j < cn; ++j) {
+        uint32_t pj = s_pr[j];
+        bool less = pj < pi || (pj == pi && (c0 + j) < i);
+        r += (s_cl[j] == mycl) && less;
+      }
+      rank += r;
+    }
+  }
+  if (i < n) {
+    int sel_pos = min(npos, max_pos);
+    int max_neg = batch_size - sel_pos;
+    bool s = (mycl == 1 && rank < max_pos) || (mycl == 2 && rank < max_neg);
+    sampled[(int64_t)b * n + i] = s ? 1.f : 0.f;
+  }
+}
+
+// One block per image: detector-assign valid proposals, balanced-sample, compact, pad.
+constexpr int SP_MAX = 1024;
+__global__ void __launch_bounds__(256)
+    k_sample_proposals(const float* proposals, const int32_t* num_prop, int max_p,
+                       const float* gt_boxes, const int32_t* num_gt, int max_gt,
+                       const float* gt_labels, int label_dim, int n2, int max_pos, uint32_t seed,
+                       uint32_t stream0, uint32_t stream_stride, float img_h, float img_w,
+                       float* out_abs, float* out_norm, int32_t* num_out) {
+  __shared__ unsigned char s_cl[SP_MAX];
+  __shared__ uint32_t s_pr[SP_MAX];
+  __shared__ unsigned char s_sel[SP_MAX];
+  __shared__ int s_scan[SP_MAX];
+  __shared__ int s_npos;
+  int b = blockIdx.x;
+  int n = min(num_prop[b], max_p);
+  int G = min(num_gt[b], max_gt);
+  uint32_t stream = stream0 + stream_stride * (uint32_t)b;
+  const float* pb = proposals + (int64_t)b * max_p * 4;
+  if (threadIdx.x == 0) s_npos = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    Box a = load_box(pb + (int64_t)i * 4);
+    float aa = box_area(a);
+    float best = -INFINITY;
+    int bi = 0;
+    for (int g = 0; g < G; ++g) {
+      Box gb = load_box(gt_boxes + ((int64_t)b * max_gt + g) * 4);
+      float q = iou_tf(gb, box_area(gb), a, aa);
+      if (q > best) { best = q; bi = g; }
+    }
+    bool matched = G > 0 && !(0.5f > best);
+    bool positive = false;
+    if (matched) {   // argmax(label row) > 0, first max wins
+      const float* lr = gt_labels + ((int64_t)b * max_gt + bi) * label_dim;
+      float mv = lr[0];
+      int mi = 0;
+      for (int c = 1; c < label_dim; ++c)
+        if (lr[c] > mv) { mv = lr[c]; mi = c; }
+      positive = mi > 0;
+    }
+    s_cl[i] = positive ? 1 : 2;      // every valid proposal is a candidate (weights are all 1)
+    s_pr[i] = sampler_priority(seed, stream, (uint32_t)i);
+    if (positive) atomicAdd(&s_npos, 1);
+  }
+  __syncthreads();
+  int sel_pos = min(s_npos, max_pos);
+  int max_neg = n2 - sel_pos;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int cl = s_cl[i];
+    uint32_t pi = s_pr[i];
+    int r = 0;
+    for (int j = 0; j < n; ++j) {
+      uint32_t pj = s_pr[j];
+      r += (s_cl[j] == cl) && (pj < pi || (pj == pi && j < i));
+    }
+    s_sel[i] = (cl == 1 && r < max_pos) || (cl == 2 && r < max_neg);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {          // n <= 1024: serial exclusive scan is fine here
+    int acc = 0;
+    for (int i = 0; i < n; ++i) { s_scan[i] = acc; acc += s_sel[i]; }
+    num_out[b] = min(acc, n2);
+  }
+  __syncthreads();
+  float ih = 1.f / img_h, iw = 1.f / img_w;
+  for (int k = threadIdx.x; k < n2; k += blockDim.x) {
+    store_box(out_abs + ((int64_t)b * n2 + k) * 4, Box{0, 0, 0, 0});
+    store_box(out_norm + ((int64_t)b * n2 + k) * 4, Box{0, 0, 0, 0});
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (s_sel[i] && s_scan[i] < n2) {
+      Box a = load_box(pb + (int64_t)i * 4);
+      int64_t o = ((int64_t)b * n2 + s_scan[i]) * 4;
+      store_box(out_abs + o, a);
+      store_box(out_norm + o, Box{a.y0 * ih, a.x0 * iw, a.y1 * ih, a.x1 * iw});
+    }
+  }
+}
+
+}  // namespace mtlssl
+
+using namespace mtlssl;
+
+extern "C" {
+
+const char* mtlssl_last_error(void) { return g_err; }
+int mtlssl_abi_version(void) { return 1; }
+
+int mtlssl_anchors_generate(float* out, int gh, int gw, const float* scales, int ns,
+                            const float* ars, int nr, float base_h, float base_w, float sy,
+                            float sx, float oy, float ox, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(ns * nr <= 64 && ns > 0 && nr > 0, "anchors: need 1..64 anchor types");
+  AnchorSizes sz;
+  sz.n = ns * nr;
+  for (int r = 0; r < nr; ++r)
+    for (int s = 0; s < ns; ++s) {   // index = aspect_idx * n_scales + scale_idx
+      float rs = sqrtf(ars[r]);
+      float h = scales[s] / rs;
+      float w = scales[s] * rs;
+      sz.h[r * ns + s] = h * base_h;
+      sz.w[r * ns + s] = w * base_w;
+    }
+  int64_t total = (int64_t)gh * gw * sz.n;
+  hipLaunchKernelGGL(k_anchors, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), out, gh, gw, sz,
+                     sy, sx, oy, ox);
+  return check_launch("anchors");
+}
+
+int mtlssl_boxes_prune_outside_window(const float* boxes, int n, float wy0, float wx0, float wy1,
+                                      float wx1, int32_t* keep, int32_t* count,
+                                      mtlssl_stream_t stream) {
+  hipLaunchKernelGGL(k_prune, dim3(1), dim3(1024), 0, S(stream), boxes, n, wy0, wx0, wy1, wx1, keep,
+                     count);
+  return check_launch("prune");
+}
+
+int mtlssl_gather_rows(const float* src, const int32_t* idx, float* dst, int batch, int n_src,
+                       int n_idx, int row_len, mtlssl_stream_t stream) {
+  if (n_idx == 0 || batch == 0) return MTLSSL_OK;
+  dim3 g(cdiv((int64_t)n_idx * row_len, 256), batch);
+  hipLaunchKernelGGL(k_gather_rows, g, dim3(256), 0, S(stream), src, idx, dst, n_src, n_idx, row_len,
+                     false);
+  return check_launch("gather_rows");
+}
+int mtlssl_scatter_rows(const float* src, const int32_t* idx, float* dst, int batch, int n_dst,
+                        int n_idx, int row_len, mtlssl_stream_t stream) {
+  if (n_idx == 0 || batch == 0) return MTLSSL_OK;
+  dim3 g(cdiv((int64_t)n_idx * row_len, 256), batch);
+  hipLaunchKernelGGL(k_gather_rows, g, dim3(256), 0, S(stream), src, idx, dst, n_dst, n_idx, row_len,
+                     true);
+  return check_launch("scatter_rows");
+}
+
+int mtlssl_boxes_decode(const float* codes, const float* anchors, float* out, int batch, int n,
+                        int anchors_batched, float sy, float sx, float sh, float sw,
+                        mtlssl_stream_t stream) {
+  if (n == 0 || batch == 0) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_decode, dim3(cdiv(n, 256), batch), dim3(256), 0, S(stream), codes, anchors,
+                     out, n, anchors_batched, sy, sx, sh, sw);
+  return check_launch("decode");
+}
+int mtlssl_boxes_encode(const float* boxes, const float* anchors, float* out, int n, float sy,
+                        float sx, float sh, float sw, mtlssl_stream_t stream) {
+  if (n == 0) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_encode, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), boxes, anchors, out, n,
+                     sy, sx, sh, sw);
+  return check_launch("encode");
+}
+
+int64_t mtlssl_rpn_proposals_workspace_bytes(int batch, int n) {
+  return nms_ws_layout(batch, n, 4096, nullptr, nullptr);
+}
+int64_t mtlssl_nms_workspace_bytes(int n) { return nms_ws_layout(1, n, 4096, nullptr, nullptr); }
+
+int mtlssl_rpn_proposals(const float* enc, const float* logits, const float* anchors, int batch,
+                         int n, float img_h, float img_w, float score_thresh, float iou_thresh,
+                         int max_proposals, float* proposals_out, float* scores_out,
+                         int32_t* num_out, void* workspace, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(max_proposals > 0 && max_proposals <= 4096, "rpn_proposals: max_proposals 1..4096");
+  MTLSSL_REQUIRE(workspace != nullptr, "rpn_proposals: workspace required");
+  hipStream_t st = S(stream);
+  NmsWs w;
+  nms_ws_layout(batch, n, 4096, (char*)workspace, &w);
+  hipMemsetAsync(w.nvalid, 0, sizeof(int32_t) * batch, st);
+  dim3 g(cdiv(n, 256), batch);
+  hipLaunchKernelGGL(k_rpn_decode_score, g, dim3(256), 0, st, enc, logits, anchors, n, img_h, img_w,
+                     score_thresh, w.boxes, w.scores, w.nvalid);
+  hipLaunchKernelGGL(k_rank_sort, g, dim3(256), 0, st, w.boxes, w.scores, n, w.sboxes, w.sscores,
+                     w.sidx);
+  int rc = run_nms_sorted(w, w.nvalid, batch, n, iou_thresh, max_proposals, num_out, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_emit_proposals, dim3(cdiv(max_proposals, 256), batch), dim3(256), 0, st,
+                     w.sboxes, w.sscores, w.sel_rank, num_out, n, max_proposals, proposals_out,
+                     scores_out);
+  return check_launch("rpn_proposals");
+}
+
+int mtlssl_nms(const float* boxes, const float* scores, int n, float iou_thresh, int max_out,
+               int32_t* selected_out, int32_t* num_out, void* workspace, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(max_out > 0 && max_out <= 4096, "nms: max_out 1..4096");
+  MTLSSL_REQUIRE(workspace != nullptr, "nms: workspace required");
+  hipStream_t st = S(stream);
+  if (n == 0) {
+    hipMemsetAsync(num_out, 0, 4, st);
+    hipMemsetAsync(selected_out, 0xff, 4 * (size_t)max_out, st);
+    return MTLSSL_OK;
+  }
+  NmsWs w;
+  nms_ws_layout(1, n, 4096, (char*)workspace, &w);
+  hipLaunchKernelGGL(k_rank_sort, dim3(cdiv(n, 256), 1), dim3(256), 0, st, boxes, scores, n,
+                     w.sboxes, w.sscores, w.sidx);
+  int rc = run_nms_sorted(w, nullptr, 1, n, iou_thresh, max_out, num_out, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_emit_selected, dim3(cdiv(max_out, 256)), dim3(256), 0, st, w.sidx,
+                     w.sel_rank, num_out, max_out, selected_out);
+  return check_launch("nms");
+}
+
+int64_t mtlssl_assign_targets_workspace_bytes(int batch, int n, int max_gt) {
+  int64_t nblocks = cdiv(n, ASSIGN_BLOCK);
+  return 2 * align_up((int64_t)batch * nblocks * (max_gt > 0 ? max_gt : 1) * 4, 256);
+}
+
+int mtlssl_assign_targets(const float* anchors, int anchors_batched, int batch, int n,
+                          const float* gt_boxes, const int32_t* num_gt, int max_gt,
+                          const float* gt_labels, int label_dim, const float* gt_extra,
+                          int extra_dim, const float* unmatched, float mthr, float uthr, int force,
+                          int32_t* match, float* cls_t, float* cls_w, float* reg_t, float* reg_w,
+                          float* extra_t, void* workspace, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(match != nullptr, "assign_targets: match_out required");
+  MTLSSL_REQUIRE(max_gt >= 1 && max_gt <= 1024, "assign_targets: max_gt must be 1..1024");
+  MTLSSL_REQUIRE(!force || workspace, "assign_targets: workspace required for force_match");
+  MTLSSL_REQUIRE(gt_labels || label_dim == 1, "assign_targets: label_dim must be 1 without labels");
+  if (n == 0 || batch == 0) return MTLSSL_OK;
+  hipStream_t st = S(stream);
+  int nblocks = (int)cdiv(n, ASSIGN_BLOCK);
+  int64_t half = align_up((int64_t)batch * nblocks * max_gt * 4, 256);
+  float* pval = (float*)workspace;
+  int32_t* pidx = workspace ? (int32_t*)((char*)workspace + half) : nullptr;
+  size_t lds = (size_t)max_gt * (4 + 1 + 4 + 4) * 4;
+  hipLaunchKernelGGL(k_match_cols, dim3(nblocks, batch), dim3(ASSIGN_BLOCK), lds, st, anchors,
+                     anchors_batched, n, gt_boxes, num_gt, max_gt, mthr, uthr, force, match, pval,
+                     pidx, nblocks);
+  if (force)
+    hipLaunchKernelGGL(k_force_match, dim3(batch), dim3(256), (size_t)max_gt * 4, st, pval, pidx,
+                       nblocks, num_gt, max_gt, n, match);
+  if (cls_t || cls_w || reg_t || reg_w || extra_t)
+    hipLaunchKernelGGL(k_assign_outputs, dim3(nblocks, batch), dim3(ASSIGN_BLOCK), 0, st, anchors,
+                       anchors_batched, n, gt_boxes, max_gt, gt_labels, label_dim, gt_extra,
+                       extra_dim, unmatched, match, cls_t, cls_w, reg_t, reg_w, extra_t);
+  return check_launch("assign_targets");
+}
+
+int mtlssl_balanced_sample(const float* indicator, const float* labels, int batch, int n,
+                           int batch_size, float positive_fraction, uint32_t seed, uint32_t stream0,
+                           uint32_t stream_stride, float* sampled, mtlssl_stream_t stream) {
+  if (n == 0 || batch == 0) return MTLSSL_OK;
+  int max_pos = (int)(positive_fraction * batch_size);
+  hipLaunchKernelGGL(k_balanced_sample, dim3(cdiv(n, 256), batch), dim3(256), 0, S(stream),
+                     indicator, labels, n, batch_size, max_pos, seed, stream0, stream_stride,
+                     sampled);
+  return check_launch("balanced_sample");
+}
+
+int mtlssl_sample_proposals(const float* proposals, const int32_t* num_proposals, int batch,
+                            int max_p, const float* gt_boxes, const int32_t* num_gt, int max_gt,
+                            const float* gt_labels_bg, int label_dim, int n2, float balance_fraction,
+                            uint32_t seed, uint32_t stream0, uint32_t stream_stride, float img_h,
+                            float img_w, float* boxes_abs, float* boxes_norm, int32_t* num_out,
+                            mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(max_p <= SP_MAX, "sample_proposals: at most %d proposals per image", SP_MAX);
+  MTLSSL_REQUIRE(gt_labels_bg != nullptr, "sample_proposals: labels required");
+  if (batch == 0) return MTLSSL_OK;
+  int max_pos = (int)(balance_fraction * n2);
+  hipLaunchKernelGGL(k_sample_proposals, dim3(batch), dim3(256), 0, S(stream), proposals,
+                     num_proposals, max_p, gt_boxes, num_gt, max_gt, gt_labels_bg, label_dim, n2,
+                     max_pos, seed, stream0, stream_stride, img_h, img_w, boxes_abs, boxes_norm,
+                     num_out);
+  return check_launch("sample_proposals");
+}
+
+}  // extern "C"

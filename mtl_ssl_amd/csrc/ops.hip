@@ -1,0 +1,485 @@
+// HBM-bound tensor ops of the mtl-ssl hot path for gfx950: ROI crop(+max-pool) forward/backward,
+// legacy bilinear resize, max-pool, spatial mean, fused loss+gradient kernels, the clipped
+// momentum update, and small elementwise helpers. Channel-contiguous (NHWC) access: a
+// wavefront covers 64 x float4 = 1 KiB of consecutive channels per load.
+#include "common.h"
+
+namespace mtlssl {
+
+// ------------------------------------------------------------------------------ ROI crop + pool
+// tf.image.crop_and_resize sampling (TF 1.7 crop_and_resize_op.cc), fused with the VALID
+// k x k max-pool that the reference applies right after (faster_rcnn_meta_arch.py:1340-1348).
+struct CropGeom {
+  float y1, x1, hs, ws;   // in = y1*(H-1) + i*hs
+  int b;
+};
+__device__ __forceinline__ CropGeom crop_geom(const float* boxes, const int32_t* box_ind, int r,
+                                              int H, int W, int crop) {
+  float4 bx = *reinterpret_cast<const float4*>(boxes + (int64_t)r * 4);
+  CropGeom g;
+  g.b = box_ind[r];
+  if (crop > 1) {
+    g.hs = (bx.z - bx.x) * (float)(H - 1) / (float)(crop - 1);
+    g.ws = (bx.w - bx.y) * (float)(W - 1) / (float)(crop - 1);
+    g.y1 = bx.x * (float)(H - 1);
+    g.x1 = bx.y * (float)(W - 1);
+  } else {
+    g.hs = 0.f; g.ws = 0.f;
+    g.y1 = 0.5f * (bx.x + bx.z) * (float)(H - 1);
+    g.x1 = 0.5f * (bx.y + bx.w) * (float)(W - 1);
+  }
+  return g;
+}
+
+// grid: (PW*PH, R); block: C/4 threads (<=256), each thread owns 4 consecutive channels.
+__global__ void __launch_bounds__(256)
+    k_roi_crop_pool_fwd(const float* __restrict__ feat, int H, int W, int C,
+                        const float* __restrict__ boxes, const int32_t* __restrict__ box_ind,
+                        int crop, int pk, int ps, int PH, int PW, float* __restrict__ out,
+                        uint8_t* __restrict__ argmax) {
+  int r = blockIdx.y;
+  int py = blockIdx.x / PW, px = blockIdx.x % PW;
+  CropGeom g = crop_geom(boxes, box_ind, r, H, W, crop);
+  const float* fb = feat + (int64_t)g.b * H * W * C;
+  for (int c4 = threadIdx.x; c4 * 4 < C; c4 += blockDim.x) {
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uint32_t bi = 0;   // 4 x uint8 packed
+    for (int dy = 0; dy < pk; ++dy) {
+      int cy = py * ps + dy;
+      float in_y = g.y1 + (float)cy * g.hs;
+      bool vy = !(in_y < 0.f || in_y > (float)(H - 1));
+      int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
+      float yl = in_y - (float)ty;
+      for (int dx = 0; dx < pk; ++dx) {
+        int cx = px * ps + dx;
+        float in_x = g.x1 + (float)cx * g.ws;
+        bool vx = !(in_x < 0.f || in_x > (float)(W - 1));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vy && vx) {
+          int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+          float xl = in_x - (float)lx;
+          float4 tl = *reinterpret_cast<const float4*>(fb + ((int64_t)ty * W + lx) * C + c4 * 4);
+          float4 tr = *reinterpret_cast<const float4*>(fb + ((int64_t)ty * W + rx) * C + c4 * 4);
+          float4 bl = *reinterpret_cast<const float4*>(fb + ((int64_t)by * W + lx) * C + c4 * 4);
+          float4 br = *reinterpret_cast<const float4*>(fb + ((int64_t)by * W + rx) * C + c4 * 4);
+#define LERP(f)                                         \
+  {                                                     \
+    float top = tl.f + (tr.f - tl.f) * xl;              \
+    float bot = bl.f + (br.f - bl.f) * xl;              \
+    v.f = top + (bot - top) * yl;                       \
+  }
+          LERP(x) LERP(y) LERP(z) LERP(w)
+#undef LERP
+        }
+        uint32_t s = (uint32_t)(dy * pk + dx);
+        if (v.x > best.x) { best.x = v.x; bi = (bi & 0xffffff00u) | s; }
+        if (v.y > best.y) { best.y = v.y; bi = (bi & 0xffff00ffu) | (s << 8); }
+        if (v.z > best.z) { best.z = v.z; bi = (bi & 0xff00ffffu) | (s << 16); }
+        if (v.w > best.w) { best.w = v.w; bi = (bi & 0x00ffffffu) | (s << 24); }
+      }
+    }
+    int64_t o = (((int64_t)r * PH + py) * PW + px) * C + c4 * 4;
+    *reinterpret_cast<float4*>(out + o) = best;
+    if (argmax) *reinterpret_cast<uint32_t*>(argmax + o) = bi;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_roi_crop_pool_bwd(const float* __restrict__ dout, const uint8_t* __restrict__ argmax, int H,
+                        int W, int C, const float* __restrict__ boxes,
+                        const int32_t* __restrict__ box_ind, int crop, int pk, int ps, int PH,
+                        int PW, float* __restrict__ dfeat) {
+  int r = blockIdx.y;
+  int py = blockIdx.x / PW, px = blockIdx.x % PW;
+  CropGeom g = crop_geom(boxes, box_ind, r, H, W, crop);
+  float* fb = dfeat + (int64_t)g.b * H * W * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    int64_t o = (((int64_t)r * PH + py) * PW + px) * C + c;
+    float gr = dout[o];
+    int s = argmax ? argmax[o] : 0;
+    int dy = s / pk, dx = s % pk;
+    float in_y = g.y1 + (float)(py * ps + dy) * g.hs;
+    float in_x = g.x1 + (float)(px * ps + dx) * g.ws;
+    if (in_y < 0.f || in_y > (float)(H - 1) || in_x < 0.f || in_x > (float)(W - 1)) continue;
+    int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
+    int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+    float yl = in_y - (float)ty, xl = in_x - (float)lx;
+    float dtop = (1.f - yl) * gr, dbot = yl * gr;
+    unsafeAtomicAdd(fb + ((int64_t)ty * W + lx) * C + c, (1.f - xl) * dtop);
+    unsafeAtomicAdd(fb + ((int64_t)ty * W + rx) * C + c, xl * dtop);
+    unsafeAtomicAdd(fb + ((int64_t)by * W + lx) * C + c, (1.f - xl) * dbot);
+    unsafeAtomicAdd(fb + ((int64_t)by * W + rx) * C + c, xl * dbot);
+  }
+}
+
+// ------------------------------------------------------------------------------ bilinear resize
+// tf.image.resize_images(BILINEAR, align_corners=False), TF 1.7: src = dst * in/out.
+__global__ void k_resize_fwd(const float* x, float* y, int H, int W, int C, int OH, int OW,
+                             float sy, float sx, int64_t total) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = i % C;
+  int64_t t = i / C;
+  int ox = t % OW; t /= OW;
+  int oy = t % OH;
+  int n = t / OH;
+  float fy = (float)oy * sy, fx = (float)ox * sx;
+  int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+  int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  float yl = fy - (float)y0, xl = fx - (float)x0;
+  const float* xb = x + (int64_t)n * H * W * C;
+  float tl = xb[((int64_t)y0 * W + x0) * C + c], tr = xb[((int64_t)y0 * W + x1) * C + c];
+  float bl = xb[((int64_t)y1 * W + x0) * C + c], br = xb[((int64_t)y1 * W + x1) * C + c];
+  float top = tl + (tr - tl) * xl, bot = bl + (br - bl) * xl;
+  y[i] = top + (bot - top) * yl;
+}
+__global__ void k_resize_bwd(const float* dy, float* dx, int H, int W, int C, int OH, int OW,
+                             float sy, float sx, int64_t total) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = i % C;
+  int64_t t = i / C;
+  int ox = t % OW; t /= OW;
+  int oy = t % OH;
+  int n = t / OH;
+  float fy = (float)oy * sy, fx = (float)ox * sx;
+  int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+  int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  float yl = fy - (float)y0, xl = fx - (float)x0;
+  float g = dy[i];
+  float* xb = dx + (int64_t)n * H * W * C;
+  unsafeAtomicAdd(xb + ((int64_t)y0 * W + x0) * C + c, g * (1.f - yl) * (1.f - xl));
+  unsafeAtomicAdd(xb + ((int64_t)y0 * W + x1) * C + c, g * (1.f - yl) * xl);
+  unsafeAtomicAdd(xb + ((int64_t)y1 * W + x0) * C + c, g * yl * (1.f - xl));
+  unsafeAtomicAdd(xb + ((int64_t)y1 * W + x1) * C + c, g * yl * xl);
+}
+
+// ------------------------------------------------------------------------------ max-pool / mean
+__global__ void k_maxpool_fwd(const float* x, float* y, int H, int W, int C4, int k, int stride,
+                              int pt, int pl, int OH, int OW, int64_t total) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c4 = i % C4;
+  int64_t t = i / C4;
+  int ox = t % OW; t /= OW;
+  int oy = t % OH;
+  int n = t / OH;
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  for (int dy = 0; dy < k; ++dy) {
+    int iy = oy * stride - pt + dy;
+    if (iy < 0 || iy >= H) continue;
+    for (int dx = 0; dx < k; ++dx) {
+      int ix = ox * stride - pl + dx;
+      if (ix < 0 || ix >= W) continue;
+      float4 v = reinterpret_cast<const float4*>(x)[(((int64_t)n * H + iy) * W + ix) * C4 + c4];
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+  }
+  reinterpret_cast<float4*>(y)[i] = m;
+}
+// Gradient goes to the first maximum in window order (TF MaxPoolGrad semantics). Windows may
+// overlap (3x3/2), so accumulate with atomics into a zeroed dx.
+__global__ void k_maxpool_bwd(const float* x, const float* y, const float* dy, float* dx, int H,
+                              int W, int C, int k, int stride, int pt, int pl, int OH, int OW,
+                              int64_t total) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = i % C;
+  int64_t t = i / C;
+  int ox = t % OW; t /= OW;
+  int oy = t % OH;
+  int n = t / OH;
+  float m = y[i], g = dy[i];
+  for (int d = 0; d < k * k; ++d) {
+    int iy = oy * stride - pt + d / k, ix = ox * stride - pl + d % k;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    int64_t o = (((int64_t)n * H + iy) * W + ix) * C + c;
+    if (x[o] == m) {
+      if (k > stride) unsafeAtomicAdd(dx + o, g);
+      else dx[o] = g;
+      break;
+    }
+  }
+}
+__global__ void k_spatial_mean_fwd(const float* x, float* y, int HW, int C) {
+  int n = blockIdx.y;
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int p = 0; p < HW; ++p) s += x[((int64_t)n * HW + p) * C + c];
+  y[(int64_t)n * C + c] = s / (float)HW;
+}
+__global__ void k_spatial_mean_bwd(const float* dy, float* dx, int HW, int C, int64_t total) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = i % C;
+  int64_t n = i / ((int64_t)HW * C);
+  dx[i] = dy[n * C + c] / (float)HW;
+}
+
+// ------------------------------------------------------------------------------ losses
+__global__ void k_smooth_l1(const float* pred, const float* target, const float* row_scale,
+                            int rows, int cs, float sigma2, float* row_loss, float* dpred) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float w = row_scale ? row_scale[r] : 1.f;
+  float acc = 0.f;
+  float inv = 1.f / sigma2;
+  for (int j = 0; j < cs; ++j) {
+    float d = pred[(int64_t)r * cs + j] - target[(int64_t)r * cs + j];
+    float ad = fabsf(d);
+    bool quad = ad < inv;
+    acc += quad ? 0.5f * ad * ad * sigma2 : ad - 0.5f * inv;
+    if (dpred) dpred[(int64_t)r * cs + j] = w * (quad ? d * sigma2 : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+  }
+  if (row_loss) row_loss[r] = acc * w;
+}
+// One wavefront per row: lanes stride over the class columns.
+__global__ void __launch_bounds__(256)
+    k_softmax_ce(const float* logits, int ldl, const float* targets, int ldt, int col0, int C,
+                 const float* row_scale, int rows, float* row_loss, float* dlogits) {
+  int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float* x = logits + (int64_t)r * ldl + col0;
+  const float* t = targets + (int64_t)r * ldt + col0;
+  float w = row_scale ? row_scale[r] : 1.f;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+  m = wave_max(m);
+  float se = 0.f, st = 0.f, stx = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    float xc = x[c] - m, tc = t[c];
+    se += expf(xc);
+    st += tc;
+    stx += tc * xc;
+  }
+  se = wave_sum(se); st = wave_sum(st); stx = wave_sum(stx);
+  float lse = logf(se);
+  if (lane == 0 && row_loss) row_loss[r] = w * (st * lse - stx);   // -sum t*(x - m - lse)
+  if (dlogits) {
+    float* d = dlogits + (int64_t)r * ldl + col0;
+    for (int c = lane; c < C; c += 64) d[c] = w * (expf(x[c] - m) / se * st - t[c]);
+  }
+}
+__global__ void __launch_bounds__(1024) k_reduce_sum(const float* x, int n, float scale, float* out) {
+  __shared__ float s[1024];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += x[i];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = s[0] * scale;
+}
+
+// ------------------------------------------------------------------------------ optimizer
+// Per-variable sum of squares: grid (chunks_per_var, num_vars); partials folded with atomics
+// into norms_ws (zeroed first). Integer-free float atomics -> order-dependent in the last
+// bits only; the clip factor tolerates that (documented in DESIGN.md).
+constexpr int NORM_CHUNK = 1 << 16;
+__global__ void __launch_bounds__(256)
+    k_var_sumsq(const float* g, const int32_t* off, float gscale, float* norms) {
+  int v = blockIdx.y;
+  int64_t lo = off[v], hi = off[v + 1];
+  int64_t s = lo + (int64_t)blockIdx.x * NORM_CHUNK;
+  if (s >= hi) return;
+  int64_t e = s + NORM_CHUNK < hi ? s + NORM_CHUNK : hi;
+  float acc = 0.f;
+  for (int64_t i = s + threadIdx.x * 4; i < e; i += 256 * 4) {
+    float4 q = *reinterpret_cast<const float4*>(g + i);
+    q.x *= gscale; q.y *= gscale; q.z *= gscale; q.w *= gscale;
+    acc += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  }
+  acc = wave_sum(acc);
+  __shared__ float sw[4];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(norms + v, sw[0] + sw[1] + sw[2] + sw[3]);
+}
+__global__ void __launch_bounds__(256)
+    k_momentum_update(float* w, const float* g, float* acc, const int32_t* off, int num_vars,
+                      int64_t total4, float lr, float mom, float clip, float gscale,
+                      const float* norms) {
+  int64_t i4 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i4 >= total4) return;
+  int64_t i = i4 * 4;
+  int lo = 0, hi = num_vars;   // largest v with off[v] <= i
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if ((int64_t)off[mid] <= i) lo = mid; else hi = mid;
+  }
+  float f = gscale;
+  if (clip > 0.f) {
+    float nrm = sqrtf(norms[lo]);
+    if (nrm > clip) f *= clip / nrm;     // tf.clip_by_norm: g * clip / max(norm, clip)
+  }
+  float4 gv = *reinterpret_cast<const float4*>(g + i);
+  float4 av = *reinterpret_cast<float4*>(acc + i);
+  float4 wv = *reinterpret_cast<float4*>(w + i);
+  av.x = mom * av.x + gv.x * f; av.y = mom * av.y + gv.y * f;
+  av.z = mom * av.z + gv.z * f; av.w = mom * av.w + gv.w * f;
+  wv.x -= lr * av.x; wv.y -= lr * av.y; wv.z -= lr * av.z; wv.w -= lr * av.w;
+  *reinterpret_cast<float4*>(acc + i) = av;
+  *reinterpret_cast<float4*>(w + i) = wv;
+}
+
+// ------------------------------------------------------------------------------ elementwise
+__global__ void k_axpby(const float* x, float* y, int64_t n, float a, float b) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) y[i] = b == 0.f ? a * x[i] : a * x[i] + b * y[i];
+}
+__global__ void k_scale_channels(const float* w, const float* sc, float* out, int64_t total, int K) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < total) out[i] = w[i] * sc[i % K];
+}
+__global__ void k_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+
+}  // namespace mtlssl
+
+using namespace mtlssl;
+
+extern "C" {
+
+int mtlssl_roi_crop_pool_fwd(const float* feat, int B, int H, int W, int C, const float* boxes,
+                             const int32_t* box_ind, int R, int crop, int pk, int ps, float* out,
+                             uint8_t* argmax, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(C % 4 == 0, "roi_crop: C must be a multiple of 4");
+  MTLSSL_REQUIRE(pk >= 1 && ps >= 1 && crop >= pk && pk * pk <= 255, "roi_crop: bad pool geometry");
+  if (R == 0) return MTLSSL_OK;
+  int PH = (crop - pk) / ps + 1;
+  int threads = (int)align_up(C / 4 < 256 ? C / 4 : 256, 64);
+  hipLaunchKernelGGL(k_roi_crop_pool_fwd, dim3(PH * PH, R), dim3(threads), 0, S(stream), feat, H, W,
+                     C, boxes, box_ind, crop, pk, ps, PH, PH, out, argmax);
+  return check_launch("roi_crop_pool_fwd");
+}
+int mtlssl_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax, int B, int H, int W, int C,
+                             const float* boxes, const int32_t* box_ind, int R, int crop, int pk,
+                             int ps, float* dfeat, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(argmax != nullptr || pk == 1, "roi_crop_bwd: argmax required when pooling");
+  if (R == 0) return MTLSSL_OK;
+  int PH = (crop - pk) / ps + 1;
+  hipLaunchKernelGGL(k_roi_crop_pool_bwd, dim3(PH * PH, R), dim3(256), 0, S(stream), dout, argmax, H,
+                     W, C, boxes, box_ind, crop, pk, ps, PH, PH, dfeat);
+  return check_launch("roi_crop_pool_bwd");
+}
+
+int mtlssl_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
+                               mtlssl_stream_t stream) {
+  int64_t total = (int64_t)N * OH * OW * C;
+  if (!total) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_resize_fwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W, C,
+                     OH, OW, (float)H / (float)OH, (float)W / (float)OW, total);
+  return check_launch("resize_fwd");
+}
+int mtlssl_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH,
+                               int OW, mtlssl_stream_t stream) {
+  int64_t total = (int64_t)N * OH * OW * C;
+  if (!total) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_resize_bwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), dy, dx, H, W, C,
+                     OH, OW, (float)H / (float)OH, (float)W / (float)OW, total);
+  return check_launch("resize_bwd");
+}
+
+int mtlssl_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, int k, int stride,
+                       int pt, int pl, int OH, int OW, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(C % 4 == 0, "maxpool: C must be a multiple of 4");
+  int64_t total = (int64_t)N * OH * OW * (C / 4);
+  if (!total) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_maxpool_fwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W,
+                     C / 4, k, stride, pt, pl, OH, OW, total);
+  return check_launch("maxpool_fwd");
+}
+int mtlssl_maxpool_bwd(const float* x, const float* y, const float* dy, float* dx, int N, int H,
+                       int W, int C, int k, int stride, int pt, int pl, int OH, int OW,
+                       mtlssl_stream_t stream) {
+  int64_t total = (int64_t)N * OH * OW * C;
+  if (!total) return MTLSSL_OK;
+  if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, S(stream)) != hipSuccess)
+    return check_launch("maxpool_bwd memset");
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, dy, dx, H,
+                     W, C, k, stride, pt, pl, OH, OW, total);
+  return check_launch("maxpool_bwd");
+}
+int mtlssl_spatial_mean_fwd(const float* x, float* y, int N, int HW, int C, mtlssl_stream_t stream) {
+  if (!N) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_spatial_mean_fwd, dim3(cdiv(C, 256), N), dim3(256), 0, S(stream), x, y, HW, C);
+  return check_launch("spatial_mean_fwd");
+}
+int mtlssl_spatial_mean_bwd(const float* dy, float* dx, int N, int HW, int C, mtlssl_stream_t stream) {
+  int64_t total = (int64_t)N * HW * C;
+  if (!total) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_spatial_mean_bwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), dy, dx, HW,
+                     C, total);
+  return check_launch("spatial_mean_bwd");
+}
+
+int mtlssl_smooth_l1_fwd_bwd(const float* pred, const float* target, const float* row_scale,
+                             int rows, int code_size, float sigma, float* row_loss, float* dpred,
+                             mtlssl_stream_t stream) {
+  if (!rows) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_smooth_l1, dim3(cdiv(rows, 256)), dim3(256), 0, S(stream), pred, target,
+                     row_scale, rows, code_size, sigma * sigma, row_loss, dpred);
+  return check_launch("smooth_l1");
+}
+int mtlssl_softmax_ce_fwd_bwd(const float* logits, int ldl, const float* targets, int ldt, int col0,
+                              int C, const float* row_scale, int rows, float* row_loss,
+                              float* dlogits, mtlssl_stream_t stream) {
+  if (!rows) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_softmax_ce, dim3(cdiv(rows, 4)), dim3(256), 0, S(stream), logits, ldl,
+                     targets, ldt, col0, C, row_scale, rows, row_loss, dlogits);
+  return check_launch("softmax_ce");
+}
+int mtlssl_reduce_sum(const float* x, int n, float scale, float* out, mtlssl_stream_t stream) {
+  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, S(stream), x, n, scale, out);
+  return check_launch("reduce_sum");
+}
+
+int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
+                             const int32_t* var_offsets, int num_vars, int64_t total,
+                             int64_t max_var_size, float lr, float momentum, float clip_norm,
+                             float grad_scale, float* norms_ws, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(total % 4 == 0, "sgd: total must be a multiple of 4");
+  MTLSSL_REQUIRE(total < (1ll << 31), "sgd: flat parameter buffer must be < 2^31 floats");
+  if (!total) return MTLSSL_OK;
+  hipStream_t st = S(stream);
+  if (clip_norm > 0.f) {
+    MTLSSL_REQUIRE(norms_ws != nullptr, "sgd: norms workspace required when clipping");
+    if (hipMemsetAsync(norms_ws, 0, sizeof(float) * num_vars, st) != hipSuccess)
+      return check_launch("sgd memset");
+    // the largest variable decides the chunk count; empty chunks exit immediately
+    int chunks = (int)cdiv(max_var_size > 0 ? max_var_size : total, NORM_CHUNK);
+    hipLaunchKernelGGL(k_var_sumsq, dim3(chunks, num_vars), dim3(256), 0, st, grads, var_offsets,
+                       grad_scale, norms_ws);
+  }
+  hipLaunchKernelGGL(k_momentum_update, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads,
+                     accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
+                     norms_ws);
+  return check_launch("sgd_momentum_clip");
+}
+
+int mtlssl_axpby(const float* x, float* y, int64_t n, float a, float b, mtlssl_stream_t stream) {
+  if (!n) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_axpby, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), x, y, n, a, b);
+  return check_launch("axpby");
+}
+int mtlssl_scale_channels(const float* w, const float* scale, float* out, int64_t rows, int K,
+                          mtlssl_stream_t stream) {
+  int64_t total = rows * K;
+  if (!total) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_scale_channels, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), w, scale, out,
+                     total, K);
+  return check_launch("scale_channels");
+}
+int mtlssl_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlssl_stream_t stream) {
+  if (!n) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_tanh_bwd, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), y, dy, dx, n);
+  return check_launch("tanh_bwd");
+}
+
+}  // extern "C"

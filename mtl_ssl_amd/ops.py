@@ -1,0 +1,353 @@
+"""Host-side operator layer over the C ABI (libmtlssl_hip.so).
+
+torch is used only as the device allocator / stream provider: every function takes and
+returns torch CUDA tensors whose storage is handed to the HIP kernels as raw pointers.
+Names follow the reference operators they replace (see include/mtlssl_hip.h).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .lib import ConvDesc, lib, ptr
+
+EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_RELU6, EPI_MASK, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
+f32 = torch.float32
+i32 = torch.int32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=f32):
+    assert t.is_cuda and t.is_contiguous() and t.dtype == dtype, (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, key="default", device=None):
+    """Grow-only device scratch buffers, one per key (caller-owned workspaces of the C ABI)."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    k = (key, device.index)
+    buf = _ws_cache.get(k)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[k] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------- conv family
+def same_pad(in_size, k, stride, dilation=1):
+    """TF 'SAME': (pad_before, out_size)."""
+    k_eff = (k - 1) * dilation + 1
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + k_eff - in_size, 0)
+    return total // 2, out
+
+
+def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding="SAME"):
+    """padding: 'SAME' | 'VALID' | 'RESNET_SAME' (slim/nets/resnet_utils.py:77-122 conv2d_same)."""
+    N, H, W, C = x_shape
+    R, S, C2, K = w_shape
+    assert C == C2, (x_shape, w_shape)
+    if padding == "RESNET_SAME" and stride > 1:
+        k_eff = R + (R - 1) * (dilation - 1)
+        pt = pl = (k_eff - 1) // 2
+        OH = (H + k_eff - 1 - k_eff) // stride + 1
+        OW = (W + k_eff - 1 - k_eff) // stride + 1
+    elif padding in ("SAME", "RESNET_SAME"):
+        pt, OH = same_pad(H, R, stride, dilation)
+        pl, OW = same_pad(W, S, stride, dilation)
+    elif padding == "VALID":
+        pt = pl = 0
+        OH = (H - ((R - 1) * dilation + 1)) // stride + 1
+        OW = (W - ((S - 1) * dilation + 1)) // stride + 1
+    else:
+        raise ValueError(padding)
+    return ConvDesc(N, H, W, C, K, R, S, OH, OW, stride, dilation, pt, pl)
+
+
+def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None):
+    y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
+    lib().conv2d_fwd(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(residual),
+                     ptr(y), epilogue, _stream())
+    return y
+
+
+def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None):
+    dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=f32, device=dy.device)
+    lib().conv2d_dgrad(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref),
+                       ptr(dx), epilogue, _stream())
+    return dx
+
+
+def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0):
+    nbytes = lib().conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = workspace(nbytes, "wgrad", x.device)
+    lib().conv2d_wgrad(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(dy)), ptr(out_scale), ptr(dw),
+                       ptr(dbias), float(beta), ptr(ws), _stream())
+    return dw
+
+
+def maxpool_fwd(x, k, stride, padding="VALID"):
+    N, H, W, C = x.shape
+    if padding == "SAME":
+        pt, OH = same_pad(H, k, stride)
+        pl, OW = same_pad(W, k, stride)
+    else:
+        pt = pl = 0
+        OH, OW = (H - k) // stride + 1, (W - k) // stride + 1
+    y = torch.empty((N, OH, OW, C), dtype=f32, device=x.device)
+    lib().maxpool_fwd(ptr(_chk(x)), ptr(y), N, H, W, C, k, stride, pt, pl, OH, OW, _stream())
+    return y, (pt, pl)
+
+
+def maxpool_bwd(x, y, dy, k, stride, pads):
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    lib().maxpool_bwd(ptr(x), ptr(y), ptr(_chk(dy)), ptr(dx), N, H, W, C, k, stride, pads[0],
+                      pads[1], y.shape[1], y.shape[2], _stream())
+    return dx
+
+
+def spatial_mean_fwd(x):
+    N, H, W, C = x.shape
+    y = torch.empty((N, C), dtype=f32, device=x.device)
+    lib().spatial_mean_fwd(ptr(_chk(x)), ptr(y), N, H * W, C, _stream())
+    return y
+
+
+def spatial_mean_bwd(dy, shape):
+    N, H, W, C = shape
+    dx = torch.empty(shape, dtype=f32, device=dy.device)
+    lib().spatial_mean_bwd(ptr(_chk(dy)), ptr(dx), N, H * W, C, _stream())
+    return dx
+
+
+# ------------------------------------------------------------------------------- detection family
+def anchors_generate(grid_h, grid_w, scales, aspect_ratios, base=(256.0, 256.0),
+                     stride=(16.0, 16.0), offset=(0.0, 0.0), device="cuda"):
+    sc = (ctypes.c_float * len(scales))(*scales)
+    ar = (ctypes.c_float * len(aspect_ratios))(*aspect_ratios)
+    n = grid_h * grid_w * len(scales) * len(aspect_ratios)
+    out = torch.empty((n, 4), dtype=f32, device=device)
+    lib().anchors_generate(ptr(out), grid_h, grid_w, ctypes.cast(sc, ctypes.c_void_p), len(scales),
+                           ctypes.cast(ar, ctypes.c_void_p), len(aspect_ratios), base[0], base[1],
+                           stride[0], stride[1], offset[0], offset[1], _stream())
+    return out
+
+
+def prune_outside_window(boxes, window):
+    n = boxes.shape[0]
+    keep = torch.empty((n,), dtype=i32, device=boxes.device)
+    cnt = torch.zeros((1,), dtype=i32, device=boxes.device)
+    lib().boxes_prune_outside_window(ptr(_chk(boxes)), n, float(window[0]), float(window[1]),
+                                     float(window[2]), float(window[3]), ptr(keep), ptr(cnt),
+                                     _stream())
+    return keep[: int(cnt.item())]       # one-time host sync (anchors are static per input size)
+
+
+def gather_rows(src, idx):
+    B, n_src, L = src.shape
+    out = torch.empty((B, idx.numel(), L), dtype=f32, device=src.device)
+    lib().gather_rows(ptr(_chk(src)), ptr(_chk(idx, i32)), ptr(out), B, n_src, idx.numel(), L,
+                      _stream())
+    return out
+
+
+def scatter_rows(src, idx, n_dst):
+    B, n_idx, L = src.shape
+    out = torch.zeros((B, n_dst, L), dtype=f32, device=src.device)
+    lib().scatter_rows(ptr(_chk(src)), ptr(_chk(idx, i32)), ptr(out), B, n_dst, n_idx, L, _stream())
+    return out
+
+
+def boxes_decode(codes, anchors, scale_factors=(10.0, 10.0, 5.0, 5.0)):
+    B, n, _ = codes.shape
+    out = torch.empty_like(codes)
+    lib().boxes_decode(ptr(_chk(codes)), ptr(_chk(anchors)), ptr(out), B, n,
+                       1 if anchors.dim() == 3 else 0, *[float(s) for s in scale_factors], _stream())
+    return out
+
+
+def boxes_encode(boxes, anchors, scale_factors=(10.0, 10.0, 5.0, 5.0)):
+    out = torch.empty_like(boxes)
+    lib().boxes_encode(ptr(_chk(boxes)), ptr(_chk(anchors)), ptr(out), boxes.shape[0],
+                       *[float(s) for s in scale_factors], _stream())
+    return out
+
+
+def rpn_proposals(enc, logits, anchors, img_h, img_w, score_thresh, iou_thresh, max_proposals):
+    B, n, _ = enc.shape
+    dev = enc.device
+    ws = workspace(lib().rpn_proposals_workspace_bytes(B, n), "nms", dev)
+    boxes = torch.empty((B, max_proposals, 4), dtype=f32, device=dev)
+    scores = torch.empty((B, max_proposals), dtype=f32, device=dev)
+    num = torch.empty((B,), dtype=i32, device=dev)
+    lib().rpn_proposals(ptr(_chk(enc)), ptr(_chk(logits)), ptr(_chk(anchors)), B, n, float(img_h),
+                        float(img_w), float(score_thresh), float(iou_thresh), max_proposals,
+                        ptr(boxes), ptr(scores), ptr(num), ptr(ws), _stream())
+    return boxes, scores, num
+
+
+def nms(boxes, scores, iou_thresh, max_out):
+    n = boxes.shape[0]
+    dev = boxes.device
+    ws = workspace(lib().nms_workspace_bytes(max(n, 1)), "nms", dev)
+    sel = torch.empty((max_out,), dtype=i32, device=dev)
+    num = torch.empty((1,), dtype=i32, device=dev)
+    lib().nms(ptr(_chk(boxes)), ptr(_chk(scores)), n, float(iou_thresh), max_out, ptr(sel), ptr(num),
+              ptr(ws), _stream())
+    return sel, num
+
+
+def assign_targets(anchors, gt_boxes, num_gt, gt_labels, unmatched_cls_target, matched_thresh,
+                   unmatched_thresh, force_match, gt_extra=None, want=("match", "cls_targets",
+                   "cls_weights", "reg_targets", "reg_weights")):
+    """anchors [n,4] or [B,n,4]; gt_boxes [B,G,4]; num_gt int32[B]; gt_labels [B,G,d] or None."""
+    dev = gt_boxes.device
+    B, G, _ = gt_boxes.shape
+    batched = anchors.dim() == 3
+    n = anchors.shape[-2]
+    d = 1 if gt_labels is None else gt_labels.shape[-1]
+    e = 0 if gt_extra is None else gt_extra.shape[-1]
+    out = {"match": torch.empty((B, n), dtype=i32, device=dev)}
+    if "cls_targets" in want:
+        out["cls_targets"] = torch.empty((B, n, d), dtype=f32, device=dev)
+    if "cls_weights" in want:
+        out["cls_weights"] = torch.empty((B, n), dtype=f32, device=dev)
+    if "reg_targets" in want:
+        out["reg_targets"] = torch.empty((B, n, 4), dtype=f32, device=dev)
+    if "reg_weights" in want:
+        out["reg_weights"] = torch.empty((B, n), dtype=f32, device=dev)
+    if gt_extra is not None:
+        out["extra_targets"] = torch.empty((B, n, e), dtype=f32, device=dev)
+    ws = workspace(lib().assign_targets_workspace_bytes(B, n, G), "assign", dev)
+    lib().assign_targets(ptr(_chk(anchors)), int(batched), B, n, ptr(_chk(gt_boxes)),
+                         ptr(_chk(num_gt, i32)), G, ptr(gt_labels), d, ptr(gt_extra), e,
+                         ptr(unmatched_cls_target), float(matched_thresh), float(unmatched_thresh),
+                         int(force_match), ptr(out["match"]), ptr(out.get("cls_targets")),
+                         ptr(out.get("cls_weights")), ptr(out.get("reg_targets")),
+                         ptr(out.get("reg_weights")), ptr(out.get("extra_targets")), ptr(ws),
+                         _stream())
+    return out
+
+
+def balanced_sample(indicator, labels, batch_size, positive_fraction, seed, stream_id0,
+                    stream_stride):
+    B, n = indicator.shape
+    out = torch.empty_like(indicator)
+    lib().balanced_sample(ptr(_chk(indicator)), ptr(_chk(labels)), B, n, batch_size,
+                          float(positive_fraction), seed, stream_id0, stream_stride, ptr(out),
+                          _stream())
+    return out
+
+
+def sample_proposals(proposals, num_proposals, gt_boxes, num_gt, gt_labels_bg, n2,
+                     balance_fraction, seed, stream_id0, stream_stride, img_h, img_w):
+    B, max_p, _ = proposals.shape
+    dev = proposals.device
+    G, d = gt_labels_bg.shape[1], gt_labels_bg.shape[2]
+    ob = torch.empty((B, n2, 4), dtype=f32, device=dev)
+    on = torch.empty((B, n2, 4), dtype=f32, device=dev)
+    num = torch.empty((B,), dtype=i32, device=dev)
+    lib().sample_proposals(ptr(_chk(proposals)), ptr(_chk(num_proposals, i32)), B, max_p,
+                           ptr(_chk(gt_boxes)), ptr(_chk(num_gt, i32)), G, ptr(_chk(gt_labels_bg)),
+                           d, n2, float(balance_fraction), seed, stream_id0, stream_stride,
+                           float(img_h), float(img_w), ptr(ob), ptr(on), ptr(num), _stream())
+    return ob, on, num
+
+
+def roi_crop_pool_fwd(feat, boxes, box_ind, crop, pool_k=1, pool_stride=1, want_argmax=True):
+    B, H, W, C = feat.shape
+    R = boxes.shape[0]
+    P = (crop - pool_k) // pool_stride + 1
+    out = torch.empty((R, P, P, C), dtype=f32, device=feat.device)
+    am = (torch.empty((R, P, P, C), dtype=torch.uint8, device=feat.device)
+          if (want_argmax and pool_k > 1) else None)
+    lib().roi_crop_pool_fwd(ptr(_chk(feat)), B, H, W, C, ptr(_chk(boxes)), ptr(_chk(box_ind, i32)),
+                            R, crop, pool_k, pool_stride, ptr(out), ptr(am), _stream())
+    return out, am
+
+
+def roi_crop_pool_bwd(dout, argmax, feat_shape, boxes, box_ind, crop, pool_k, pool_stride,
+                      dfeat=None):
+    B, H, W, C = feat_shape
+    if dfeat is None:
+        dfeat = torch.zeros(feat_shape, dtype=f32, device=dout.device)
+    lib().roi_crop_pool_bwd(ptr(_chk(dout)), ptr(argmax), B, H, W, C, ptr(boxes), ptr(box_ind),
+                            boxes.shape[0], crop, pool_k, pool_stride, ptr(dfeat), _stream())
+    return dfeat
+
+
+def resize_bilinear_fwd(x, OH, OW):
+    N, H, W, C = x.shape
+    y = torch.empty((N, OH, OW, C), dtype=f32, device=x.device)
+    lib().resize_bilinear_fwd(ptr(_chk(x)), ptr(y), N, H, W, C, OH, OW, _stream())
+    return y
+
+
+def resize_bilinear_bwd(dy, in_shape):
+    N, H, W, C = in_shape
+    dx = torch.zeros(in_shape, dtype=f32, device=dy.device)
+    lib().resize_bilinear_bwd(ptr(_chk(dy)), ptr(dx), N, H, W, C, dy.shape[1], dy.shape[2], _stream())
+    return dx
+
+
+# ------------------------------------------------------------------------------- losses / optimizer
+def smooth_l1(pred, target, row_scale, sigma, want_grad=True):
+    rows, cs = pred.numel() // pred.shape[-1], pred.shape[-1]
+    rl = torch.empty((rows,), dtype=f32, device=pred.device)
+    dp = torch.empty_like(pred) if want_grad else None
+    lib().smooth_l1_fwd_bwd(ptr(_chk(pred)), ptr(_chk(target)), ptr(row_scale), rows, cs,
+                            float(sigma), ptr(rl), ptr(dp), _stream())
+    return rl, dp
+
+
+def softmax_ce(logits, targets, row_scale=None, col0=0, C=None, want_grad=True, dlogits=None):
+    ldl, ldt = logits.shape[-1], targets.shape[-1]
+    rows = logits.numel() // ldl
+    C = C if C is not None else ldl - col0
+    rl = torch.empty((rows,), dtype=f32, device=logits.device)
+    if want_grad and dlogits is None:
+        dlogits = torch.zeros_like(logits) if (col0 or C != ldl) else torch.empty_like(logits)
+    lib().softmax_ce_fwd_bwd(ptr(_chk(logits)), ldl, ptr(_chk(targets)), ldt, col0, C, ptr(row_scale),
+                             rows, ptr(rl), ptr(dlogits), _stream())
+    return rl, dlogits
+
+
+def reduce_sum(x, scale=1.0, out=None):
+    out = out if out is not None else torch.empty((1,), dtype=f32, device=x.device)
+    lib().reduce_sum(ptr(_chk(x)), x.numel(), float(scale), ptr(out), _stream())
+    return out
+
+
+def sgd_momentum_clip(weights, grads, accum, var_offsets, max_var_size, lr, momentum, clip_norm,
+                      grad_scale=1.0):
+    nv = var_offsets.numel() - 1
+    norms = workspace(4 * max(nv, 1), "norms", weights.device)
+    lib().sgd_momentum_clip(ptr(_chk(weights)), ptr(_chk(grads)), ptr(_chk(accum)),
+                            ptr(_chk(var_offsets, i32)), nv, weights.numel(), int(max_var_size),
+                            float(lr), float(momentum), float(clip_norm), float(grad_scale),
+                            ptr(norms), _stream())
+
+
+def axpby(x, y, a, b):
+    lib().axpby(ptr(_chk(x)), ptr(_chk(y)), x.numel(), float(a), float(b), _stream())
+    return y
+
+
+def scale_channels(w, scale, out=None):
+    out = out if out is not None else torch.empty_like(w)
+    K = w.shape[-1]
+    lib().scale_channels(ptr(_chk(w)), ptr(_chk(scale)), ptr(out), w.numel() // K, K, _stream())
+    return out
+
+
+def tanh_bwd(y, dy):
+    dx = torch.empty_like(dy)
+    lib().tanh_bwd(ptr(_chk(y)), ptr(_chk(dy)), ptr(dx), y.numel(), _stream())
+    return dx

@@ -1,0 +1,252 @@
+"""GPU parity: convolution family (fp32 MFMA implicit GEMM), ROI crop/pool, resize, pooling,
+losses and the optimizer, each against the torch-CPU fp32 oracle (autograd for backward).
+Tolerance 1e-3 relative fp32 (BASELINE.json north_star); in practice ~1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_torch as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import ops
+    assert torch.cuda.is_available()
+    return ops
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+CONV_CASES = [
+    # N, H, W, C, K, R, stride, dil, padding                      (what it stands for)
+    (2, 19, 23, 64, 64, 1, 1, 1, "SAME"),        # bottleneck 1x1, 64x64 tile, ragged M
+    (2, 19, 23, 64, 256, 1, 1, 1, "SAME"),       # 1x1 expand
+    (1, 38, 64, 256, 256, 3, 1, 1, "SAME"),      # block3 3x3 at full feature-map size
+    (2, 14, 14, 128, 128, 3, 2, 1, "RESNET_SAME"),  # strided 3x3 (conv2d_same), even input
+    (2, 15, 17, 128, 128, 3, 2, 1, "RESNET_SAME"),  # strided 3x3, odd input
+    (2, 12, 12, 64, 128, 3, 1, 2, "SAME"),       # atrous rate 2
+    (64, 7, 7, 1024, 512, 1, 1, 1, "SAME"),      # block4 on ROI crops: 128x128 tile
+    (32, 7, 7, 512, 512, 3, 1, 1, "SAME"),       # block4 3x3
+    (2, 9, 9, 512, 48, 1, 1, 1, "SAME"),         # RPN box head: direct path (K%64 != 0)
+    (2, 33, 41, 3, 64, 7, 2, 1, "RESNET_SAME"),  # stem 7x7/2: direct path (C = 3)
+    (100, 1, 1, 2048, 91, 1, 1, 1, "VALID"),     # FC head as 1x1 conv
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    N, H, W, C, K, R, stride, dil, padding = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(N, H, W, C, generator=g)
+    w = torch.randn(R, R, C, K, generator=g) / np.sqrt(R * R * C)
+    bias = torch.randn(K, generator=g)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    if padding == "RESNET_SAME":
+        yr = T.conv2d_same(xr, wr, stride, dil)
+    else:
+        yr = T.conv2d(xr, wr, stride, dil, padding)
+    res = torch.randn(yr.shape, generator=g)
+    ref = torch.relu(yr + bias + res)
+    d = ops.conv_desc(x.shape, w.shape, stride, dil, padding)
+    assert (d.N, d.OH, d.OW, d.K) == tuple(yr.shape)
+    xd, wd = x.cuda(), w.cuda()
+    y = ops.conv2d_fwd(d, xd, wd, bias.cuda(), res.cuda(), ops.EPI_BIAS | ops.EPI_RESIDUAL | ops.EPI_RELU)
+    assert relerr(y, ref) < 1e-4
+    y_plain = ops.conv2d_fwd(d, xd, wd)
+    assert relerr(y_plain, yr) < 1e-4
+    # backward of the raw conv
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    gyd = gy.cuda()
+    dx = ops.conv2d_dgrad(d, gyd, wd)
+    assert relerr(dx, xr.grad) < 1e-4
+    # dgrad epilogue: + residual, * relu mask, accumulate
+    mref = torch.randn(x.shape, generator=g); addend = torch.randn(x.shape, generator=g)
+    prev = torch.randn(x.shape, generator=g)
+    dx2 = prev.cuda().clone()
+    ops.conv2d_dgrad(d, gyd, wd, addend.cuda(), mref.cuda(),
+                     ops.EPI_RESIDUAL | ops.EPI_MASK | ops.EPI_ACCUM, out=dx2)
+    ref2 = (xr.grad + addend + prev) * (mref > 0)
+    assert relerr(dx2, ref2) < 1e-4
+    # wgrad (+ per-channel scale, dbias, accumulate)
+    scale = torch.rand(K, generator=g) + 0.5
+    dw = torch.ones(w.shape).cuda()
+    db = torch.zeros(K).cuda()
+    ops.conv2d_wgrad(d, xd, gyd, dw, out_scale=scale.cuda(), dbias=db, beta=0.0)
+    assert relerr(dw, wr.grad * scale) < 1e-4
+    assert relerr(db, gy.sum((0, 1, 2))) < 1e-4
+    ops.conv2d_wgrad(d, xd, gyd, dw, out_scale=scale.cuda(), beta=1.0)
+    assert relerr(dw, 2 * wr.grad * scale) < 1e-4
+
+
+def test_conv_same_padding_matches_reference_known_answer(ops):
+    """Known answers of slim/nets/resnet_v1_test.py:72-111 (testConv2DSameEven): x[i,j] = i+j on
+    4x4, w[i,j] = i+j on 3x3; SAME stride 1, conv2d_same stride 2 (== subsample of the former)
+    and plain SAME stride 2 (differs on even inputs)."""
+    n = 4
+    x = torch.tensor([[float(i + j) for j in range(n)] for i in range(n)]).reshape(1, n, n, 1)
+    w = torch.tensor([[float(i + j) for j in range(3)] for i in range(3)]).reshape(3, 3, 1, 1)
+    y1_expected = torch.tensor([[14, 28, 43, 26], [28, 48, 66, 37], [43, 66, 84, 46],
+                                [26, 37, 46, 22]], dtype=torch.float32).reshape(1, n, n, 1)
+    y2_expected = torch.tensor([[14, 43], [43, 84]], dtype=torch.float32).reshape(1, 2, 2, 1)
+    y4_expected = torch.tensor([[48, 37], [37, 22]], dtype=torch.float32).reshape(1, 2, 2, 1)
+    d1 = ops.conv_desc(x.shape, w.shape, 1, 1, "SAME")
+    np.testing.assert_allclose(ops.conv2d_fwd(d1, x.cuda(), w.cuda()).cpu(), y1_expected)
+    d3 = ops.conv_desc(x.shape, w.shape, 2, 1, "RESNET_SAME")      # conv2d_same == subsample(SAME s1)
+    np.testing.assert_allclose(ops.conv2d_fwd(d3, x.cuda(), w.cuda()).cpu(), y2_expected)
+    d4 = ops.conv_desc(x.shape, w.shape, 2, 1, "SAME")             # plain SAME stride 2 differs
+    np.testing.assert_allclose(ops.conv2d_fwd(d4, x.cuda(), w.cuda()).cpu(), y4_expected)
+    # oracle agrees with the same known answers
+    np.testing.assert_allclose(T.conv2d_same(x, w, 2), y2_expected)
+    np.testing.assert_allclose(T.conv2d(x, w, 2, 1, "SAME"), y4_expected)
+
+
+def test_conv_linearity_full_size(ops):
+    """Size-independent property at config[1]'s dominant shape (block4 1x1 on 512 ROIs):
+    conv(a*x1 + x2) == a*conv(x1) + conv(x2)."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x1 = torch.randn(512, 7, 7, 1024, device="cuda", generator=g)
+    x2 = torch.randn(512, 7, 7, 1024, device="cuda", generator=g)
+    w = torch.randn(1, 1, 1024, 512, device="cuda", generator=g) / 32
+    d = ops.conv_desc(x1.shape, w.shape)
+    lhs = ops.conv2d_fwd(d, 0.5 * x1 + x2, w)
+    rhs = 0.5 * ops.conv2d_fwd(d, x1, w) + ops.conv2d_fwd(d, x2, w)
+    assert relerr(lhs, rhs) < 1e-5
+    # spot-check 64 rows against fp64 on the host
+    rows = torch.arange(0, 512 * 49, 392)
+    xa = x1.reshape(-1, 1024)[rows].cpu().double()
+    ref = xa @ w.reshape(1024, 512).cpu().double()
+    got = ops.conv2d_fwd(d, x1, w).reshape(-1, 512)[rows].cpu().double()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("crop,pk,ps", [(14, 2, 2), (7, 1, 1), (1, 1, 1)])
+def test_roi_crop_pool(ops, crop, pk, ps):
+    g = torch.Generator().manual_seed(crop)
+    feat = torch.randn(2, 38, 64, 128, generator=g)
+    R = 70
+    yx = torch.rand(R, 2, generator=g) * 0.9 - 0.05        # some boxes poke outside -> extrapolation
+    hw = torch.rand(R, 2, generator=g) * 0.6 + 0.02
+    boxes = torch.cat([yx, yx + hw], 1)
+    boxes[0] = torch.tensor([0.0, 0.0, 1.0, 1.0]); boxes[1] = torch.tensor([0.3, 0.3, 0.3, 0.3])
+    bi = (torch.arange(R) % 2).int()
+    fr = feat.clone().requires_grad_()
+    ref = T.crop_and_resize(fr, boxes, bi, crop)
+    if pk > 1:
+        ref = T.max_pool(ref, pk, ps, "VALID")
+    out, am = ops.roi_crop_pool_fwd(feat.cuda(), boxes.cuda(), bi.cuda(), crop, pk, ps)
+    assert relerr(out, ref) < 1e-5
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    df = ops.roi_crop_pool_bwd(gy.cuda(), am, feat.shape, boxes.cuda(), bi.cuda(), crop, pk, ps)
+    assert relerr(df, fr.grad) < 1e-4
+
+
+def test_resize_bilinear_legacy(ops):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 38, 64, 2, generator=g)
+    xr = x.clone().requires_grad_()
+    ref = T.resize_bilinear_legacy(xr, 64, 64)
+    y = ops.resize_bilinear_fwd(x.cuda(), 64, 64)
+    assert relerr(y, ref) < 1e-5
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    assert relerr(ops.resize_bilinear_bwd(gy.cuda(), x.shape), xr.grad) < 1e-5
+    # identity when sizes match, and an exact 2x case: out[2i] = in[i]
+    x2 = torch.arange(8.0).reshape(1, 2, 4, 1)
+    y2 = ops.resize_bilinear_fwd(x2.cuda(), 4, 8).cpu()
+    np.testing.assert_allclose(y2[0, ::2, ::2, 0], x2[0, :, :, 0])
+
+
+@pytest.mark.parametrize("k,s,pad,shape", [(3, 2, "SAME", (2, 30, 52, 64)), (1, 2, "SAME", (2, 15, 15, 128)),
+                                           (2, 2, "VALID", (8, 14, 14, 64))])
+def test_maxpool(ops, k, s, pad, shape):
+    g = torch.Generator().manual_seed(k)
+    x = torch.randn(shape, generator=g)
+    xr = x.clone().requires_grad_()
+    ref = T.max_pool(xr, k, s, pad)
+    y, pads = ops.maxpool_fwd(x.cuda(), k, s, pad)
+    np.testing.assert_array_equal(y.cpu().numpy(), ref.detach().numpy())
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    dx = ops.maxpool_bwd(x.cuda(), y, gy.cuda(), k, s, pads)
+    assert relerr(dx, xr.grad) < 1e-6
+
+
+def test_spatial_mean(ops):
+    x = torch.randn(33, 7, 7, 2048)
+    y = ops.spatial_mean_fwd(x.cuda())
+    assert relerr(y, x.mean((1, 2))) < 1e-5
+    gy = torch.randn(33, 2048)
+    dx = ops.spatial_mean_bwd(gy.cuda(), x.shape)
+    assert relerr(dx, (gy / 49)[:, None, None, :].expand(x.shape)) < 1e-6
+
+
+def test_losses_golden_and_grad(ops, golden_dir):
+    import json, os
+    vec = json.load(open(os.path.join(golden_dir, "reference_vectors.json")))
+    v = vec["smooth_l1"]
+    p = torch.tensor(v["pred"]).reshape(-1, 4)
+    w = torch.tensor(v["weights"], dtype=torch.float32).reshape(-1)
+    rl, _ = ops.smooth_l1(p.cuda(), torch.zeros_like(p).cuda(), w.cuda(), 1.0)
+    assert abs(float(ops.reduce_sum(rl).item()) - v["expected_sum"]) < 1e-5
+    v = vec["softmax_ce"]
+    lg = torch.tensor(v["pred"], dtype=torch.float32).reshape(-1, 3)
+    tg = torch.tensor(v["target"], dtype=torch.float32).reshape(-1, 3)
+    w = torch.tensor(v["weights"], dtype=torch.float32).reshape(-1)
+    rl, _ = ops.softmax_ce(lg.cuda(), tg.cuda(), w.cuda())
+    np.testing.assert_allclose(rl.cpu().numpy().reshape(2, 4), v["expected_anchorwise"], atol=1e-6)
+    # gradients vs autograd, incl. sigma=3, soft targets and a column window (closeness [:,1:])
+    g = torch.Generator().manual_seed(0)
+    pr = torch.randn(500, 4, generator=g).requires_grad_()
+    tt = torch.randn(500, 4, generator=g) * 0.3
+    ws = torch.rand(500, generator=g)
+    ref = T.smooth_l1(pr[None], tt[None], ws[None], sigma=3.0).sum()
+    ref.backward()
+    rl, dp = ops.smooth_l1(pr.detach().cuda(), tt.cuda(), ws.cuda(), 3.0)
+    assert abs(float(ops.reduce_sum(rl).item()) - float(ref)) / float(ref) < 1e-5
+    assert relerr(dp, pr.grad) < 1e-5
+    lg = (torch.randn(300, 91, generator=g) * 3).requires_grad_()
+    tg = torch.rand(300, 91, generator=g) * (torch.rand(300, 91, generator=g) > 0.9)
+    ref = T.softmax_ce(lg[:, 1:], tg[:, 1:], ws[:300]).sum()
+    ref.backward()
+    rl, dl = ops.softmax_ce(lg.detach().cuda(), tg.cuda(), ws[:300].cuda(), col0=1)
+    assert abs(float(ops.reduce_sum(rl).item()) - float(ref)) / abs(float(ref)) < 1e-5
+    assert relerr(dl, lg.grad) < 1e-5
+
+
+def test_sgd_momentum_clip(ops):
+    g = torch.Generator().manual_seed(4)
+    sizes = [64, 4096, 70000, 12, 300000]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    total = int(offs[-1])
+    w = torch.randn(total, generator=g); gr = torch.randn(total, generator=g) * 0.05
+    gr[offs[2]:offs[3]] *= 30                                  # this variable gets clipped
+    acc = torch.randn(total, generator=g) * 0.01
+    wd, ad = w.cuda().clone(), acc.cuda().clone()
+    ops.sgd_momentum_clip(wd, gr.cuda(), ad, torch.from_numpy(offs).cuda(), max(sizes), 0.01, 0.9, 10.0)
+    w_ref, a_ref = w.clone(), acc.clone()
+    for i in range(len(sizes)):
+        s = slice(int(offs[i]), int(offs[i + 1]))
+        gv = gr[s]
+        nrm = gv.norm()
+        gv = gv * (10.0 / max(float(nrm), 10.0))
+        a_ref[s] = 0.9 * acc[s] + gv
+        w_ref[s] = w[s] - 0.01 * a_ref[s]
+    assert relerr(ad, a_ref) < 1e-5 and relerr(wd, w_ref) < 1e-6
+
+
+def test_scale_axpby_tanh(ops):
+    w = torch.randn(3, 3, 8, 16); sc = torch.rand(16)
+    assert relerr(ops.scale_channels(w.cuda(), sc.cuda()), w * sc) < 1e-6
+    x, y = torch.randn(1000), torch.randn(1000)
+    assert relerr(ops.axpby(x.cuda(), y.cuda().clone(), 2.0, -0.5), 2 * x - 0.5 * y) < 1e-6
+    t = torch.tanh(x); gy = torch.randn(1000)
+    assert relerr(ops.tanh_bwd(t.cuda(), gy.cuda()), gy * (1 - t * t)) < 1e-6
