@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): training images/sec of Faster R-CNN ResNet-101 + the three
+auxiliary heads + refine on synthetic 1024x600 COCO-shaped batches, per-GPU batch 2 (config[1];
+config[3] = the same step on 8 ranks, weak scaling).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0. `value` = global_batch * K / max-over-ranks time of K steps
+(slim/learning.py:489-518: instances/sec = batch / step wall-time). Inputs are resident in HBM
+before the timed region. `roofline` is the dominant kernel (fp32-MFMA implicit-GEMM conv forward,
+128x128 tile) timed with HIP events on the launch stream inside the timed region; `cpu_baseline`
+is the CPU oracle of the identical step timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+# SURVEY.md §8d / BASELINE.md §4: algorithmic FLOPs per 600x1024 image, ResNet-101, 3 aux heads
+# + refine, forward + backward (dgrad+wgrad of the trainable convs).
+FLOP_PER_IMAGE = 4.93e12
+
+
+def hyper_params_for_oracle(cfg):
+    fr, mtl = cfg.model.faster_rcnn, cfg.model.mtl
+    g = fr.first_stage_anchor_generator.grid_anchor_generator
+    return dict(
+        arch={"faster_rcnn_resnet50": "resnet_v1_50", "faster_rcnn_resnet101": "resnet_v1_101",
+              "faster_rcnn_resnet152": "resnet_v1_152"}[fr.feature_extractor.type],
+        num_classes=int(fr.num_classes), scales=list(g.scales), aspect_ratios=list(g.aspect_ratios),
+        nms_score_threshold=fr.first_stage_nms_score_threshold,
+        nms_iou_threshold=fr.first_stage_nms_iou_threshold, max_proposals=int(fr.first_stage_max_proposals),
+        first_stage_minibatch_size=int(fr.first_stage_minibatch_size),
+        first_stage_positive_balance_fraction=fr.first_stage_positive_balance_fraction,
+        first_stage_localization_loss_weight=fr.first_stage_localization_loss_weight,
+        first_stage_objectness_loss_weight=fr.first_stage_objectness_loss_weight,
+        initial_crop_size=int(fr.initial_crop_size), maxpool_kernel_size=int(fr.maxpool_kernel_size),
+        maxpool_stride=int(fr.maxpool_stride), second_stage_batch_size=int(fr.second_stage_batch_size),
+        second_stage_balance_fraction=fr.second_stage_balance_fraction,
+        second_stage_localization_loss_weight=fr.second_stage_localization_loss_weight,
+        second_stage_classification_loss_weight=fr.second_stage_classification_loss_weight,
+        mtl=dict(refine=bool(mtl.refine), window=bool(mtl.window), closeness=bool(mtl.closeness),
+                 edgemask=bool(mtl.edgemask),
+                 refined_classification_loss_weight=mtl.refined_classification_loss_weight,
+                 window_class_loss_weight=mtl.window_class_loss_weight,
+                 closeness_loss_weight=mtl.closeness_loss_weight,
+                 edgemask_loss_weight=mtl.edgemask_loss_weight, refine_residue=bool(mtl.refine_residue),
+                 stop_gradient_for_aux_tasks=bool(mtl.stop_gradient_for_aux_tasks),
+                 global_closeness=bool(mtl.global_closeness)))
+
+
+def cpu_baseline(cfg, model, H, W, seed):
+    """The CPU oracle (torch-CPU fp32 + numpy, oracle/model.py) of the identical training step —
+    forward + losses + backward — timed on this host. Bounded sample: ONE step on ONE image
+    (the reference's own TF-CPU path cannot run here: no TensorFlow)."""
+    import torch
+    from mtl_ssl_amd import synthetic
+    from oracle.model import Oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    K = int(cfg.model.faster_rcnn.num_classes)
+    batch = synthetic.make_batch(1, H, W, K, seed=seed, device="cpu")
+    batch["images"] = batch["images"].numpy()
+    ora = Oracle(hyper_params_for_oracle(cfg), model.ps.state_dict())
+    t0 = time.time()
+    losses, _, _ = ora.step(batch, seed=model.seed, step=0)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 training step (fwd+loss+bwd, no optimizer) on 1 synthetic 600x1024 image, "
+                      "torch-CPU fp32 oracle, %.1f s" % dt,
+            "total_loss": float(sum(losses.values()))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "frcnn_resnet101_coco_mtl.config"))
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    else:
+        torch.cuda.set_device(0)
+    from mtl_ssl_amd import config, model_builder, ops, synthetic, trainer
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    cfg = config.parse_pipeline_config(open(a.config).read())
+    B = int(cfg.train_config.batch_size)                     # per-GPU batch (weak scaling)
+    K = int(cfg.model.faster_rcnn.num_classes)
+    model = model_builder.build(cfg.model, True, dev, seed=0)
+    if world > 1:                                            # C2: identical weights on every replica
+        dist.broadcast(model.ps.weights, 0)
+        dist.broadcast(model.ps.frozen, 0)
+        model.prepare()
+    tr = trainer.Trainer(model, cfg.train_config, world)
+    batch = tr.stage_batch(synthetic.make_batch(B, a.height, a.width, K, seed=1234 + rank, device=dev))
+
+    for _ in range(a.warmup):
+        tr.step(batch)
+    if not a.no_roofline:
+        ops.PROFILER = ops.ConvProfiler()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = tr.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILER = ops.PROFILER, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_loss = float(sum(v.item() for v in losses.values()))
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    value = B * world * a.steps / dt
+    out = {
+        "metric": "images/sec training, Faster R-CNN ResNet-101 + aux heads",
+        "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Faster R-CNN ResNet-101 + window/closeness/edgemask heads + refine, "
+                               "synthetic %dx%d COCO-shaped (90 classes), per-GPU batch %d "
+                               "(BASELINE.json configs[%d])" % (a.width, a.height, B, 1 if world == 1 else 3),
+                   "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "pipeline_config": os.path.relpath(a.config, ROOT)},
+        "final_total_loss": total_loss,
+        "frac_of_fp32_mfma_roofline_whole_step": FLOP_PER_IMAGE * value / world / FP32_MFMA_PEAK,
+    }
+    if prof is not None:
+        s = prof.summary()
+        dom = s.get(("fwd", 0))
+        if dom and dom["seconds"] > 0:
+            out["roofline"] = {
+                "bound": "mfma", "achieved": dom["flops"] / dom["seconds"] / 1e12,
+                "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": dom["flops"] / dom["seconds"] / FP32_MFMA_PEAK, "traffic": None,
+                "kernel": "mtlssl::k_conv_mfma<128,128,0> (implicit-GEMM conv forward)",
+                "launches": dom["launches"], "avg_launch_us": 1e6 * dom["seconds"] / dom["launches"],
+                "algorithmic_flop_per_launch_avg": dom["flops"] / dom["launches"],
+            }
+        fam_f = sum(v["flops"] for k, v in s.items() if k[1] >= 0)
+        fam_t = sum(v["seconds"] for k, v in s.items() if k[1] >= 0)
+        out["conv_family"] = {
+            "achieved_tflops": fam_f / fam_t / 1e12 if fam_t else None,
+            "seconds_per_step": fam_t / a.steps,
+            "by_kernel": {"%s/cfg%d" % k: {"launches": v["launches"], "tflops": v["flops"] / v["seconds"] / 1e12,
+                                            "ms_per_step": 1e3 * v["seconds"] / a.steps}
+                          for k, v in sorted(s.items()) if v["seconds"] > 0},
+        }
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, model, a.height, a.width, seed=1234)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,10 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
  * per output channel by out_scale[k] (frozen-BN fold) and dbias[k] = sum dy (nullable).
  * workspace: mtlssl_conv2d_wgrad_workspace_bytes(d) bytes. */
 int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d);
+/* Which kernel instantiation a call will use: mode 0 fwd / 1 dgrad / 2 wgrad ->
+ * 0: k_conv_mfma<128,128,mode>, 1: <128,64,mode>, 2: <64,64,mode>, -1: direct (non-MFMA) path.
+ * For profiling attribution only. */
+int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode);
 int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,
                         const float* out_scale, float* dw, float* dbias, float beta,
                         void* workspace, mtlssl_stream_t stream);
@@ -213,6 +217,7 @@ int mtlssl_reduce_sum(const float* x, int n, float scale, float* out, mtlssl_str
 /* ------------------------------------------------------------------ optimizer family
  * slim.learning.clip_gradient_norms (per-variable tf.clip_by_norm, slim/learning.py:282-301)
  * + tf.train.MomentumOptimizer (builders/optimizer_builder.py:48-52):
+ *   g <- grad_scale*grad + var_weight_decay[v]*w  (L2 regulariser gradient, nullable table);
  *   g <- g * min(1, clip/||g||_2) per variable; acc <- momentum*acc + g; w <- w - lr*acc.
  * The parameters live in one flat buffer; var_offsets int32[num_vars+1] (device) delimits the
  * variables (offsets in floats, multiples of 4); max_var_size = largest variable (floats).
@@ -220,13 +225,60 @@ int mtlssl_reduce_sum(const float* x, int n, float scale, float* out, mtlssl_str
 int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              const int32_t* var_offsets, int num_vars, int64_t total,
                              int64_t max_var_size, float lr, float momentum, float clip_norm,
-                             float grad_scale, float* norms_ws, mtlssl_stream_t stream);
+                             float grad_scale, const float* var_weight_decay, float* norms_ws,
+                             mtlssl_stream_t stream);
 
 /* Elementwise helpers used by the graph glue. */
 int mtlssl_axpby(const float* x, float* y, int64_t n, float a, float b, mtlssl_stream_t s); /* y=a*x+b*y */
 int mtlssl_scale_channels(const float* w, const float* scale, float* out, int64_t rows, int K,
                           mtlssl_stream_t s); /* out[r,k] = w[r,k]*scale[k] (BN fold) */
 int mtlssl_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlssl_stream_t s);
+int mtlssl_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlssl_stream_t s);
+/* out[r,c] = x[r,c] + bias[c]: channel-mean subtraction of
+ * models/faster_rcnn_resnet_v1_feature_extractor.py:74-90 (pass the negated means). */
+int mtlssl_bias_add_channels(const float* x, const float* bias, float* out, int64_t rows, int C,
+                             mtlssl_stream_t s);
+/* tf.one_hot(depth=2) of a 0/1 float vector (faster_rcnn_meta_arch.py:1646-1647). */
+int mtlssl_onehot2(const float* t, float* out, int64_t n, mtlssl_stream_t s);
+
+/* ------------------------------------------------------------------ loss-weight glue
+ * Per-image normalisers are computed on the device so the step never syncs with the host. */
+
+/* _loss_rpn normalisation (faster_rcnn_meta_arch.py:1644-1659): S_b = sum_i sampled[b,i];
+ * loc_scale = sampled*reg_w*loc_coef/S_b; obj_scale = sampled*obj_coef/S_b
+ * (coef = loss_weight / batch). */
+int mtlssl_rpn_loss_scales(const float* sampled, const float* reg_w, int batch, int n,
+                           float loc_coef, float obj_coef, float* loc_scale_out,
+                           float* obj_scale_out, mtlssl_stream_t stream);
+/* _loss_box_classifier normalisation (faster_rcnn_meta_arch.py:1715-1725,1774-1789):
+ * normalizer = max(1,num_proposals[b])*batch; pad = i < num_proposals[b];
+ * cls_scale = cls_w*pad/normalizer*cls_coef; loc_scale = reg_w*pad/normalizer*loc_coef;
+ * clo_scale (nullable) = reg_w/max(1,sum_i reg_w[b,i]) * sum_{k>=1} closeness_targets[b,i,k] * clo_coef. */
+int mtlssl_detector_loss_scales(const float* cls_w, const float* reg_w, const int32_t* num_proposals,
+                                const float* closeness_targets, int batch, int n2, int k1,
+                                float cls_coef, float loc_coef, float clo_coef, float* cls_scale_out,
+                                float* loc_scale_out, float* clo_scale_out, mtlssl_stream_t stream);
+/* Second-stage localisation loss (faster_rcnn_meta_arch.py:1735-1749): pick, per proposal, the
+ * box encoding of its target class (background slot = zeros) and apply smooth-L1.
+ * refined [rows,K,4]; cls_targets [rows,K+1]; d_refined is zero-filled then written. */
+int mtlssl_box_select_smooth_l1(const float* refined, const float* cls_targets,
+                                const float* reg_targets, const float* row_scale, int rows, int K,
+                                float sigma, float* row_loss_out, float* d_refined_out,
+                                mtlssl_stream_t stream);
+/* _loss_edgemask target preparation (faster_rcnn_meta_arch.py:1862-1868):
+ * gt [B,2,H,W] (fg, weight) -> targets [B,H,W,2] = (1-fg, fg), row_scale = weight*coef. */
+int mtlssl_edgemask_targets(const float* gt, int batch, int H, int W, float coef,
+                            float* targets_out, float* row_scale_out, mtlssl_stream_t stream);
+/* predict_with_mtl_results window expansion (faster_rcnn_meta_arch.py:774-803):
+ * out [B,n_expand,n2,4], window i = proposal pushed i/(n_expand-1) of the way to the image. */
+int mtlssl_expand_windows(const float* proposals_norm, int batch, int n2, int n_expand, float* out,
+                          mtlssl_stream_t stream);
+/* Refiner input (faster_rcnn_meta_arch.py:817-831), per image: [cls (k1) | window predictions
+ * win[B,n_expand,n2,k1] laid out proposal-major (nullable) | closeness (nullable; per-image mean
+ * tiled when global_closeness)] -> out [B*n2, ld]. */
+int mtlssl_refine_concat(const float* cls, const float* win, const float* clo, int batch, int n2,
+                         int k1, int n_expand, int global_closeness, float* out,
+                         mtlssl_stream_t stream);
 
 #ifdef __cplusplus
 }

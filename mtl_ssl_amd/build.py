@@ -19,8 +19,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 SOURCES = {
     "detection.hip": ["-ffp-contract=off"],
-    "ops.hip": [],
+    "ops.hip": ["-ffp-contract=off"],   # ROI max-pool arg-max must not flip on fma rounding
     "conv.hip": [],
+    "glue.hip": ["-ffp-contract=off"],
 }
 
 

@@ -506,6 +506,21 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   return check_launch("conv2d_dgrad");
 }
 
+int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
+  if (!d) return -1;
+  if (mode == MODE_FWD)
+    return (d->C % BK == 0 && d->K % 64 == 0) ? pick_tile((int64_t)d->N * d->OH * d->OW, d->K, 1) : -1;
+  if (mode == MODE_DGRAD)
+    return (d->K % BK == 0 && d->C % 64 == 0) ? pick_tile((int64_t)d->N * d->H * d->W, d->C, 1) : -1;
+  if (mode == MODE_WGRAD) {
+    if (d->C % 64 || d->K % 64) return -1;
+    int cfg, ns, pps;
+    wgrad_plan(d, &cfg, &ns, &pps);
+    return cfg;
+  }
+  return -1;
+}
+
 int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
   if (!d || d->C % 64 || d->K % 64) return 256;
   int cfg, ns, pps;

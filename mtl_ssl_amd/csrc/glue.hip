@@ -1,0 +1,250 @@
+// Small device-side glue of the Faster R-CNN + aux-head step: loss-weight preparation (per-image
+// normalisers computed on the device so the step never syncs with the host), class-selected box
+// loss, edgemask targets, refine-input assembly, expanded windows. Tiny tensors; one block per
+// image where a per-image reduction is needed.
+#include "common.h"
+
+namespace mtlssl {
+
+__device__ __forceinline__ float block_sum_256(float v, float* s4) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s4[0] + s4[1] + s4[2] + s4[3];
+}
+
+// faster_rcnn_meta_arch.py:1644-1659: normaliser = sum(sampled) per image; mean over batch.
+__global__ void __launch_bounds__(256)
+    k_rpn_loss_scales(const float* sampled, const float* reg_w, int n, float loc_coef,
+                      float obj_coef, float* loc_scale, float* obj_scale) {
+  __shared__ float s4[4];
+  int b = blockIdx.x;
+  const float* sp = sampled + (int64_t)b * n;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += sp[i];
+  float S = block_sum_256(acc, s4);
+  float inv = S > 0.f ? 1.f / S : 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int64_t o = (int64_t)b * n + i;
+    float s = sp[i];
+    loc_scale[o] = s * reg_w[o] * loc_coef * inv;
+    obj_scale[o] = s * obj_coef * inv;
+  }
+}
+
+// faster_rcnn_meta_arch.py:1715-1725,1774-1789.
+__global__ void __launch_bounds__(256)
+    k_detector_loss_scales(const float* cls_w, const float* reg_w, const int32_t* num_prop,
+                           const float* clo_t, int B, int n2, int k1, float cls_coef,
+                           float loc_coef, float clo_coef, float* cls_scale, float* loc_scale,
+                           float* clo_scale) {
+  __shared__ float s4[4];
+  int b = blockIdx.x;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n2; i += 256) acc += reg_w[(int64_t)b * n2 + i];
+  float R = block_sum_256(acc, s4);
+  float norm_reg = fmaxf(1.f, R);
+  int np_ = num_prop[b];
+  float normalizer = (float)max(np_, 1) * (float)B;
+  for (int i = threadIdx.x; i < n2; i += 256) {
+    int64_t o = (int64_t)b * n2 + i;
+    float pad = i < np_ ? 1.f : 0.f;
+    cls_scale[o] = cls_w[o] * pad / normalizer * cls_coef;
+    loc_scale[o] = reg_w[o] * pad / normalizer * loc_coef;
+    if (clo_scale) {
+      float st = 0.f;
+      for (int k = 1; k < k1; ++k) st += clo_t[o * k1 + k];
+      clo_scale[o] = reg_w[o] / norm_reg * st * clo_coef;
+    }
+  }
+}
+
+// faster_rcnn_meta_arch.py:1735-1749: pad a background slot, pick the encoding of the target
+// class (first column with target > 0), smooth-L1 against the regression target.
+__global__ void k_box_select_smooth_l1(const float* refined, const float* cls_t,
+                                       const float* reg_t, const float* row_scale, int rows, int K,
+                                       float sigma2, float* row_loss, float* d_refined) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  int c = 0;
+  for (int k = 0; k <= K; ++k)
+    if (cls_t[(int64_t)r * (K + 1) + k] > 0.f) { c = k; break; }
+  float w = row_scale[r];
+  float inv = 1.f / sigma2;
+  float acc = 0.f;
+  for (int j = 0; j < 4; ++j) {
+    float p = c > 0 ? refined[((int64_t)r * K + (c - 1)) * 4 + j] : 0.f;
+    float d = p - reg_t[(int64_t)r * 4 + j];
+    float ad = fabsf(d);
+    bool quad = ad < inv;
+    acc += quad ? 0.5f * ad * ad * sigma2 : ad - 0.5f * inv;
+    if (c > 0 && d_refined)
+      d_refined[((int64_t)r * K + (c - 1)) * 4 + j] =
+          w * (quad ? d * sigma2 : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+  }
+  row_loss[r] = acc * w;
+}
+
+// faster_rcnn_meta_arch.py:1862-1868: gt [B,2,H,W] (fg, weight) -> targets [B,H,W,2] = (1-fg, fg),
+// row scale = weight * coef.
+__global__ void k_edgemask_targets(const float* gt, int HW, float coef, float* tgt, float* scale,
+                                   int64_t total) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int64_t b = i / HW, p = i % HW;
+  float fg = gt[(b * 2 + 0) * HW + p], w = gt[(b * 2 + 1) * HW + p];
+  tgt[i * 2 + 0] = 1.f - fg;
+  tgt[i * 2 + 1] = fg;
+  scale[i] = w * coef;
+}
+
+// faster_rcnn_meta_arch.py:776-803: window i = proposal pushed i/4 of the way to the full image.
+__global__ void k_expand_windows(const float* prop, int n2, int n_expand, float* out) {
+  int b = blockIdx.y;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_expand * n2) return;
+  int i = t / n2, p = t % n2;
+  float4 v = *reinterpret_cast<const float4*>(prop + ((int64_t)b * n2 + p) * 4);
+  float ne = (float)(n_expand - 1);
+  float dyn = v.x / ne, dxn = v.y / ne, dyp = (1.f - v.z) / ne, dxp = (1.f - v.w) / ne;
+  float fi = (float)i;
+  *reinterpret_cast<float4*>(out + (((int64_t)b * n_expand + i) * n2 + p) * 4) =
+      make_float4(v.x - dyn * fi, v.y - dxn * fi, v.z + dyp * fi, v.w + dxp * fi);
+}
+
+// faster_rcnn_meta_arch.py:817-831 per image: [cls | window preds (proposal-major over the
+// n_expand windows) | closeness (batch-mean tiled when global)].
+__global__ void __launch_bounds__(256)
+    k_refine_concat(const float* cls, const float* win, const float* clo, int n2, int k1,
+                    int n_expand, int use_win, int use_clo, int global_clo, float* out, int ld) {
+  extern __shared__ float s_mean[];
+  int b = blockIdx.x;
+  if (use_clo && global_clo) {
+    for (int k = threadIdx.x; k < k1; k += 256) {
+      float s = 0.f;
+      for (int p = 0; p < n2; ++p) s += clo[((int64_t)b * n2 + p) * k1 + k];
+      s_mean[k] = s / (float)n2;
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < n2 * ld; t += 256) {
+    int p = t / ld, c = t % ld;
+    float v;
+    if (c < k1) {
+      v = cls[((int64_t)b * n2 + p) * k1 + c];
+    } else if (use_win && c < k1 + n_expand * k1) {
+      int i = (c - k1) / k1, k = (c - k1) % k1;
+      v = win[(((int64_t)b * n_expand + i) * n2 + p) * k1 + k];
+    } else {
+      int k = c - k1 - (use_win ? n_expand * k1 : 0);
+      v = global_clo ? s_mean[k] : clo[((int64_t)b * n2 + p) * k1 + k];
+    }
+    out[((int64_t)b * n2 + p) * ld + c] = v;
+  }
+}
+
+__global__ void k_bias_add_channels(const float* x, const float* bias, float* out, int64_t total, int C) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < total) out[i] = x[i] + bias[i % C];
+}
+__global__ void k_relu_bwd(const float* y, const float* dy, float* dx, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+__global__ void k_onehot2(const float* t, float* out, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int c = (int)t[i];
+  out[i * 2 + 0] = c == 0 ? 1.f : 0.f;
+  out[i * 2 + 1] = c == 1 ? 1.f : 0.f;
+}
+
+}  // namespace mtlssl
+
+using namespace mtlssl;
+
+extern "C" {
+
+int mtlssl_rpn_loss_scales(const float* sampled, const float* reg_w, int batch, int n,
+                           float loc_coef, float obj_coef, float* loc_scale, float* obj_scale,
+                           mtlssl_stream_t stream) {
+  if (!batch || !n) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_rpn_loss_scales, dim3(batch), dim3(256), 0, S(stream), sampled, reg_w, n,
+                     loc_coef, obj_coef, loc_scale, obj_scale);
+  return check_launch("rpn_loss_scales");
+}
+
+int mtlssl_detector_loss_scales(const float* cls_w, const float* reg_w, const int32_t* num_proposals,
+                                const float* closeness_targets, int batch, int n2, int k1,
+                                float cls_coef, float loc_coef, float clo_coef, float* cls_scale,
+                                float* loc_scale, float* clo_scale, mtlssl_stream_t stream) {
+  if (!batch || !n2) return MTLSSL_OK;
+  MTLSSL_REQUIRE(!clo_scale || closeness_targets, "detector_loss_scales: closeness targets required");
+  hipLaunchKernelGGL(k_detector_loss_scales, dim3(batch), dim3(256), 0, S(stream), cls_w, reg_w,
+                     num_proposals, closeness_targets, batch, n2, k1, cls_coef, loc_coef, clo_coef,
+                     cls_scale, loc_scale, clo_scale);
+  return check_launch("detector_loss_scales");
+}
+
+int mtlssl_box_select_smooth_l1(const float* refined, const float* cls_targets,
+                                const float* reg_targets, const float* row_scale, int rows, int K,
+                                float sigma, float* row_loss, float* d_refined,
+                                mtlssl_stream_t stream) {
+  if (!rows) return MTLSSL_OK;
+  if (d_refined &&
+      hipMemsetAsync(d_refined, 0, sizeof(float) * (size_t)rows * K * 4, S(stream)) != hipSuccess)
+    return check_launch("box_select memset");
+  hipLaunchKernelGGL(k_box_select_smooth_l1, dim3(cdiv(rows, 256)), dim3(256), 0, S(stream), refined,
+                     cls_targets, reg_targets, row_scale, rows, K, sigma * sigma, row_loss, d_refined);
+  return check_launch("box_select_smooth_l1");
+}
+
+int mtlssl_edgemask_targets(const float* gt, int batch, int H, int W, float coef, float* targets,
+                            float* row_scale, mtlssl_stream_t stream) {
+  int64_t total = (int64_t)batch * H * W;
+  if (!total) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_edgemask_targets, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), gt, H * W,
+                     coef, targets, row_scale, total);
+  return check_launch("edgemask_targets");
+}
+
+int mtlssl_expand_windows(const float* proposals_norm, int batch, int n2, int n_expand, float* out,
+                          mtlssl_stream_t stream) {
+  if (!batch || !n2) return MTLSSL_OK;
+  MTLSSL_REQUIRE(n_expand >= 2, "expand_windows: n_expand must be >= 2");
+  hipLaunchKernelGGL(k_expand_windows, dim3(cdiv(n_expand * n2, 256), batch), dim3(256), 0, S(stream),
+                     proposals_norm, n2, n_expand, out);
+  return check_launch("expand_windows");
+}
+
+int mtlssl_refine_concat(const float* cls, const float* win, const float* clo, int batch, int n2,
+                         int k1, int n_expand, int global_closeness, float* out,
+                         mtlssl_stream_t stream) {
+  if (!batch || !n2) return MTLSSL_OK;
+  int ld = k1 + (win ? n_expand * k1 : 0) + (clo ? k1 : 0);
+  hipLaunchKernelGGL(k_refine_concat, dim3(batch), dim3(256), sizeof(float) * k1, S(stream), cls, win,
+                     clo, n2, k1, n_expand, win != nullptr, clo != nullptr, global_closeness, out, ld);
+  return check_launch("refine_concat");
+}
+
+int mtlssl_bias_add_channels(const float* x, const float* bias, float* out, int64_t rows, int C,
+                             mtlssl_stream_t stream) {
+  int64_t total = rows * C;
+  if (!total) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_bias_add_channels, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, bias,
+                     out, total, C);
+  return check_launch("bias_add_channels");
+}
+int mtlssl_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlssl_stream_t stream) {
+  if (!n) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_relu_bwd, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), y, dy, dx, n);
+  return check_launch("relu_bwd");
+}
+int mtlssl_onehot2(const float* t, float* out, int64_t n, mtlssl_stream_t stream) {
+  if (!n) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_onehot2, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), t, out, n);
+  return check_launch("onehot2");
+}
+
+}  // extern "C"

@@ -281,8 +281,10 @@ __global__ void __launch_bounds__(1024) k_reduce_sum(const float* x, int n, floa
 // bits only; the clip factor tolerates that (documented in DESIGN.md).
 constexpr int NORM_CHUNK = 1 << 16;
 __global__ void __launch_bounds__(256)
-    k_var_sumsq(const float* g, const int32_t* off, float gscale, float* norms) {
+    k_var_sumsq(const float* g, const float* w, const float* var_wd, const int32_t* off,
+                float gscale, float* norms) {
   int v = blockIdx.y;
+  const float wd = var_wd ? var_wd[v] : 0.f;
   int64_t lo = off[v], hi = off[v + 1];
   int64_t s = lo + (int64_t)blockIdx.x * NORM_CHUNK;
   if (s >= hi) return;
@@ -291,6 +293,10 @@ __global__ void __launch_bounds__(256)
   for (int64_t i = s + threadIdx.x * 4; i < e; i += 256 * 4) {
     float4 q = *reinterpret_cast<const float4*>(g + i);
     q.x *= gscale; q.y *= gscale; q.z *= gscale; q.w *= gscale;
+    if (wd != 0.f) {   // gradient of the L2 regulariser wd * 0.5*||w||^2 (slim.l2_regularizer)
+      float4 ww = *reinterpret_cast<const float4*>(w + i);
+      q.x += wd * ww.x; q.y += wd * ww.y; q.z += wd * ww.z; q.w += wd * ww.w;
+    }
     acc += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
   }
   acc = wave_sum(acc);
@@ -302,7 +308,7 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     k_momentum_update(float* w, const float* g, float* acc, const int32_t* off, int num_vars,
                       int64_t total4, float lr, float mom, float clip, float gscale,
-                      const float* norms) {
+                      const float* norms, const float* var_wd) {
   int64_t i4 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i4 >= total4) return;
   int64_t i = i4 * 4;
@@ -311,14 +317,17 @@ __global__ void __launch_bounds__(256)
     int mid = (lo + hi) >> 1;
     if ((int64_t)off[mid] <= i) lo = mid; else hi = mid;
   }
-  float f = gscale;
+  float f = 1.f;
   if (clip > 0.f) {
     float nrm = sqrtf(norms[lo]);
-    if (nrm > clip) f *= clip / nrm;     // tf.clip_by_norm: g * clip / max(norm, clip)
+    if (nrm > clip) f = clip / nrm;      // tf.clip_by_norm: g * clip / max(norm, clip)
   }
+  const float wd = var_wd ? var_wd[lo] : 0.f;
   float4 gv = *reinterpret_cast<const float4*>(g + i);
   float4 av = *reinterpret_cast<float4*>(acc + i);
   float4 wv = *reinterpret_cast<float4*>(w + i);
+  gv.x = gv.x * gscale + wd * wv.x; gv.y = gv.y * gscale + wd * wv.y;
+  gv.z = gv.z * gscale + wd * wv.z; gv.w = gv.w * gscale + wd * wv.w;
   av.x = mom * av.x + gv.x * f; av.y = mom * av.y + gv.y * f;
   av.z = mom * av.z + gv.z * f; av.w = mom * av.w + gv.w * f;
   wv.x -= lr * av.x; wv.y -= lr * av.y; wv.z -= lr * av.z; wv.w -= lr * av.w;
@@ -443,7 +452,8 @@ int mtlssl_reduce_sum(const float* x, int n, float scale, float* out, mtlssl_str
 int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              const int32_t* var_offsets, int num_vars, int64_t total,
                              int64_t max_var_size, float lr, float momentum, float clip_norm,
-                             float grad_scale, float* norms_ws, mtlssl_stream_t stream) {
+                             float grad_scale, const float* var_weight_decay, float* norms_ws,
+                             mtlssl_stream_t stream) {
   MTLSSL_REQUIRE(total % 4 == 0, "sgd: total must be a multiple of 4");
   MTLSSL_REQUIRE(total < (1ll << 31), "sgd: flat parameter buffer must be < 2^31 floats");
   if (!total) return MTLSSL_OK;
@@ -454,12 +464,12 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
       return check_launch("sgd memset");
     // the largest variable decides the chunk count; empty chunks exit immediately
     int chunks = (int)cdiv(max_var_size > 0 ? max_var_size : total, NORM_CHUNK);
-    hipLaunchKernelGGL(k_var_sumsq, dim3(chunks, num_vars), dim3(256), 0, st, grads, var_offsets,
-                       grad_scale, norms_ws);
+    hipLaunchKernelGGL(k_var_sumsq, dim3(chunks, num_vars), dim3(256), 0, st, grads, weights,
+                       var_weight_decay, var_offsets, grad_scale, norms_ws);
   }
   hipLaunchKernelGGL(k_momentum_update, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads,
                      accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
-                     norms_ws);
+                     norms_ws, var_weight_decay);
   return check_launch("sgd_momentum_clip");
 }
 

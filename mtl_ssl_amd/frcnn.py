@@ -1,0 +1,515 @@
+"""FasterRCNNMetaArch: the two-stage detector with the three auxiliary heads (window, closeness,
+edgemask) and the refine step, as an explicit forward/backward program over the C-ABI kernels.
+
+Mirrors object_detection/meta_architectures/faster_rcnn_meta_arch.py:208-2013 — same method
+names, prediction_dict keys and loss_dict keys — so the parity tests read like the reference's.
+Differences that are deliberate: refine runs per image (Q2); sampling
+uses counter-hash priorities instead of tf.random_shuffle (Q6); target assignment treats every
+groundtruth box as a normal box (Q1, the reference's effective behaviour).
+"""
+import numpy as np
+import torch
+
+from . import nn, ops
+
+f32, i32 = torch.float32, torch.int32
+
+
+def _init_from_hyperparams(hp):
+    """builders/hyperparams_builder.py:115-156."""
+    ini = hp.initializer
+    which = ini.which_oneof(["truncated_normal_initializer", "variance_scaling_initializer"])
+    if which == "truncated_normal_initializer":
+        return ("truncated_normal", float(ini.truncated_normal_initializer.stddev))
+    if which == "variance_scaling_initializer":
+        v = ini.variance_scaling_initializer
+        return ("variance_scaling", float(v.factor), str(v.mode), bool(v.uniform))
+    return ("variance_scaling", 1.0, "FAN_AVG", True)      # slim default: xavier
+
+
+def _l2_from_hyperparams(hp):
+    reg = hp.regularizer
+    if reg.has("l2_regularizer"):
+        return float(reg.l2_regularizer.weight)
+    return 0.0
+
+
+class MaskRCNNBoxPredictor:
+    """core/box_predictor.py:339-611: spatial mean -> FC heads."""
+
+    def __init__(self, ps, scope, cin, num_classes, cfg, is_training, class_only):
+        if not cfg.spatial_average:
+            raise ValueError("mask_rcnn_box_predictor without spatial_average is not supported "
+                             "(every paper config sets spatial_average: true)")
+        init, wd = _init_from_hyperparams(cfg.fc_hyperparams), _l2_from_hyperparams(cfg.fc_hyperparams)
+        self.num_classes, self.class_only = num_classes, class_only
+        self.box = None
+        if not class_only:
+            self.box = nn.Conv(ps, scope + "/BoxEncodingPredictor", cin, num_classes * 4, 1, init,
+                               is_training, wd, fc=True)
+            self.cls = nn.Conv(ps, scope + "/ClassPredictor", cin, num_classes + 1, 1, init, is_training,
+                               wd, fc=True)
+        else:
+            self.cls = nn.Conv(ps, scope + "/ClassPredictor", cin, num_classes, 1, init, is_training, wd,
+                               fc=True)
+
+    def layers(self):
+        return [l for l in (self.box, self.cls) if l is not None]
+
+    def predict(self, feat):
+        pooled = ops.spatial_mean_fwd(feat)
+        out = {"pooled": pooled, "class": self.cls.forward(pooled)}
+        if self.box is not None:
+            out["box"] = self.box.forward(pooled)
+        return out
+
+    def backward(self, pred, d_class, d_box, feat_shape, need_feat_grad=True):
+        pooled = pred["pooled"]
+        self.cls.wgrad(pooled, d_class)
+        if d_box is not None:
+            self.box.wgrad(pooled, d_box)
+        if not need_feat_grad:
+            return None
+        dp = self.cls.dgrad(pooled.shape, d_class)
+        if d_box is not None:
+            self.box.dgrad(pooled.shape, d_box, out=dp, accum=True)
+        return ops.spatial_mean_bwd(dp, feat_shape)
+
+
+class FasterRCNNMetaArch:
+    first_stage_feature_extractor_scope = "FirstStageFeatureExtractor"
+    second_stage_feature_extractor_scope = "SecondStageFeatureExtractor"
+    first_stage_box_predictor_scope = "FirstStageBoxPredictor"
+    second_stage_box_predictor_scope = "SecondStageBoxPredictor"
+    window_box_predictor_scope = "WindowBoxPredictor"
+    closeness_box_predictor_scope = "ClosenessBoxPredictor"
+    edgemask_predictor_scope = "EdgeMaskPredictor"
+    mtl_refiner_scope = "MTLClassRefiner"
+    N_EXPAND = 5            # n_expand_window_for_refine + 1 (faster_rcnn_meta_arch.py:774-788)
+
+    def __init__(self, ps, is_training, frcnn, mtl, feature_extractor, seed=0):
+        self.ps, self._is_training, self.cfg, self._mtl = ps, is_training, frcnn, mtl
+        self._feature_extractor = fe = feature_extractor
+        self.num_classes = K = int(frcnn.num_classes)
+        if frcnn.second_stage_batch_size > frcnn.first_stage_max_proposals:
+            raise ValueError("second_stage_batch_size should be no greater than first_stage_max_proposals.")
+        ag = frcnn.first_stage_anchor_generator
+        if not ag.has("grid_anchor_generator"):
+            raise ValueError("first_stage_anchor_generator must be of type grid_anchor_generator.")
+        if frcnn.first_stage_only:
+            raise ValueError("first_stage_only is not supported by this build")
+        if frcnn.has("hard_example_miner"):
+            raise ValueError("hard_example_miner is not supported by this build (unused by the paper configs)")
+        if mtl.shared_feature != "proposal_feature_maps":
+            raise ValueError("mtl.shared_feature must be 'proposal_feature_maps' (the proto default; "
+                             "no paper config overrides it)")
+        self._anchor_cfg = ag.grid_anchor_generator
+        self.seed = seed
+        self.step = 0
+        hp = frcnn.first_stage_box_predictor_conv_hyperparams
+        init, wd = _init_from_hyperparams(hp), _l2_from_hyperparams(hp)
+        rpn_tr = is_training and frcnn.first_stage_box_predictor_trainable
+        A = len(self._anchor_cfg.scales) * len(self._anchor_cfg.aspect_ratios)
+        self.num_anchors_per_location = A
+        s = self.first_stage_box_predictor_scope
+        depth, ks = int(frcnn.first_stage_box_predictor_depth), int(frcnn.first_stage_box_predictor_kernel_size)
+        if int(frcnn.first_stage_atrous_rate) != 1:
+            raise ValueError("first_stage_atrous_rate != 1 is not supported")
+        self.rpn_conv = nn.Conv(ps, s + "/Conv", fe.cout, depth, ks, init, rpn_tr, wd,
+                                activation="relu" if hp.activation == "RELU" else None)
+        self.rpn_box = nn.Conv(ps, s + "/BoxEncodingPredictor", depth, A * 4, 1, init, rpn_tr, wd)
+        self.rpn_cls = nn.Conv(ps, s + "/ClassPredictor", depth, A * 2, 1, init, rpn_tr, wd)
+        # second stage
+        self.tower = fe.box_classifier_tower(self.second_stage_feature_extractor_scope, True)
+        bp = frcnn.second_stage_box_predictor
+        if not bp.has("mask_rcnn_box_predictor"):
+            raise ValueError("FasterRCNNMetaArch needs mask_rcnn_box_predictor (use RFCNMetaArch for rfcn)")
+        self.box_predictor = MaskRCNNBoxPredictor(ps, self.second_stage_box_predictor_scope, self.tower.cout,
+                                                  K, bp.mask_rcnn_box_predictor,
+                                                  is_training and bp.trainable, False)
+        self.layers = fe.layers() + [self.rpn_conv, self.rpn_box, self.rpn_cls] + self.tower.layers() \
+            + self.box_predictor.layers()
+        # aux heads (builders/model_builder.py:287-315: aux predictors get num_classes+1 "classes")
+        self.closeness_tower = self.window_tower = None
+        if mtl.closeness:
+            self.closeness_tower = fe.box_classifier_tower(self.closeness_box_predictor_scope, True)
+            cb = mtl.closeness_box_predictor
+            self.closeness_predictor = MaskRCNNBoxPredictor(
+                ps, self.closeness_box_predictor_scope, self.tower.cout, K + 1, cb.mask_rcnn_box_predictor,
+                is_training and cb.trainable, True)
+            self.layers += self.closeness_tower.layers() + self.closeness_predictor.layers()
+        if mtl.window:
+            self.window_tower = fe.box_classifier_tower(self.window_box_predictor_scope, True)
+            wb = mtl.window_box_predictor
+            self.window_predictor = MaskRCNNBoxPredictor(
+                ps, self.window_box_predictor_scope, self.tower.cout, K + 1, wb.mask_rcnn_box_predictor,
+                is_training and wb.trainable, True)
+            self.layers += self.window_tower.layers() + self.window_predictor.layers()
+        if mtl.edgemask:
+            ep = mtl.edgemask_predictor
+            self.edgemask_conv = nn.Conv(ps, self.edgemask_predictor_scope + "/BoxEncodingPredictor", fe.cout,
+                                         2, int(ep.kernel_size), _init_from_hyperparams(ep.conv_hyperparams),
+                                         is_training and ep.trainable, _l2_from_hyperparams(ep.conv_hyperparams),
+                                         activation="tanh")
+            self.layers.append(self.edgemask_conv)
+        if mtl.refine:
+            if int(mtl.refine_num_fc_layers) != 0:
+                raise ValueError("refine_num_fc_layers > 0 is not supported (all paper configs use 0)")
+            n_feat = (K + 1) * (1 + (self.N_EXPAND if mtl.window else 0) + (1 if mtl.closeness else 0))
+            rh = mtl.refiner_fc_hyperparams
+            self.refine_fc = nn.Conv(ps, self.mtl_refiner_scope + "/fc1", n_feat, K + 1, 1,
+                                     _init_from_hyperparams(rh), is_training, _l2_from_hyperparams(rh),
+                                     fc=True)
+            self.layers.append(self.refine_fc)
+        self._anchors = {}
+        self._gt = None
+        self._window = None
+        self._edgemask = None
+
+    # ------------------------------------------------------------------ properties / plumbing
+    @property
+    def max_num_proposals(self):
+        """faster_rcnn_meta_arch.py:463-477."""
+        if self._is_training:
+            return int(self.cfg.second_stage_batch_size)
+        return int(self.cfg.first_stage_max_proposals)
+
+    def prepare(self):
+        for l in self.layers:
+            l.prepare()
+
+    def refold(self):
+        for l in self.layers:
+            if getattr(l, "trainable", False):
+                l.refold()
+
+    def preprocess(self, inputs):
+        """faster_rcnn_meta_arch.py:479-505. Inputs must already have the resized shape (the
+        synthetic benchmark feeds 600x1024, for which keep_aspect_ratio_resizer is the identity)."""
+        if inputs.dtype != f32:
+            raise ValueError("`preprocess` expects a tf.float32 tensor")
+        r = self.cfg.image_resizer.keep_aspect_ratio_resizer
+        H, W = inputs.shape[1], inputs.shape[2]
+        if min(H, W) != r.min_dimension and max(H, W) != r.max_dimension:
+            raise ValueError("inputs must be pre-resized by keep_aspect_ratio_resizer(%d,%d); got %dx%d"
+                             % (r.min_dimension, r.max_dimension, H, W))
+        return self._feature_extractor.preprocess(inputs)
+
+    @staticmethod
+    def _pad_list(lst, device, width=None):
+        n = [int(t.shape[0]) for t in lst]
+        G = max(max(n), 1)
+        first = torch.as_tensor(lst[0])
+        tail = tuple(first.shape[1:]) if width is None else (width,)
+        out = torch.zeros((len(lst), G) + tail, dtype=f32)
+        for b, t in enumerate(lst):
+            if n[b]:
+                out[b, :n[b]] = torch.as_tensor(t, dtype=f32)
+        return out.to(device), torch.tensor(n, dtype=i32, device=device)
+
+    def provide_groundtruth(self, groundtruth_boxes_list, groundtruth_classes_list,
+                            groundtruth_closeness_list=None):
+        """core/model.py:225-267. boxes normalised [G,4]; classes one-hot [G,K]; closeness [G,K+1]."""
+        dev = self.ps.device
+        boxes, num = self._pad_list(groundtruth_boxes_list, dev)
+        cls, _ = self._pad_list(groundtruth_classes_list, dev, self.num_classes)
+        cls_bg = torch.cat([torch.zeros_like(cls[..., :1]), cls], -1).contiguous()   # pad bg slot
+        clo = None
+        if groundtruth_closeness_list is not None and groundtruth_closeness_list[0] is not None:
+            clo, _ = self._pad_list(groundtruth_closeness_list, dev, self.num_classes + 1)
+        self._gt = dict(boxes_norm=boxes, num=num, classes_bg=cls_bg, closeness=clo)
+
+    def provide_window(self, window_boxes_list, window_classes_list):
+        """core/model.py:269-283 (all images must carry the same number of windows, Q5)."""
+        dev = self.ps.device
+        wb = torch.stack([torch.as_tensor(w, dtype=f32) for w in window_boxes_list]).to(dev)
+        wc = torch.stack([torch.as_tensor(w, dtype=f32) for w in window_classes_list]).to(dev)
+        self._window = dict(boxes=wb.contiguous(), classes=wc.contiguous())
+
+    def provide_edgemask(self, groundtruth_edgemask_list):
+        dev = self.ps.device
+        self._edgemask = torch.stack([torch.as_tensor(e, dtype=f32) for e in groundtruth_edgemask_list]) \
+            .to(dev).contiguous()
+
+    def _anchors_for(self, Hf, Wf, H, W, device):
+        key = (Hf, Wf, H, W)
+        if key not in self._anchors:
+            g = self._anchor_cfg
+            anchors = ops.anchors_generate(Hf, Wf, list(g.scales), list(g.aspect_ratios),
+                                           (float(g.height), float(g.width)),
+                                           (float(g.height_stride), float(g.width_stride)),
+                                           (float(g.height_offset), float(g.width_offset)), device)
+            if self._is_training and not self.cfg.first_stage_clip_window:
+                keep = ops.prune_outside_window(anchors, [0, 0, H, W]).contiguous()
+                kept = ops.gather_rows(anchors[None].contiguous(), keep)[0].contiguous()
+            else:
+                raise NotImplementedError("inference-mode anchor clipping lands with postprocess()")
+            self._anchors[key] = (kept, keep, anchors.shape[0])
+        return self._anchors[key]
+
+    # ------------------------------------------------------------------ forward
+    def predict(self, preprocessed_inputs):
+        """faster_rcnn_meta_arch.py:507-609 (training mode)."""
+        x = preprocessed_inputs
+        B, H, W, _ = x.shape
+        F, trunk_ctx = self._feature_extractor.extract_proposal_features(x, save=self._is_training)
+        Hf, Wf = F.shape[1], F.shape[2]
+        anchors, keep, n_all = self._anchors_for(Hf, Wf, H, W, x.device)
+        rpn_feat = self.rpn_conv.forward(F)
+        enc_all = self.rpn_box.forward(rpn_feat).view(B, n_all, 4)
+        cls_all = self.rpn_cls.forward(rpn_feat).view(B, n_all, 2)
+        enc = ops.gather_rows(enc_all, keep)
+        logits = ops.gather_rows(cls_all, keep)
+        pd = {
+            "rpn_box_predictor_features": rpn_feat, "rpn_features_to_crop": F,
+            "image_shape": (B, H, W, 3), "rpn_box_encodings": enc,
+            "rpn_objectness_predictions_with_background": logits, "anchors": anchors,
+            "_trunk_ctx": trunk_ctx, "_keep": keep, "_n_all": n_all,
+        }
+        pd.update(self._predict_second_stage(pd))
+        return pd
+
+    def _format_groundtruth_data(self, H, W):
+        """faster_rcnn_meta_arch.py:1218-1266: absolute boxes (+ bg-padded classes)."""
+        if "boxes_abs" not in self._gt:
+            scale = torch.tensor([H, W, H, W], dtype=f32, device=self.ps.device)
+            self._gt["boxes_abs"] = (self._gt["boxes_norm"] * scale).contiguous()
+        return self._gt
+
+    def _crop(self, F, boxes_norm_flat, box_ind, want_argmax):
+        c = self.cfg
+        return ops.roi_crop_pool_fwd(F, boxes_norm_flat, box_ind, int(c.initial_crop_size),
+                                     int(c.maxpool_kernel_size), int(c.maxpool_stride), want_argmax)
+
+    def _box_ind(self, B, n, device):
+        return (torch.arange(B * n, device=device, dtype=i32) // n).contiguous()
+
+    def _predict_second_stage(self, pd):
+        """faster_rcnn_meta_arch.py:611-719."""
+        c, mtl = self.cfg, self._mtl
+        B, H, W, _ = pd["image_shape"]
+        F = pd["rpn_features_to_crop"]
+        gt = self._format_groundtruth_data(H, W)
+        # _postprocess_rpn :1055-1132
+        props, _scores, nprop = ops.rpn_proposals(
+            pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"],
+            H, W, c.first_stage_nms_score_threshold, c.first_stage_nms_iou_threshold,
+            int(c.first_stage_max_proposals))
+        N2 = self.max_num_proposals
+        stream0 = (2 * self.step * 65536 + 1) & 0xFFFFFFFF
+        boxes_abs, boxes_norm, num = ops.sample_proposals(
+            props, nprop, gt["boxes_abs"], gt["num"], gt["classes_bg"], N2,
+            c.second_stage_balance_fraction, self.seed, stream0, 2, H, W)
+        box_ind = self._box_ind(B, N2, F.device)
+        flat = boxes_norm.view(B * N2, 4)
+        crops, argmax = self._crop(F, flat, box_ind, True)
+        feat, tower_ctx = self.tower.forward(crops, self._is_training)
+        bp = self.box_predictor.predict(feat)
+        out = {
+            "refined_box_encodings": bp["box"].view(B * N2, self.num_classes, 4),
+            "class_predictions_with_background": bp["class"],
+            "num_proposals": num, "proposal_boxes": boxes_abs, "proposal_boxes_normalized": boxes_norm,
+            "_crops": crops, "_argmax": argmax, "_box_ind": box_ind, "_feat": feat,
+            "_tower_ctx": tower_ctx, "_bp": bp,
+        }
+        if mtl.closeness:
+            # stop_gradient_for_aux_tasks only decides whether d(crops) is propagated (:668-673)
+            cfeat, cctx = self.closeness_tower.forward(crops, self._is_training)
+            cp = self.closeness_predictor.predict(cfeat)
+            out.update({"closeness_predictions": cp["class"], "_cfeat": cfeat, "_cctx": cctx, "_cp": cp})
+        return out
+
+    def predict_with_window(self, pd, window_boxes_normalized=None):
+        """faster_rcnn_meta_arch.py:721-755."""
+        F = pd["rpn_features_to_crop"]
+        B = F.shape[0]
+        wb = self._window["boxes"] if window_boxes_normalized is None else window_boxes_normalized
+        Wn = wb.shape[1]
+        flat = wb.reshape(B * Wn, 4)
+        box_ind = self._box_ind(B, Wn, F.device)
+        need_crop_grad = not self._mtl.stop_gradient_for_aux_tasks
+        crops, argmax = self._crop(F, flat, box_ind, need_crop_grad)
+        feat, ctx = self.window_tower.forward(crops, self._is_training)
+        wp = self.window_predictor.predict(feat)
+        pd.update({"window_class_predictions": wp["class"], "_wfeat": feat, "_wctx": ctx, "_wp": wp,
+                   "_wcrops": crops, "_wargmax": argmax, "_wboxes": flat, "_wbox_ind": box_ind})
+        return pd
+
+    def predict_edgemask(self, pd):
+        """faster_rcnn_meta_arch.py:757-762."""
+        pd["edgemask_predictions"] = self.edgemask_conv.forward(pd["rpn_features_to_crop"])
+        return pd
+
+    def predict_with_mtl_results(self, pd):
+        """faster_rcnn_meta_arch.py:764-846, executed per image."""
+        mtl = self._mtl
+        F = pd["rpn_features_to_crop"]
+        B = F.shape[0]
+        N2 = self.max_num_proposals
+        K1 = self.num_classes + 1
+        cls = pd["class_predictions_with_background"]
+        win = None
+        if mtl.window:
+            ew = ops.expand_windows(pd["proposal_boxes_normalized"], self.N_EXPAND)    # [B,5,N2,4]
+            flat = ew.view(B * self.N_EXPAND * N2, 4)
+            box_ind = self._box_ind(B, self.N_EXPAND * N2, F.device)
+            crops, _ = self._crop(F, flat, box_ind, False)
+            feat, _ = self.window_tower.forward(crops, False)               # forward only (:834)
+            win = self.window_predictor.predict(feat)["class"]             # [B*5*N2, K1]
+            pd["expand_window_class_predictions"] = win.view(B, self.N_EXPAND, N2, K1)
+        clo = pd["closeness_predictions"] if mtl.closeness else None
+        net = ops.refine_concat(cls, win, clo, B, N2, self.N_EXPAND, bool(mtl.global_closeness))
+        refined = self.refine_fc.forward(net)
+        if mtl.refine_residue:
+            ops.axpby(cls, refined, 1.0, 1.0)
+        pd["mtl_refined_class_predictions_with_background"] = refined
+        pd["_refine_in"] = net
+        return pd
+
+    # ------------------------------------------------------------------ loss (+ d/d predictions)
+    def loss(self, pd, loss_scale=1.0):
+        """faster_rcnn_meta_arch.py:1514-1589. Returns {name: 1-element device tensor}; the
+        gradients w.r.t. the prediction tensors are stored in pd['_d'] for backward().
+        loss_scale multiplies every gradient (1/world_size for data parallelism,
+        slim/deployment/model_deploy.py:221-223) but not the reported loss values."""
+        c, mtl = self.cfg, self._mtl
+        B, H, W, _ = pd["image_shape"]
+        gt = self._format_groundtruth_data(H, W)
+        dev = self.ps.device
+        losses, d = {}, {}
+        g = float(loss_scale)
+        # ---- _loss_rpn :1591-1668
+        anchors = pd["anchors"]
+        n = anchors.shape[0]
+        um = torch.zeros((1,), dtype=f32, device=dev)
+        tg = ops.assign_targets(anchors, gt["boxes_abs"], gt["num"], None, um, 0.7, 0.3, True)
+        cls_t = tg["cls_targets"].view(B, n)
+        sampled = ops.balanced_sample(tg["cls_weights"], cls_t, int(c.first_stage_minibatch_size),
+                                      c.first_stage_positive_balance_fraction, self.seed,
+                                      (2 * self.step * 65536) & 0xFFFFFFFF, 2)
+        loc_s, obj_s = ops.rpn_loss_scales(sampled, tg["reg_weights"],
+                                           c.first_stage_localization_loss_weight / B,
+                                           c.first_stage_objectness_loss_weight / B)
+        rl, d_enc = ops.smooth_l1(pd["rpn_box_encodings"], tg["reg_targets"], loc_s, 3.0)
+        losses["first_stage_localization_loss"] = ops.reduce_sum(rl)
+        rl, d_obj = ops.softmax_ce(pd["rpn_objectness_predictions_with_background"], ops.onehot2(cls_t), obj_s)
+        losses["first_stage_objectness_loss"] = ops.reduce_sum(rl)
+        d["rpn_box_encodings"], d["rpn_objectness"] = d_enc, d_obj
+        pd["_rpn_targets"] = dict(tg, sampled=sampled)
+        # ---- _loss_box_classifier :1670-1793
+        N2, K, K1 = self.max_num_proposals, self.num_classes, self.num_classes + 1
+        um2 = torch.zeros((K1,), dtype=f32, device=dev)
+        um2[0] = 1
+        dt = ops.assign_targets(pd["proposal_boxes"], gt["boxes_abs"], gt["num"], gt["classes_bg"], um2,
+                                0.5, 0.5, False, gt_extra=gt["closeness"] if mtl.closeness else None)
+        cls_s, loc_s2, clo_s = ops.detector_loss_scales(
+            dt["cls_weights"], dt["reg_weights"], pd["num_proposals"],
+            dt.get("extra_targets") if mtl.closeness else None,
+            c.second_stage_classification_loss_weight, c.second_stage_localization_loss_weight,
+            mtl.closeness_loss_weight)
+        cls_targets = dt["cls_targets"].view(B * N2, K1)
+        rl, d_box = ops.box_select_smooth_l1(pd["refined_box_encodings"], cls_targets,
+                                             dt["reg_targets"].view(B * N2, 4), loc_s2.view(-1), 1.0)
+        losses["second_stage_localization_loss"] = ops.reduce_sum(rl)
+        rl, d_cls = ops.softmax_ce(pd["class_predictions_with_background"], cls_targets, cls_s.view(-1))
+        losses["second_stage_classification_loss"] = ops.reduce_sum(rl)
+        d["refined_box_encodings"], d["class_predictions"] = d_box, d_cls
+        pd["_det_targets"] = dt
+        if mtl.closeness:
+            rl, d_clo = ops.softmax_ce(pd["closeness_predictions"], dt["extra_targets"].view(B * N2, K1),
+                                       clo_s.view(-1), col0=1)
+            losses["closeness_classification_loss"] = ops.reduce_sum(rl)
+            d["closeness_predictions"] = d_clo
+        # ---- _loss_window_class :1839-1858
+        if mtl.window:
+            wc = self._window["classes"].view(-1, K1)
+            ws = torch.full((wc.shape[0],), mtl.window_class_loss_weight / wc.shape[0], dtype=f32, device=dev)
+            rl, d_win = ops.softmax_ce(pd["window_class_predictions"], wc, ws)
+            losses["window_class_loss"] = ops.reduce_sum(rl)
+            d["window_class_predictions"] = d_win
+        # ---- _loss_edgemask :1860-1881
+        if mtl.edgemask:
+            em = self._edgemask
+            mh, mw = em.shape[2], em.shape[3]
+            tgt, sc = ops.edgemask_targets(em, mtl.edgemask_loss_weight / (B * mh * mw))
+            pr = ops.resize_bilinear_fwd(pd["edgemask_predictions"], mh, mw)
+            rl, d_pr = ops.softmax_ce(pr, tgt, sc.view(-1))
+            losses["edgemask_loss"] = ops.reduce_sum(rl)
+            d["edgemask_resized"] = d_pr
+        # ---- _loss_refined_classifier :1795-1837
+        if mtl.refine:
+            rs = cls_s if c.second_stage_classification_loss_weight == mtl.refined_classification_loss_weight \
+                else ops.detector_loss_scales(dt["cls_weights"], dt["reg_weights"], pd["num_proposals"], None,
+                                              mtl.refined_classification_loss_weight, 0.0, 0.0)[0]
+            rl, d_ref = ops.softmax_ce(pd["mtl_refined_class_predictions_with_background"], cls_targets,
+                                       rs.view(-1))
+            losses["refined_classification_loss"] = ops.reduce_sum(rl)
+            d["refined_class_predictions"] = d_ref
+        if g != 1.0:
+            for k in d:
+                ops.axpby(d[k], d[k], g, 0.0)
+        pd["_d"] = d
+        return losses
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, pd):
+        """Accumulates dLoss/dW into the flat gradient buffer (ParamStore.grads)."""
+        mtl = self._mtl
+        d = pd["_d"]
+        F = pd["rpn_features_to_crop"]
+        B = F.shape[0]
+        dF = torch.zeros_like(F)
+        d_cls = d["class_predictions"]
+        # refine: gradient reaches the refiner weights and, through the residual, the class logits
+        if mtl.refine:
+            d_ref = d["refined_class_predictions"]
+            self.refine_fc.wgrad(pd["_refine_in"], d_ref)        # refiner input is stop_gradient (:834)
+            if mtl.refine_residue and not mtl.stop_gradient_for_prediction_org:
+                ops.axpby(d_ref, d_cls, 1.0, 1.0)
+        # main head -> tower -> crops -> dF
+        feat = pd["_feat"]
+        g_feat = self.box_predictor.backward(pd["_bp"], d_cls, d["refined_box_encodings"].view(feat.shape[0], -1),
+                                             feat.shape)
+        g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True)
+        c = self.cfg
+        ops.roi_crop_pool_bwd(g_crops, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
+                              pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
+                              int(c.maxpool_stride), dfeat=dF)
+        stop = bool(mtl.stop_gradient_for_aux_tasks)
+        if mtl.closeness:
+            cfeat = pd["_cfeat"]
+            g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat.shape)
+            gc = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop)
+            if not stop:
+                ops.roi_crop_pool_bwd(gc, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
+                                      pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
+                                      int(c.maxpool_stride), dfeat=dF)
+        if mtl.window:
+            wfeat = pd["_wfeat"]
+            g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat.shape)
+            gw = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop)
+            if not stop:
+                ops.roi_crop_pool_bwd(gw, pd["_wargmax"], F.shape, pd["_wboxes"], pd["_wbox_ind"],
+                                      int(c.initial_crop_size), int(c.maxpool_kernel_size),
+                                      int(c.maxpool_stride), dfeat=dF)
+        if mtl.edgemask:
+            em_pred = pd["edgemask_predictions"]
+            g = ops.resize_bilinear_bwd(d["edgemask_resized"], em_pred.shape)
+            g = ops.tanh_bwd(em_pred, g)
+            self.edgemask_conv.wgrad(F, g)
+            self.edgemask_conv.dgrad(F.shape, g, out=dF, accum=True)
+        # RPN heads
+        rpn_feat = pd["rpn_box_predictor_features"]
+        n_all = pd["_n_all"]
+        g_enc = ops.scatter_rows(d["rpn_box_encodings"], pd["_keep"], n_all).view(B, F.shape[1], F.shape[2], -1)
+        g_obj = ops.scatter_rows(d["rpn_objectness"], pd["_keep"], n_all).view(B, F.shape[1], F.shape[2], -1)
+        self.rpn_box.wgrad(rpn_feat, g_enc)
+        self.rpn_cls.wgrad(rpn_feat, g_obj)
+        g_rf = self.rpn_box.dgrad(rpn_feat.shape, g_enc)
+        relu = self.rpn_conv.activation == "relu"
+        self.rpn_cls.dgrad(rpn_feat.shape, g_obj, out=g_rf, accum=True, mask_ref=rpn_feat if relu else None)
+        self.rpn_conv.wgrad(F, g_rf)
+        # last consumer of F: accumulate and apply the ReLU mask of the trunk output
+        gpF = self.rpn_conv.dgrad(F.shape, g_rf, out=dF, accum=True, mask_ref=F)
+        pd["_gpF"] = gpF
+        self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"])

@@ -1,0 +1,52 @@
+"""model_builder.build — object_detection/builders/model_builder.py:51-95,213-380.
+
+`FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP` is the reference's plugin registry: feature
+extractors register by the `feature_extractor.type` string of the pipeline config.
+"""
+from . import frcnn, resnet
+from .params import ParamStore
+
+
+def _resnet(arch):
+    def make(ps, fe_cfg, is_training):
+        kwargs = {}
+        if fe_cfg.has("weight_decay"):
+            kwargs["weight_decay"] = float(fe_cfg.weight_decay)
+        return resnet.FasterRCNNResnetV1FeatureExtractor(
+            ps, arch, is_training, int(fe_cfg.first_stage_features_stride),
+            freeze_layer=fe_cfg.freeze_layer, batch_norm_trainable=bool(fe_cfg.batch_norm_trainable),
+            **kwargs)
+    return make
+
+
+FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP = {
+    "faster_rcnn_resnet50": _resnet("resnet_v1_50"),
+    "faster_rcnn_resnet101": _resnet("resnet_v1_101"),
+    "faster_rcnn_resnet152": _resnet("resnet_v1_152"),
+}
+
+
+def build(model_config, is_training, device="cuda", seed=0, values=None):
+    """Builds a DetectionModel from a `model { ... }` config message (Msg).
+
+    Raises ValueError on an unknown meta architecture / feature extractor, like the reference
+    (model_builder.py:88-95,176-180)."""
+    which = model_config.which_oneof(["faster_rcnn", "ssd"])
+    if which == "ssd":
+        raise ValueError("ssd meta-architecture is out of scope of this build (SURVEY.md §2.1 #5)")
+    if which != "faster_rcnn":
+        raise ValueError("Unknown meta architecture: {}".format(which))
+    fr = model_config.faster_rcnn
+    fe_cfg = fr.feature_extractor
+    ftype = fe_cfg.get("type")
+    if ftype not in FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP:
+        raise ValueError("Unknown Faster R-CNN feature_extractor: {}".format(ftype))
+    ps = ParamStore()
+    fe = FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP[ftype](ps, fe_cfg, is_training and fe_cfg.trainable)
+    bp = fr.second_stage_box_predictor
+    if bp.has("rfcn_box_predictor"):
+        raise ValueError("rfcn_box_predictor: RFCNMetaArch is not built yet in this round")
+    model = frcnn.FasterRCNNMetaArch(ps, is_training, fr, model_config.mtl, fe, seed=seed)
+    ps.finalize(device, seed=seed, values=values)
+    model.prepare()
+    return model

@@ -1,0 +1,206 @@
+"""Layer objects with explicit forward/backward over the C-ABI kernels (no autograd, no tracing).
+
+Gradient convention between residual units: `backward(gp)` receives gp = dL/d(pre-activation of
+the unit's output) — i.e. already multiplied by the ReLU mask of the unit's output — and returns
+the same quantity for the unit's input. The ReLU masks are applied in the dgrad epilogues, so
+there are no stand-alone elementwise backward kernels in the trunk.
+
+Frozen BatchNorm (the reference always runs BN in inference mode during detector training,
+models/faster_rcnn_resnet_v1_feature_extractor.py:138,171) is folded: w_eff = w * scale[k],
+y = conv(x, w_eff) + shift[k]; dW = scale[k] * wgrad(x, g).
+"""
+import torch
+
+from . import ops
+
+f32 = torch.float32
+
+
+class ConvBN:
+    """slim.conv2d + frozen slim.batch_norm (+ReLU) — slim/nets/resnet_v1.py:102-119."""
+
+    def __init__(self, ps, scope, cin, cout, k, stride=1, dilation=1, padding="SAME",
+                 trainable=True, weight_decay=0.0, eps=1e-5, gamma_init=1.0, relu=True):
+        self.ps, self.scope = ps, scope
+        self.k, self.stride, self.dilation, self.padding, self.eps = k, stride, dilation, padding, eps
+        self.trainable, self.relu = trainable, relu
+        self.w = ps.add(scope + "/weights", (k, k, cin, cout), ("variance_scaling", 2.0, "FAN_IN", False),
+                        trainable, weight_decay)
+        bn = scope + "/BatchNorm/"
+        self.gamma = ps.add(bn + "gamma", (cout,), ("uniform", 0.8 * gamma_init, 1.2 * gamma_init), False)
+        self.beta = ps.add(bn + "beta", (cout,), ("uniform", -0.1, 0.1), False)
+        self.mean = ps.add(bn + "moving_mean", (cout,), ("uniform", -0.1, 0.1), False)
+        self.var = ps.add(bn + "moving_variance", (cout,), ("uniform", 0.8, 1.2), False)
+        self._desc = {}
+        self.w_eff = None
+
+    def prepare(self):
+        ps = self.ps
+        g, b = ps.value(self.gamma.name), ps.value(self.beta.name)
+        m, v = ps.value(self.mean.name), ps.value(self.var.name)
+        self.scale = (g / torch.sqrt(v + self.eps)).contiguous()
+        self.shift = (b - m * self.scale).contiguous()
+        self.w_eff = torch.empty(self.w.shape, dtype=f32, device=ps.device)
+        self.refold()
+
+    def refold(self):
+        ops.scale_channels(self.ps.value(self.w.name), self.scale, self.w_eff)
+
+    def desc(self, shape):
+        d = self._desc.get(tuple(shape))
+        if d is None:
+            d = ops.conv_desc(shape, self.w.shape, self.stride, self.dilation, self.padding)
+            self._desc[tuple(shape)] = d
+        return d
+
+    def forward(self, x, residual=None, relu=None):
+        relu = self.relu if relu is None else relu
+        epi = ops.EPI_BIAS | (ops.EPI_RELU if relu else 0) | (ops.EPI_RESIDUAL if residual is not None else 0)
+        return ops.conv2d_fwd(self.desc(x.shape), x, self.w_eff, self.shift, residual, epi)
+
+    def wgrad(self, x, g):
+        if self.trainable:
+            ops.conv2d_wgrad(self.desc(x.shape), x, g, self.ps.grad(self.w.name), out_scale=self.scale,
+                             beta=1.0)
+
+    def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False):
+        epi = ((ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_MASK if mask_ref is not None else 0)
+               | (ops.EPI_ACCUM if accum else 0))
+        return ops.conv2d_dgrad(self.desc(x_shape), g, self.w_eff, residual, mask_ref, epi, out=out)
+
+
+class Conv:
+    """slim.conv2d / slim.fully_connected with biases, no normaliser (RPN conv, predictors)."""
+
+    def __init__(self, ps, scope, cin, cout, k, init, trainable=True, weight_decay=0.0,
+                 activation=None, fc=False):
+        self.ps, self.scope, self.k, self.trainable, self.activation = ps, scope, k, trainable, activation
+        shape = (cin, cout) if fc else (k, k, cin, cout)
+        self.fc = fc
+        self.w = ps.add(scope + "/weights", shape, init, trainable, weight_decay)
+        self.b = ps.add(scope + "/biases", (cout,), ("zeros",), trainable)
+        self.cin, self.cout = cin, cout
+        self._desc = {}
+
+    def prepare(self):
+        pass
+
+    def refold(self):
+        pass
+
+    def _w4(self):
+        w = self.ps.value(self.w.name)
+        return w.view(1, 1, self.cin, self.cout) if self.fc else w
+
+    def desc(self, shape):
+        d = self._desc.get(tuple(shape))
+        if d is None:
+            d = ops.conv_desc(shape, (self.k, self.k, self.cin, self.cout), 1, 1, "SAME")
+            self._desc[tuple(shape)] = d
+        return d
+
+    def forward(self, x):
+        """x: NHWC, or [rows, cin] for fc=True (treated as rows x 1 x 1 x cin)."""
+        x4 = x.view(x.shape[0], 1, 1, self.cin) if self.fc else x
+        epi = ops.EPI_BIAS | {None: 0, "relu": ops.EPI_RELU, "tanh": ops.EPI_TANH}[self.activation]
+        y = ops.conv2d_fwd(self.desc(x4.shape), x4, self._w4(), self.ps.value(self.b.name), None, epi)
+        return y.view(x.shape[0], self.cout) if self.fc else y
+
+    def wgrad(self, x, g):
+        if not self.trainable:
+            return
+        x4 = x.view(x.shape[0], 1, 1, self.cin) if self.fc else x
+        g4 = g.view(g.shape[0], 1, 1, self.cout) if self.fc else g
+        gw = self.ps.grad(self.w.name)
+        ops.conv2d_wgrad(self.desc(x4.shape), x4, g4, gw.view(self.k, self.k, self.cin, self.cout),
+                         dbias=self.ps.grad(self.b.name), beta=1.0)
+
+    def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False):
+        x4s = (x_shape[0], 1, 1, self.cin) if self.fc else tuple(x_shape)
+        g4 = g.view(g.shape[0], 1, 1, self.cout) if self.fc else g
+        epi = ((ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_MASK if mask_ref is not None else 0)
+               | (ops.EPI_ACCUM if accum else 0))
+        dx = ops.conv2d_dgrad(self.desc(x4s), g4, self._w4(), residual, mask_ref, epi, out=out)
+        return dx.view(x_shape) if self.fc else dx
+
+
+class Bottleneck:
+    """slim/nets/resnet_v1.py:69-130 bottleneck (v1: BN after conv, stride in the 3x3)."""
+
+    def __init__(self, ps, scope, cin, depth, depth_bottleneck, stride, rate=1, trainable=True,
+                 weight_decay=0.0):
+        s = scope + "/bottleneck_v1/"
+        self.stride, self.cin, self.depth = stride, cin, depth
+        self.shortcut = None
+        if depth != cin:
+            self.shortcut = ConvBN(ps, s + "shortcut", cin, depth, 1, stride, 1, "SAME", trainable,
+                                   weight_decay, relu=False)
+        self.conv1 = ConvBN(ps, s + "conv1", cin, depth_bottleneck, 1, 1, 1, "SAME", trainable, weight_decay)
+        self.conv2 = ConvBN(ps, s + "conv2", depth_bottleneck, depth_bottleneck, 3, stride, rate,
+                            "RESNET_SAME", trainable, weight_decay)
+        self.conv3 = ConvBN(ps, s + "conv3", depth_bottleneck, depth, 1, 1, 1, "SAME", trainable,
+                            weight_decay, gamma_init=0.3, relu=True)
+        self.trainable = trainable
+
+    def layers(self):
+        return [l for l in (self.shortcut, self.conv1, self.conv2, self.conv3) if l is not None]
+
+    def forward(self, x, save):
+        if self.shortcut is not None:
+            sc = self.shortcut.forward(x)
+        elif self.stride > 1:
+            sc, _ = ops.maxpool_fwd(x, 1, self.stride, "SAME")     # resnet_utils.subsample
+        else:
+            sc = x
+        a1 = self.conv1.forward(x)
+        a2 = self.conv2.forward(a1)
+        out = self.conv3.forward(a2, residual=sc)
+        ctx = (x, a1, a2, sc if (self.shortcut is None and self.stride > 1) else None) if save else None
+        return out, ctx
+
+    def backward(self, gp, ctx, need_input_grad=True, mask_input=True):
+        """gp: dL/d(pre-activation of out). Returns dL/d(pre-activation of x) (masked by x>0 when
+        mask_input), or None."""
+        x, a1, a2, sc_sub = ctx
+        self.conv3.wgrad(a2, gp)
+        gp2 = self.conv3.dgrad(a2.shape, gp, mask_ref=a2)
+        self.conv2.wgrad(a1, gp2)
+        gp1 = self.conv2.dgrad(a1.shape, gp2, mask_ref=a1)
+        self.conv1.wgrad(x, gp1)
+        if self.shortcut is not None:
+            self.shortcut.wgrad(x, gp)
+        if not need_input_grad:
+            return None
+        if self.shortcut is not None:
+            addend = self.shortcut.dgrad(x.shape, gp)
+        elif self.stride > 1:
+            addend = ops.maxpool_bwd(x, sc_sub, gp, 1, self.stride, (0, 0))
+        else:
+            addend = gp
+        return self.conv1.dgrad(x.shape, gp1, residual=addend, mask_ref=x if mask_input else None)
+
+
+class BlockStack:
+    """resnet_utils.stack_blocks_dense (slim/nets/resnet_utils.py:126-200) for a list of
+    (scope, depth, depth_bottleneck, stride-of-last-unit, num_units, trainable)."""
+
+    def __init__(self, ps, prefix, cin, blocks, output_stride=None, current_stride=1, weight_decay=0.0):
+        self.units = []
+        rate = 1
+        for (scope, base_depth, num_units, stride, trainable) in blocks:
+            for i in range(num_units):
+                ustride = stride if i == num_units - 1 else 1
+                name = "%s/%s/unit_%d" % (prefix, scope, i + 1)
+                if output_stride is not None and current_stride == output_stride:
+                    u = Bottleneck(ps, name, cin, base_depth * 4, base_depth, 1, rate, trainable, weight_decay)
+                    rate *= ustride
+                else:
+                    u = Bottleneck(ps, name, cin, base_depth * 4, base_depth, ustride, 1, trainable, weight_decay)
+                    current_stride *= ustride
+                u.block = scope
+                self.units.append(u)
+                cin = base_depth * 4
+        self.cout = cin
+
+    def layers(self):
+        return [l for u in self.units for l in u.layers()]

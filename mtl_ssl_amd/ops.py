@@ -70,25 +70,69 @@ def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding="SAME"):
     return ConvDesc(N, H, W, C, K, R, S, OH, OW, stride, dilation, pt, pl)
 
 
+class ConvProfiler:
+    """Per-launch HIP-event timing of the conv family, keyed by (mode, tile config). Events are
+    recorded on the stream the kernels are launched on (torch's current stream). Used by bench.py
+    for the `roofline` object; off by default (PROFILER is None)."""
+    MODES = ("fwd", "dgrad", "wgrad")
+
+    def __init__(self):
+        self.pending = []          # (key, flops, start_event, end_event)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, d, mode, start):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        cfg = lib().conv2d_tile_config(ctypes.byref(d), mode)
+        flops = 2.0 * d.N * d.OH * d.OW * d.K * d.C * d.R * d.S
+        self.pending.append(((self.MODES[mode], cfg), flops, start, e))
+
+    def summary(self):
+        """{(mode, cfg): dict(launches, seconds, flops)} — call after torch.cuda.synchronize()."""
+        out = {}
+        for key, flops, s, e in self.pending:
+            r = out.setdefault(key, {"launches": 0, "seconds": 0.0, "flops": 0.0})
+            r["launches"] += 1
+            r["seconds"] += s.elapsed_time(e) * 1e-3
+            r["flops"] += flops
+        return out
+
+
+PROFILER = None
+
+
 def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None):
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
+    t0 = PROFILER.begin() if PROFILER is not None else None
     lib().conv2d_fwd(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(residual),
                      ptr(y), epilogue, _stream())
+    if t0 is not None:
+        PROFILER.end(d, 0, t0)
     return y
 
 
 def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None):
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=f32, device=dy.device)
+    t0 = PROFILER.begin() if PROFILER is not None else None
     lib().conv2d_dgrad(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref),
                        ptr(dx), epilogue, _stream())
+    if t0 is not None:
+        PROFILER.end(d, 1, t0)
     return dx
 
 
 def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0):
     nbytes = lib().conv2d_wgrad_workspace_bytes(ctypes.byref(d))
     ws = workspace(nbytes, "wgrad", x.device)
+    t0 = PROFILER.begin() if PROFILER is not None else None
     lib().conv2d_wgrad(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(dy)), ptr(out_scale), ptr(dw),
                        ptr(dbias), float(beta), ptr(ws), _stream())
+    if t0 is not None:
+        PROFILER.end(d, 2, t0)
     return dw
 
 
@@ -326,13 +370,13 @@ def reduce_sum(x, scale=1.0, out=None):
 
 
 def sgd_momentum_clip(weights, grads, accum, var_offsets, max_var_size, lr, momentum, clip_norm,
-                      grad_scale=1.0):
+                      grad_scale=1.0, var_weight_decay=None):
     nv = var_offsets.numel() - 1
     norms = workspace(4 * max(nv, 1), "norms", weights.device)
     lib().sgd_momentum_clip(ptr(_chk(weights)), ptr(_chk(grads)), ptr(_chk(accum)),
                             ptr(_chk(var_offsets, i32)), nv, weights.numel(), int(max_var_size),
                             float(lr), float(momentum), float(clip_norm), float(grad_scale),
-                            ptr(norms), _stream())
+                            ptr(var_weight_decay), ptr(norms), _stream())
 
 
 def axpby(x, y, a, b):
@@ -351,3 +395,75 @@ def tanh_bwd(y, dy):
     dx = torch.empty_like(dy)
     lib().tanh_bwd(ptr(_chk(y)), ptr(_chk(dy)), ptr(dx), y.numel(), _stream())
     return dx
+
+
+def relu_bwd(y, dy, out=None):
+    dx = out if out is not None else torch.empty_like(dy)
+    lib().relu_bwd(ptr(_chk(y)), ptr(_chk(dy)), ptr(dx), y.numel(), _stream())
+    return dx
+
+
+def bias_add_channels(x, bias):
+    out = torch.empty_like(x)
+    C = x.shape[-1]
+    lib().bias_add_channels(ptr(_chk(x)), ptr(_chk(bias)), ptr(out), x.numel() // C, C, _stream())
+    return out
+
+
+def onehot2(t):
+    out = torch.empty(tuple(t.shape) + (2,), dtype=f32, device=t.device)
+    lib().onehot2(ptr(_chk(t)), ptr(out), t.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------- loss glue
+def rpn_loss_scales(sampled, reg_w, loc_coef, obj_coef):
+    B, n = sampled.shape
+    ls, os_ = torch.empty_like(sampled), torch.empty_like(sampled)
+    lib().rpn_loss_scales(ptr(_chk(sampled)), ptr(_chk(reg_w)), B, n, float(loc_coef), float(obj_coef),
+                          ptr(ls), ptr(os_), _stream())
+    return ls, os_
+
+
+def detector_loss_scales(cls_w, reg_w, num_proposals, closeness_targets, cls_coef, loc_coef, clo_coef):
+    B, n2 = cls_w.shape
+    k1 = closeness_targets.shape[-1] if closeness_targets is not None else 0
+    cs, ls = torch.empty_like(cls_w), torch.empty_like(cls_w)
+    qs = torch.empty_like(cls_w) if closeness_targets is not None else None
+    lib().detector_loss_scales(ptr(_chk(cls_w)), ptr(_chk(reg_w)), ptr(_chk(num_proposals, i32)),
+                               ptr(closeness_targets), B, n2, k1, float(cls_coef), float(loc_coef),
+                               float(clo_coef), ptr(cs), ptr(ls), ptr(qs), _stream())
+    return cs, ls, qs
+
+
+def box_select_smooth_l1(refined, cls_targets, reg_targets, row_scale, sigma=1.0, want_grad=True):
+    rows, K = refined.shape[0], refined.shape[1]
+    rl = torch.empty((rows,), dtype=f32, device=refined.device)
+    dr = torch.empty_like(refined) if want_grad else None
+    lib().box_select_smooth_l1(ptr(_chk(refined)), ptr(_chk(cls_targets)), ptr(_chk(reg_targets)),
+                               ptr(_chk(row_scale)), rows, K, float(sigma), ptr(rl), ptr(dr), _stream())
+    return rl, dr
+
+
+def edgemask_targets(gt, coef):
+    B, _, H, W = gt.shape
+    tgt = torch.empty((B, H, W, 2), dtype=f32, device=gt.device)
+    sc = torch.empty((B, H, W), dtype=f32, device=gt.device)
+    lib().edgemask_targets(ptr(_chk(gt)), B, H, W, float(coef), ptr(tgt), ptr(sc), _stream())
+    return tgt, sc
+
+
+def expand_windows(proposals_norm, n_expand=5):
+    B, n2, _ = proposals_norm.shape
+    out = torch.empty((B, n_expand, n2, 4), dtype=f32, device=proposals_norm.device)
+    lib().expand_windows(ptr(_chk(proposals_norm)), B, n2, n_expand, ptr(out), _stream())
+    return out
+
+
+def refine_concat(cls, win, clo, B, n2, n_expand, global_closeness):
+    k1 = cls.shape[-1]
+    ld = k1 + (n_expand * k1 if win is not None else 0) + (k1 if clo is not None else 0)
+    out = torch.empty((B * n2, ld), dtype=f32, device=cls.device)
+    lib().refine_concat(ptr(_chk(cls)), ptr(win), ptr(clo), B, n2, k1, n_expand, int(global_closeness),
+                        ptr(out), _stream())
+    return out

@@ -1,0 +1,200 @@
+"""Whole-step CPU oracle: Faster R-CNN ResNet-v1 + window / closeness / edgemask heads + refine,
+forward + losses on torch-CPU fp32 with autograd for the gradients (test infrastructure).
+
+Independent restatement of object_detection/meta_architectures/faster_rcnn_meta_arch.py
+(predict :507-846, loss :1514-1881) + models/faster_rcnn_resnet_v1_feature_extractor.py +
+slim/nets/resnet_v1.py / resnet_utils.py. Variables are looked up by the reference's names.
+Parity pinning: the detection arithmetic is pinned by tests/test_oracle_golden.py; the conv /
+crop / resize / aux-loss pieces are "parity unpinned" (TensorFlow 1.7 is absent; see
+oracle/__init__.py).
+"""
+import numpy as np
+import torch
+
+from . import boxes as B
+from . import frcnn_losses as L
+from . import nms as N
+from . import ops_torch as T
+
+F = np.float32
+UNITS = {"resnet_v1_50": (3, 4, 6, 3), "resnet_v1_101": (3, 4, 23, 3), "resnet_v1_152": (3, 8, 36, 3)}
+MEANS = (123.68, 116.779, 103.939)
+
+
+class Oracle:
+    def __init__(self, hp, values):
+        """hp: dict of hyper-parameters (see tests/test_gpu_model.py); values: {name: ndarray}."""
+        self.hp = hp
+        self.v = {k: torch.tensor(np.asarray(a, F), requires_grad=True) for k, a in values.items()}
+
+    # ------------------------------------------------------------------ building blocks
+    def conv_bn(self, x, scope, stride=1, rate=1, relu=True, same="SAME"):
+        w = self.v[scope + "/weights"]
+        if same == "RESNET":
+            y = T.conv2d_same(x, w, stride, rate)
+        else:
+            y = T.conv2d(x, w, stride, rate, "SAME")
+        bn = scope + "/BatchNorm/"
+        y = T.frozen_bn(y, self.v[bn + "gamma"].detach(), self.v[bn + "beta"].detach(),
+                        self.v[bn + "moving_mean"].detach(), self.v[bn + "moving_variance"].detach(), 1e-5)
+        return torch.relu(y) if relu else y
+
+    def bottleneck(self, x, scope, depth, stride, rate):
+        s = scope + "/bottleneck_v1/"
+        if depth == x.shape[-1]:
+            sc = x if stride == 1 else T.max_pool(x, 1, stride, "SAME")
+        else:
+            sc = self.conv_bn(x, s + "shortcut", stride, 1, relu=False)
+        r = self.conv_bn(x, s + "conv1")
+        r = self.conv_bn(r, s + "conv2", stride, rate, same="RESNET")
+        r = self.conv_bn(r, s + "conv3", relu=False)
+        return torch.relu(sc + r)
+
+    def trunk(self, x):
+        """resnet_v1 to block3 with output_stride 16 (slim/nets/resnet_v1.py:133-237)."""
+        hp = self.hp
+        p = "FirstStageFeatureExtractor/%s" % hp["arch"]
+        x = self.conv_bn(x, p + "/conv1", 2, 1, same="RESNET")
+        x = T.max_pool(x, 3, 2, "SAME")
+        units = UNITS[hp["arch"]]
+        cur, rate, target = 1, 1, hp.get("stride", 16) // 4
+        for bi, (name, base, st) in enumerate((("block1", 64, 2), ("block2", 128, 2), ("block3", 256, 2))):
+            for u in range(units[bi]):
+                ust = st if u == units[bi] - 1 else 1
+                sc = "%s/%s/unit_%d" % (p, name, u + 1)
+                if cur == target:
+                    x = self.bottleneck(x, sc, base * 4, 1, rate)
+                    rate *= ust
+                else:
+                    x = self.bottleneck(x, sc, base * 4, ust, 1)
+                    cur *= ust
+        return x
+
+    def tower(self, crops, scope):
+        p = "%s/%s/block4" % (scope, self.hp["arch"])
+        x = crops
+        for u in range(3):
+            x = self.bottleneck(x, "%s/unit_%d" % (p, u + 1), 2048, 1, 1)
+        return x
+
+    def fc(self, x, scope):
+        return x @ self.v[scope + "/weights"] + self.v[scope + "/biases"]
+
+    def conv(self, x, scope, act=None):
+        y = T.conv2d(x, self.v[scope + "/weights"], 1, 1, "SAME") + self.v[scope + "/biases"]
+        return {None: y, "relu": torch.relu(y), "tanh": torch.tanh(y)}[act]
+
+    def crop(self, feat, boxes_norm, box_ind):
+        hp = self.hp
+        c = T.crop_and_resize(feat, boxes_norm, box_ind, hp["initial_crop_size"])
+        if hp["maxpool_kernel_size"] > 1 or hp["maxpool_stride"] > 1:
+            c = T.max_pool(c, hp["maxpool_kernel_size"], hp["maxpool_stride"], "VALID")
+        return c
+
+    # ------------------------------------------------------------------ one training step
+    def step(self, batch, seed, step=0):
+        """Returns (losses {name: float}, grads {name: ndarray}, aux dict)."""
+        hp = self.hp
+        mtl = hp["mtl"]
+        img = torch.as_tensor(np.asarray(batch["images"], F))
+        Bn, H, W, _ = img.shape
+        K = hp["num_classes"]
+        K1 = K + 1
+        x = img - torch.tensor(MEANS)
+        Fm = self.trunk(x)
+        Fm.retain_grad()
+        Hf, Wf = Fm.shape[1], Fm.shape[2]
+        anchors_all = B.grid_anchors(Hf, Wf, hp["scales"], hp["aspect_ratios"], (256.0, 256.0),
+                                     (16.0, 16.0), (0.0, 0.0))
+        anchors, keep = B.prune_outside_window(anchors_all, [0, 0, H, W])
+        A = len(hp["scales"]) * len(hp["aspect_ratios"])
+        rf = self.conv(Fm, "FirstStageBoxPredictor/Conv", "relu")
+        enc = self.conv(rf, "FirstStageBoxPredictor/BoxEncodingPredictor").reshape(Bn, -1, 4)[:, keep]
+        obj = self.conv(rf, "FirstStageBoxPredictor/ClassPredictor").reshape(Bn, -1, 2)[:, keep]
+        gt_abs = [B.to_absolute(np.asarray(g, F), H, W) for g in batch["groundtruth_boxes"]]
+        gt_cls_bg = [np.pad(np.asarray(c, F), [[0, 0], [1, 0]]) for c in batch["groundtruth_classes"]]
+        gt_clo = [np.asarray(c, F) for c in batch["groundtruth_closeness"]] if mtl["closeness"] else None
+        # proposals (no gradient: tf.stop_gradient, faster_rcnn_meta_arch.py:1117)
+        pb, _, _, pn = N.rpn_proposals(enc.detach().numpy(), obj.detach().numpy(), anchors, (H, W),
+                                       hp["nms_score_threshold"], hp["nms_iou_threshold"], hp["max_proposals"])
+        N2 = hp["second_stage_batch_size"]
+        boxes_abs, num, _ = L.sample_box_classifier_batch(pb, pn, gt_abs, gt_cls_bg, N2,
+                                                          hp["second_stage_balance_fraction"], seed, step)
+        boxes_norm = np.stack([B.to_normalized(boxes_abs[b], H, W) for b in range(Bn)])
+        box_ind = np.repeat(np.arange(Bn), N2)
+        crops = self.crop(Fm, boxes_norm.reshape(-1, 4), box_ind)
+        feat = self.tower(crops, "SecondStageFeatureExtractor").mean((1, 2))
+        box_enc = self.fc(feat, "SecondStageBoxPredictor/BoxEncodingPredictor").reshape(Bn * N2, K, 4)
+        cls = self.fc(feat, "SecondStageBoxPredictor/ClassPredictor")
+        aux_crops = crops.detach() if mtl["stop_gradient_for_aux_tasks"] else crops
+        clo = None
+        if mtl["closeness"]:
+            cf = self.tower(aux_crops, "ClosenessBoxPredictor").mean((1, 2))
+            clo = self.fc(cf, "ClosenessBoxPredictor/ClassPredictor")
+        losses = {}
+        # ---- RPN loss
+        tg = L.rpn_targets(anchors, gt_abs, hp["first_stage_minibatch_size"],
+                           hp["first_stage_positive_balance_fraction"], seed, step)
+        losses.update(L.loss_rpn(enc, obj, tg, hp["first_stage_localization_loss_weight"],
+                                 hp["first_stage_objectness_loss_weight"]))
+        # ---- detector loss
+        dt = L.detector_targets(boxes_abs, gt_abs, gt_cls_bg, gt_clo)
+        losses.update(L.loss_box_classifier(box_enc, cls, num, dt,
+                                            hp["second_stage_localization_loss_weight"],
+                                            hp["second_stage_classification_loss_weight"],
+                                            clo if mtl["closeness"] else None, mtl["closeness_loss_weight"]))
+        win_logits = None
+        if mtl["window"]:
+            wb = np.stack([np.asarray(w, F) for w in batch["window_boxes"]])
+            Wn = wb.shape[1]
+            wc = self.crop(Fm, wb.reshape(-1, 4), np.repeat(np.arange(Bn), Wn))
+            if mtl["stop_gradient_for_aux_tasks"]:
+                wc = wc.detach()
+            wf = self.tower(wc, "WindowBoxPredictor").mean((1, 2))
+            win_logits = self.fc(wf, "WindowBoxPredictor/ClassPredictor")
+            losses.update(L.loss_window_class(win_logits, np.stack(batch["window_classes"]),
+                                              mtl["window_class_loss_weight"]))
+        if mtl["edgemask"]:
+            em = self.conv(Fm, "EdgeMaskPredictor/BoxEncodingPredictor", "tanh")
+            losses.update(L.loss_edgemask(em, np.stack(batch["groundtruth_edgemask"]),
+                                          mtl["edgemask_loss_weight"]))
+        refined = None
+        if mtl["refine"]:
+            src = [cls]
+            if mtl["window"]:
+                per_img = []
+                for b in range(Bn):                       # per image == per clone
+                    pbn = boxes_norm[b]
+                    ymin, xmin, ymax, xmax = pbn[:, 0], pbn[:, 1], pbn[:, 2], pbn[:, 3]
+                    ne = F(4)
+                    wins = []
+                    for i in range(5):
+                        fi = F(i)
+                        wins.append(np.stack([ymin - ymin / ne * fi, xmin - xmin / ne * fi,
+                                              ymax + (F(1) - ymax) / ne * fi,
+                                              xmax + (F(1) - xmax) / ne * fi], 1).astype(F))
+                    ew = np.concatenate(wins, 0)                       # [5*N2,4], window-major
+                    ec = self.crop(Fm.detach(), ew, np.full(len(ew), b))
+                    ef = self.tower(ec, "WindowBoxPredictor").mean((1, 2))
+                    ep = self.fc(ef, "WindowBoxPredictor/ClassPredictor")          # [5*N2,K1]
+                    per_img.append(ep.reshape(5, N2, K1).permute(1, 0, 2).reshape(N2, 5 * K1))
+                src.append(torch.cat(per_img, 0))
+            if mtl["closeness"]:
+                c3 = clo.reshape(Bn, N2, K1)
+                if mtl["global_closeness"]:
+                    c3 = c3.mean(1, keepdim=True).expand(Bn, N2, K1)
+                src.append(c3.reshape(Bn * N2, K1))
+            net = torch.cat(src, 1).detach()                               # tf.stop_gradient :834
+            refined = self.fc(net, "MTLClassRefiner/fc1")
+            if mtl["refine_residue"]:
+                refined = refined + cls
+            losses.update(L.loss_refined_classifier(refined, num, dt, mtl["refined_classification_loss_weight"]))
+        total = sum(losses.values())
+        total.backward()
+        grads = {k: t.grad.numpy() for k, t in self.v.items() if t.grad is not None}
+        aux = dict(proposal_boxes=boxes_abs, num_proposals=num, rpn_match=tg["match"],
+                   rpn_sampled=tg["samp"], det_match=dt["match"], rpn_box_encodings=enc.detach().numpy(),
+                   class_predictions=cls.detach().numpy(), features=Fm.detach().numpy(),
+                   refined=None if refined is None else refined.detach().numpy(),
+                   d_features=Fm.grad.numpy())
+        return {k: float(v) for k, v in losses.items()}, grads, aux
