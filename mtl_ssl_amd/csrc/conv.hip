@@ -17,6 +17,7 @@
 namespace mtlssl {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 constexpr int BK = 16;
@@ -33,9 +34,19 @@ struct ConvArgs {
   int NG;                // GEMM cols
   int epi;
   int tiles_m, tiles_n;
+  unsigned a_bytes, b_bytes;   // extents of the a / b tensors (buffer-load range checks)
   int nsplit;            // wgrad: splits of the pixel range
   int pix_per_split;     // wgrad
 };
+
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ floatx4 bufload4(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset,
+                                            unsigned soffset) {
+  // raw buffer load: an offset beyond num_records returns zeros, which is exactly the zero
+  // padding / ragged-tile semantics the gathers need — no branches around the loads.
+  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+}
 
 template <int BM, int BN, int MODE>
 __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
@@ -44,8 +55,10 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);     // A float4 runs along k (else along m)
   constexpr bool B_KC = (MODE == MODE_DGRAD);     // B float4 runs along k (else along n)
   constexpr int A_LD = BM / 64, B_LD = BN / 64;   // float4 loads per thread per K-step
-  __shared__ __attribute__((aligned(16))) float sA[2][BK * LDA];
-  __shared__ __attribute__((aligned(16))) float sB[2][BK * LDB];
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+  float* const sA = smem;
+  float* const sB = smem + 2 * BK * LDA;
 
   // XCD-aware tile order: the dispatcher places block b on XCD b%8; give each XCD a contiguous
   // range of tiles (n fastest) so blocks sharing an A row-panel share an L2.
@@ -60,6 +73,12 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int lo = lane & 31, hi = lane >> 5;
+  const int kq4 = (tid & 3) * 4;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
 
   // ---- K-loop extent
   int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps;
@@ -76,11 +95,12 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
     ksteps = (max(pix1 - pix0, 0) + BK - 1) / BK;
   }
 
-  // ---- per-thread gather state for the rows this thread stages
-  // KC loaders: thread -> (row = tid/4 + 64*i, kq = tid%4)   [float4 along k]
-  // MC loaders: thread -> (krow = tid/(B?/4) + pass, col4)   [float4 along m or n]
-  int a_n[A_LD], a_y[A_LD], a_x[A_LD];
+  // ---- per-thread gather state (32-bit element offsets; the host guarantees < 2^30 elements)
+  // KC loaders: thread -> (row = tid/4 + 64*i, 4 consecutive k at kq4)
+  // MC loaders: thread -> float4 unit u = tid + 256*i of the [16][B?/4] tile
+  int a_base[A_LD], a_y[A_LD], a_x[A_LD], a_n[A_LD];
   bool a_ok[A_LD];
+  unsigned b_base[B_LD];
   if constexpr (A_KC) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
@@ -92,59 +112,74 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
         a_x[i] = ow * p.stride - p.pl;
         a_y[i] = (t % p.OH) * p.stride - p.pt;
         a_n[i] = t / p.OH;
+        a_base[i] = ((a_n[i] * p.H + a_y[i]) * p.W + a_x[i]) * p.C + kq4;
       } else {
         int iw = mm % p.W, t = mm / p.W;
         a_x[i] = iw + p.pl;
         a_y[i] = (t % p.H) + p.pt;
         a_n[i] = t / p.H;
+        a_base[i] = ((a_n[i] * p.OH + a_y[i]) * p.OW + a_x[i]) * p.K + kq4;   // stride-1 form
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    if constexpr (MODE == MODE_FWD) {
+      int u = tid + 256 * i;
+      b_base[i] = (unsigned)((u / (BN / 4)) * p.K + n0 + (u % (BN / 4)) * 4) * 4u;
+    } else if constexpr (MODE == MODE_DGRAD) {
+      b_base[i] = (unsigned)((n0 + (tid >> 2) + 64 * i) * p.K + kq4) * 4u;
+    } else {
+      int u = tid + 256 * i;
+      b_base[i] = (unsigned)(n0 + (u % (BN / 4)) * 4) * 4u;
+    }
+  }
 
-  float4 ra[A_LD], rb[B_LD];
+  floatx4 ra[A_LD], rb[B_LD];
 
   auto load_tile = [&](int ks) {
     if constexpr (MODE == MODE_FWD) {
       int cpk = p.C / BK;
       int rs = ks / cpk, c0 = (ks - rs * cpk) * BK;
       int r = rs / p.S, s = rs - r * p.S;
+      int dy = r * p.dil, dx = s * p.dil;
+      int tapoff = (dy * p.W + dx) * p.C + c0;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
-        int ih = a_y[i] + r * p.dil, iw = a_x[i] + s * p.dil;
-        bool ok = a_ok[i] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-        ra[i] = ok ? *reinterpret_cast<const float4*>(
-                         p.a + (((int64_t)a_n[i] * p.H + ih) * p.W + iw) * p.C + c0 + (tid & 3) * 4)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        int ih = a_y[i] + dy, iw = a_x[i] + dx;
+        bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        ra[i] = bufload4(rsrc_a, ok ? (unsigned)(a_base[i] + tapoff) * 4u : OOB, 0);
       }
+      unsigned so = (unsigned)(ks * BK * p.K) * 4u;
 #pragma unroll
-      for (int i = 0; i < B_LD; ++i) {
-        int u = tid + 256 * i;                 // float4 unit in the [16][BN/4] tile
-        int kr = u / (BN / 4), n4 = u % (BN / 4);
-        rb[i] = *reinterpret_cast<const float4*>(p.b + ((int64_t)ks * BK + kr) * p.K + n0 + n4 * 4);
-      }
+      for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, b_base[i], so);
     } else if constexpr (MODE == MODE_DGRAD) {
       int kpk = p.K / BK;
       int rs = ks / kpk, k0 = (ks - rs * kpk) * BK;
       int r = rs / p.S, s = rs - r * p.S;
+      int dy = r * p.dil, dx = s * p.dil;
+      if (p.stride == 1) {
+        int tapoff = k0 - (dy * p.OW + dx) * p.K;
 #pragma unroll
-      for (int i = 0; i < A_LD; ++i) {
-        int ny = a_y[i] - r * p.dil, nx = a_x[i] - s * p.dil;
-        bool ok = a_ok[i] && ny >= 0 && nx >= 0;
-        int oh = ny, ow = nx;
-        if (p.stride > 1) {
-          ok = ok && (ny % p.stride == 0) && (nx % p.stride == 0);
-          oh = ny / p.stride; ow = nx / p.stride;
+        for (int i = 0; i < A_LD; ++i) {
+          int oh = a_y[i] - dy, ow = a_x[i] - dx;
+          bool ok = a_ok[i] && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
+          ra[i] = bufload4(rsrc_a, ok ? (unsigned)(a_base[i] + tapoff) * 4u : OOB, 0);
         }
-        ok = ok && oh < p.OH && ow < p.OW;
-        ra[i] = ok ? *reinterpret_cast<const float4*>(
-                         p.a + (((int64_t)a_n[i] * p.OH + oh) * p.OW + ow) * p.K + k0 + (tid & 3) * 4)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      } else {
 #pragma unroll
-      for (int i = 0; i < B_LD; ++i) {
-        int c = n0 + (tid >> 2) + 64 * i;      // GEMM column = input channel
-        rb[i] = *reinterpret_cast<const float4*>(p.b + ((int64_t)rs * p.C + c) * p.K + k0 + (tid & 3) * 4);
+        for (int i = 0; i < A_LD; ++i) {
+          int ny = a_y[i] - dy, nx = a_x[i] - dx;
+          bool ok = a_ok[i] && ny >= 0 && nx >= 0 && (ny % p.stride == 0) && (nx % p.stride == 0);
+          int oh = ny / p.stride, ow = nx / p.stride;
+          ok = ok && oh < p.OH && ow < p.OW;
+          int off = ((a_n[i] * p.OH + oh) * p.OW + ow) * p.K + k0 + kq4;
+          ra[i] = bufload4(rsrc_a, ok ? (unsigned)off * 4u : OOB, 0);
+        }
       }
+      unsigned so = (unsigned)(rs * p.C * p.K + k0) * 4u;
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, b_base[i], so);
     } else {
       int r = rs_fixed / p.S, s = rs_fixed - r * p.S;
 #pragma unroll
@@ -153,57 +188,50 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
         int kr = u / (BM / 4), m4 = u % (BM / 4);
         int pix = pix0 + ks * BK + kr;
         bool ok = pix < pix1;
-        int64_t off = 0;
-        if (ok) {
-          if (p.R == 1 && p.S == 1 && p.stride == 1) {
-            off = (int64_t)pix * p.C;
-          } else {
-            int ow = pix % p.OW, t = pix / p.OW;
-            int oh = t % p.OH, n = t / p.OH;
-            int ih = oh * p.stride - p.pt + r * p.dil, iw = ow * p.stride - p.pl + s * p.dil;
-            ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            off = (((int64_t)n * p.H + ih) * p.W + iw) * p.C;
-          }
+        int off = 0;
+        if (p.R == 1 && p.S == 1 && p.stride == 1) {
+          off = pix * p.C;
+        } else {
+          int ow = pix % p.OW, t = pix / p.OW;
+          int oh = t % p.OH, n = t / p.OH;
+          int ih = oh * p.stride - p.pt + r * p.dil, iw = ow * p.stride - p.pl + s * p.dil;
+          ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          off = ((n * p.H + ih) * p.W + iw) * p.C;
         }
-        ra[i] = ok ? *reinterpret_cast<const float4*>(p.a + off + m0 + m4 * 4)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        ra[i] = bufload4(rsrc_a, ok ? (unsigned)(off + m0 + m4 * 4) * 4u : OOB, 0);
       }
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
         int u = tid + 256 * i;
-        int kr = u / (BN / 4), n4 = u % (BN / 4);
-        int pix = pix0 + ks * BK + kr;
-        rb[i] = pix < pix1 ? *reinterpret_cast<const float4*>(p.b + (int64_t)pix * p.K + n0 + n4 * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        int pix = pix0 + ks * BK + u / (BN / 4);
+        rb[i] = bufload4(rsrc_b, pix < pix1 ? b_base[i] + (unsigned)(pix * p.K) * 4u : OOB, 0);
       }
     }
   };
 
   auto store_tile = [&](int buf) {
-    float* a = sA[buf];
-    float* b = sB[buf];
+    float* a = sA + buf * (BK * LDA);
+    float* b = sB + buf * (BK * LDB);
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       if constexpr (A_KC) {
-        int row = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
-        a[(k + 0) * LDA + row] = ra[i].x; a[(k + 1) * LDA + row] = ra[i].y;
-        a[(k + 2) * LDA + row] = ra[i].z; a[(k + 3) * LDA + row] = ra[i].w;
+        int row = (tid >> 2) + 64 * i;
+        a[(kq4 + 0) * LDA + row] = ra[i].x; a[(kq4 + 1) * LDA + row] = ra[i].y;
+        a[(kq4 + 2) * LDA + row] = ra[i].z; a[(kq4 + 3) * LDA + row] = ra[i].w;
       } else {
         int u = tid + 256 * i;
-        int kr = u / (BM / 4), m4 = u % (BM / 4);
-        *reinterpret_cast<float4*>(a + kr * LDA + m4 * 4) = ra[i];
+        *reinterpret_cast<floatx4*>(a + (u / (BM / 4)) * LDA + (u % (BM / 4)) * 4) = ra[i];
       }
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       if constexpr (B_KC) {
-        int row = (tid >> 2) + 64 * i, k = (tid & 3) * 4;
-        b[(k + 0) * LDB + row] = rb[i].x; b[(k + 1) * LDB + row] = rb[i].y;
-        b[(k + 2) * LDB + row] = rb[i].z; b[(k + 3) * LDB + row] = rb[i].w;
+        int row = (tid >> 2) + 64 * i;
+        b[(kq4 + 0) * LDB + row] = rb[i].x; b[(kq4 + 1) * LDB + row] = rb[i].y;
+        b[(kq4 + 2) * LDB + row] = rb[i].z; b[(kq4 + 3) * LDB + row] = rb[i].w;
       } else {
         int u = tid + 256 * i;
-        int kr = u / (BN / 4), n4 = u % (BN / 4);
-        *reinterpret_cast<float4*>(b + kr * LDB + n4 * 4) = rb[i];
+        *reinterpret_cast<floatx4*>(b + (u / (BN / 4)) * LDB + (u % (BN / 4)) * 4) = rb[i];
       }
     }
   };
@@ -224,20 +252,33 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
   for (int ks = 0; ks < ksteps; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < ksteps) load_tile(ks + 1);
-    const float* a = sA[cur] + wr * (BM / 2) + lo;
-    const float* b = sB[cur] + wc * (BN / 2) + lo;
+    const float* a = sA + cur * (BK * LDA) + wr * (BM / 2) + lo;
+    const float* b = sB + cur * (BK * LDB) + wc * (BN / 2) + lo;
+    // Software-pipelined fragments: the ds_reads of k-pair kk+1 are issued BEFORE the MFMAs of
+    // k-pair kk (two register sets), pinned with sched_barrier so hipcc does not re-serialise them
+    // into read -> wait -> MFMA; LDS latency is then exposed once per K-step instead of 8 times.
+    float fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = a[hi * LDA + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = b[hi * LDB + j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float fa[TM], fb[TN];
+      const int cs = kk & 1, ns = cs ^ 1;
+      if (kk + 1 < BK / 2) {
+        const int kr = 2 * (kk + 1) + hi;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = a[(2 * kk + hi) * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) fa[ns][i] = a[kr * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = b[(2 * kk + hi) * LDB + j * 32];
+        for (int j = 0; j < TN; ++j) fb[ns][j] = b[kr * LDB + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cs][i], fb[cs][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (ks + 1 < ksteps) store_tile(cur ^ 1);
     __syncthreads();
@@ -394,6 +435,176 @@ __global__ void k_conv_direct_wgrad(ConvArgs p, const float* scale, float* dw, f
   }
 }
 
+// ------------------------------------------------------------------------------ small layers
+// 1x1 stride-1 layers whose channel counts do not fit the MFMA tiling (RPN heads 512->48/24,
+// FC heads 2048->360/91, edgemask 1024->2, refiner 637->91): plain GEMMs. VALU kernel, 64x64x16
+// tile, 4x4 outputs per thread, every access bounds-checked (no alignment assumptions). These
+// layers are ~6 GFLOP per step (<0.1 % of the step) so the goal is just "not slow".
+//   GM_FWD  : out[m][n] = sum_k A[m][k] * B[k][n]            A = x [M,K],  B = w [K,N]
+//   GM_DGRAD: out[m][n] = sum_k A[m][k] * B[n][k]            A = dy [M,K], B = w [N,K] (w is [C,Kout])
+//   GM_WGRAD: out[z][m][n] = sum_{k in split z} A[k][m] * B[k][n]   A = x [P,C], B = dy [P,Kout]
+enum { GM_FWD = 0, GM_DGRAD = 1, GM_WGRAD = 2 };
+struct GemmArgs {
+  const float* a; const float* b; float* out;
+  const float* bias; const float* residual; const float* mask;
+  int M, N, K, epi, k_per_split;
+};
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gemm_small(GemmArgs p) {
+  __shared__ float sA[16][64 + 1];
+  __shared__ float sB[16][64 + 1];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  int k_lo = 0, k_hi = p.K;
+  if constexpr (MODE == GM_WGRAD) {
+    k_lo = blockIdx.z * p.k_per_split;
+    k_hi = min(p.K, k_lo + p.k_per_split);
+  }
+  float acc[4][4] = {};
+  for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+    // stage A (as sA[k][m]) and B (as sB[k][n]); consecutive threads walk the contiguous axis
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int u = tid + 256 * e;                      // 1024 elements per operand tile
+      if constexpr (MODE == GM_WGRAD) {           // A[k][m]: m contiguous
+        int k = u >> 6, m = u & 63;
+        sA[k][m] = (k0 + k < k_hi && m0 + m < p.M) ? p.a[(int64_t)(k0 + k) * p.M + m0 + m] : 0.f;
+      } else {                                    // A[m][k]: k contiguous
+        int m = u >> 4, k = u & 15;
+        sA[k][m] = (k0 + k < k_hi && m0 + m < p.M) ? p.a[(int64_t)(m0 + m) * p.K + k0 + k] : 0.f;
+      }
+      if constexpr (MODE == GM_DGRAD) {           // B[n][k]: k contiguous
+        int n = u >> 4, k = u & 15;
+        sB[k][n] = (k0 + k < k_hi && n0 + n < p.N) ? p.b[(int64_t)(n0 + n) * p.K + k0 + k] : 0.f;
+      } else {                                    // B[k][n]: n contiguous
+        int k = u >> 6, n = u & 63;
+        sB[k][n] = (k0 + k < k_hi && n0 + n < p.N) ? p.b[(int64_t)(k0 + k) * p.N + n0 + n] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = sA[k][ty + 16 * i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = sB[k][tx + 16 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  float* outp = p.out;
+  if constexpr (MODE == GM_WGRAD) outp += (int64_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + ty + 16 * i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int n = n0 + tx + 16 * j;
+      if (n >= p.N) continue;
+      int64_t o = (int64_t)m * p.N + n;
+      float v = acc[i][j];
+      if constexpr (MODE == GM_FWD) {
+        if (p.epi & MTLSSL_EPI_BIAS) v += p.bias[n];
+        if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
+        if (p.epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
+        if (p.epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+        if (p.epi & MTLSSL_EPI_TANH) v = tanhf(v);
+      } else if constexpr (MODE == GM_DGRAD) {
+        if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
+        if (p.epi & MTLSSL_EPI_ACCUM) v += outp[o];
+        if (p.epi & MTLSSL_EPI_MASK) v = p.mask[o] > 0.f ? v : 0.f;
+      }
+      outp[o] = v;
+    }
+  }
+}
+// Fold of the small wgrad partials (+ BN scale, beta) — scalar version of k_wgrad_reduce.
+__global__ void k_small_reduce(const float* ws, int nsplit, int64_t total, int K, const float* scale,
+                               float* dw, float beta) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += ws[(int64_t)k * total + i];
+  if (scale) s *= scale[i % K];
+  dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+}
+// dbias: two-stage column sum, rows split over blockIdx.y; partials [gridDim.y][K] in workspace.
+__global__ void __launch_bounds__(256) k_colsum_partial(const float* dy, int64_t rows, int K,
+                                                        int rows_per_block, float* part) {
+  __shared__ float s[4][64];
+  int k = blockIdx.x * 64 + (threadIdx.x & 63);
+  int w = threadIdx.x >> 6;
+  int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float acc = 0.f;
+  if (k < K)
+    for (int64_t r = r0 + w; r < r1; r += 4) acc += dy[r * K + k];
+  s[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && k < K)
+    part[(int64_t)blockIdx.y * K + k] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+
+// Stem: 7x7/2 conv on 3 input channels -> 64 (slim/nets/resnet_v1.py:216-219). Weights and the
+// input patch of a 16x16 output tile live in LDS; each thread owns 2x2 pixels x 16 channels.
+// fp32 VALU (K_gemm = 147 is too ragged for the 16-wide MFMA K-step; ~23 GFLOP per step).
+constexpr int STEM_T = 16;
+__global__ void __launch_bounds__(256) k_conv_smallc_fwd(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int RSC = p.R * p.S * p.C;
+  float* sW = sm;                                    // [RSC][64]
+  const int PH = (STEM_T - 1) * p.stride + (p.R - 1) * p.dil + 1;
+  const int PW = (STEM_T - 1) * p.stride + (p.S - 1) * p.dil + 1;
+  float* sX = sm + RSC * 64;                         // [PH][PW][C]
+  const int tid = threadIdx.x;
+  const int n = blockIdx.z, oy0 = blockIdx.y * STEM_T, ox0 = blockIdx.x * STEM_T;
+  for (int i = tid; i < RSC * 64; i += 256) sW[i] = p.b[i];
+  const int iy0 = oy0 * p.stride - p.pt, ix0 = ox0 * p.stride - p.pl;
+  for (int i = tid; i < PH * PW * p.C; i += 256) {
+    int c = i % p.C, t = i / p.C, px = t % PW, py = t / PW;
+    int iy = iy0 + py, ix = ix0 + px;
+    sX[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                ? p.a[(((int64_t)n * p.H + iy) * p.W + ix) * p.C + c] : 0.f;
+  }
+  __syncthreads();
+  const int cq = tid & 3, pg = tid >> 2;             // channel quarter, 2x2 pixel group (8x8 groups)
+  const int gy = (pg >> 3) * 2, gx = (pg & 7) * 2;
+  float acc[4][16] = {};
+  for (int r = 0; r < p.R; ++r)
+    for (int s = 0; s < p.S; ++s)
+      for (int c = 0; c < p.C; ++c) {
+        const float* wp = sW + ((r * p.S + s) * p.C + c) * 64 + cq * 16;
+        float wv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<floatx4*>(wv + 4 * j) = *reinterpret_cast<const floatx4*>(wp + 4 * j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int py = (gy + (q >> 1)) * p.stride + r * p.dil, px = (gx + (q & 1)) * p.stride + s * p.dil;
+          float xv = sX[(py * PW + px) * p.C + c];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc[q][j] = fmaf(xv, wv[j], acc[q][j]);
+        }
+      }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int oy = oy0 + gy + (q >> 1), ox = ox0 + gx + (q & 1);
+    if (oy >= p.OH || ox >= p.OW) continue;
+    float* op = p.out + (((int64_t)n * p.OH + oy) * p.OW + ox) * 64 + cq * 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float v = acc[q][j];
+      if (p.epi & MTLSSL_EPI_BIAS) v += p.bias[cq * 16 + j];
+      if (p.epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
+      op[j] = v;
+    }
+  }
+}
+
 static ConvArgs make_args(const mtlssl_conv_desc* d) {
   ConvArgs p;
   memset(&p, 0, sizeof(p));
@@ -408,9 +619,9 @@ static int check_desc(const mtlssl_conv_desc* d) {
   MTLSSL_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0 &&
                      d->OH > 0 && d->OW > 0 && d->stride > 0 && d->dilation > 0,
                  "conv: non-positive dimension");
-  MTLSSL_REQUIRE((int64_t)d->N * d->H * d->W * d->C < (1ll << 31) &&
-                     (int64_t)d->N * d->OH * d->OW * d->K < (1ll << 31),
-                 "conv: tensor exceeds 2^31 elements");
+  MTLSSL_REQUIRE((int64_t)d->N * d->H * d->W * d->C < (1ll << 30) &&
+                     (int64_t)d->N * d->OH * d->OW * d->K < (1ll << 30),
+                 "conv: tensor exceeds 2^30 elements (32-bit buffer offsets)");
   return MTLSSL_OK;
 }
 
@@ -430,6 +641,29 @@ static int pick_tile(int64_t M, int64_t NG, int64_t zmul) {
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
+}
+
+constexpr int COLSUM_MAX_PARTS = 64;
+static bool is_pointwise(const mtlssl_conv_desc* d) {
+  return d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->OH == d->H &&
+         d->OW == d->W;
+}
+static size_t stem_lds_bytes(const mtlssl_conv_desc* d) {
+  int PH = (STEM_T - 1) * d->stride + (d->R - 1) * d->dilation + 1;
+  int PW = (STEM_T - 1) * d->stride + (d->S - 1) * d->dilation + 1;
+  return sizeof(float) * ((size_t)d->R * d->S * d->C * 64 + (size_t)PH * PW * d->C);
+}
+static void small_wgrad_plan(const mtlssl_conv_desc* d, int* nsplit, int* k_per_split) {
+  int64_t P = (int64_t)d->N * d->OH * d->OW;
+  int64_t tiles = cdiv(d->C, 64) * cdiv(d->K, 64);
+  int64_t s = cdiv(512, tiles);
+  int64_t maxs = cdiv(P, 128);
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  int64_t per = align_up(cdiv(P, s), 16);
+  *nsplit = (int)cdiv(P, per);
+  *k_per_split = (int)per;
 }
 
 template <int MODE>
@@ -476,10 +710,19 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_fwd: residual pointer required");
   ConvArgs p = make_args(d);
   p.a = x; p.b = w; p.out = y; p.bias = bias; p.residual = residual; p.epi = epi;
+  p.a_bytes = (unsigned)((int64_t)d->N * d->H * d->W * d->C * 4);
+  p.b_bytes = (unsigned)((int64_t)d->R * d->S * d->C * d->K * 4);
   p.M = d->N * d->OH * d->OW;
   p.NG = d->K;
   if (d->C % BK == 0 && d->K % 64 == 0) {
     launch_mfma<MODE_FWD>(pick_tile(p.M, p.NG, 1), p, dim3(1, 1, 1), S(stream));
+  } else if (is_pointwise(d)) {
+    GemmArgs g{x, w, y, bias, residual, nullptr, p.M, d->K, d->C, epi, 0};
+    hipLaunchKernelGGL(k_gemm_small<GM_FWD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, S(stream), g);
+  } else if (d->K == 64 && d->C <= 4 && !(epi & ~(MTLSSL_EPI_BIAS | MTLSSL_EPI_RELU)) &&
+             stem_lds_bytes(d) <= 160 * 1024) {
+    dim3 grid(cdiv(d->OW, STEM_T), cdiv(d->OH, STEM_T), d->N);
+    hipLaunchKernelGGL(k_conv_smallc_fwd, grid, dim3(256), stem_lds_bytes(d), S(stream), p);
   } else {
     int64_t total = (int64_t)p.M * p.K;
     hipLaunchKernelGGL(k_conv_direct_fwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), p);
@@ -495,10 +738,15 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_dgrad: residual pointer required");
   ConvArgs p = make_args(d);
   p.a = dy; p.b = w; p.out = dx; p.residual = residual; p.mask = mask_ref; p.epi = epi;
+  p.a_bytes = (unsigned)((int64_t)d->N * d->OH * d->OW * d->K * 4);
+  p.b_bytes = (unsigned)((int64_t)d->R * d->S * d->C * d->K * 4);
   p.M = d->N * d->H * d->W;
   p.NG = d->C;
   if (d->K % BK == 0 && d->C % 64 == 0) {
     launch_mfma<MODE_DGRAD>(pick_tile(p.M, p.NG, 1), p, dim3(1, 1, 1), S(stream));
+  } else if (is_pointwise(d)) {
+    GemmArgs g{dy, w, dx, nullptr, residual, mask_ref, p.M, d->C, d->K, epi, 0};
+    hipLaunchKernelGGL(k_gemm_small<GM_DGRAD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, S(stream), g);
   } else {
     int64_t total = (int64_t)p.M * p.C;
     hipLaunchKernelGGL(k_conv_direct_dgrad, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), p);
@@ -522,10 +770,17 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
 }
 
 int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
-  if (!d || d->C % 64 || d->K % 64) return 256;
+  if (!d) return 256;
+  int64_t bias_part = align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256);
+  if (d->C % 64 || d->K % 64) {
+    if (!is_pointwise(d)) return bias_part;
+    int ns, kps;
+    small_wgrad_plan(d, &ns, &kps);
+    return bias_part + align_up((int64_t)ns * d->C * d->K * 4, 256);
+  }
   int cfg, ns, pps;
   wgrad_plan(d, &cfg, &ns, &pps);
-  return align_up((int64_t)ns * d->R * d->S * d->C * d->K * 4, 256);
+  return bias_part + align_up((int64_t)ns * d->R * d->S * d->C * d->K * 4, 256);
 }
 
 int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,
@@ -535,22 +790,40 @@ int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* 
   hipStream_t st = S(stream);
   ConvArgs p = make_args(d);
   p.a = x; p.b = dy;
+  p.a_bytes = (unsigned)((int64_t)d->N * d->H * d->W * d->C * 4);
+  p.b_bytes = (unsigned)((int64_t)d->N * d->OH * d->OW * d->K * 4);
   int64_t P = (int64_t)d->N * d->OH * d->OW;
+  MTLSSL_REQUIRE(workspace != nullptr, "conv_wgrad: workspace required");
+  float* ws_main = (float*)((char*)workspace + align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256));
   if (d->C % 64 == 0 && d->K % 64 == 0) {
-    MTLSSL_REQUIRE(workspace != nullptr, "conv_wgrad: workspace required");
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);
-    p.out = (float*)workspace;
+    p.out = ws_main;
     p.M = d->C; p.NG = d->K; p.nsplit = ns; p.pix_per_split = pps;
     launch_mfma<MODE_WGRAD>(cfg, p, dim3(1, d->R * d->S, ns), st);
     int64_t total4 = (int64_t)d->R * d->S * d->C * d->K / 4;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(total4, 256)), dim3(256), 0, st,
-                       (const float*)workspace, ns, total4, d->K, out_scale, dw, beta);
+                       (const float*)ws_main, ns, total4, d->K, out_scale, dw, beta);
+  } else if (is_pointwise(d)) {
+    int ns, kps;
+    small_wgrad_plan(d, &ns, &kps);
+    GemmArgs g{x, dy, ws_main, nullptr, nullptr, nullptr, d->C, d->K, (int)P, 0, kps};
+    hipLaunchKernelGGL(k_gemm_small<GM_WGRAD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64), ns), dim3(256), 0, st, g);
+    int64_t total = (int64_t)d->C * d->K;
+    hipLaunchKernelGGL(k_small_reduce, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)ws_main, ns,
+                       total, d->K, out_scale, dw, beta);
   } else {
     hipLaunchKernelGGL(k_conv_direct_wgrad, dim3(d->C, d->R * d->S), dim3(64), 0, st, p, out_scale,
                        dw, beta);
   }
-  if (dbias) hipLaunchKernelGGL(k_colsum, dim3(cdiv(d->K, 64)), dim3(256), 0, st, dy, P, d->K, dbias, beta);
+  if (dbias) {
+    int parts = (int)(cdiv(P, 256) < COLSUM_MAX_PARTS ? cdiv(P, 256) : COLSUM_MAX_PARTS);
+    int rpb = (int)cdiv(P, parts);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(cdiv(d->K, 64), parts), dim3(256), 0, st, dy, P, d->K, rpb,
+                       (float*)workspace);
+    hipLaunchKernelGGL(k_small_reduce, dim3(cdiv(d->K, 256)), dim3(256), 0, st, (const float*)workspace,
+                       parts, (int64_t)d->K, d->K, (const float*)nullptr, dbias, beta);
+  }
   return check_launch("conv2d_wgrad");
 }
 
