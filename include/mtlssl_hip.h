@@ -54,15 +54,19 @@ typedef struct {
 #define MTLSSL_EPI_MASK 32     /* dgrad only: out *= (mask_ref > 0)  (ReLU backward)         */
 #define MTLSSL_EPI_ACCUM 64    /* dgrad only: out += existing contents of the output buffer */
 
+/* Scratch needed by a call in the given mode (0 fwd, 1 dgrad, 2 wgrad); fwd/dgrad use it for
+ * split-K partials when the tile grid alone would not fill the 256 CUs (0 when not split).
+ * A null workspace is allowed for fwd/dgrad and simply disables split-K. */
+int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode);
 /* y = epilogue(conv(x, w)). */
 int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
                       const float* bias, const float* residual, float* y, int epilogue,
-                      mtlssl_stream_t stream);
+                      void* workspace, mtlssl_stream_t stream);
 /* dx = conv_transpose(dy, w); epilogue flags MASK (mask_ref, same shape as dx) / ACCUM /
  * RESIDUAL (adds `residual`, same shape as dx, before the mask). */
 int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float* w,
                         const float* residual, const float* mask_ref, float* dx, int epilogue,
-                        mtlssl_stream_t stream);
+                        void* workspace, mtlssl_stream_t stream);
 /* dw[r,s,c,k] (beta=0: overwrite, beta=1: accumulate) = sum_pixels x*dy, optionally scaled
  * per output channel by out_scale[k] (frozen-BN fold) and dbias[k] = sum dy (nullable).
  * workspace: mtlssl_conv2d_wgrad_workspace_bytes(d) bytes. */

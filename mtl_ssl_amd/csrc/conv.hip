@@ -29,13 +29,15 @@ struct ConvArgs {
   const float* bias;     // fwd
   const float* residual; // fwd / dgrad
   const float* mask;     // dgrad
+  float* splitk_ws;      // fwd/dgrad split-K partials [nsplit][M][NG]
   int N, H, W, C, K, R, S, OH, OW, stride, dil, pt, pl;
   int M;                 // GEMM rows
   int NG;                // GEMM cols
   int epi;
   int tiles_m, tiles_n;
   unsigned a_bytes, b_bytes;   // extents of the a / b tensors (buffer-load range checks)
-  int nsplit;            // wgrad: splits of the pixel range
+  int nsplit;            // wgrad: splits of the pixel range; fwd/dgrad: splits of the K loop
+  int ks_per_split;      // fwd/dgrad split-K: K-steps per split
   int pix_per_split;     // wgrad
 };
 
@@ -49,7 +51,7 @@ __device__ __forceinline__ floatx4 bufload4(__amdgpu_buffer_rsrc_t rsrc, unsigne
 }
 
 template <int BM, int BN, int MODE>
-__global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
+__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mfma(ConvArgs p) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave in m / n
   constexpr bool A_KC = (MODE != MODE_WGRAD);     // A float4 runs along k (else along m)
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
 
   // ---- K-loop extent
-  int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps;
+  int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps, ks_begin = 0;
   if constexpr (MODE == MODE_FWD) {
     ksteps = p.R * p.S * (p.C / BK);
   } else if constexpr (MODE == MODE_DGRAD) {
@@ -93,6 +95,12 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
     pix0 = split * p.pix_per_split;
     pix1 = min(P, pix0 + p.pix_per_split);
     ksteps = (max(pix1 - pix0, 0) + BK - 1) / BK;
+  }
+  if constexpr (MODE != MODE_WGRAD) {
+    if (p.nsplit > 1) {          // split-K: this block covers K-steps [ks_begin, ksteps)
+      ks_begin = blockIdx.z * p.ks_per_split;
+      ksteps = min(ksteps, ks_begin + p.ks_per_split);
+    }
   }
 
   // ---- per-thread gather state (32-bit element offsets; the host guarantees < 2^30 elements)
@@ -244,12 +252,12 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (ksteps > 0) {
-    load_tile(0);
-    store_tile(0);
+  if (ksteps > ks_begin) {
+    load_tile(ks_begin);
+    store_tile(ks_begin & 1);
   }
   __syncthreads();
-  for (int ks = 0; ks < ksteps; ++ks) {
+  for (int ks = ks_begin; ks < ksteps; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < ksteps) load_tile(ks + 1);
     const float* a = sA + cur * (BK * LDA) + wr * (BM / 2) + lo;
@@ -289,6 +297,8 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
   float* outp = p.out;
   if constexpr (MODE == MODE_WGRAD)
     outp += ((int64_t)blockIdx.z * (p.R * p.S) + rs_fixed) * (int64_t)p.M * p.NG;
+  const bool raw = (MODE != MODE_WGRAD) && p.nsplit > 1;   // split-K partial: epilogue runs later
+  if (raw) outp = p.splitk_ws + (int64_t)blockIdx.z * (int64_t)p.M * p.NG;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -303,6 +313,10 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs p) {
         if (row >= p.M) continue;
         const int64_t o = (int64_t)row * ldo + col;
         float v = acc[i][j][e];
+        if (raw) {
+          outp[o] = v;
+          continue;
+        }
         if constexpr (MODE == MODE_FWD) {
           v += bv;
           if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
@@ -643,6 +657,75 @@ static int pick_tile(int64_t M, int64_t NG, int64_t zmul) {
   return best;
 }
 
+// Split-K fold for fwd/dgrad: out = epilogue(sum_z ws[z]); float4 over the channel axis.
+template <int MODE>
+__global__ void k_splitk_epilogue(ConvArgs p) {
+  int64_t i4 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t total4 = (int64_t)p.M * p.NG / 4;
+  if (i4 >= total4) return;
+  floatx4 v = reinterpret_cast<const floatx4*>(p.splitk_ws)[i4];
+  for (int z = 1; z < p.nsplit; ++z) v += reinterpret_cast<const floatx4*>(p.splitk_ws)[(int64_t)z * total4 + i4];
+  int64_t o = i4 * 4;
+  int col = (int)(o % p.NG);
+  if constexpr (MODE == MODE_FWD) {
+    if (p.epi & MTLSSL_EPI_BIAS) v += *reinterpret_cast<const floatx4*>(p.bias + col);
+    if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (p.epi & MTLSSL_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+      if (p.epi & MTLSSL_EPI_RELU6) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
+      if (p.epi & MTLSSL_EPI_TANH) v[e] = tanhf(v[e]);
+    }
+  } else {
+    if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
+    if (p.epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const floatx4*>(p.out + o);
+    if (p.epi & MTLSSL_EPI_MASK) {
+      floatx4 m = *reinterpret_cast<const floatx4*>(p.mask + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+    }
+  }
+  *reinterpret_cast<floatx4*>(p.out + o) = v;
+}
+
+// Launch plan for fwd/dgrad: tile config + K split, from a per-CU MFMA time model (a CU retires
+// one 32-deep block-step of an bm x bn tile in bm*bn*32 / 614 GFLOP/s; blocks beyond 256 queue).
+struct Plan { int cfg, nsplit, ks_per_split; };
+// Time model shared by the planners (microseconds). A CU retires one 16-deep K-step of a
+// bm x bn tile in bm*bn*32 FLOP / 614 GFLOP/s (fp32 MFMA peak per CU); blocks beyond what is
+// resident queue up. A CU holding a single block (one wave per SIMD) cannot hide its own LDS /
+// barrier latencies, hence the occupancy factor. Constants fitted to tools/bench_conv.py.
+static double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block) {
+  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+  const int resident[3] = {3, 6, 8};
+  const double base_eff[3] = {0.80, 0.76, 0.72};
+  int64_t per_cu = cdiv(nblocks, 256);
+  int64_t occ = per_cu < resident[cfg] ? per_cu : resident[cfg];
+  double occ_eff = occ <= 1 ? 0.55 : (occ == 2 ? 0.80 : 1.0);
+  double step_us = bm[cfg] * bn[cfg] * 32.0 / 614e9 * 1e6 / (base_eff[cfg] * occ_eff);
+  return (double)per_cu * (ksteps_per_block + 6) * step_us;
+}
+
+static Plan plan_gemm(int64_t M, int64_t NG, int ksteps) {
+  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+  Plan best{2, 1, ksteps};
+  double best_t = 1e30;
+  for (int c = 0; c < 3; ++c) {
+    if (NG % bn[c]) continue;
+    int64_t tiles = cdiv(M, bm[c]) * (NG / bn[c]);
+    for (int s = 1; s <= 8; ++s) {
+      if (s > 1 && ksteps / s < 12) break;
+      int per = (int)cdiv(ksteps, s);
+      int ns = (int)cdiv(ksteps, per);
+      if (ns != s) continue;
+      double t = tile_time_us(c, tiles * ns, per);
+      if (ns > 1) t += 3.0 + (double)M * NG * 4.0 * (ns + 2) / 3.0e6;    // fold kernel: launch + traffic
+      if (t < best_t) { best_t = t; best = Plan{c, ns, per}; }
+    }
+  }
+  return best;
+}
+
 constexpr int COLSUM_MAX_PARTS = 64;
 static bool is_pointwise(const mtlssl_conv_desc* d) {
   return d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->OH == d->H &&
@@ -680,21 +763,26 @@ static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st) {
 }
 
 static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pps) {
+  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
   int64_t P = (int64_t)d->N * d->OH * d->OW;
   int RS = d->R * d->S;
-  // aim for >= ~3 blocks per CU; each split should still cover >= 256 pixels
-  int c = pick_tile(d->C, d->K, RS);
-  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
-  int64_t tiles = cdiv(d->C, bm[c]) * (d->K / bn[c]) * RS;
-  int64_t want = cdiv(768, tiles);
-  int64_t maxs = P / 256 > 0 ? P / 256 : 1;
-  int64_t s = want < maxs ? want : maxs;
-  if (s < 1) s = 1;
-  if (s > 64) s = 64;
-  int64_t per = align_up(cdiv(P, s), BK);
-  *nsplit = (int)cdiv(P, per);
-  *pps = (int)per;
-  *cfg = c;
+  int ksteps = (int)cdiv(P, BK);
+  double best_t = 1e30;
+  *cfg = 2; *nsplit = 1; *pps = (int)align_up(P, BK);
+  for (int c = 0; c < 3; ++c) {
+    if (d->C % bm[c] || d->K % bn[c]) continue;
+    int64_t tiles = (int64_t)(d->C / bm[c]) * (d->K / bn[c]) * RS;
+    for (int s = 1; s <= 64; ++s) {
+      if (s > 1 && ksteps / s < 8) break;
+      int per = (int)cdiv(ksteps, s);
+      int ns = (int)cdiv(ksteps, per);
+      if (ns != s) continue;
+      // partial tiles written + read once by the fold kernel
+      double t = tile_time_us(c, tiles * ns, per) +
+                 2.0 + (double)RS * d->C * d->K * 4.0 * (ns + 1) / 3.0e6;
+      if (t < best_t) { best_t = t; *cfg = c; *nsplit = ns; *pps = per * BK; }
+    }
+  }
 }
 
 }  // namespace mtlssl
@@ -703,8 +791,20 @@ using namespace mtlssl;
 
 extern "C" {
 
+int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
+  if (!d) return 0;
+  if (mode == MODE_WGRAD) return mtlssl_conv2d_wgrad_workspace_bytes(d);
+  int64_t M = mode == MODE_FWD ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W;
+  int64_t NG = mode == MODE_FWD ? d->K : d->C;
+  int kc = mode == MODE_FWD ? d->C : d->K;
+  if (kc % BK || NG % 64) return 0;
+  Plan pl = plan_gemm(M, NG, d->R * d->S * (kc / BK));
+  return pl.nsplit > 1 ? align_up(M * NG * 4 * pl.nsplit, 256) : 0;
+}
+
 int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w, const float* bias,
-                      const float* residual, float* y, int epi, mtlssl_stream_t stream) {
+                      const float* residual, float* y, int epi, void* workspace,
+                      mtlssl_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_BIAS) || bias, "conv_fwd: bias pointer required");
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_fwd: residual pointer required");
@@ -715,7 +815,13 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
   p.M = d->N * d->OH * d->OW;
   p.NG = d->K;
   if (d->C % BK == 0 && d->K % 64 == 0) {
-    launch_mfma<MODE_FWD>(pick_tile(p.M, p.NG, 1), p, dim3(1, 1, 1), S(stream));
+    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S * (d->C / BK));
+    if (pl.nsplit > 1 && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0};
+    p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split; p.splitk_ws = (float*)workspace;
+    launch_mfma<MODE_FWD>(pl.cfg, p, dim3(1, 1, pl.nsplit), S(stream));
+    if (pl.nsplit > 1)
+      hipLaunchKernelGGL(k_splitk_epilogue<MODE_FWD>, dim3(cdiv((int64_t)p.M * p.NG / 4, 256)), dim3(256), 0,
+                         S(stream), p);
   } else if (is_pointwise(d)) {
     GemmArgs g{x, w, y, bias, residual, nullptr, p.M, d->K, d->C, epi, 0};
     hipLaunchKernelGGL(k_gemm_small<GM_FWD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, S(stream), g);
@@ -732,7 +838,7 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
 
 int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float* w,
                         const float* residual, const float* mask_ref, float* dx, int epi,
-                        mtlssl_stream_t stream) {
+                        void* workspace, mtlssl_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_MASK) || mask_ref, "conv_dgrad: mask_ref pointer required");
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_dgrad: residual pointer required");
@@ -743,7 +849,13 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   p.M = d->N * d->H * d->W;
   p.NG = d->C;
   if (d->K % BK == 0 && d->C % 64 == 0) {
-    launch_mfma<MODE_DGRAD>(pick_tile(p.M, p.NG, 1), p, dim3(1, 1, 1), S(stream));
+    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S * (d->K / BK));
+    if (pl.nsplit > 1 && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0};
+    p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split; p.splitk_ws = (float*)workspace;
+    launch_mfma<MODE_DGRAD>(pl.cfg, p, dim3(1, 1, pl.nsplit), S(stream));
+    if (pl.nsplit > 1)
+      hipLaunchKernelGGL(k_splitk_epilogue<MODE_DGRAD>, dim3(cdiv((int64_t)p.M * p.NG / 4, 256)), dim3(256), 0,
+                         S(stream), p);
   } else if (is_pointwise(d)) {
     GemmArgs g{dy, w, dx, nullptr, residual, mask_ref, p.M, d->C, d->K, epi, 0};
     hipLaunchKernelGGL(k_gemm_small<GM_DGRAD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, S(stream), g);
@@ -757,9 +869,11 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
 int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
   if (!d) return -1;
   if (mode == MODE_FWD)
-    return (d->C % BK == 0 && d->K % 64 == 0) ? pick_tile((int64_t)d->N * d->OH * d->OW, d->K, 1) : -1;
+    return (d->C % BK == 0 && d->K % 64 == 0)
+               ? plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S * (d->C / BK)).cfg : -1;
   if (mode == MODE_DGRAD)
-    return (d->K % BK == 0 && d->C % 64 == 0) ? pick_tile((int64_t)d->N * d->H * d->W, d->C, 1) : -1;
+    return (d->K % BK == 0 && d->C % 64 == 0)
+               ? plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S * (d->K / BK)).cfg : -1;
   if (mode == MODE_WGRAD) {
     if (d->C % 64 || d->K % 64) return -1;
     int cfg, ns, pps;

@@ -108,8 +108,10 @@ PROFILER = None
 def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None):
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
     t0 = PROFILER.begin() if PROFILER is not None else None
+    nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 0)
+    ws = workspace(nb, "splitk", x.device) if nb else None
     lib().conv2d_fwd(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(residual),
-                     ptr(y), epilogue, _stream())
+                     ptr(y), epilogue, ptr(ws), _stream())
     if t0 is not None:
         PROFILER.end(d, 0, t0)
     return y
@@ -118,8 +120,10 @@ def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None):
 def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None):
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=f32, device=dy.device)
     t0 = PROFILER.begin() if PROFILER is not None else None
+    nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 1)
+    ws = workspace(nb, "splitk", dy.device) if nb else None
     lib().conv2d_dgrad(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref),
-                       ptr(dx), epilogue, _stream())
+                       ptr(dx), epilogue, ptr(ws), _stream())
     if t0 is not None:
         PROFILER.end(d, 1, t0)
     return dx
