@@ -65,26 +65,18 @@ def cpu_baseline(cfg, model, H, W, seed):
     cores = min(os.cpu_count() or 1, 64)       # torch-CPU stops scaling well past ~64 threads
     torch.set_num_threads(cores)
     K = int(cfg.model.faster_rcnn.num_classes)
-    # Bounded sample: the full-size trunk + RPN on one image, with 1/8 of the second-stage work
-    # (32 sampled proposals instead of 256, 8 windows instead of 64, 160 refine crops instead of
-    # 1280). Algorithmic FLOPs of the sample (SURVEY.md §8d figures): trunk+RPN fwd 186.1 GF,
-    # their backward 344.2 GF, block4 1.464 GF/ROI x (1856 fwd + 2x576 bwd) x 1/8.
-    frac = 1.0 / 8.0
+    # Bounded sample: ONE full training step (all 1 856 second-stage ROIs, fwd + losses + bwd) on
+    # ONE synthetic image = 4.93 TFLOP of algorithmic work, ~20 s on 64 threads.
     hp = hyper_params_for_oracle(cfg)
-    hp["second_stage_batch_size"] = int(hp["second_stage_batch_size"] * frac)
-    sample_flop = (186.1 + 344.2 + 1.464 * (1856 + 2 * 576) * frac) * 1e9
-    batch = synthetic.make_batch(1, H, W, K, seed=seed, device="cpu", num_windows=int(64 * frac))
+    batch = synthetic.make_batch(1, H, W, K, seed=seed, device="cpu")
     batch["images"] = batch["images"].numpy()
     ora = Oracle(hp, model.ps.state_dict())
     t0 = time.time()
     losses, _, _ = ora.step(batch, seed=model.seed, step=0)
     dt = time.time() - t0
-    return {"value": sample_flop / dt / FLOP_PER_IMAGE, "unit": "images/sec", "cores": cores,
-            "kind": "port",
-            "sample": "CPU oracle (torch-CPU fp32 + numpy), 1 training step (fwd+loss+bwd) on 1 synthetic "
-                      "%dx%d image with 1/8 of the second-stage ROIs: %.2f TFLOP in %.1f s on %d threads; "
-                      "value = sample FLOP/s / %.2f TFLOP per full image"
-                      % (W, H, sample_flop / 1e12, dt, cores, FLOP_PER_IMAGE / 1e12),
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "CPU oracle (torch-CPU fp32 + numpy): 1 full training step (fwd+loss+bwd, no "
+                      "optimizer) on 1 synthetic %dx%d image, %.1f s on %d threads" % (W, H, dt, cores),
             "total_loss": float(sum(losses.values()))}
 
 
