@@ -30,7 +30,13 @@ FLOP_PER_IMAGE = 4.93e12
 def hyper_params_for_oracle(cfg):
     fr, mtl = cfg.model.faster_rcnn, cfg.model.mtl
     g = fr.first_stage_anchor_generator.grid_anchor_generator
+    rf = None
+    if fr.second_stage_box_predictor.has("rfcn_box_predictor"):
+        r = fr.second_stage_box_predictor.rfcn_box_predictor
+        rf = dict(crop=(int(r.crop_height), int(r.crop_width)),
+                  bins=(int(r.num_spatial_bins_height), int(r.num_spatial_bins_width)), depth=int(r.depth))
     return dict(
+        rfcn=rf,
         arch={"faster_rcnn_resnet50": "resnet_v1_50", "faster_rcnn_resnet101": "resnet_v1_101",
               "faster_rcnn_resnet152": "resnet_v1_152"}[fr.feature_extractor.type],
         num_classes=int(fr.num_classes), scales=list(g.scales), aspect_ratios=list(g.aspect_ratios),
@@ -40,8 +46,8 @@ def hyper_params_for_oracle(cfg):
         first_stage_positive_balance_fraction=fr.first_stage_positive_balance_fraction,
         first_stage_localization_loss_weight=fr.first_stage_localization_loss_weight,
         first_stage_objectness_loss_weight=fr.first_stage_objectness_loss_weight,
-        initial_crop_size=int(fr.initial_crop_size), maxpool_kernel_size=int(fr.maxpool_kernel_size),
-        maxpool_stride=int(fr.maxpool_stride), second_stage_batch_size=int(fr.second_stage_batch_size),
+        initial_crop_size=int(fr.get("initial_crop_size", 1)),
+        maxpool_kernel_size=int(fr.get("maxpool_kernel_size", 1)), maxpool_stride=int(fr.get("maxpool_stride", 1)), second_stage_batch_size=int(fr.second_stage_batch_size),
         second_stage_balance_fraction=fr.second_stage_balance_fraction,
         second_stage_localization_loss_weight=fr.second_stage_localization_loss_weight,
         second_stage_classification_loss_weight=fr.second_stage_classification_loss_weight,

@@ -192,6 +192,16 @@ int mtlssl_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax, int B, in
                              const float* boxes, const int32_t* box_ind, int R, int crop,
                              int pool_k, int pool_stride, float* dfeat, mtlssl_stream_t stream);
 
+/* ops.position_sensitive_crop_regions(global_pool=True) (utils/ops.py:462-609; call sites
+ * core/box_predictor.py:228-264,312-330): fmap [B,H,W,C] with C = bins_y*bins_x*Cc; out [R,Cc].
+ * The backward accumulates into dfmap (caller zeroes it or passes an accumulated gradient). */
+int mtlssl_psroi_fwd(const float* fmap, int B, int H, int W, int C, const float* boxes,
+                     const int32_t* box_ind, int R, int crop_h, int crop_w, int bins_y, int bins_x,
+                     float* out, mtlssl_stream_t stream);
+int mtlssl_psroi_bwd(const float* dout, int B, int H, int W, int C, const float* boxes,
+                     const int32_t* box_ind, int R, int crop_h, int crop_w, int bins_y, int bins_x,
+                     float* dfmap, mtlssl_stream_t stream);
+
 /* tf.image.resize_images bilinear, align_corners=False (faster_rcnn_meta_arch.py:1870). */
 int mtlssl_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH,
                                int OW, mtlssl_stream_t stream);

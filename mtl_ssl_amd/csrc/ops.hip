@@ -112,6 +112,93 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ------------------------------------------------------------------------------ PS-RoI pooling
+// ops.position_sensitive_crop_regions(global_pool=True) (utils/ops.py:462-609): the box is cut
+// into bins_y x bins_x sub-boxes; bin g crops (crop_and_resize, bs x bs samples) ITS OWN channel
+// group [g*Cc,(g+1)*Cc) of the score map; the result is the mean over bins and samples.
+// One block per RoI; thread = (bin, channel): lanes run along the channels of a group.
+__global__ void __launch_bounds__(256)
+    k_psroi_fwd(const float* __restrict__ fmap, int H, int W, int Ctot, const float* __restrict__ boxes,
+                const int32_t* __restrict__ box_ind, int bins_y, int bins_x, int bs_y, int bs_x, int Cc,
+                float* __restrict__ out) {
+  extern __shared__ float s_acc[];                 // [Cc]
+  int r = blockIdx.x;
+  float4 bx = *reinterpret_cast<const float4*>(boxes + (int64_t)r * 4);
+  const float* fb = fmap + (int64_t)box_ind[r] * H * W * Ctot;
+  for (int c = threadIdx.x; c < Cc; c += blockDim.x) s_acc[c] = 0.f;
+  __syncthreads();
+  int nb = bins_y * bins_x;
+  float step_y = (bx.z - bx.x) / (float)bins_y, step_x = (bx.w - bx.y) / (float)bins_x;
+  for (int t = threadIdx.x; t < nb * Cc; t += blockDim.x) {
+    int g = t / Cc, c = t % Cc;
+    int by = g / bins_x, bxi = g % bins_x;
+    float y1 = bx.x + (float)by * step_y, y2 = bx.x + (float)(by + 1) * step_y;
+    float x1 = bx.y + (float)bxi * step_x, x2 = bx.y + (float)(bxi + 1) * step_x;
+    float hs = bs_y > 1 ? (y2 - y1) * (float)(H - 1) / (float)(bs_y - 1) : 0.f;
+    float ws = bs_x > 1 ? (x2 - x1) * (float)(W - 1) / (float)(bs_x - 1) : 0.f;
+    float acc = 0.f;
+    for (int iy = 0; iy < bs_y; ++iy) {
+      float in_y = bs_y > 1 ? y1 * (float)(H - 1) + (float)iy * hs : 0.5f * (y1 + y2) * (float)(H - 1);
+      if (in_y < 0.f || in_y > (float)(H - 1)) continue;
+      int ty = (int)floorf(in_y), byy = (int)ceilf(in_y);
+      float yl = in_y - (float)ty;
+      for (int ix = 0; ix < bs_x; ++ix) {
+        float in_x = bs_x > 1 ? x1 * (float)(W - 1) + (float)ix * ws : 0.5f * (x1 + x2) * (float)(W - 1);
+        if (in_x < 0.f || in_x > (float)(W - 1)) continue;
+        int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+        float xl = in_x - (float)lx;
+        int ch = g * Cc + c;
+        float tl = fb[((int64_t)ty * W + lx) * Ctot + ch], tr = fb[((int64_t)ty * W + rx) * Ctot + ch];
+        float bl = fb[((int64_t)byy * W + lx) * Ctot + ch], br = fb[((int64_t)byy * W + rx) * Ctot + ch];
+        float top = tl + (tr - tl) * xl, bot = bl + (br - bl) * xl;
+        acc += top + (bot - top) * yl;
+      }
+    }
+    atomicAdd(&s_acc[c], acc);                       // LDS atomic; 9 bins per channel
+  }
+  __syncthreads();
+  float inv = 1.f / (float)(nb * bs_y * bs_x);
+  for (int c = threadIdx.x; c < Cc; c += blockDim.x) out[(int64_t)r * Cc + c] = s_acc[c] * inv;
+}
+__global__ void __launch_bounds__(256)
+    k_psroi_bwd(const float* __restrict__ dout, int H, int W, int Ctot, const float* __restrict__ boxes,
+                const int32_t* __restrict__ box_ind, int bins_y, int bins_x, int bs_y, int bs_x, int Cc,
+                float* __restrict__ dfmap) {
+  int r = blockIdx.x;
+  float4 bx = *reinterpret_cast<const float4*>(boxes + (int64_t)r * 4);
+  float* fb = dfmap + (int64_t)box_ind[r] * H * W * Ctot;
+  int nb = bins_y * bins_x;
+  float step_y = (bx.z - bx.x) / (float)bins_y, step_x = (bx.w - bx.y) / (float)bins_x;
+  float inv = 1.f / (float)(nb * bs_y * bs_x);
+  for (int t = threadIdx.x; t < nb * Cc; t += blockDim.x) {
+    int g = t / Cc, c = t % Cc;
+    int by = g / bins_x, bxi = g % bins_x;
+    float y1 = bx.x + (float)by * step_y, y2 = bx.x + (float)(by + 1) * step_y;
+    float x1 = bx.y + (float)bxi * step_x, x2 = bx.y + (float)(bxi + 1) * step_x;
+    float hs = bs_y > 1 ? (y2 - y1) * (float)(H - 1) / (float)(bs_y - 1) : 0.f;
+    float ws = bs_x > 1 ? (x2 - x1) * (float)(W - 1) / (float)(bs_x - 1) : 0.f;
+    float gr = dout[(int64_t)r * Cc + c] * inv;
+    int ch = g * Cc + c;
+    for (int iy = 0; iy < bs_y; ++iy) {
+      float in_y = bs_y > 1 ? y1 * (float)(H - 1) + (float)iy * hs : 0.5f * (y1 + y2) * (float)(H - 1);
+      if (in_y < 0.f || in_y > (float)(H - 1)) continue;
+      int ty = (int)floorf(in_y), byy = (int)ceilf(in_y);
+      float yl = in_y - (float)ty;
+      for (int ix = 0; ix < bs_x; ++ix) {
+        float in_x = bs_x > 1 ? x1 * (float)(W - 1) + (float)ix * ws : 0.5f * (x1 + x2) * (float)(W - 1);
+        if (in_x < 0.f || in_x > (float)(W - 1)) continue;
+        int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+        float xl = in_x - (float)lx;
+        float dtop = (1.f - yl) * gr, dbot = yl * gr;
+        unsafeAtomicAdd(fb + ((int64_t)ty * W + lx) * Ctot + ch, (1.f - xl) * dtop);
+        unsafeAtomicAdd(fb + ((int64_t)ty * W + rx) * Ctot + ch, xl * dtop);
+        unsafeAtomicAdd(fb + ((int64_t)byy * W + lx) * Ctot + ch, (1.f - xl) * dbot);
+        unsafeAtomicAdd(fb + ((int64_t)byy * W + rx) * Ctot + ch, xl * dbot);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ bilinear resize
 // tf.image.resize_images(BILINEAR, align_corners=False), TF 1.7: src = dst * in/out.
 __global__ void k_resize_fwd(const float* x, float* y, int H, int W, int C, int OH, int OW,
@@ -376,6 +463,31 @@ int mtlssl_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax, int B, in
   hipLaunchKernelGGL(k_roi_crop_pool_bwd, dim3(PH * PH, R), dim3(256), 0, S(stream), dout, argmax, H,
                      W, C, boxes, box_ind, crop, pk, ps, PH, PH, dfeat);
   return check_launch("roi_crop_pool_bwd");
+}
+
+int mtlssl_psroi_fwd(const float* fmap, int B, int H, int W, int C, const float* boxes,
+                     const int32_t* box_ind, int R, int crop_h, int crop_w, int bins_y, int bins_x,
+                     float* out, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(bins_y >= 1 && bins_x >= 1, "num_spatial_bins should be >= 1");
+  MTLSSL_REQUIRE(crop_h % bins_y == 0 && crop_w % bins_x == 0,
+                 "crop_size should be divisible by num_spatial_bins");
+  MTLSSL_REQUIRE(C % (bins_y * bins_x) == 0, "depth must be divisible by the number of bins");
+  if (R == 0) return MTLSSL_OK;
+  int Cc = C / (bins_y * bins_x);
+  hipLaunchKernelGGL(k_psroi_fwd, dim3(R), dim3(256), sizeof(float) * Cc, S(stream), fmap, H, W, C, boxes,
+                     box_ind, bins_y, bins_x, crop_h / bins_y, crop_w / bins_x, Cc, out);
+  return check_launch("psroi_fwd");
+}
+int mtlssl_psroi_bwd(const float* dout, int B, int H, int W, int C, const float* boxes,
+                     const int32_t* box_ind, int R, int crop_h, int crop_w, int bins_y, int bins_x,
+                     float* dfmap, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(bins_y >= 1 && bins_x >= 1 && crop_h % bins_y == 0 && crop_w % bins_x == 0 &&
+                     C % (bins_y * bins_x) == 0, "psroi_bwd: bad geometry");
+  if (R == 0) return MTLSSL_OK;
+  int Cc = C / (bins_y * bins_x);
+  hipLaunchKernelGGL(k_psroi_bwd, dim3(R), dim3(256), 0, S(stream), dout, H, W, C, boxes, box_ind, bins_y,
+                     bins_x, crop_h / bins_y, crop_w / bins_x, Cc, dfmap);
+  return check_launch("psroi_bwd");
 }
 
 int mtlssl_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,

@@ -119,31 +119,23 @@ class FasterRCNNMetaArch:
                                 activation="relu" if hp.activation == "RELU" else None)
         self.rpn_box = nn.Conv(ps, s + "/BoxEncodingPredictor", depth, A * 4, 1, init, rpn_tr, wd)
         self.rpn_cls = nn.Conv(ps, s + "/ClassPredictor", depth, A * 2, 1, init, rpn_tr, wd)
-        # second stage
+        # second stage (+ aux heads: builders/model_builder.py:287-315 give the aux predictors
+        # num_classes+1 "classes")
         self.tower = fe.box_classifier_tower(self.second_stage_feature_extractor_scope, True)
         bp = frcnn.second_stage_box_predictor
-        if not bp.has("mask_rcnn_box_predictor"):
-            raise ValueError("FasterRCNNMetaArch needs mask_rcnn_box_predictor (use RFCNMetaArch for rfcn)")
-        self.box_predictor = MaskRCNNBoxPredictor(ps, self.second_stage_box_predictor_scope, self.tower.cout,
-                                                  K, bp.mask_rcnn_box_predictor,
-                                                  is_training and bp.trainable, False)
+        self.box_predictor = self._make_predictor(self.second_stage_box_predictor_scope, K, bp, False)
         self.layers = fe.layers() + [self.rpn_conv, self.rpn_box, self.rpn_cls] + self.tower.layers() \
             + self.box_predictor.layers()
-        # aux heads (builders/model_builder.py:287-315: aux predictors get num_classes+1 "classes")
         self.closeness_tower = self.window_tower = None
         if mtl.closeness:
             self.closeness_tower = fe.box_classifier_tower(self.closeness_box_predictor_scope, True)
-            cb = mtl.closeness_box_predictor
-            self.closeness_predictor = MaskRCNNBoxPredictor(
-                ps, self.closeness_box_predictor_scope, self.tower.cout, K + 1, cb.mask_rcnn_box_predictor,
-                is_training and cb.trainable, True)
+            self.closeness_predictor = self._make_predictor(self.closeness_box_predictor_scope, K + 1,
+                                                            mtl.closeness_box_predictor, True)
             self.layers += self.closeness_tower.layers() + self.closeness_predictor.layers()
         if mtl.window:
             self.window_tower = fe.box_classifier_tower(self.window_box_predictor_scope, True)
-            wb = mtl.window_box_predictor
-            self.window_predictor = MaskRCNNBoxPredictor(
-                ps, self.window_box_predictor_scope, self.tower.cout, K + 1, wb.mask_rcnn_box_predictor,
-                is_training and wb.trainable, True)
+            self.window_predictor = self._make_predictor(self.window_box_predictor_scope, K + 1,
+                                                         mtl.window_box_predictor, True)
             self.layers += self.window_tower.layers() + self.window_predictor.layers()
         if mtl.edgemask:
             ep = mtl.edgemask_predictor
@@ -165,6 +157,15 @@ class FasterRCNNMetaArch:
         self._gt = None
         self._window = None
         self._edgemask = None
+
+    def _make_predictor(self, scope, num_classes, bp_cfg, class_only):
+        """builders/box_predictor_builder.py:23-110 (mask_rcnn_box_predictor branch)."""
+        if not bp_cfg.has("mask_rcnn_box_predictor"):
+            raise ValueError("FasterRCNNMetaArch needs mask_rcnn_box_predictor (RFCNMetaArch handles "
+                             "rfcn_box_predictor)")
+        return MaskRCNNBoxPredictor(self.ps, scope, self.tower.cout, num_classes,
+                                    bp_cfg.mask_rcnn_box_predictor, self._is_training and bp_cfg.trainable,
+                                    class_only)
 
     # ------------------------------------------------------------------ properties / plumbing
     @property

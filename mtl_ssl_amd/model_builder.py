@@ -3,7 +3,7 @@
 `FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP` is the reference's plugin registry: feature
 extractors register by the `feature_extractor.type` string of the pipeline config.
 """
-from . import frcnn, resnet
+from . import frcnn, resnet, rfcn
 from .params import ParamStore
 
 
@@ -44,9 +44,9 @@ def build(model_config, is_training, device="cuda", seed=0, values=None):
     ps = ParamStore()
     fe = FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP[ftype](ps, fe_cfg, is_training and fe_cfg.trainable)
     bp = fr.second_stage_box_predictor
-    if bp.has("rfcn_box_predictor"):
-        raise ValueError("rfcn_box_predictor: RFCNMetaArch is not built yet in this round")
-    model = frcnn.FasterRCNNMetaArch(ps, is_training, fr, model_config.mtl, fe, seed=seed)
+    # builders/model_builder.py:352-380: rfcn_box_predictor selects the R-FCN meta-architecture
+    arch = rfcn.RFCNMetaArch if bp.has("rfcn_box_predictor") else frcnn.FasterRCNNMetaArch
+    model = arch(ps, is_training, fr, model_config.mtl, fe, seed=seed)
     ps.finalize(device, seed=seed, values=values)
     model.prepare()
     return model

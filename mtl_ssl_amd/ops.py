@@ -331,6 +331,25 @@ def roi_crop_pool_bwd(dout, argmax, feat_shape, boxes, box_ind, crop, pool_k, po
     return dfeat
 
 
+def psroi_fwd(fmap, boxes, box_ind, crop, bins):
+    B, H, W, C = fmap.shape
+    R = boxes.shape[0]
+    Cc = C // max(bins[0] * bins[1], 1)     # invalid geometry is rejected by the C ABI below
+    out = torch.empty((R, Cc), dtype=f32, device=fmap.device)
+    lib().psroi_fwd(ptr(_chk(fmap)), B, H, W, C, ptr(_chk(boxes)), ptr(_chk(box_ind, i32)), R, crop[0],
+                    crop[1], bins[0], bins[1], ptr(out), _stream())
+    return out
+
+
+def psroi_bwd(dout, fmap_shape, boxes, box_ind, crop, bins, dfmap=None):
+    B, H, W, C = fmap_shape
+    if dfmap is None:
+        dfmap = torch.zeros(fmap_shape, dtype=f32, device=dout.device)
+    lib().psroi_bwd(ptr(_chk(dout)), B, H, W, C, ptr(_chk(boxes)), ptr(_chk(box_ind, i32)), boxes.shape[0],
+                    crop[0], crop[1], bins[0], bins[1], ptr(dfmap), _stream())
+    return dfmap
+
+
 def resize_bilinear_fwd(x, OH, OW):
     N, H, W, C = x.shape
     y = torch.empty((N, OH, OW, C), dtype=f32, device=x.device)

@@ -1,0 +1,211 @@
+"""RFCNMetaArch — object_detection/meta_architectures/rfcn_meta_arch.py:48-381 — and
+RfcnBoxPredictor — core/box_predictor.py:131-337.
+
+R-FCN differs from Faster R-CNN only in the second stage: block4 runs ONCE on the whole feature
+map per head scope (not per ROI crop); a 1x1 `reduce_depth` conv and 1x1 score-map convs follow,
+and per-proposal predictions come from position-sensitive ROI pooling of the score maps
+(`mtlssl_psroi_fwd/bwd`). The aux heads (closeness / window) are R-FCN predictors too.
+RPN, target assignment, sampling and every loss are inherited from FasterRCNNMetaArch.
+"""
+import torch
+
+from . import nn, ops
+from .frcnn import FasterRCNNMetaArch, _init_from_hyperparams, _l2_from_hyperparams
+
+f32, i32 = torch.float32, torch.int32
+
+
+class RfcnBoxPredictor:
+    def __init__(self, ps, scope, cin, num_classes, cfg, is_training, class_only):
+        init, wd = _init_from_hyperparams(cfg.conv_hyperparams), _l2_from_hyperparams(cfg.conv_hyperparams)
+        act = {"RELU": "relu", "NONE": None}.get(cfg.conv_hyperparams.activation)
+        if cfg.conv_hyperparams.activation not in ("RELU", "NONE"):
+            raise ValueError("rfcn_box_predictor: activation %s not supported" % cfg.conv_hyperparams.activation)
+        if cfg.conv_hyperparams.has("batch_norm"):
+            raise ValueError("rfcn_box_predictor with batch_norm hyperparams is not supported")
+        self.bins = (int(cfg.num_spatial_bins_height), int(cfg.num_spatial_bins_width))
+        self.crop = (int(cfg.crop_height), int(cfg.crop_width))
+        self.depth, self.num_classes, self.class_only = int(cfg.depth), num_classes, class_only
+        nb = self.bins[0] * self.bins[1]
+        self.reduce = nn.Conv(ps, scope + "/reduce_depth", cin, self.depth, 1, init, is_training, wd,
+                              activation=act)
+        self.loc = None
+        if not class_only:
+            self.loc = nn.Conv(ps, scope + "/refined_locations", self.depth, nb * num_classes * 4, 1, init,
+                               is_training, wd)
+            self.cls = nn.Conv(ps, scope + "/class_predictions", self.depth, nb * (num_classes + 1), 1, init,
+                               is_training, wd)
+        else:
+            self.cls = nn.Conv(ps, scope + "/class_predictions", self.depth, nb * num_classes, 1, init,
+                               is_training, wd)
+
+    def layers(self):
+        return [l for l in (self.reduce, self.loc, self.cls) if l is not None]
+
+    def predict(self, feat, boxes_flat, box_ind):
+        net = self.reduce.forward(feat)
+        cls_map = self.cls.forward(net)
+        out = {"net": net, "cls_map_shape": tuple(cls_map.shape), "boxes": boxes_flat, "box_ind": box_ind,
+               "class": ops.psroi_fwd(cls_map, boxes_flat, box_ind, self.crop, self.bins)}
+        if self.loc is not None:
+            loc_map = self.loc.forward(net)
+            out["loc_map_shape"] = tuple(loc_map.shape)
+            out["box"] = ops.psroi_fwd(loc_map, boxes_flat, box_ind, self.crop, self.bins)
+        return out
+
+    def backward(self, pred, d_class, d_box, feat, need_feat_grad=True):
+        """Returns dL/d(feat) (unmasked) or None."""
+        net = pred["net"]
+        g_cls_map = ops.psroi_bwd(d_class, pred["cls_map_shape"], pred["boxes"], pred["box_ind"], self.crop,
+                                  self.bins)
+        self.cls.wgrad(net, g_cls_map)
+        relu = self.reduce.activation == "relu"
+        if d_box is not None:
+            g_loc_map = ops.psroi_bwd(d_box, pred["loc_map_shape"], pred["boxes"], pred["box_ind"], self.crop,
+                                      self.bins)
+            self.loc.wgrad(net, g_loc_map)
+            g_net = self.loc.dgrad(net.shape, g_loc_map)
+            self.cls.dgrad(net.shape, g_cls_map, out=g_net, accum=True, mask_ref=net if relu else None)
+        else:
+            g_net = self.cls.dgrad(net.shape, g_cls_map, mask_ref=net if relu else None)
+        self.reduce.wgrad(feat, g_net)
+        if not need_feat_grad:
+            return None
+        return self.reduce.dgrad(feat.shape, g_net)
+
+
+class RFCNMetaArch(FasterRCNNMetaArch):
+    def _make_predictor(self, scope, num_classes, bp_cfg, class_only):
+        if not bp_cfg.has("rfcn_box_predictor"):
+            raise ValueError("RFCNMetaArch needs rfcn_box_predictor for %s" % scope)
+        return RfcnBoxPredictor(self.ps, scope, self.tower.cout, num_classes, bp_cfg.rfcn_box_predictor,
+                                self._is_training and bp_cfg.trainable, class_only)
+
+    # ------------------------------------------------------------------ forward
+    def _predict_second_stage(self, pd):
+        """rfcn_meta_arch.py:208-310."""
+        c, mtl = self.cfg, self._mtl
+        B, H, W, _ = pd["image_shape"]
+        F = pd["rpn_features_to_crop"]
+        gt = self._format_groundtruth_data(H, W)
+        props, _scores, nprop = ops.rpn_proposals(
+            pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"],
+            H, W, c.first_stage_nms_score_threshold, c.first_stage_nms_iou_threshold,
+            int(c.first_stage_max_proposals))
+        N2 = self.max_num_proposals
+        stream0 = (2 * self.step * 65536 + 1) & 0xFFFFFFFF
+        boxes_abs, boxes_norm, num = ops.sample_proposals(
+            props, nprop, gt["boxes_abs"], gt["num"], gt["classes_bg"], N2,
+            c.second_stage_balance_fraction, self.seed, stream0, 2, H, W)
+        box_ind = self._box_ind(B, N2, F.device)
+        flat = boxes_norm.view(B * N2, 4)
+        feat, tower_ctx = self.tower.forward(F, self._is_training)
+        bp = self.box_predictor.predict(feat, flat, box_ind)
+        out = {
+            "refined_box_encodings": bp["box"].view(B * N2, self.num_classes, 4),
+            "class_predictions_with_background": bp["class"],
+            "num_proposals": num, "proposal_boxes": boxes_abs, "proposal_boxes_normalized": boxes_norm,
+            "_box_ind": box_ind, "_feat": feat, "_tower_ctx": tower_ctx, "_bp": bp,
+        }
+        if mtl.closeness:
+            cfeat, cctx = self.closeness_tower.forward(F, self._is_training)
+            cp = self.closeness_predictor.predict(cfeat, flat, box_ind)
+            out.update({"closeness_predictions": cp["class"], "_cfeat": cfeat, "_cctx": cctx, "_cp": cp})
+        return out
+
+    def _window_features(self, pd, save):
+        """block4 (window scope) on the whole map; computed once per step and shared by the
+        window loss head and the refine windows (the reference rebuilds the identical ops)."""
+        if "_wfeat" not in pd:
+            feat, ctx = self.window_tower.forward(pd["rpn_features_to_crop"], save)
+            pd["_wfeat"], pd["_wctx"] = feat, ctx
+        return pd["_wfeat"]
+
+    def predict_with_window(self, pd, window_boxes_normalized=None):
+        """rfcn_meta_arch.py:312-381."""
+        F = pd["rpn_features_to_crop"]
+        B = F.shape[0]
+        wb = self._window["boxes"] if window_boxes_normalized is None else window_boxes_normalized
+        Wn = wb.shape[1]
+        flat = wb.reshape(B * Wn, 4)
+        box_ind = self._box_ind(B, Wn, F.device)
+        feat = self._window_features(pd, self._is_training)
+        wp = self.window_predictor.predict(feat, flat, box_ind)
+        pd.update({"window_class_predictions": wp["class"], "_wp": wp})
+        return pd
+
+    def predict_with_mtl_results(self, pd):
+        """faster_rcnn_meta_arch.py:764-846 with the R-FCN window head, per image."""
+        mtl = self._mtl
+        F = pd["rpn_features_to_crop"]
+        B = F.shape[0]
+        N2 = self.max_num_proposals
+        K1 = self.num_classes + 1
+        cls = pd["class_predictions_with_background"]
+        win = None
+        if mtl.window:
+            ew = ops.expand_windows(pd["proposal_boxes_normalized"], self.N_EXPAND)
+            flat = ew.view(B * self.N_EXPAND * N2, 4)
+            box_ind = self._box_ind(B, self.N_EXPAND * N2, F.device)
+            feat = self._window_features(pd, self._is_training)
+            win = self.window_predictor.predict(feat, flat, box_ind)["class"]
+            pd["expand_window_class_predictions"] = win.view(B, self.N_EXPAND, N2, K1)
+        clo = pd["closeness_predictions"] if mtl.closeness else None
+        net = ops.refine_concat(cls, win, clo, B, N2, self.N_EXPAND, bool(mtl.global_closeness))
+        refined = self.refine_fc.forward(net)
+        if mtl.refine_residue:
+            ops.axpby(cls, refined, 1.0, 1.0)
+        pd["mtl_refined_class_predictions_with_background"] = refined
+        pd["_refine_in"] = net
+        return pd
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, pd):
+        mtl = self._mtl
+        d = pd["_d"]
+        F = pd["rpn_features_to_crop"]
+        B = F.shape[0]
+        dF = torch.zeros_like(F)
+        d_cls = d["class_predictions"]
+        if mtl.refine:
+            d_ref = d["refined_class_predictions"]
+            self.refine_fc.wgrad(pd["_refine_in"], d_ref)
+            if mtl.refine_residue and not mtl.stop_gradient_for_prediction_org:
+                ops.axpby(d_ref, d_cls, 1.0, 1.0)
+        feat = pd["_feat"]
+        g_feat = self.box_predictor.backward(pd["_bp"], d_cls,
+                                             d["refined_box_encodings"].view(d_cls.shape[0], -1), feat)
+        g_F = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True)
+        ops.axpby(g_F, dF, 1.0, 1.0)
+        stop = bool(mtl.stop_gradient_for_aux_tasks)
+        if mtl.closeness:
+            cfeat = pd["_cfeat"]
+            g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat)
+            g_F = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop)
+            if not stop:
+                ops.axpby(g_F, dF, 1.0, 1.0)
+        if mtl.window:
+            wfeat = pd["_wfeat"]
+            g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat)
+            g_F = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop)
+            if not stop:
+                ops.axpby(g_F, dF, 1.0, 1.0)
+        if mtl.edgemask:
+            em_pred = pd["edgemask_predictions"]
+            g = ops.resize_bilinear_bwd(d["edgemask_resized"], em_pred.shape)
+            g = ops.tanh_bwd(em_pred, g)
+            self.edgemask_conv.wgrad(F, g)
+            self.edgemask_conv.dgrad(F.shape, g, out=dF, accum=True)
+        rpn_feat = pd["rpn_box_predictor_features"]
+        n_all = pd["_n_all"]
+        g_enc = ops.scatter_rows(d["rpn_box_encodings"], pd["_keep"], n_all).view(B, F.shape[1], F.shape[2], -1)
+        g_obj = ops.scatter_rows(d["rpn_objectness"], pd["_keep"], n_all).view(B, F.shape[1], F.shape[2], -1)
+        self.rpn_box.wgrad(rpn_feat, g_enc)
+        self.rpn_cls.wgrad(rpn_feat, g_obj)
+        g_rf = self.rpn_box.dgrad(rpn_feat.shape, g_enc)
+        relu = self.rpn_conv.activation == "relu"
+        self.rpn_cls.dgrad(rpn_feat.shape, g_obj, out=g_rf, accum=True, mask_ref=rpn_feat if relu else None)
+        self.rpn_conv.wgrad(F, g_rf)
+        gpF = self.rpn_conv.dgrad(F.shape, g_rf, out=dF, accum=True, mask_ref=F)
+        pd["_gpF"] = gpF
+        self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"])

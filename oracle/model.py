@@ -84,6 +84,18 @@ class Oracle:
         y = T.conv2d(x, self.v[scope + "/weights"], 1, 1, "SAME") + self.v[scope + "/biases"]
         return {None: y, "relu": torch.relu(y), "tanh": torch.tanh(y)}[act]
 
+    def rfcn_predict(self, fmap, scope, boxes_flat, box_ind, with_loc):
+        """core/box_predictor.py:180-337 (RfcnBoxPredictor._predict / _predict_class)."""
+        r = self.hp["rfcn"]
+        net = self.conv(fmap, scope + "/reduce_depth", "relu")
+        cm = self.conv(net, scope + "/class_predictions")
+        cls = T.position_sensitive_crop_regions(cm, boxes_flat, box_ind, r["crop"], r["bins"], True)[:, 0, 0, :]
+        loc = None
+        if with_loc:
+            lm = self.conv(net, scope + "/refined_locations")
+            loc = T.position_sensitive_crop_regions(lm, boxes_flat, box_ind, r["crop"], r["bins"], True)[:, 0, 0, :]
+        return cls, loc
+
     def crop(self, feat, boxes_norm, box_ind):
         hp = self.hp
         c = T.crop_and_resize(feat, boxes_norm, box_ind, hp["initial_crop_size"])
@@ -122,15 +134,27 @@ class Oracle:
                                                           hp["second_stage_balance_fraction"], seed, step)
         boxes_norm = np.stack([B.to_normalized(boxes_abs[b], H, W) for b in range(Bn)])
         box_ind = np.repeat(np.arange(Bn), N2)
-        crops = self.crop(Fm, boxes_norm.reshape(-1, 4), box_ind)
-        feat = self.tower(crops, "SecondStageFeatureExtractor").mean((1, 2))
-        box_enc = self.fc(feat, "SecondStageBoxPredictor/BoxEncodingPredictor").reshape(Bn * N2, K, 4)
-        cls = self.fc(feat, "SecondStageBoxPredictor/ClassPredictor")
-        aux_crops = crops.detach() if mtl["stop_gradient_for_aux_tasks"] else crops
+        rfcn = hp.get("rfcn")
+        stop_aux = mtl["stop_gradient_for_aux_tasks"]
         clo = None
-        if mtl["closeness"]:
-            cf = self.tower(aux_crops, "ClosenessBoxPredictor").mean((1, 2))
-            clo = self.fc(cf, "ClosenessBoxPredictor/ClassPredictor")
+        if rfcn is None:
+            crops = self.crop(Fm, boxes_norm.reshape(-1, 4), box_ind)
+            feat = self.tower(crops, "SecondStageFeatureExtractor").mean((1, 2))
+            box_enc = self.fc(feat, "SecondStageBoxPredictor/BoxEncodingPredictor").reshape(Bn * N2, K, 4)
+            cls = self.fc(feat, "SecondStageBoxPredictor/ClassPredictor")
+            aux_crops = crops.detach() if stop_aux else crops
+            if mtl["closeness"]:
+                cf = self.tower(aux_crops, "ClosenessBoxPredictor").mean((1, 2))
+                clo = self.fc(cf, "ClosenessBoxPredictor/ClassPredictor")
+        else:
+            # rfcn_meta_arch.py:208-310: block4 on the whole map, then position-sensitive pooling
+            flat = boxes_norm.reshape(-1, 4)
+            fmap = self.tower(Fm, "SecondStageFeatureExtractor")
+            cls, box_enc = self.rfcn_predict(fmap, "SecondStageBoxPredictor", flat, box_ind, True)
+            box_enc = box_enc.reshape(Bn * N2, K, 4)
+            if mtl["closeness"]:
+                cmap = self.tower(Fm.detach() if stop_aux else Fm, "ClosenessBoxPredictor")
+                clo, _ = self.rfcn_predict(cmap, "ClosenessBoxPredictor", flat, box_ind, False)
         losses = {}
         # ---- RPN loss
         tg = L.rpn_targets(anchors, gt_abs, hp["first_stage_minibatch_size"],
@@ -147,11 +171,16 @@ class Oracle:
         if mtl["window"]:
             wb = np.stack([np.asarray(w, F) for w in batch["window_boxes"]])
             Wn = wb.shape[1]
-            wc = self.crop(Fm, wb.reshape(-1, 4), np.repeat(np.arange(Bn), Wn))
-            if mtl["stop_gradient_for_aux_tasks"]:
-                wc = wc.detach()
-            wf = self.tower(wc, "WindowBoxPredictor").mean((1, 2))
-            win_logits = self.fc(wf, "WindowBoxPredictor/ClassPredictor")
+            if rfcn is None:
+                wc = self.crop(Fm, wb.reshape(-1, 4), np.repeat(np.arange(Bn), Wn))
+                if stop_aux:
+                    wc = wc.detach()
+                wf = self.tower(wc, "WindowBoxPredictor").mean((1, 2))
+                win_logits = self.fc(wf, "WindowBoxPredictor/ClassPredictor")
+            else:
+                wmap = self.tower(Fm.detach() if stop_aux else Fm, "WindowBoxPredictor")
+                win_logits, _ = self.rfcn_predict(wmap, "WindowBoxPredictor", wb.reshape(-1, 4),
+                                                  np.repeat(np.arange(Bn), Wn), False)
             losses.update(L.loss_window_class(win_logits, np.stack(batch["window_classes"]),
                                               mtl["window_class_loss_weight"]))
         if mtl["edgemask"]:
@@ -174,9 +203,13 @@ class Oracle:
                                               ymax + (F(1) - ymax) / ne * fi,
                                               xmax + (F(1) - xmax) / ne * fi], 1).astype(F))
                     ew = np.concatenate(wins, 0)                       # [5*N2,4], window-major
-                    ec = self.crop(Fm.detach(), ew, np.full(len(ew), b))
-                    ef = self.tower(ec, "WindowBoxPredictor").mean((1, 2))
-                    ep = self.fc(ef, "WindowBoxPredictor/ClassPredictor")          # [5*N2,K1]
+                    if rfcn is None:
+                        ec = self.crop(Fm.detach(), ew, np.full(len(ew), b))
+                        ef = self.tower(ec, "WindowBoxPredictor").mean((1, 2))
+                        ep = self.fc(ef, "WindowBoxPredictor/ClassPredictor")          # [5*N2,K1]
+                    else:
+                        ep, _ = self.rfcn_predict(wmap.detach(), "WindowBoxPredictor", ew,
+                                                  np.full(len(ew), b), False)
                     per_img.append(ep.reshape(5, N2, K1).permute(1, 0, 2).reshape(N2, 5 * K1))
                 src.append(torch.cat(per_img, 0))
             if mtl["closeness"]:

@@ -107,6 +107,34 @@ def crop_and_resize(feat, boxes, box_ind, crop_size):
     return torch.where(valid, out, torch.zeros((), dtype=out.dtype))
 
 
+def position_sensitive_crop_regions(image, boxes, box_ind, crop_size, num_spatial_bins, global_pool):
+    """object_detection/utils/ops.py:462-609. image [B,H,W,C]; boxes [R,4]; -> [R,1,1,Cc] when
+    global_pool else [R,crop_h,crop_w,Cc] with Cc = C / (bins_y*bins_x)."""
+    bins_y, bins_x = num_spatial_bins
+    if bins_y < 1 or bins_x < 1:
+        raise ValueError("num_spatial_bins should be >= 1")
+    if crop_size[0] % bins_y or crop_size[1] % bins_x:
+        raise ValueError("crop_size should be divisible by num_spatial_bins")
+    bs = (crop_size[0] // bins_y, crop_size[1] // bins_x)
+    boxes = torch.as_tensor(boxes, dtype=torch.float32)
+    ymin, xmin, ymax, xmax = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+    nb = bins_y * bins_x
+    Cc = image.shape[-1] // nb
+    crops = []
+    for by in range(bins_y):
+        step_y = (ymax - ymin) / bins_y
+        for bx in range(bins_x):
+            step_x = (xmax - xmin) / bins_x
+            sub = torch.stack([ymin + by * step_y, xmin + bx * step_x,
+                               ymin + (by + 1) * step_y, xmin + (bx + 1) * step_x], 1)
+            g = by * bins_x + bx
+            crops.append(crop_and_resize(image[..., g * Cc:(g + 1) * Cc], sub, box_ind, bs))
+    if global_pool:
+        return (sum(crops) / len(crops)).mean((1, 2), keepdim=True)
+    rows = [torch.cat(crops[by * bins_x:(by + 1) * bins_x], 2) for by in range(bins_y)]
+    return torch.cat(rows, 1)
+
+
 def resize_bilinear_legacy(x, out_h, out_w):
     """tf.image.resize_images(..., BILINEAR, align_corners=False), TF 1.7
     (tensorflow/core/kernels/resize_bilinear_op.cc): src = dst * (in/out), no half-pixel

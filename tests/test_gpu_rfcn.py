@@ -1,0 +1,104 @@
+"""GPU parity for the R-FCN path (BASELINE.json configs[2]): position-sensitive ROI pooling vs the
+oracle restatement of utils/ops.py:462-609 (incl. the reference's known answers), and the whole
+R-FCN training step (RFCNMetaArch, aux heads as R-FCN predictors, aux gradients NOT stopped) vs
+the torch-CPU autograd oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_torch as T
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import ops
+    return ops
+
+
+def test_psroi_known_answers(ops):
+    # utils/ops_test.py:711-733: channel c holds the constant c+1 -> every box pools to 3.5
+    image = torch.tensor(list(range(1, 7)) * 6, dtype=torch.float32).reshape(1, 3, 2, 6)
+    boxes = torch.tensor([[0.1, 0.2, 0.8, 0.9], [0.3, 0.0, 0.4, 1.0]])
+    bi = torch.zeros(2, dtype=torch.int32)
+    for mult in (1, 2):
+        out = ops.psroi_fwd(image.cuda(), boxes.cuda(), bi.cuda(), (3 * mult, 2 * mult), (3, 2))
+        np.testing.assert_allclose(out.cpu().numpy(), [[3.5], [3.5]], rtol=1e-6)
+    # utils/ops_test.py:863-898 (global_pool=False expectations; pooled here): whole image and first row
+    image = torch.tensor(list(range(1, 17)) * 2, dtype=torch.float32).reshape(2, 2, 2, 4)
+    boxes = torch.tensor([[0., 0., 1., 1.], [0., 0., 0.5, 1.]])
+    bi = torch.tensor([0, 1], dtype=torch.int32)
+    out = ops.psroi_fwd(image.cuda(), boxes.cuda(), bi.cuda(), (2, 2), (2, 2))
+    np.testing.assert_allclose(out.cpu().numpy(), [[(4 + 7 + 10 + 13) / 4.0], [(3 + 6 + 7 + 10) / 4.0]])
+    ref = T.position_sensitive_crop_regions(image, boxes, bi, (2, 2), (2, 2), False)
+    np.testing.assert_allclose(ref.numpy()[:, :, :, 0], [[[4, 7], [10, 13]], [[3, 6], [7, 10]]])
+    with pytest.raises(Exception, match="num_spatial_bins should be >= 1"):
+        ops.psroi_fwd(image.cuda(), boxes.cuda(), bi.cuda(), (2, 2), (1, 0))
+    with pytest.raises(Exception, match="divisible"):
+        ops.psroi_fwd(image.cuda(), boxes.cuda(), bi.cuda(), (3, 2), (2, 2))
+
+
+@pytest.mark.parametrize("K", [6, 21])
+def test_psroi_fwd_bwd_vs_oracle(ops, K):
+    g = torch.Generator().manual_seed(K)
+    fmap = torch.randn(2, 19, 27, 9 * K, generator=g)
+    R = 40
+    yx = torch.rand(R, 2, generator=g) * 0.9 - 0.05
+    hw = torch.rand(R, 2, generator=g) * 0.6 + 0.02
+    boxes = torch.cat([yx, yx + hw], 1)
+    boxes[0] = torch.tensor([0.0, 0.0, 1.0, 1.0])
+    boxes[1] = 0.0                                               # zero-padded proposal
+    bi = (torch.arange(R) % 2).int()
+    fr = fmap.clone().requires_grad_()
+    ref = T.position_sensitive_crop_regions(fr, boxes, bi, (18, 18), (3, 3), True)[:, 0, 0, :]
+    out = ops.psroi_fwd(fmap.cuda(), boxes.cuda(), bi.cuda(), (18, 18), (3, 3))
+    assert float((out.cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    df = ops.psroi_bwd(gy.cuda(), fmap.shape, boxes.cuda(), bi.cuda(), (18, 18), (3, 3))
+    assert float((df.cpu() - fr.grad).abs().max() / fr.grad.abs().max()) < 1e-4
+
+
+def test_rfcn_step_matches_oracle():
+    import bench
+    from mtl_ssl_amd import config, model_builder, rfcn, synthetic, trainer
+    from oracle.model import Oracle
+    cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", "smoke_rfcn_resnet50_mtl.config")).read())
+    model = model_builder.build(cfg.model, True, "cuda", seed=3)
+    assert isinstance(model, rfcn.RFCNMetaArch)
+    tr = trainer.Trainer(model, cfg.train_config, 1)
+    assert tr.var_wd is not None                                   # L2 regularisers are configured
+    batch = synthetic.make_batch(2, 160, 224, 5, seed=11, device="cuda", max_gt=4, num_windows=6)
+    values = model.ps.state_dict()
+    losses = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    got = {k: float(v.item()) for k, v in losses.items()}
+    hb = dict(batch)
+    hb["images"] = batch["images"].cpu().numpy()
+    ref, rgrads, aux = Oracle(bench.hyper_params_for_oracle(cfg), values).step(hb, seed=model.seed, step=0)
+    pd = tr._pd
+    np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
+    np.testing.assert_array_equal(pd["_det_targets"]["match"].cpu().numpy(), aux["det_match"])
+    assert set(got) == set(ref)
+    for k in ref:
+        assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
+    grads = model.ps.grads_dict()
+    l2errs = []
+    for name, gv in grads.items():
+        r = rgrads.get(name)
+        if r is None:
+            assert np.abs(gv).max() == 0, name
+            continue
+        l2 = np.linalg.norm((gv - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-12)
+        assert l2 < 5e-3, (name, l2)
+        l2errs.append(l2)
+    assert len(l2errs) > 60 and np.median(l2errs) < 1e-3
+    # aux gradients are NOT stopped in the R-FCN configs: the trunk sees them
+    tr.apply_gradients()
+    assert np.isfinite(model.ps.weights.sum().item())
