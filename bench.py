@@ -38,7 +38,7 @@ def hyper_params_for_oracle(cfg):
     return dict(
         rfcn=rf,
         arch={"faster_rcnn_resnet50": "resnet_v1_50", "faster_rcnn_resnet101": "resnet_v1_101",
-              "faster_rcnn_resnet152": "resnet_v1_152"}[fr.feature_extractor.type],
+              "faster_rcnn_resnet152": "resnet_v1_152", "frcnn_mobilenet_v1": "mobilenet_v1"}[fr.feature_extractor.type],
         num_classes=int(fr.num_classes), scales=list(g.scales), aspect_ratios=list(g.aspect_ratios),
         nms_score_threshold=fr.first_stage_nms_score_threshold,
         nms_iou_threshold=fr.first_stage_nms_iou_threshold, max_proposals=int(fr.first_stage_max_proposals),

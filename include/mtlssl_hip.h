@@ -53,6 +53,7 @@ typedef struct {
 #define MTLSSL_EPI_RELU6 16    /* min(max(.,0),6) (slim/nets/mobilenet_v1.py)               */
 #define MTLSSL_EPI_MASK 32     /* dgrad only: out *= (mask_ref > 0)  (ReLU backward)         */
 #define MTLSSL_EPI_ACCUM 64    /* dgrad only: out += existing contents of the output buffer */
+#define MTLSSL_EPI_MASK6 128   /* dgrad only: out *= (0 < mask_ref < 6)  (ReLU6 backward)    */
 
 /* Scratch needed by a call in the given mode (0 fwd, 1 dgrad, 2 wgrad); fwd/dgrad use it for
  * split-K partials when the tile grid alone would not fill the 256 CUs (0 when not split).
@@ -78,6 +79,28 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode);
 int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,
                         const float* out_scale, float* dw, float* dbias, float beta,
                         void* workspace, mtlssl_stream_t stream);
+
+/* Depthwise convolution (slim.separable_conv2d with num_outputs=None, depth_multiplier 1:
+ * slim/nets/mobilenet_v1.py:229-245; models/faster_rcnn_mobilenet_v1_feature_extractor.py:145-184).
+ * Descriptor with C == K; filter layout [R,S,C]. Epilogue flags BIAS / RELU / RELU6 (fwd) and
+ * MASK / MASK6 (dgrad). HBM-bound. */
+int mtlssl_depthwise_fwd(const mtlssl_conv_desc* d, const float* x, const float* w, const float* bias,
+                         float* y, int epilogue, mtlssl_stream_t stream);
+int mtlssl_depthwise_dgrad(const mtlssl_conv_desc* d, const float* dy, const float* w,
+                           const float* mask_ref, float* dx, int epilogue, mtlssl_stream_t stream);
+int64_t mtlssl_depthwise_wgrad_workspace_bytes(const mtlssl_conv_desc* d);
+int mtlssl_depthwise_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,
+                           const float* out_scale, float* dw, float beta, void* workspace,
+                           mtlssl_stream_t stream);
+/* Gradients of the trainable gamma/beta of an inference-mode slim.batch_norm that has been folded
+ * into its producing convolution (slim/nets/mobilenet_v1.py:376-413: the MobileNet arg scope runs
+ * BatchNorm with is_training=False but leaves gamma/beta trainable). y [rows,C] = the layer's
+ * post-activation output, g [rows,C] = dL/d(pre-activation) (already ReLU/ReLU6-masked):
+ * dbeta = colsum(g), dgamma = colsum(g*(y-beta))/gamma; `accum` != 0 adds into dgamma/dbeta. */
+int64_t mtlssl_bn_param_grads_workspace_bytes(int C);
+int mtlssl_bn_param_grads(const float* y, const float* g, const float* gamma, const float* beta,
+                          float* dgamma, float* dbeta, int64_t rows, int C, float accum, void* workspace,
+                          mtlssl_stream_t stream);
 
 /* slim.max_pool2d (slim/nets/resnet_v1.py:222; resnet_utils.subsample :59-74). */
 int mtlssl_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, int k, int stride,
@@ -248,6 +271,8 @@ int mtlssl_scale_channels(const float* w, const float* scale, float* out, int64_
                           mtlssl_stream_t s); /* out[r,k] = w[r,k]*scale[k] (BN fold) */
 int mtlssl_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlssl_stream_t s);
 int mtlssl_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlssl_stream_t s);
+/* dx = dy * (0 < y < 6): gradient of tf.nn.relu6 (slim/nets/mobilenet_v1.py:376-413 arg scope). */
+int mtlssl_relu6_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlssl_stream_t s);
 /* out[r,c] = x[r,c] + bias[c]: channel-mean subtraction of
  * models/faster_rcnn_resnet_v1_feature_extractor.py:74-90 (pass the negated means). */
 int mtlssl_bias_add_channels(const float* x, const float* bias, float* out, int64_t rows, int C,

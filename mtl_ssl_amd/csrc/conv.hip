@@ -20,6 +20,12 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+// ReLU / ReLU6 backward: pass the gradient where the activation was in its linear range.
+__device__ __forceinline__ float act_mask(float g, float y, int epi) {
+  bool on = y > 0.f && (!(epi & MTLSSL_EPI_MASK6) || y < 6.f);
+  return on ? g : 0.f;
+}
+constexpr int MASK_ANY = MTLSSL_EPI_MASK | MTLSSL_EPI_MASK6;
 constexpr int BK = 16;
 
 struct ConvArgs {
@@ -326,7 +332,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
         } else if constexpr (MODE == MODE_DGRAD) {
           if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
           if (p.epi & MTLSSL_EPI_ACCUM) v += outp[o];
-          if (p.epi & MTLSSL_EPI_MASK) v = p.mask[o] > 0.f ? v : 0.f;
+          if (p.epi & MASK_ANY) v = act_mask(v, p.mask[o], p.epi);
         }
         outp[o] = v;
       }
@@ -427,7 +433,7 @@ __global__ void k_conv_direct_dgrad(ConvArgs p) {
   }
   if (p.epi & MTLSSL_EPI_RESIDUAL) acc += p.residual[i];
   if (p.epi & MTLSSL_EPI_ACCUM) acc += p.out[i];
-  if (p.epi & MTLSSL_EPI_MASK) acc = p.mask[i] > 0.f ? acc : 0.f;
+  if (p.epi & MASK_ANY) acc = act_mask(acc, p.mask[i], p.epi);
   p.out[i] = acc;
 }
 // wgrad for small layers: one block per (rs, c), threads over k, pixels reduced serially.
@@ -447,6 +453,66 @@ __global__ void k_conv_direct_wgrad(ConvArgs p, const float* scale, float* dw, f
     int64_t o = ((int64_t)rs * p.C + c) * p.K + k;
     dw[o] = beta != 0.f ? beta * dw[o] + acc : acc;
   }
+}
+
+// wgrad of a trainable network stem (MobileNet Conv2d_0: 3x3x3 -> 32, 300k output pixels): the
+// filter has only R*S*C*K <= 2k entries but the reduction runs over every output pixel, so the
+// pixels are split over the grid. Thread = (k lane, pixel group); each keeps the R*S*C taps of its
+// output channel in registers; dy is read once, coalesced over k; x taps are wave-uniform
+// broadcasts. Partials [chunk][R*S*C][K] are folded by k_small_reduce.
+constexpr int STEM_MAX_CHUNKS = 512;
+template <int R_, int S_, int C_>
+__global__ void __launch_bounds__(256) k_conv_stem_wgrad(ConvArgs p, int pix_per_chunk, float* part) {
+  constexpr int T = R_ * S_ * C_;
+  const int KL = p.K <= 32 ? 32 : 64;
+  const int k = threadIdx.x % KL, grp = threadIdx.x / KL, ngrp = 256 / KL;
+  const int64_t P = (int64_t)p.N * p.OH * p.OW;
+  int64_t p0 = (int64_t)blockIdx.x * pix_per_chunk;
+  int64_t p1 = p0 + pix_per_chunk < P ? p0 + pix_per_chunk : P;
+  float acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  if (k < p.K) {
+    for (int64_t pix = p0 + grp; pix < p1; pix += ngrp) {
+      int ow = pix % p.OW;
+      int64_t t2 = pix / p.OW;
+      int oh = t2 % p.OH, n = t2 / p.OH;
+      float g = p.b[pix * p.K + k];
+#pragma unroll
+      for (int r = 0; r < R_; ++r) {
+        int ih = oh * p.stride - p.pt + r * p.dil;
+#pragma unroll
+        for (int s = 0; s < S_; ++s) {
+          int iw = ow * p.stride - p.pl + s * p.dil;
+          bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+          const float* xp = p.a + (((int64_t)n * p.H + (ok ? ih : 0)) * p.W + (ok ? iw : 0)) * C_;
+#pragma unroll
+          for (int c = 0; c < C_; ++c) acc[(r * S_ + s) * C_ + c] += ok ? xp[c] * g : 0.f;
+        }
+      }
+    }
+  }
+  __shared__ float red[8][64];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    red[grp][k] = acc[t];
+    __syncthreads();
+    if (grp == 0 && k < p.K) {
+      float v = 0.f;
+      for (int g2 = 0; g2 < ngrp; ++g2) v += red[g2][k];
+      part[((int64_t)blockIdx.x * T + t) * p.K + k] = v;
+    }
+    __syncthreads();
+  }
+}
+static inline bool is_stem3(const mtlssl_conv_desc* d) {
+  return d->R == 3 && d->S == 3 && d->C == 3 && d->K <= 64;
+}
+static inline void stem_plan(const mtlssl_conv_desc* d, int* chunks, int* ppc) {
+  int64_t P = (int64_t)d->N * d->OH * d->OW;
+  int c = (int)(cdiv(P, 128) < STEM_MAX_CHUNKS ? cdiv(P, 128) : STEM_MAX_CHUNKS);
+  *ppc = (int)cdiv(P, c);
+  *chunks = (int)cdiv(P, *ppc);
 }
 
 // ------------------------------------------------------------------------------ small layers
@@ -531,7 +597,7 @@ __global__ void __launch_bounds__(256) k_gemm_small(GemmArgs p) {
       } else if constexpr (MODE == GM_DGRAD) {
         if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
         if (p.epi & MTLSSL_EPI_ACCUM) v += outp[o];
-        if (p.epi & MTLSSL_EPI_MASK) v = p.mask[o] > 0.f ? v : 0.f;
+        if (p.epi & MASK_ANY) v = act_mask(v, p.mask[o], p.epi);
       }
       outp[o] = v;
     }
@@ -679,10 +745,10 @@ __global__ void k_splitk_epilogue(ConvArgs p) {
   } else {
     if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
     if (p.epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const floatx4*>(p.out + o);
-    if (p.epi & MTLSSL_EPI_MASK) {
+    if (p.epi & MASK_ANY) {
       floatx4 m = *reinterpret_cast<const floatx4*>(p.mask + o);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = act_mask(v[e], m[e], p.epi);
     }
   }
   *reinterpret_cast<floatx4*>(p.out + o) = v;
@@ -840,7 +906,7 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
                         const float* residual, const float* mask_ref, float* dx, int epi,
                         void* workspace, mtlssl_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
-  MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_MASK) || mask_ref, "conv_dgrad: mask_ref pointer required");
+  MTLSSL_REQUIRE(!(epi & MASK_ANY) || mask_ref, "conv_dgrad: mask_ref pointer required");
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_dgrad: residual pointer required");
   ConvArgs p = make_args(d);
   p.a = dy; p.b = w; p.out = dx; p.residual = residual; p.mask = mask_ref; p.epi = epi;
@@ -887,6 +953,7 @@ int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
   if (!d) return 256;
   int64_t bias_part = align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256);
   if (d->C % 64 || d->K % 64) {
+    if (is_stem3(d)) return bias_part + align_up((int64_t)STEM_MAX_CHUNKS * 27 * d->K * 4, 256);
     if (!is_pointwise(d)) return bias_part;
     int ns, kps;
     small_wgrad_plan(d, &ns, &kps);
@@ -925,6 +992,13 @@ int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* 
     hipLaunchKernelGGL(k_gemm_small<GM_WGRAD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64), ns), dim3(256), 0, st, g);
     int64_t total = (int64_t)d->C * d->K;
     hipLaunchKernelGGL(k_small_reduce, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)ws_main, ns,
+                       total, d->K, out_scale, dw, beta);
+  } else if (is_stem3(d)) {
+    int chunks, ppc;
+    stem_plan(d, &chunks, &ppc);
+    hipLaunchKernelGGL((k_conv_stem_wgrad<3, 3, 3>), dim3(chunks), dim3(256), 0, st, p, ppc, ws_main);
+    int64_t total = (int64_t)27 * d->K;
+    hipLaunchKernelGGL(k_small_reduce, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)ws_main, chunks,
                        total, d->K, out_scale, dw, beta);
   } else {
     hipLaunchKernelGGL(k_conv_direct_wgrad, dim3(d->C, d->R * d->S), dim3(64), 0, st, p, out_scale,

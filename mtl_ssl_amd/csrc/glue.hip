@@ -152,6 +152,10 @@ __global__ void k_relu_bwd(const float* y, const float* dy, float* dx, int64_t n
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
+__global__ void k_relu6_bwd(const float* y, const float* dy, float* dx, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = (y[i] > 0.f && y[i] < 6.f) ? dy[i] : 0.f;
+}
 __global__ void k_onehot2(const float* t, float* out, int64_t n) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -240,6 +244,11 @@ int mtlssl_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlss
   if (!n) return MTLSSL_OK;
   hipLaunchKernelGGL(k_relu_bwd, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), y, dy, dx, n);
   return check_launch("relu_bwd");
+}
+int mtlssl_relu6_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlssl_stream_t stream) {
+  if (!n) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_relu6_bwd, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), y, dy, dx, n);
+  return check_launch("relu6_bwd");
 }
 int mtlssl_onehot2(const float* t, float* out, int64_t n, mtlssl_stream_t stream) {
   if (!n) return MTLSSL_OK;

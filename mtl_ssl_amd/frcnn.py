@@ -511,6 +511,7 @@ class FasterRCNNMetaArch:
         self.rpn_cls.dgrad(rpn_feat.shape, g_obj, out=g_rf, accum=True, mask_ref=rpn_feat if relu else None)
         self.rpn_conv.wgrad(F, g_rf)
         # last consumer of F: accumulate and apply the ReLU mask of the trunk output
-        gpF = self.rpn_conv.dgrad(F.shape, g_rf, out=dF, accum=True, mask_ref=F)
+        gpF = self.rpn_conv.dgrad(F.shape, g_rf, out=dF, accum=True, mask_ref=F,
+                                  mask6=getattr(self._feature_extractor, "output_relu6", False))
         pd["_gpF"] = gpF
         self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"])

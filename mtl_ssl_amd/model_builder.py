@@ -3,7 +3,7 @@
 `FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP` is the reference's plugin registry: feature
 extractors register by the `feature_extractor.type` string of the pipeline config.
 """
-from . import frcnn, resnet, rfcn
+from . import frcnn, mobilenet, resnet, rfcn
 from .params import ParamStore
 
 
@@ -19,7 +19,16 @@ def _resnet(arch):
     return make
 
 
+def _mobilenet(ps, fe_cfg, is_training):
+    kwargs = {}
+    if fe_cfg.has("weight_decay"):
+        kwargs["weight_decay"] = float(fe_cfg.weight_decay)
+    return mobilenet.FasterRCNNMobilenetV1FeatureExtractor(
+        ps, is_training, int(fe_cfg.first_stage_features_stride), **kwargs)
+
+
 FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP = {
+    "frcnn_mobilenet_v1": _mobilenet,
     "faster_rcnn_resnet50": _resnet("resnet_v1_50"),
     "faster_rcnn_resnet101": _resnet("resnet_v1_101"),
     "faster_rcnn_resnet152": _resnet("resnet_v1_152"),

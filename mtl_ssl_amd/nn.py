@@ -16,19 +16,32 @@ from . import ops
 f32 = torch.float32
 
 
+def _refresh_bn(layer):
+    """Recompute scale/shift in place after an optimizer step moved gamma/beta."""
+    if layer.bn_trainable:
+        ps = layer.ps
+        torch.mul(ps.value(layer.gamma.name), layer.inv_std, out=layer.scale)
+        torch.addcmul(ps.value(layer.beta.name), ps.value(layer.mean.name), layer.scale, value=-1.0,
+                      out=layer.shift)
+
+
 class ConvBN:
     """slim.conv2d + frozen slim.batch_norm (+ReLU) — slim/nets/resnet_v1.py:102-119."""
 
     def __init__(self, ps, scope, cin, cout, k, stride=1, dilation=1, padding="SAME",
-                 trainable=True, weight_decay=0.0, eps=1e-5, gamma_init=1.0, relu=True):
+                 trainable=True, weight_decay=0.0, eps=1e-5, gamma_init=1.0, relu=True, act=None,
+                 init=("variance_scaling", 2.0, "FAN_IN", False), bn_trainable=False,
+                 weights_name="weights"):
         self.ps, self.scope = ps, scope
+        self.bn_trainable = bn_trainable
         self.k, self.stride, self.dilation, self.padding, self.eps = k, stride, dilation, padding, eps
-        self.trainable, self.relu = trainable, relu
-        self.w = ps.add(scope + "/weights", (k, k, cin, cout), ("variance_scaling", 2.0, "FAN_IN", False),
-                        trainable, weight_decay)
+        self.trainable = trainable
+        self.act = act if act is not None else ("relu" if relu else None)     # 'relu' | 'relu6' | None
+        self.relu = self.act is not None
+        self.w = ps.add(scope + "/" + weights_name, (k, k, cin, cout), init, trainable, weight_decay)
         bn = scope + "/BatchNorm/"
-        self.gamma = ps.add(bn + "gamma", (cout,), ("uniform", 0.8 * gamma_init, 1.2 * gamma_init), False)
-        self.beta = ps.add(bn + "beta", (cout,), ("uniform", -0.1, 0.1), False)
+        self.gamma = ps.add(bn + "gamma", (cout,), ("uniform", 0.8 * gamma_init, 1.2 * gamma_init), bn_trainable)
+        self.beta = ps.add(bn + "beta", (cout,), ("uniform", -0.1, 0.1), bn_trainable)
         self.mean = ps.add(bn + "moving_mean", (cout,), ("uniform", -0.1, 0.1), False)
         self.var = ps.add(bn + "moving_variance", (cout,), ("uniform", 0.8, 1.2), False)
         self._desc = {}
@@ -38,13 +51,23 @@ class ConvBN:
         ps = self.ps
         g, b = ps.value(self.gamma.name), ps.value(self.beta.name)
         m, v = ps.value(self.mean.name), ps.value(self.var.name)
-        self.scale = (g / torch.sqrt(v + self.eps)).contiguous()
+        self.inv_std = torch.rsqrt(v + self.eps)
+        self.scale = (g * self.inv_std).contiguous()
         self.shift = (b - m * self.scale).contiguous()
         self.w_eff = torch.empty(self.w.shape, dtype=f32, device=ps.device)
         self.refold()
 
     def refold(self):
+        _refresh_bn(self)
         ops.scale_channels(self.ps.value(self.w.name), self.scale, self.w_eff)
+
+    def bn_grad(self, y, gp):
+        """d(gamma), d(beta) of the inference-mode normaliser from the layer output `y` and
+        gp = dL/d(pre-activation) (slim arg-scopes that leave BatchNorm trainable: MobileNet)."""
+        if self.bn_trainable:
+            ps = self.ps
+            ops.bn_param_grads(y, gp, ps.value(self.gamma.name), ps.value(self.beta.name),
+                               ps.grad(self.gamma.name), ps.grad(self.beta.name), beta=1.0)
 
     def desc(self, shape):
         d = self._desc.get(tuple(shape))
@@ -54,8 +77,9 @@ class ConvBN:
         return d
 
     def forward(self, x, residual=None, relu=None):
-        relu = self.relu if relu is None else relu
-        epi = ops.EPI_BIAS | (ops.EPI_RELU if relu else 0) | (ops.EPI_RESIDUAL if residual is not None else 0)
+        act = self.act if relu is None else ("relu" if relu else None)
+        epi = ops.EPI_BIAS | {None: 0, "relu": ops.EPI_RELU, "relu6": ops.EPI_RELU6}[act] \
+            | (ops.EPI_RESIDUAL if residual is not None else 0)
         return ops.conv2d_fwd(self.desc(x.shape), x, self.w_eff, self.shift, residual, epi)
 
     def wgrad(self, x, g):
@@ -63,10 +87,65 @@ class ConvBN:
             ops.conv2d_wgrad(self.desc(x.shape), x, g, self.ps.grad(self.w.name), out_scale=self.scale,
                              beta=1.0)
 
-    def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False):
-        epi = ((ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_MASK if mask_ref is not None else 0)
-               | (ops.EPI_ACCUM if accum else 0))
+    def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False, mask6=False):
+        epi = ((ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_ACCUM if accum else 0)
+               | ((ops.EPI_MASK6 if mask6 else ops.EPI_MASK) if mask_ref is not None else 0))
         return ops.conv2d_dgrad(self.desc(x_shape), g, self.w_eff, residual, mask_ref, epi, out=out)
+
+
+class DepthwiseBN:
+    """slim.separable_conv2d(num_outputs=None, depth_multiplier=1) + frozen batch_norm + ReLU6
+    (slim/nets/mobilenet_v1.py:229-245). Filter [k,k,C,1] named `depthwise_weights` like slim."""
+
+    def __init__(self, ps, scope, c, k=3, stride=1, dilation=1, trainable=True, weight_decay=0.0, eps=1e-3,
+                 act="relu6", init=("truncated_normal", 0.09), bn_trainable=False, gamma_init=1.0):
+        self.ps, self.scope, self.c = ps, scope, c
+        self.bn_trainable = bn_trainable
+        self.k, self.stride, self.dilation, self.eps, self.act = k, stride, dilation, eps, act
+        self.trainable = trainable
+        self.w = ps.add(scope + "/depthwise_weights", (k, k, c, 1), init, trainable, weight_decay)
+        bn = scope + "/BatchNorm/"
+        self.gamma = ps.add(bn + "gamma", (c,), ("uniform", 0.8 * gamma_init, 1.2 * gamma_init), bn_trainable)
+        self.beta = ps.add(bn + "beta", (c,), ("uniform", -0.1, 0.1), bn_trainable)
+        self.mean = ps.add(bn + "moving_mean", (c,), ("uniform", -0.1, 0.1), False)
+        self.var = ps.add(bn + "moving_variance", (c,), ("uniform", 0.8, 1.2), False)
+        self._desc = {}
+
+    def prepare(self):
+        ps = self.ps
+        g, b = ps.value(self.gamma.name), ps.value(self.beta.name)
+        m, v = ps.value(self.mean.name), ps.value(self.var.name)
+        self.inv_std = torch.rsqrt(v + self.eps)
+        self.scale = (g * self.inv_std).contiguous()
+        self.shift = (b - m * self.scale).contiguous()
+        self.w_eff = torch.empty((self.k, self.k, self.c), dtype=f32, device=ps.device)
+        self.refold()
+
+    bn_grad = ConvBN.bn_grad
+
+    def refold(self):
+        _refresh_bn(self)
+        ops.scale_channels(self.ps.value(self.w.name).view(self.k, self.k, self.c), self.scale, self.w_eff)
+
+    def desc(self, shape):
+        d = self._desc.get(tuple(shape))
+        if d is None:
+            d = ops.conv_desc(shape, (self.k, self.k, self.c, self.c), self.stride, self.dilation, "SAME")
+            self._desc[tuple(shape)] = d
+        return d
+
+    def forward(self, x):
+        epi = ops.EPI_BIAS | {None: 0, "relu": ops.EPI_RELU, "relu6": ops.EPI_RELU6}[self.act]
+        return ops.depthwise_fwd(self.desc(x.shape), x, self.w_eff, self.shift, epi)
+
+    def wgrad(self, x, g):
+        if self.trainable:
+            ops.depthwise_wgrad(self.desc(x.shape), x, g, self.ps.grad(self.w.name), out_scale=self.scale,
+                                beta=1.0)
+
+    def dgrad(self, x_shape, g, mask_ref=None, mask6=False):
+        epi = (ops.EPI_MASK6 if mask6 else ops.EPI_MASK) if mask_ref is not None else 0
+        return ops.depthwise_dgrad(self.desc(x_shape), g, self.w_eff, mask_ref, epi)
 
 
 class Conv:
@@ -115,11 +194,11 @@ class Conv:
         ops.conv2d_wgrad(self.desc(x4.shape), x4, g4, gw.view(self.k, self.k, self.cin, self.cout),
                          dbias=self.ps.grad(self.b.name), beta=1.0)
 
-    def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False):
+    def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False, mask6=False):
         x4s = (x_shape[0], 1, 1, self.cin) if self.fc else tuple(x_shape)
         g4 = g.view(g.shape[0], 1, 1, self.cout) if self.fc else g
-        epi = ((ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_MASK if mask_ref is not None else 0)
-               | (ops.EPI_ACCUM if accum else 0))
+        epi = ((ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_ACCUM if accum else 0)
+               | ((ops.EPI_MASK6 if mask6 else ops.EPI_MASK) if mask_ref is not None else 0))
         dx = ops.conv2d_dgrad(self.desc(x4s), g4, self._w4(), residual, mask_ref, epi, out=out)
         return dx.view(x_shape) if self.fc else dx
 

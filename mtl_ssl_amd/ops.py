@@ -11,7 +11,7 @@ import torch
 
 from .lib import ConvDesc, lib, ptr
 
-EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_RELU6, EPI_MASK, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
+EPI_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_TANH, EPI_RELU6, EPI_MASK, EPI_ACCUM, EPI_MASK6 = 1, 2, 4, 8, 16, 32, 64, 128
 f32 = torch.float32
 i32 = torch.int32
 
@@ -138,6 +138,35 @@ def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0):
     if t0 is not None:
         PROFILER.end(d, 2, t0)
     return dw
+
+
+def depthwise_fwd(d, x, w, bias=None, epilogue=0):
+    y = torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
+    lib().depthwise_fwd(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(y), epilogue, _stream())
+    return y
+
+
+def depthwise_dgrad(d, dy, w, mask_ref=None, epilogue=0):
+    dx = torch.empty((d.N, d.H, d.W, d.C), dtype=f32, device=dy.device)
+    lib().depthwise_dgrad(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(mask_ref), ptr(dx), epilogue,
+                          _stream())
+    return dx
+
+
+def depthwise_wgrad(d, x, dy, dw, out_scale=None, beta=0.0):
+    ws = workspace(lib().depthwise_wgrad_workspace_bytes(ctypes.byref(d)), "dwgrad", x.device)
+    lib().depthwise_wgrad(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(dy)), ptr(out_scale), ptr(dw), float(beta),
+                          ptr(ws), _stream())
+    return dw
+
+
+def bn_param_grads(y, g, gamma, beta_param, dgamma, dbeta, beta=0.0):
+    """dgamma/dbeta of a folded inference-mode BatchNorm; `beta` != 0 accumulates."""
+    C = y.shape[-1]
+    ws = workspace(lib().bn_param_grads_workspace_bytes(int(C)), "bngrad", y.device)
+    lib().bn_param_grads(ptr(_chk(y)), ptr(_chk(g)), ptr(gamma), ptr(beta_param), ptr(dgamma), ptr(dbeta),
+                         y.numel() // C, int(C), float(beta), ptr(ws), _stream())
+    return dgamma, dbeta
 
 
 def maxpool_fwd(x, k, stride, padding="VALID"):
@@ -423,6 +452,12 @@ def tanh_bwd(y, dy):
 def relu_bwd(y, dy, out=None):
     dx = out if out is not None else torch.empty_like(dy)
     lib().relu_bwd(ptr(_chk(y)), ptr(_chk(dy)), ptr(dx), y.numel(), _stream())
+    return dx
+
+
+def relu6_bwd(y, dy, out=None):
+    dx = out if out is not None else torch.empty_like(dy)
+    lib().relu6_bwd(ptr(_chk(y)), ptr(_chk(dy)), ptr(dx), y.numel(), _stream())
     return dx
 
 

@@ -70,7 +70,38 @@ class Oracle:
                     cur *= ust
         return x
 
+    # ---- MobileNet-v1 (slim/nets/mobilenet_v1.py:120-266; BatchNorm gamma/beta are trainable
+    # there: mobilenet_v1_arg_scope leaves slim.batch_norm's `trainable` at its default)
+    def bn6(self, y, scope):
+        bn = scope + "/BatchNorm/"
+        y = T.frozen_bn(y, self.v[bn + "gamma"], self.v[bn + "beta"], self.v[bn + "moving_mean"].detach(),
+                        self.v[bn + "moving_variance"].detach(), 1e-3)
+        return torch.clamp(y, 0.0, 6.0)
+
+    def mobilenet_trunk(self, x):
+        p = "FirstStageFeatureExtractor/MobilenetV1/"
+        x = self.bn6(T.conv2d(x, self.v[p + "Conv2d_0/weights"], 2, 1, "SAME"), p + "Conv2d_0")
+        strides = (1, 2, 1, 2, 1, 2, 1, 1, 1, 1, 1)
+        for i, st in enumerate(strides, 1):
+            d = p + "Conv2d_%d_depthwise" % i
+            x = self.bn6(T.depthwise_conv2d(x, self.v[d + "/depthwise_weights"], st), d)
+            q = p + "Conv2d_%d_pointwise" % i
+            x = self.bn6(T.conv2d(x, self.v[q + "/weights"], 1, 1, "SAME"), q)
+        return x
+
+    def mobilenet_tower(self, crops, scope):
+        """models/faster_rcnn_mobilenet_v1_feature_extractor.py:145-184: two full
+        slim.separable_conv2d layers (depthwise, then pointwise + BN + ReLU6)."""
+        x = crops
+        for name, st in (("Conv2d_12_pointwise", 2), ("Conv2d_13_pointwise", 1)):
+            s = "%s/MobilenetV1/%s" % (scope, name)
+            x = T.depthwise_conv2d(x, self.v[s + "/depthwise_weights"], st)
+            x = self.bn6(T.conv2d(x, self.v[s + "/pointwise_weights"], 1, 1, "SAME"), s)
+        return x
+
     def tower(self, crops, scope):
+        if self.hp["arch"] == "mobilenet_v1":
+            return self.mobilenet_tower(crops, scope)
         p = "%s/%s/block4" % (scope, self.hp["arch"])
         x = crops
         for u in range(3):
@@ -112,8 +143,10 @@ class Oracle:
         Bn, H, W, _ = img.shape
         K = hp["num_classes"]
         K1 = K + 1
-        x = img - torch.tensor(MEANS)
-        Fm = self.trunk(x)
+        if hp["arch"] == "mobilenet_v1":
+            Fm = self.mobilenet_trunk(img * F(2.0 / 255.0) - 1.0)
+        else:
+            Fm = self.trunk(img - torch.tensor(MEANS))
         Fm.retain_grad()
         Hf, Wf = Fm.shape[1], Fm.shape[2]
         anchors_all = B.grid_anchors(Hf, Wf, hp["scales"], hp["aspect_ratios"], (256.0, 256.0),

@@ -36,6 +36,17 @@ def conv2d(x, w, stride=1, dilation=1, padding="SAME", bias=None):
     return y.permute(0, 2, 3, 1)
 
 
+def depthwise_conv2d(x, w, stride=1, dilation=1):
+    """tf.nn.depthwise_conv2d (slim.separable_conv2d's depthwise stage, SAME padding) on NHWC
+    input with filter [R,S,C,1] (channel multiplier 1): a grouped convolution with C groups."""
+    R, S, C = w.shape[0], w.shape[1], w.shape[2]
+    pt, pb, _ = same_pad(x.shape[1], R, stride, dilation)
+    pl, pr, _ = same_pad(x.shape[2], S, stride, dilation)
+    xn = Fnn.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    y = Fnn.conv2d(xn, w.permute(2, 3, 0, 1), stride=stride, dilation=dilation, groups=C)
+    return y.permute(0, 2, 3, 1)
+
+
 def conv2d_same(x, w, stride, dilation=1):
     """slim/nets/resnet_utils.py:77-122: stride 1 -> SAME; stride>1 -> explicit pad of
     k_eff-1 (pad_beg = (k_eff-1)//2) then VALID."""

@@ -87,6 +87,38 @@ def test_param_store_layout_and_reference_names():
     assert ps.by_name["SecondStageBoxPredictor/BoxEncodingPredictor/weights"].shape == (2048, 360)
 
 
+def test_mobilenet_variables_follow_slim_names_and_trainability():
+    """slim/nets/mobilenet_v1.py:120-266,376-413 + models/faster_rcnn_mobilenet_v1_feature_extractor.py:
+    145-184: BatchNorm gamma/beta train (moving stats do not); depthwise filters and the second-stage
+    separable convs carry no L2 regulariser, conv / pointwise filters carry `weight_decay`."""
+    from mtl_ssl_amd import frcnn, model_builder
+    from mtl_ssl_amd.params import ParamStore
+    cfg = _cfg("frcnn_mobilenet_v1_voc_mtl.config")
+    ps = ParamStore()
+    fe = model_builder.FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP["frcnn_mobilenet_v1"](
+        ps, cfg.model.faster_rcnn.feature_extractor, True)
+    frcnn.FasterRCNNMetaArch(ps, True, cfg.model.faster_rcnn, cfg.model.mtl, fe)
+    by = ps.by_name
+    p = "FirstStageFeatureExtractor/MobilenetV1/"
+    assert by[p + "Conv2d_0/weights"].shape == (3, 3, 3, 32) and by[p + "Conv2d_0/weights"].weight_decay == 1e-4
+    assert by[p + "Conv2d_11_pointwise/weights"].shape == (1, 1, 512, 512)
+    assert by[p + "Conv2d_6_depthwise/depthwise_weights"].shape == (3, 3, 256, 1)
+    assert by[p + "Conv2d_6_depthwise/depthwise_weights"].weight_decay == 0.0
+    assert by[p + "Conv2d_3_pointwise/BatchNorm/gamma"].trainable
+    assert not by[p + "Conv2d_3_pointwise/BatchNorm/moving_mean"].trainable
+    for scope in ("SecondStageFeatureExtractor", "ClosenessBoxPredictor", "WindowBoxPredictor"):
+        q = scope + "/MobilenetV1/"
+        assert by[q + "Conv2d_12_pointwise/depthwise_weights"].shape == (3, 3, 512, 1)
+        assert by[q + "Conv2d_13_pointwise/pointwise_weights"].shape == (1, 1, 1024, 1024)
+        assert by[q + "Conv2d_13_pointwise/pointwise_weights"].weight_decay == 0.0
+        assert q + "Conv2d_12_pointwise/BatchNorm/beta" in by
+        assert q + "Conv2d_12_depthwise/depthwise_weights" not in by
+    assert by["SecondStageBoxPredictor/ClassPredictor/weights"].shape == (1024, 21)
+    with pytest.raises(ValueError, match="must be 8 or 16"):
+        from mtl_ssl_amd import mobilenet
+        mobilenet.FasterRCNNMobilenetV1FeatureExtractor(ParamStore(), True, first_stage_features_stride=4)
+
+
 def test_manual_step_learning_rate():
     from mtl_ssl_amd import trainer
     f, mom = trainer.learning_rate_fn(_cfg("smoke_resnet50_mtl.config").train_config.optimizer)
