@@ -61,6 +61,75 @@ def hyper_params_for_oracle(cfg):
                  global_closeness=bool(mtl.global_closeness)))
 
 
+HBM_PEAK = 8.0e12   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def hbm_kernels(tr, iters=10):
+    """Achieved GB/s of the HBM-bound kernels of the step (north_star: ROIAlign / NMS vs gfx950
+    peak), timed stand-alone with HIP events on the step's own tensors after the timed region.
+    Algorithmic bytes follow SURVEY.md §8(d): ROI crop = samples read once + pooled output (+argmax
+    byte) written; NMS = Nv*20 B read + the Nv^2/8 B suppression bitmask written and re-read;
+    optimizer = 20 B per parameter (+4 B/param for the per-variable norm pass)."""
+    import torch
+    from mtl_ssl_amd import ops
+    model, pd = tr.model, tr._pd
+    c = model.cfg
+    res = []
+
+    def timed(fn):
+        fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) * 1e-3 / iters
+
+    def add(name, nbytes, sec, note):
+        res.append({"kernel": name, "algorithmic_bytes": nbytes, "avg_us": 1e6 * sec,
+                    "achieved_GBps": nbytes / sec / 1e9, "frac_of_hbm_peak": nbytes / sec / HBM_PEAK,
+                    "note": note})
+
+    F = pd["rpn_features_to_crop"]
+    B, Hf, Wf, C = F.shape
+    crop = int(c.initial_crop_size)
+    pk, pst = int(c.maxpool_kernel_size), int(c.maxpool_stride)
+    boxes = pd["proposal_boxes_normalized"].reshape(-1, 4).contiguous()
+    bi = pd["_box_ind"]
+    R = boxes.shape[0]
+    P = (crop - pk) // pst + 1
+    sec = timed(lambda: ops.roi_crop_pool_fwd(F, boxes, bi, crop, pk, pst))
+    nbytes = R * (crop * crop * C * 4 + P * P * C * 4 + (P * P * C if pk > 1 else 0))
+    add("k_roi_crop_pool_fwd", nbytes, sec, "%d ROIs, crop %d -> pool %d, C=%d" % (R, crop, pk, C))
+    if True:
+        H, W = pd["image_shape"][1], pd["image_shape"][2]
+        enc, obj, anc = pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"]
+        Nv = anc.shape[0]
+        sec = timed(lambda: ops.rpn_proposals(enc, obj, anc, H, W, c.first_stage_nms_score_threshold,
+                                              c.first_stage_nms_iou_threshold, int(c.first_stage_max_proposals)))
+        nbytes = B * (Nv * (16 + 8 + 16) + Nv * 20 + 2 * (Nv * Nv // 8))
+        add("rpn_proposals (decode+softmax+clip+rank-sort+k_nms_mask+k_nms_scan)", nbytes, sec,
+            "%d images x %d anchors -> %d proposals" % (B, Nv, int(c.first_stage_max_proposals)))
+    ps = model.ps
+    n = ps.weights.numel()
+    g0 = ps.grads.clone()
+
+    def opt():
+        ps.grads.copy_(g0)
+        ops.sgd_momentum_clip(ps.weights, ps.grads, ps.accum, ps.var_offsets, ps.max_var_size, 0.0,
+                              tr.momentum, tr.clip, 1.0, tr.var_wd)
+    w0, a0 = ps.weights.clone(), ps.accum.clone()
+    t_copy = timed(lambda: ps.grads.copy_(g0))
+    sec = timed(opt) - t_copy
+    ps.weights.copy_(w0)
+    ps.accum.copy_(a0)
+    add("k_var_sumsq + k_momentum_update (per-variable clip + momentum + L2)", n * 24, sec,
+        "%d parameters" % n)
+    return res
+
+
 def cpu_baseline(cfg, model, H, W, seed):
     """The CPU oracle (torch-CPU fp32 + numpy, oracle/model.py) of the identical training step —
     forward + losses + backward — timed on this host. Bounded sample: ONE step on ONE image
@@ -154,19 +223,26 @@ def main():
             dist.destroy_process_group()
         return
     value = B * world * a.steps / dt
+    default_cfg = os.path.basename(a.config) == "frcnn_resnet101_coco_mtl.config"
+    fe_type = cfg.model.faster_rcnn.feature_extractor.type
     out = {
-        "metric": "images/sec training, Faster R-CNN ResNet-101 + aux heads",
+        "metric": "images/sec training, Faster R-CNN ResNet-101 + aux heads" if default_cfg
+                  else "images/sec training, %s + aux heads" % fe_type,
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Faster R-CNN ResNet-101 + window/closeness/edgemask heads + refine, "
-                               "synthetic %dx%d COCO-shaped (90 classes), per-GPU batch %d "
-                               "(BASELINE.json configs[%d])" % (a.width, a.height, B, 1 if world == 1 else 3),
+        "config": {"workload": ("Faster R-CNN ResNet-101 + window/closeness/edgemask heads + refine, "
+                                "synthetic %dx%d COCO-shaped (90 classes), per-GPU batch %d "
+                                "(BASELINE.json configs[%d])" % (a.width, a.height, B, 1 if world == 1 else 3))
+                   if default_cfg else
+                   "%s + window/closeness/edgemask heads + refine, synthetic %dx%d (%d classes), per-GPU "
+                   "batch %d" % (fe_type, a.width, a.height, K, B),
                    "global_batch": B * world, "parallelism": "dp%d" % world,
                    "pipeline_config": os.path.relpath(a.config, ROOT)},
         "final_total_loss": total_loss,
-        "frac_of_fp32_mfma_roofline_whole_step": FLOP_PER_IMAGE * value / world / FP32_MFMA_PEAK,
     }
+    if default_cfg:
+        out["frac_of_fp32_mfma_roofline_whole_step"] = FLOP_PER_IMAGE * value / world / FP32_MFMA_PEAK
     if prof is not None:
         s = prof.summary()
         dom = s.get(("fwd", 0))
@@ -188,6 +264,8 @@ def main():
                                             "ms_per_step": 1e3 * v["seconds"] / a.steps}
                           for k, v in sorted(s.items()) if v["seconds"] > 0},
         }
+    if world == 1 and not a.no_roofline:
+        out["hbm_kernels"] = hbm_kernels(tr)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, model, a.height, a.width, seed=1234)
     print(json.dumps(out), flush=True)

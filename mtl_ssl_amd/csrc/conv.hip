@@ -136,16 +136,21 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
       }
     }
   }
+  // Ragged N (channel counts that are not a multiple of the tile): columns >= NG get the
+  // out-of-range offset, so their LDS image is zero and the epilogue skips them.
 #pragma unroll
   for (int i = 0; i < B_LD; ++i) {
     if constexpr (MODE == MODE_FWD) {
       int u = tid + 256 * i;
-      b_base[i] = (unsigned)((u / (BN / 4)) * p.K + n0 + (u % (BN / 4)) * 4) * 4u;
+      int col = n0 + (u % (BN / 4)) * 4;
+      b_base[i] = col < p.NG ? (unsigned)((u / (BN / 4)) * p.K + col) * 4u : OOB;
     } else if constexpr (MODE == MODE_DGRAD) {
-      b_base[i] = (unsigned)((n0 + (tid >> 2) + 64 * i) * p.K + kq4) * 4u;
+      int row = n0 + (tid >> 2) + 64 * i;
+      b_base[i] = row < p.NG ? (unsigned)(row * p.K + kq4) * 4u : OOB;
     } else {
       int u = tid + 256 * i;
-      b_base[i] = (unsigned)(n0 + (u % (BN / 4)) * 4) * 4u;
+      int col = n0 + (u % (BN / 4)) * 4;
+      b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
     }
   }
 
@@ -212,13 +217,14 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
           ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
           off = ((n * p.H + ih) * p.W + iw) * p.C;
         }
+        ok = ok && (m0 + m4 * 4) < p.M;
         ra[i] = bufload4(rsrc_a, ok ? (unsigned)(off + m0 + m4 * 4) * 4u : OOB, 0);
       }
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
         int u = tid + 256 * i;
         int pix = pix0 + ks * BK + u / (BN / 4);
-        rb[i] = bufload4(rsrc_b, pix < pix1 ? b_base[i] + (unsigned)(pix * p.K) * 4u : OOB, 0);
+        rb[i] = bufload4(rsrc_b, (pix < pix1 && b_base[i] != OOB) ? b_base[i] + (unsigned)(pix * p.K) * 4u : OOB, 0);
       }
     }
   };
@@ -310,13 +316,14 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wc * (BN / 2) + j * 32 + lo;
+      const bool col_ok = col < p.NG;
       float bv = 0.f;
       if constexpr (MODE == MODE_FWD)
-        if (p.epi & MTLSSL_EPI_BIAS) bv = p.bias[col];
+        if ((p.epi & MTLSSL_EPI_BIAS) && col_ok) bv = p.bias[col];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        if (row >= p.M) continue;
+        if (row >= p.M || !col_ok) continue;
         const int64_t o = (int64_t)row * ldo + col;
         float v = acc[i][j][e];
         if (raw) {
@@ -685,6 +692,14 @@ __global__ void __launch_bounds__(256) k_conv_smallc_fwd(ConvArgs p) {
   }
 }
 
+// Shapes the MFMA implicit-GEMM kernel takes: the reduction channel count must be a multiple of
+// the 16-deep K-step, the GEMM N (and the wgrad M) only of the float4 load width.
+static inline bool mfma_fwd_ok(const mtlssl_conv_desc* d) { return d->C % BK == 0 && d->K % 4 == 0 && d->K >= 16; }
+static inline bool mfma_dgrad_ok(const mtlssl_conv_desc* d) { return d->K % BK == 0 && d->C % 4 == 0 && d->C >= 16; }
+static inline bool mfma_wgrad_ok(const mtlssl_conv_desc* d) {
+  return d->C % 4 == 0 && d->K % 4 == 0 && d->C >= 16 && d->K >= 16;
+}
+
 static ConvArgs make_args(const mtlssl_conv_desc* d) {
   ConvArgs p;
   memset(&p, 0, sizeof(p));
@@ -712,8 +727,7 @@ static int pick_tile(int64_t M, int64_t NG, int64_t zmul) {
   int best = 2;
   double best_cost = 1e30;
   for (int c = 0; c < 3; ++c) {
-    if (NG % bn[c]) continue;
-    int64_t blocks = cdiv(M, bm[c]) * (NG / bn[c]) * zmul;
+    int64_t blocks = cdiv(M, bm[c]) * cdiv(NG, bn[c]) * zmul;
     double per_cu = (double)cdiv(blocks, 256);                 // rounds of work on the busiest CU
     double work = per_cu * bm[c] * bn[c];                      // ~ MFMA time
     double eff_penalty = (c == 0 ? 1.0 : (c == 1 ? 1.04 : 1.10));  // smaller tiles: more staging
@@ -777,8 +791,7 @@ static Plan plan_gemm(int64_t M, int64_t NG, int ksteps) {
   Plan best{2, 1, ksteps};
   double best_t = 1e30;
   for (int c = 0; c < 3; ++c) {
-    if (NG % bn[c]) continue;
-    int64_t tiles = cdiv(M, bm[c]) * (NG / bn[c]);
+    int64_t tiles = cdiv(M, bm[c]) * cdiv(NG, bn[c]);
     for (int s = 1; s <= 8; ++s) {
       if (s > 1 && ksteps / s < 12) break;
       int per = (int)cdiv(ksteps, s);
@@ -819,7 +832,7 @@ template <int MODE>
 static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st) {
   const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
   p.tiles_m = (int)cdiv(p.M, bm[cfg]);
-  p.tiles_n = p.NG / bn[cfg];
+  p.tiles_n = (int)cdiv(p.NG, bn[cfg]);
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
   switch (cfg) {
     case 0: hipLaunchKernelGGL((k_conv_mfma<128, 128, MODE>), grid, dim3(256), 0, st, p); break;
@@ -836,8 +849,7 @@ static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pp
   double best_t = 1e30;
   *cfg = 2; *nsplit = 1; *pps = (int)align_up(P, BK);
   for (int c = 0; c < 3; ++c) {
-    if (d->C % bm[c] || d->K % bn[c]) continue;
-    int64_t tiles = (int64_t)(d->C / bm[c]) * (d->K / bn[c]) * RS;
+    int64_t tiles = cdiv(d->C, bm[c]) * cdiv(d->K, bn[c]) * RS;
     for (int s = 1; s <= 64; ++s) {
       if (s > 1 && ksteps / s < 8) break;
       int per = (int)cdiv(ksteps, s);
@@ -863,7 +875,7 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
   int64_t M = mode == MODE_FWD ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W;
   int64_t NG = mode == MODE_FWD ? d->K : d->C;
   int kc = mode == MODE_FWD ? d->C : d->K;
-  if (kc % BK || NG % 64) return 0;
+  if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : mfma_dgrad_ok(d))) return 0;
   Plan pl = plan_gemm(M, NG, d->R * d->S * (kc / BK));
   return pl.nsplit > 1 ? align_up(M * NG * 4 * pl.nsplit, 256) : 0;
 }
@@ -880,7 +892,7 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
   p.b_bytes = (unsigned)((int64_t)d->R * d->S * d->C * d->K * 4);
   p.M = d->N * d->OH * d->OW;
   p.NG = d->K;
-  if (d->C % BK == 0 && d->K % 64 == 0) {
+  if (mfma_fwd_ok(d)) {
     Plan pl = plan_gemm(p.M, p.NG, d->R * d->S * (d->C / BK));
     if (pl.nsplit > 1 && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0};
     p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split; p.splitk_ws = (float*)workspace;
@@ -914,7 +926,7 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   p.b_bytes = (unsigned)((int64_t)d->R * d->S * d->C * d->K * 4);
   p.M = d->N * d->H * d->W;
   p.NG = d->C;
-  if (d->K % BK == 0 && d->C % 64 == 0) {
+  if (mfma_dgrad_ok(d)) {
     Plan pl = plan_gemm(p.M, p.NG, d->R * d->S * (d->K / BK));
     if (pl.nsplit > 1 && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0};
     p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split; p.splitk_ws = (float*)workspace;
@@ -935,13 +947,13 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
 int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
   if (!d) return -1;
   if (mode == MODE_FWD)
-    return (d->C % BK == 0 && d->K % 64 == 0)
+    return mfma_fwd_ok(d)
                ? plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S * (d->C / BK)).cfg : -1;
   if (mode == MODE_DGRAD)
-    return (d->K % BK == 0 && d->C % 64 == 0)
+    return mfma_dgrad_ok(d)
                ? plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S * (d->K / BK)).cfg : -1;
   if (mode == MODE_WGRAD) {
-    if (d->C % 64 || d->K % 64) return -1;
+    if (!mfma_wgrad_ok(d)) return -1;
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);
     return cfg;
@@ -952,7 +964,7 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
 int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
   if (!d) return 256;
   int64_t bias_part = align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256);
-  if (d->C % 64 || d->K % 64) {
+  if (!mfma_wgrad_ok(d)) {
     if (is_stem3(d)) return bias_part + align_up((int64_t)STEM_MAX_CHUNKS * 27 * d->K * 4, 256);
     if (!is_pointwise(d)) return bias_part;
     int ns, kps;
@@ -976,7 +988,7 @@ int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* 
   int64_t P = (int64_t)d->N * d->OH * d->OW;
   MTLSSL_REQUIRE(workspace != nullptr, "conv_wgrad: workspace required");
   float* ws_main = (float*)((char*)workspace + align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256));
-  if (d->C % 64 == 0 && d->K % 64 == 0) {
+  if (mfma_wgrad_ok(d)) {
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);
     p.out = ws_main;

@@ -37,15 +37,29 @@ CONV_CASES = [
     (2, 9, 9, 512, 48, 1, 1, 1, "SAME"),         # RPN box head: direct path (K%64 != 0)
     (2, 33, 41, 3, 64, 7, 2, 1, "RESNET_SAME"),  # stem 7x7/2: direct path (C = 3)
     (100, 1, 1, 2048, 91, 1, 1, 1, "VALID"),     # FC head as 1x1 conv
+    # Inception-ResNet-v2 shapes: channel counts that are not multiples of the 64-wide tile,
+    # asymmetric filters, VALID stride-2 reductions (slim/nets/inception_resnet_v2.py:33-262)
+    (2, 17, 21, 32, 48, 3, 1, 1, "SAME"),        # block35 branch_2 3x3 32->48
+    (2, 35, 35, 320, 32, 1, 1, 1, "SAME"),       # block35 1x1 320->32
+    (1, 20, 20, 80, 192, 3, 1, 1, "VALID"),      # Conv2d_4a_3x3
+    (2, 17, 17, 48, 64, 5, 1, 1, "SAME"),        # Mixed_5b 5x5
+    (2, 17, 19, 128, 160, (1, 7), 1, 1, "SAME"),  # block17 1x7
+    (2, 17, 19, 160, 192, (7, 1), 1, 1, "SAME"),  # block17 7x1
+    (2, 33, 33, 320, 384, 3, 2, 1, "SAME"),      # Mixed_6a reduction (aligned feature maps)
+    (8, 17, 17, 256, 288, 3, 2, 1, "VALID"),     # Mixed_7a reduction on ROI crops
+    (4, 8, 8, 2080, 192, 1, 1, 1, "SAME"),       # block8 1x1 in
+    (4, 8, 8, 448, 2080, 1, 1, 1, "SAME"),       # block8 1x1 up (ragged N = 2080)
+    (3, 8, 8, 192, 224, (1, 3), 1, 1, "SAME"),   # block8 1x3
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(ops, case):
     N, H, W, C, K, R, stride, dil, padding = case
+    R, S = R if isinstance(R, tuple) else (R, R)
     g = torch.Generator().manual_seed(hash(case) % 2**31)
     x = torch.randn(N, H, W, C, generator=g)
-    w = torch.randn(R, R, C, K, generator=g) / np.sqrt(R * R * C)
+    w = torch.randn(R, S, C, K, generator=g) / np.sqrt(R * S * C)
     bias = torch.randn(K, generator=g)
     xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
     if padding == "RESNET_SAME":
