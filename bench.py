@@ -36,9 +36,11 @@ def hyper_params_for_oracle(cfg):
         rf = dict(crop=(int(r.crop_height), int(r.crop_width)),
                   bins=(int(r.num_spatial_bins_height), int(r.num_spatial_bins_width)), depth=int(r.depth))
     return dict(
-        rfcn=rf,
+        rfcn=rf, stride=int(fr.feature_extractor.first_stage_features_stride),
+        first_stage_atrous_rate=int(fr.first_stage_atrous_rate), anchor_stride=int(g.height_stride),
         arch={"faster_rcnn_resnet50": "resnet_v1_50", "faster_rcnn_resnet101": "resnet_v1_101",
-              "faster_rcnn_resnet152": "resnet_v1_152", "frcnn_mobilenet_v1": "mobilenet_v1"}[fr.feature_extractor.type],
+              "faster_rcnn_resnet152": "resnet_v1_152", "frcnn_mobilenet_v1": "mobilenet_v1",
+              "faster_rcnn_inception_resnet_v2": "inception_resnet_v2"}[fr.feature_extractor.type],
         num_classes=int(fr.num_classes), scales=list(g.scales), aspect_ratios=list(g.aspect_ratios),
         nms_score_threshold=fr.first_stage_nms_score_threshold,
         nms_iou_threshold=fr.first_stage_nms_iou_threshold, max_proposals=int(fr.first_stage_max_proposals),

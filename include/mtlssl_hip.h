@@ -102,6 +102,17 @@ int mtlssl_bn_param_grads(const float* y, const float* g, const float* gamma, co
                           float* dgamma, float* dbeta, int64_t rows, int C, float accum, void* workspace,
                           mtlssl_stream_t stream);
 
+/* slim.avg_pool2d with TF 'SAME'/'VALID' semantics — the divisor is the number of in-bounds
+ * cells of each window (slim/nets/inception_resnet_v2.py:181-184, Mixed_5b Branch_3). */
+int mtlssl_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad_t,
+                       int pad_l, int OH, int OW, mtlssl_stream_t stream);
+int mtlssl_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int k, int stride, int pad_t,
+                       int pad_l, int OH, int OW, mtlssl_stream_t stream);
+/* tf.concat(axis=3) and its gradient as channel-slice copies (slim/nets/inception_resnet_v2.py:46,
+ * 67,88,185-186,213,253): dst[row, dst_c0 + j] (=|+=) src[row, src_c0 + j] for j < nc. */
+int mtlssl_copy_channels(const float* src, int src_ld, int src_c0, float* dst, int dst_ld, int dst_c0,
+                         int64_t rows, int nc, int accumulate, mtlssl_stream_t stream);
+
 /* slim.max_pool2d (slim/nets/resnet_v1.py:222; resnet_utils.subsample :59-74). */
 int mtlssl_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, int k, int stride,
                        int pad_t, int pad_l, int OH, int OW, mtlssl_stream_t stream);

@@ -22,7 +22,7 @@ SOURCES = {
     "ops.hip": ["-ffp-contract=off"],   # ROI max-pool arg-max must not flip on fma rounding
     "conv.hip": [],
     "glue.hip": ["-ffp-contract=off"],
-    "depthwise.hip": [],
+    "depthwise.hip": [], "pool_concat.hip": [],
 }
 
 

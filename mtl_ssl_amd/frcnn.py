@@ -113,10 +113,9 @@ class FasterRCNNMetaArch:
         self.num_anchors_per_location = A
         s = self.first_stage_box_predictor_scope
         depth, ks = int(frcnn.first_stage_box_predictor_depth), int(frcnn.first_stage_box_predictor_kernel_size)
-        if int(frcnn.first_stage_atrous_rate) != 1:
-            raise ValueError("first_stage_atrous_rate != 1 is not supported")
         self.rpn_conv = nn.Conv(ps, s + "/Conv", fe.cout, depth, ks, init, rpn_tr, wd,
-                                activation="relu" if hp.activation == "RELU" else None)
+                                activation="relu" if hp.activation == "RELU" else None,
+                                rate=int(frcnn.first_stage_atrous_rate))      # faster_rcnn_meta_arch.py:870-877
         self.rpn_box = nn.Conv(ps, s + "/BoxEncodingPredictor", depth, A * 4, 1, init, rpn_tr, wd)
         self.rpn_cls = nn.Conv(ps, s + "/ClassPredictor", depth, A * 2, 1, init, rpn_tr, wd)
         # second stage (+ aux heads: builders/model_builder.py:287-315 give the aux predictors

@@ -3,7 +3,7 @@
 `FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP` is the reference's plugin registry: feature
 extractors register by the `feature_extractor.type` string of the pipeline config.
 """
-from . import frcnn, mobilenet, resnet, rfcn
+from . import frcnn, inception_resnet_v2, mobilenet, resnet, rfcn
 from .params import ParamStore
 
 
@@ -27,7 +27,16 @@ def _mobilenet(ps, fe_cfg, is_training):
         ps, is_training, int(fe_cfg.first_stage_features_stride), **kwargs)
 
 
+def _inception_resnet_v2(ps, fe_cfg, is_training):
+    kwargs = {}
+    if fe_cfg.has("weight_decay"):
+        kwargs["weight_decay"] = float(fe_cfg.weight_decay)
+    return inception_resnet_v2.FasterRCNNInceptionResnetV2FeatureExtractor(
+        ps, is_training, int(fe_cfg.first_stage_features_stride), **kwargs)
+
+
 FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP = {
+    "faster_rcnn_inception_resnet_v2": _inception_resnet_v2,
     "frcnn_mobilenet_v1": _mobilenet,
     "faster_rcnn_resnet50": _resnet("resnet_v1_50"),
     "faster_rcnn_resnet101": _resnet("resnet_v1_101"),

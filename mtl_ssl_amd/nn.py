@@ -20,7 +20,8 @@ def _refresh_bn(layer):
     """Recompute scale/shift in place after an optimizer step moved gamma/beta."""
     if layer.bn_trainable:
         ps = layer.ps
-        torch.mul(ps.value(layer.gamma.name), layer.inv_std, out=layer.scale)
+        if layer.gamma is not None:
+            torch.mul(ps.value(layer.gamma.name), layer.inv_std, out=layer.scale)
         torch.addcmul(ps.value(layer.beta.name), ps.value(layer.mean.name), layer.scale, value=-1.0,
                       out=layer.shift)
 
@@ -31,16 +32,20 @@ class ConvBN:
     def __init__(self, ps, scope, cin, cout, k, stride=1, dilation=1, padding="SAME",
                  trainable=True, weight_decay=0.0, eps=1e-5, gamma_init=1.0, relu=True, act=None,
                  init=("variance_scaling", 2.0, "FAN_IN", False), bn_trainable=False,
-                 weights_name="weights"):
+                 weights_name="weights", bn_scale=True):
+        """k: int or (kh, kw). bn_scale=False: slim.batch_norm(scale=False) — no gamma variable
+        (Inception arg scopes); bn_trainable: gamma/beta receive gradients (moving stats never do)."""
         self.ps, self.scope = ps, scope
         self.bn_trainable = bn_trainable
         self.k, self.stride, self.dilation, self.padding, self.eps = k, stride, dilation, padding, eps
         self.trainable = trainable
         self.act = act if act is not None else ("relu" if relu else None)     # 'relu' | 'relu6' | None
         self.relu = self.act is not None
-        self.w = ps.add(scope + "/" + weights_name, (k, k, cin, cout), init, trainable, weight_decay)
+        kh, kw = k if isinstance(k, tuple) else (k, k)
+        self.w = ps.add(scope + "/" + weights_name, (kh, kw, cin, cout), init, trainable, weight_decay)
         bn = scope + "/BatchNorm/"
-        self.gamma = ps.add(bn + "gamma", (cout,), ("uniform", 0.8 * gamma_init, 1.2 * gamma_init), bn_trainable)
+        self.gamma = (ps.add(bn + "gamma", (cout,), ("uniform", 0.8 * gamma_init, 1.2 * gamma_init), bn_trainable)
+                      if bn_scale else None)
         self.beta = ps.add(bn + "beta", (cout,), ("uniform", -0.1, 0.1), bn_trainable)
         self.mean = ps.add(bn + "moving_mean", (cout,), ("uniform", -0.1, 0.1), False)
         self.var = ps.add(bn + "moving_variance", (cout,), ("uniform", 0.8, 1.2), False)
@@ -49,10 +54,11 @@ class ConvBN:
 
     def prepare(self):
         ps = self.ps
-        g, b = ps.value(self.gamma.name), ps.value(self.beta.name)
+        b = ps.value(self.beta.name)
         m, v = ps.value(self.mean.name), ps.value(self.var.name)
         self.inv_std = torch.rsqrt(v + self.eps)
-        self.scale = (g * self.inv_std).contiguous()
+        self.scale = ((ps.value(self.gamma.name) * self.inv_std) if self.gamma is not None
+                      else self.inv_std.clone()).contiguous()
         self.shift = (b - m * self.scale).contiguous()
         self.w_eff = torch.empty(self.w.shape, dtype=f32, device=ps.device)
         self.refold()
@@ -64,7 +70,7 @@ class ConvBN:
     def bn_grad(self, y, gp):
         """d(gamma), d(beta) of the inference-mode normaliser from the layer output `y` and
         gp = dL/d(pre-activation) (slim arg-scopes that leave BatchNorm trainable: MobileNet)."""
-        if self.bn_trainable:
+        if self.bn_trainable and self.gamma is not None:
             ps = self.ps
             ops.bn_param_grads(y, gp, ps.value(self.gamma.name), ps.value(self.beta.name),
                                ps.grad(self.gamma.name), ps.grad(self.beta.name), beta=1.0)
@@ -84,8 +90,10 @@ class ConvBN:
 
     def wgrad(self, x, g):
         if self.trainable:
+            # without a gamma, d(beta) is just the column sum of g: ride on the wgrad's dbias pass
+            db = self.ps.grad(self.beta.name) if (self.bn_trainable and self.gamma is None) else None
             ops.conv2d_wgrad(self.desc(x.shape), x, g, self.ps.grad(self.w.name), out_scale=self.scale,
-                             beta=1.0)
+                             dbias=db, beta=1.0)
 
     def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False, mask6=False):
         epi = ((ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_ACCUM if accum else 0)
@@ -152,8 +160,9 @@ class Conv:
     """slim.conv2d / slim.fully_connected with biases, no normaliser (RPN conv, predictors)."""
 
     def __init__(self, ps, scope, cin, cout, k, init, trainable=True, weight_decay=0.0,
-                 activation=None, fc=False):
+                 activation=None, fc=False, rate=1):
         self.ps, self.scope, self.k, self.trainable, self.activation = ps, scope, k, trainable, activation
+        self.rate = rate
         shape = (cin, cout) if fc else (k, k, cin, cout)
         self.fc = fc
         self.w = ps.add(scope + "/weights", shape, init, trainable, weight_decay)
@@ -174,7 +183,7 @@ class Conv:
     def desc(self, shape):
         d = self._desc.get(tuple(shape))
         if d is None:
-            d = ops.conv_desc(shape, (self.k, self.k, self.cin, self.cout), 1, 1, "SAME")
+            d = ops.conv_desc(shape, (self.k, self.k, self.cin, self.cout), 1, self.rate, "SAME")
             self._desc[tuple(shape)] = d
         return d
 

@@ -190,6 +190,48 @@ def maxpool_bwd(x, y, dy, k, stride, pads):
     return dx
 
 
+def avgpool_fwd(x, k, stride, padding="SAME"):
+    N, H, W, C = x.shape
+    if padding == "SAME":
+        pt, OH = same_pad(H, k, stride)
+        pl, OW = same_pad(W, k, stride)
+    else:
+        pt = pl = 0
+        OH, OW = (H - k) // stride + 1, (W - k) // stride + 1
+    y = torch.empty((N, OH, OW, C), dtype=f32, device=x.device)
+    lib().avgpool_fwd(ptr(_chk(x)), ptr(y), N, H, W, C, k, stride, pt, pl, OH, OW, _stream())
+    return y, (pt, pl)
+
+
+def avgpool_bwd(dy, x_shape, k, stride, pads):
+    N, H, W, C = x_shape
+    dx = torch.empty(tuple(x_shape), dtype=f32, device=dy.device)
+    lib().avgpool_bwd(ptr(_chk(dy)), ptr(dx), N, H, W, C, k, stride, pads[0], pads[1], dy.shape[1], dy.shape[2],
+                      _stream())
+    return dx
+
+
+def concat_channels(parts):
+    """tf.concat(axis=3) of NHWC tensors."""
+    C = sum(int(t.shape[-1]) for t in parts)
+    out = torch.empty(tuple(parts[0].shape[:-1]) + (C,), dtype=f32, device=parts[0].device)
+    rows = out.numel() // C
+    c0 = 0
+    for t in parts:
+        nc = int(t.shape[-1])
+        lib().copy_channels(ptr(_chk(t)), nc, 0, ptr(out), C, c0, rows, nc, 0, _stream())
+        c0 += nc
+    return out
+
+
+def slice_channels(t, c0, nc):
+    """t[..., c0:c0+nc] as a contiguous tensor."""
+    C = int(t.shape[-1])
+    out = torch.empty(tuple(t.shape[:-1]) + (nc,), dtype=f32, device=t.device)
+    lib().copy_channels(ptr(_chk(t)), C, c0, ptr(out), nc, 0, t.numel() // C, nc, 0, _stream())
+    return out
+
+
 def spatial_mean_fwd(x):
     N, H, W, C = x.shape
     y = torch.empty((N, C), dtype=f32, device=x.device)

@@ -99,9 +99,88 @@ class Oracle:
             x = self.bn6(T.conv2d(x, self.v[s + "/pointwise_weights"], 1, 1, "SAME"), s)
         return x
 
+    # ---- Inception-ResNet-v2 (slim/nets/inception_resnet_v2.py:33-262; arg scope :331-360:
+    # batch_norm without gamma, eps 1e-3, beta trainable, ReLU)
+    def iconv(self, x, scope, stride=1, padding="SAME", rate=1):
+        bn = scope + "/BatchNorm/"
+        y = T.conv2d(x, self.v[scope + "/weights"], stride, rate, padding)
+        inv = torch.rsqrt(self.v[bn + "moving_variance"].detach() + 1e-3)
+        return torch.relu((y - self.v[bn + "moving_mean"].detach()) * inv + self.v[bn + "beta"])
+
+    def iup(self, net, mixed, scope, scale, relu=True):
+        up = T.conv2d(mixed, self.v[scope + "/Conv2d_1x1/weights"], 1, 1, "SAME") + self.v[scope + "/Conv2d_1x1/biases"]
+        net = net + scale * up
+        return torch.relu(net) if relu else net
+
+    def block35(self, net, s):
+        b0 = self.iconv(net, s + "/Branch_0/Conv2d_1x1")
+        b1 = self.iconv(self.iconv(net, s + "/Branch_1/Conv2d_0a_1x1"), s + "/Branch_1/Conv2d_0b_3x3")
+        b2 = self.iconv(self.iconv(self.iconv(net, s + "/Branch_2/Conv2d_0a_1x1"), s + "/Branch_2/Conv2d_0b_3x3"),
+                        s + "/Branch_2/Conv2d_0c_3x3")
+        return self.iup(net, torch.cat([b0, b1, b2], 3), s, 0.17)
+
+    def block17(self, net, s, rate):
+        b0 = self.iconv(net, s + "/Branch_0/Conv2d_1x1")
+        b1 = self.iconv(net, s + "/Branch_1/Conv2d_0a_1x1")
+        b1 = self.iconv(b1, s + "/Branch_1/Conv2d_0b_1x7", rate=rate)
+        b1 = self.iconv(b1, s + "/Branch_1/Conv2d_0c_7x1", rate=rate)
+        return self.iup(net, torch.cat([b0, b1], 3), s, 0.10)
+
+    def block8(self, net, s, scale=0.20, relu=True):
+        b0 = self.iconv(net, s + "/Branch_0/Conv2d_1x1")
+        b1 = self.iconv(net, s + "/Branch_1/Conv2d_0a_1x1")
+        b1 = self.iconv(b1, s + "/Branch_1/Conv2d_0b_1x3")
+        b1 = self.iconv(b1, s + "/Branch_1/Conv2d_0c_3x1")
+        return self.iup(net, torch.cat([b0, b1], 3), s, scale, relu)
+
+    def inception_trunk(self, x):
+        p = "FirstStageFeatureExtractor/InceptionResnetV2/"
+        atrous = self.hp.get("stride", 16) == 8
+        x = self.iconv(x, p + "Conv2d_1a_3x3", 2)
+        x = self.iconv(x, p + "Conv2d_2a_3x3")
+        x = self.iconv(x, p + "Conv2d_2b_3x3")
+        x = T.max_pool(x, 3, 2, "SAME")
+        x = self.iconv(x, p + "Conv2d_3b_1x1")
+        x = self.iconv(x, p + "Conv2d_4a_3x3")
+        x = T.max_pool(x, 3, 2, "SAME")
+        m = p + "Mixed_5b/"
+        b0 = self.iconv(x, m + "Branch_0/Conv2d_1x1")
+        b1 = self.iconv(self.iconv(x, m + "Branch_1/Conv2d_0a_1x1"), m + "Branch_1/Conv2d_0b_5x5")
+        b2 = self.iconv(self.iconv(self.iconv(x, m + "Branch_2/Conv2d_0a_1x1"), m + "Branch_2/Conv2d_0b_3x3"),
+                        m + "Branch_2/Conv2d_0c_3x3")
+        b3 = self.iconv(T.avg_pool_same(x, 3, 1), m + "Branch_3/Conv2d_0b_1x1")
+        x = torch.cat([b0, b1, b2, b3], 3)
+        for i in range(10):
+            x = self.block35(x, p + "Repeat/block35_%d" % (i + 1))
+        m = p + "Mixed_6a/"
+        s6 = 1 if atrous else 2
+        b0 = self.iconv(x, m + "Branch_0/Conv2d_1a_3x3", s6)
+        b1 = self.iconv(self.iconv(self.iconv(x, m + "Branch_1/Conv2d_0a_1x1"), m + "Branch_1/Conv2d_0b_3x3"),
+                        m + "Branch_1/Conv2d_1a_3x3", s6)
+        x = torch.cat([b0, b1, T.max_pool(x, 3, s6, "SAME")], 3)
+        for i in range(20):
+            x = self.block17(x, p + "Repeat_1/block17_%d" % (i + 1), 2 if atrous else 1)
+        return x
+
+    def inception_tower(self, crops, scope):
+        """models/faster_rcnn_inception_resnet_v2_feature_extractor.py:118-171."""
+        p = scope + "/InceptionResnetV2/"
+        m = p + "Mixed_7a/"
+        b0 = self.iconv(self.iconv(crops, m + "Branch_0/Conv2d_0a_1x1"), m + "Branch_0/Conv2d_1a_3x3", 2, "VALID")
+        b1 = self.iconv(self.iconv(crops, m + "Branch_1/Conv2d_0a_1x1"), m + "Branch_1/Conv2d_1a_3x3", 2, "VALID")
+        b2 = self.iconv(self.iconv(self.iconv(crops, m + "Branch_2/Conv2d_0a_1x1"), m + "Branch_2/Conv2d_0b_3x3"),
+                        m + "Branch_2/Conv2d_1a_3x3", 2, "VALID")
+        x = torch.cat([b0, b1, b2, T.max_pool(crops, 3, 2, "VALID")], 3)
+        for i in range(9):
+            x = self.block8(x, p + "Repeat/block8_%d" % (i + 1))
+        x = self.block8(x, p + "Block8", 1.0, False)
+        return self.iconv(x, p + "Conv2d_7b_1x1")
+
     def tower(self, crops, scope):
         if self.hp["arch"] == "mobilenet_v1":
             return self.mobilenet_tower(crops, scope)
+        if self.hp["arch"] == "inception_resnet_v2":
+            return self.inception_tower(crops, scope)
         p = "%s/%s/block4" % (scope, self.hp["arch"])
         x = crops
         for u in range(3):
@@ -111,8 +190,8 @@ class Oracle:
     def fc(self, x, scope):
         return x @ self.v[scope + "/weights"] + self.v[scope + "/biases"]
 
-    def conv(self, x, scope, act=None):
-        y = T.conv2d(x, self.v[scope + "/weights"], 1, 1, "SAME") + self.v[scope + "/biases"]
+    def conv(self, x, scope, act=None, rate=1):
+        y = T.conv2d(x, self.v[scope + "/weights"], 1, rate, "SAME") + self.v[scope + "/biases"]
         return {None: y, "relu": torch.relu(y), "tanh": torch.tanh(y)}[act]
 
     def rfcn_predict(self, fmap, scope, boxes_flat, box_ind, with_loc):
@@ -145,15 +224,18 @@ class Oracle:
         K1 = K + 1
         if hp["arch"] == "mobilenet_v1":
             Fm = self.mobilenet_trunk(img * F(2.0 / 255.0) - 1.0)
+        elif hp["arch"] == "inception_resnet_v2":
+            Fm = self.inception_trunk(img * F(2.0 / 255.0) - 1.0)
         else:
             Fm = self.trunk(img - torch.tensor(MEANS))
         Fm.retain_grad()
         Hf, Wf = Fm.shape[1], Fm.shape[2]
+        ast = float(hp.get("anchor_stride", 16))
         anchors_all = B.grid_anchors(Hf, Wf, hp["scales"], hp["aspect_ratios"], (256.0, 256.0),
-                                     (16.0, 16.0), (0.0, 0.0))
+                                     (ast, ast), (0.0, 0.0))
         anchors, keep = B.prune_outside_window(anchors_all, [0, 0, H, W])
         A = len(hp["scales"]) * len(hp["aspect_ratios"])
-        rf = self.conv(Fm, "FirstStageBoxPredictor/Conv", "relu")
+        rf = self.conv(Fm, "FirstStageBoxPredictor/Conv", "relu", hp.get("first_stage_atrous_rate", 1))
         enc = self.conv(rf, "FirstStageBoxPredictor/BoxEncodingPredictor").reshape(Bn, -1, 4)[:, keep]
         obj = self.conv(rf, "FirstStageBoxPredictor/ClassPredictor").reshape(Bn, -1, 2)[:, keep]
         gt_abs = [B.to_absolute(np.asarray(g, F), H, W) for g in batch["groundtruth_boxes"]]
@@ -263,4 +345,4 @@ class Oracle:
                    class_predictions=cls.detach().numpy(), features=Fm.detach().numpy(),
                    refined=None if refined is None else refined.detach().numpy(),
                    d_features=Fm.grad.numpy())
-        return {k: float(v) for k, v in losses.items()}, grads, aux
+        return {k: float(v.detach()) for k, v in losses.items()}, grads, aux

@@ -69,6 +69,16 @@ def max_pool(x, k, stride, padding="VALID"):
     return Fnn.max_pool2d(xn, k, stride).permute(0, 2, 3, 1)
 
 
+def avg_pool_same(x, k, stride=1):
+    """slim.avg_pool2d(padding='SAME'): TF averages over the in-bounds cells of each window."""
+    pt, pb, _ = same_pad(x.shape[1], k, stride)
+    pl, pr, _ = same_pad(x.shape[2], k, stride)
+    xn = x.permute(0, 3, 1, 2)
+    num = Fnn.avg_pool2d(Fnn.pad(xn, (pl, pr, pt, pb)), k, stride, divisor_override=1)
+    cnt = Fnn.avg_pool2d(Fnn.pad(torch.ones_like(xn[:1, :1]), (pl, pr, pt, pb)), k, stride, divisor_override=1)
+    return (num / cnt).permute(0, 2, 3, 1)
+
+
 def frozen_bn(x, gamma, beta, mean, var, eps):
     """slim.batch_norm, is_training=False: gamma*(x-mean)/sqrt(var+eps)+beta."""
     scale = gamma / torch.sqrt(var + eps)
