@@ -63,6 +63,18 @@ def hyper_params_for_oracle(cfg):
                  global_closeness=bool(mtl.global_closeness)))
 
 
+def pmc_traffic(default_cfg):
+    """HBM bytes per launch of the roofline kernel. PMC counters cannot be read from inside the
+    process being timed, so this is the committed result of the separate `rocprofv3 --pmc FETCH_SIZE`
+    / `--pmc WRITE_SIZE` passes over this same command (tools/pmc_bench.sh -> tools/pmc_summary.py ->
+    profiles/r01_pmc_traffic.json); null when that file is absent or the config is not the default."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not default_cfg or not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
+
+
 HBM_PEAK = 8.0e12   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -252,7 +264,7 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "achieved": dom["flops"] / dom["seconds"] / 1e12,
                 "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": dom["flops"] / dom["seconds"] / FP32_MFMA_PEAK, "traffic": None,
+                "frac": dom["flops"] / dom["seconds"] / FP32_MFMA_PEAK, "traffic": pmc_traffic(default_cfg),
                 "kernel": "mtlssl::k_conv_mfma<128,128,0> (implicit-GEMM conv forward)",
                 "launches": dom["launches"], "avg_launch_us": 1e6 * dom["seconds"] / dom["launches"],
                 "algorithmic_flop_per_launch_avg": dom["flops"] / dom["launches"],
