@@ -276,6 +276,15 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              float grad_scale, const float* var_weight_decay, float* norms_ws,
                              mtlssl_stream_t stream);
 
+/* Batched fold of per-output-channel scales into a shadow copy of the flat parameter buffer, one
+ * launch for every convolution of the model: eff[i] = weights[i] * scale_v[(i - var_offsets[v]) %
+ * scale_len[v]] for each variable v whose entry of `scale_ptrs` (device array of num_vars device
+ * pointers) is non-null; other variables are left untouched. Replaces the per-layer
+ * slim.batch_norm(is_training=False) multiply of slim/nets/resnet_v1.py:102-119 (and the residual
+ * scale of slim/nets/inception_resnet_v2.py:47-52) after each optimizer step. */
+int mtlssl_fold_scales(const float* weights, float* eff, const int32_t* var_offsets, int num_vars,
+                       int64_t total, const void* scale_ptrs, const int32_t* scale_len,
+                       mtlssl_stream_t stream);
 /* Elementwise helpers used by the graph glue. */
 int mtlssl_axpby(const float* x, float* y, int64_t n, float a, float b, mtlssl_stream_t s); /* y=a*x+b*y */
 int mtlssl_scale_channels(const float* w, const float* scale, float* out, int64_t rows, int K,

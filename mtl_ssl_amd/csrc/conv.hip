@@ -172,6 +172,14 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
       unsigned so = (unsigned)(ks * BK * p.K) * 4u;
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, b_base[i], so);
+      if (p.NG & 3) {   // filter rows are only dword aligned and the last quad runs into the next row
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+          int left = p.NG - (n0 + ((tid + 256 * i) % (BN / 4)) * 4);
+#pragma unroll
+          for (int e = 1; e < 4; ++e) rb[i][e] = e < left ? rb[i][e] : 0.f;
+        }
+      }
     } else if constexpr (MODE == MODE_DGRAD) {
       int kpk = p.K / BK;
       int rs = ks / kpk, k0 = (ks - rs * kpk) * BK;
@@ -694,7 +702,7 @@ __global__ void __launch_bounds__(256) k_conv_smallc_fwd(ConvArgs p) {
 
 // Shapes the MFMA implicit-GEMM kernel takes: the reduction channel count must be a multiple of
 // the 16-deep K-step, the GEMM N (and the wgrad M) only of the float4 load width.
-static inline bool mfma_fwd_ok(const mtlssl_conv_desc* d) { return d->C % BK == 0 && d->K % 4 == 0 && d->K >= 16; }
+static inline bool mfma_fwd_ok(const mtlssl_conv_desc* d) { return d->C % BK == 0 && d->K >= 16; }
 static inline bool mfma_dgrad_ok(const mtlssl_conv_desc* d) { return d->K % BK == 0 && d->C % 4 == 0 && d->C >= 16; }
 static inline bool mfma_wgrad_ok(const mtlssl_conv_desc* d) {
   return d->C % 4 == 0 && d->K % 4 == 0 && d->C >= 16 && d->K >= 16;
@@ -793,7 +801,7 @@ static Plan plan_gemm(int64_t M, int64_t NG, int ksteps) {
   for (int c = 0; c < 3; ++c) {
     int64_t tiles = cdiv(M, bm[c]) * cdiv(NG, bn[c]);
     for (int s = 1; s <= 8; ++s) {
-      if (s > 1 && ksteps / s < 12) break;
+      if (s > 1 && (ksteps / s < 12 || (NG & 3))) break;   // the fold kernel is float4 over N
       int per = (int)cdiv(ksteps, s);
       int ns = (int)cdiv(ksteps, per);
       if (ns != s) continue;

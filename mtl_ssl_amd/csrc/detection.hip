@@ -731,7 +731,7 @@ int mtlssl_rpn_proposals(const float* enc, const float* logits, const float* anc
   hipStream_t st = S(stream);
   NmsWs w;
   nms_ws_layout(batch, n, 4096, (char*)workspace, &w);
-  hipMemsetAsync(w.nvalid, 0, sizeof(int32_t) * batch, st);
+  (void)hipMemsetAsync(w.nvalid, 0, sizeof(int32_t) * batch, st);
   dim3 g(cdiv(n, 256), batch);
   hipLaunchKernelGGL(k_rpn_decode_score, g, dim3(256), 0, st, enc, logits, anchors, n, img_h, img_w,
                      score_thresh, w.boxes, w.scores, w.nvalid);
@@ -751,8 +751,8 @@ int mtlssl_nms(const float* boxes, const float* scores, int n, float iou_thresh,
   MTLSSL_REQUIRE(workspace != nullptr, "nms: workspace required");
   hipStream_t st = S(stream);
   if (n == 0) {
-    hipMemsetAsync(num_out, 0, 4, st);
-    hipMemsetAsync(selected_out, 0xff, 4 * (size_t)max_out, st);
+    (void)hipMemsetAsync(num_out, 0, 4, st);
+    (void)hipMemsetAsync(selected_out, 0xff, 4 * (size_t)max_out, st);
     return MTLSSL_OK;
   }
   NmsWs w;

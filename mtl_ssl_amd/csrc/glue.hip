@@ -115,21 +115,29 @@ __global__ void k_expand_windows(const float* prop, int n2, int n_expand, float*
 
 // faster_rcnn_meta_arch.py:817-831 per image: [cls | window preds (proposal-major over the
 // n_expand windows) | closeness (batch-mean tiled when global)].
+constexpr int RC_ROWS = 8;   // proposals per block
 __global__ void __launch_bounds__(256)
     k_refine_concat(const float* cls, const float* win, const float* clo, int n2, int k1,
                     int n_expand, int use_win, int use_clo, int global_clo, float* out, int ld) {
-  extern __shared__ float s_mean[];
-  int b = blockIdx.x;
+  extern __shared__ float s_mean[];          // [4][k1] partial sums, then the mean in row 0
+  const int b = blockIdx.x, p0 = blockIdx.y * RC_ROWS;
   if (use_clo && global_clo) {
-    for (int k = threadIdx.x; k < k1; k += 256) {
+    // batch mean of the closeness logits (tf.reduce_mean over the image's proposals), recomputed
+    // per block: 4 row-interleaved partial sums per class keep many loads in flight
+    for (int idx = threadIdx.x; idx < 4 * k1; idx += 256) {
+      int k = idx % k1, part = idx / k1;
       float s = 0.f;
-      for (int p = 0; p < n2; ++p) s += clo[((int64_t)b * n2 + p) * k1 + k];
-      s_mean[k] = s / (float)n2;
+      for (int p = part; p < n2; p += 4) s += clo[((int64_t)b * n2 + p) * k1 + k];
+      s_mean[part * k1 + k] = s;
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < k1; k += 256)
+      s_mean[k] = (s_mean[k] + s_mean[k1 + k] + s_mean[2 * k1 + k] + s_mean[3 * k1 + k]) / (float)n2;
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < n2 * ld; t += 256) {
-    int p = t / ld, c = t % ld;
+  const int rows = min(RC_ROWS, n2 - p0);
+  for (int t = threadIdx.x; t < rows * ld; t += 256) {
+    int p = p0 + t / ld, c = t % ld;
     float v;
     if (c < k1) {
       v = cls[((int64_t)b * n2 + p) * k1 + c];
@@ -227,7 +235,7 @@ int mtlssl_refine_concat(const float* cls, const float* win, const float* clo, i
                          mtlssl_stream_t stream) {
   if (!batch || !n2) return MTLSSL_OK;
   int ld = k1 + (win ? n_expand * k1 : 0) + (clo ? k1 : 0);
-  hipLaunchKernelGGL(k_refine_concat, dim3(batch), dim3(256), sizeof(float) * k1, S(stream), cls, win,
+  hipLaunchKernelGGL(k_refine_concat, dim3(batch, cdiv(n2, RC_ROWS)), dim3(256), sizeof(float) * 4 * k1, S(stream), cls, win,
                      clo, n2, k1, n_expand, win != nullptr, clo != nullptr, global_closeness, out, ld);
   return check_launch("refine_concat");
 }

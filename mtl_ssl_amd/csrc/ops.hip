@@ -431,6 +431,32 @@ __global__ void k_scale_channels(const float* w, const float* sc, float* out, in
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < total) out[i] = w[i] * sc[i % K];
 }
+// Batched BatchNorm / residual-scale fold over the flat parameter buffer: eff[i] = w[i] *
+// scale_v[(i - off[v]) % K_v] for every variable v that has a scale vector registered.
+__global__ void __launch_bounds__(256)
+    k_fold_scales(const float* w, float* eff, const int32_t* off, int num_vars, int64_t total4,
+                  const float* const* scales, const int32_t* Ks) {
+  int64_t i4 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i4 >= total4) return;
+  int64_t i = i4 * 4;
+  int lo = 0, hi = num_vars;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if ((int64_t)off[mid] <= i) lo = mid; else hi = mid;
+  }
+  const float* sc = scales[lo];
+  if (!sc) return;
+  const int K = Ks[lo];
+  int r = (int)((i - off[lo]) % K);
+  float4 wv = *reinterpret_cast<const float4*>(w + i);
+  float o[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] *= sc[r];
+    r = r + 1 == K ? 0 : r + 1;
+  }
+  *reinterpret_cast<float4*>(eff + i) = make_float4(o[0], o[1], o[2], o[3]);
+}
 __global__ void k_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) dx[i] = dy[i] * (1.f - y[i] * y[i]);
@@ -583,6 +609,16 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                      accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
                      norms_ws, var_weight_decay);
   return check_launch("sgd_momentum_clip");
+}
+
+int mtlssl_fold_scales(const float* weights, float* eff, const int32_t* var_offsets, int num_vars,
+                       int64_t total, const void* scale_ptrs, const int32_t* scale_len,
+                       mtlssl_stream_t stream) {
+  if (!total || !num_vars) return MTLSSL_OK;
+  MTLSSL_REQUIRE(total % 4 == 0, "fold_scales: buffer length must be a multiple of 4");
+  hipLaunchKernelGGL(k_fold_scales, dim3(cdiv(total / 4, 256)), dim3(256), 0, S(stream), weights, eff,
+                     var_offsets, num_vars, total / 4, (const float* const*)scale_ptrs, scale_len);
+  return check_launch("fold_scales");
 }
 
 int mtlssl_axpby(const float* x, float* y, int64_t n, float a, float b, mtlssl_stream_t stream) {

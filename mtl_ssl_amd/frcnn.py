@@ -177,11 +177,15 @@ class FasterRCNNMetaArch:
     def prepare(self):
         for l in self.layers:
             l.prepare()
+        ops.fold_scales(self.ps)
 
     def refold(self):
+        """After an optimizer step: per-layer normaliser refresh (only layers whose BatchNorm
+        parameters train do anything), then ONE batched fold of every scale into the shadow weights."""
         for l in self.layers:
             if getattr(l, "trainable", False):
                 l.refold()
+        ops.fold_scales(self.ps)
 
     def preprocess(self, inputs):
         """faster_rcnn_meta_arch.py:479-505. Inputs must already have the resized shape (the

@@ -65,16 +65,20 @@ class ResidualUp:
         self._desc = {}
 
     def prepare(self):
-        dev = self.ps.device
-        self.w_eff = torch.empty(self.w.shape, dtype=torch.float32, device=dev)
-        self.b_eff = torch.empty((self.cout,), dtype=torch.float32, device=dev)
+        ps, dev = self.ps, self.ps.device
         self.scale_vec = torch.full((self.cout,), float(self.scale), dtype=torch.float32, device=dev)
         self.db_tmp = torch.zeros((self.cout,), dtype=torch.float32, device=dev)
-        self.refold()
+        if self.w.trainable:       # refreshed by the batched fold (ops.fold_scales) after each update
+            self.w_eff = ps.register_fold(self.w, self.scale_vec)
+            self.b_eff = ps.register_fold(self.b, self.scale_vec)
+        else:
+            self.w_eff = torch.empty(self.w.shape, dtype=torch.float32, device=dev)
+            self.b_eff = torch.empty((self.cout,), dtype=torch.float32, device=dev)
+            ops.axpby(ps.value(self.w.name), self.w_eff, self.scale, 0.0)
+            ops.axpby(ps.value(self.b.name), self.b_eff, self.scale, 0.0)
 
     def refold(self):
-        ops.axpby(self.ps.value(self.w.name), self.w_eff, self.scale, 0.0)
-        ops.axpby(self.ps.value(self.b.name), self.b_eff, self.scale, 0.0)
+        pass
 
     def desc(self, shape):
         d = self._desc.get(tuple(shape))

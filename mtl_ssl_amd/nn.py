@@ -60,12 +60,14 @@ class ConvBN:
         self.scale = ((ps.value(self.gamma.name) * self.inv_std) if self.gamma is not None
                       else self.inv_std.clone()).contiguous()
         self.shift = (b - m * self.scale).contiguous()
-        self.w_eff = torch.empty(self.w.shape, dtype=f32, device=ps.device)
-        self.refold()
+        if self.w.trainable:       # refreshed by the batched fold (ops.fold_scales) after each update
+            self.w_eff = ps.register_fold(self.w, self.scale)
+        else:
+            self.w_eff = torch.empty(self.w.shape, dtype=f32, device=ps.device)
+            ops.scale_channels(ps.value(self.w.name), self.scale, self.w_eff)
 
     def refold(self):
         _refresh_bn(self)
-        ops.scale_channels(self.ps.value(self.w.name), self.scale, self.w_eff)
 
     def bn_grad(self, y, gp):
         """d(gamma), d(beta) of the inference-mode normaliser from the layer output `y` and
@@ -126,14 +128,16 @@ class DepthwiseBN:
         self.inv_std = torch.rsqrt(v + self.eps)
         self.scale = (g * self.inv_std).contiguous()
         self.shift = (b - m * self.scale).contiguous()
-        self.w_eff = torch.empty((self.k, self.k, self.c), dtype=f32, device=ps.device)
-        self.refold()
+        if self.w.trainable:
+            self.w_eff = ps.register_fold(self.w, self.scale).view(self.k, self.k, self.c)
+        else:
+            self.w_eff = torch.empty((self.k, self.k, self.c), dtype=f32, device=ps.device)
+            ops.scale_channels(ps.value(self.w.name).view(self.k, self.k, self.c), self.scale, self.w_eff)
 
     bn_grad = ConvBN.bn_grad
 
     def refold(self):
         _refresh_bn(self)
-        ops.scale_channels(self.ps.value(self.w.name).view(self.k, self.k, self.c), self.scale, self.w_eff)
 
     def desc(self, shape):
         d = self._desc.get(tuple(shape))

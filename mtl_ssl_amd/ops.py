@@ -473,6 +473,14 @@ def sgd_momentum_clip(weights, grads, accum, var_offsets, max_var_size, lr, mome
                             ptr(var_weight_decay), ptr(norms), _stream())
 
 
+def fold_scales(ps):
+    """Refresh ParamStore.eff (all registered BatchNorm / residual-scale folds) in one launch."""
+    if ps.eff is None:
+        return
+    lib().fold_scales(ptr(ps.weights), ptr(ps.eff), ptr(ps.var_offsets), len(ps.trainable_specs),
+                      ps.weights.numel(), ptr(ps.fold_ptrs), ptr(ps.fold_len), _stream())
+
+
 def axpby(x, y, a, b):
     lib().axpby(ptr(_chk(x)), ptr(_chk(y)), x.numel(), float(a), float(b), _stream())
     return y

@@ -113,8 +113,27 @@ class ParamStore:
         self.var_offsets = torch.tensor(offs, dtype=torch.int32, device=self.device)
         self.max_var_size = max([offs[i + 1] - offs[i] for i in range(len(tr))] + [0])
         self.trainable_specs = tr
+        self._index = {sp.name: i for i, sp in enumerate(tr)}
+        # shadow copy of the weights with per-output-channel scales folded in (frozen BatchNorm,
+        # residual scales), refreshed by ONE launch after each optimizer step (ops.fold_scales)
+        self.eff = None
+        self._fold_refs = {}
         self.finalized = True
         return self
+
+    def register_fold(self, spec, scale):
+        """eff[spec] = weights[spec] * scale[channel] (channel = flat index % scale.numel());
+        returns the view of the shadow buffer the kernels read."""
+        assert spec.trainable and scale.is_contiguous() and scale.dtype == torch.float32
+        if self.eff is None:
+            self.eff = torch.zeros_like(self.weights)
+            self.fold_ptrs = torch.zeros(len(self.trainable_specs), dtype=torch.int64, device=self.device)
+            self.fold_len = torch.ones(len(self.trainable_specs), dtype=torch.int32, device=self.device)
+        i = self._index[spec.name]
+        self.fold_ptrs[i] = scale.data_ptr()
+        self.fold_len[i] = scale.numel()
+        self._fold_refs[spec.name] = scale           # keeps the device pointer alive
+        return self._view(self.eff, spec)
 
     def _view(self, buf, s):
         return buf[s.offset:s.offset + s.size].view(s.shape)
