@@ -56,17 +56,19 @@ __device__ __forceinline__ floatx4 bufload4(__amdgpu_buffer_rsrc_t rsrc, unsigne
   return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
 }
 
-template <int BM, int BN, int MODE>
-__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mfma(ConvArgs p) {
+template <int BM, int BN, int MODE, int BKT>
+__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3) : 4)) k_conv_mfma(ConvArgs p) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int KQ = BKT / 4;                     // float4 quads along k per tile row
+  constexpr int RP = 256 / KQ;                    // tile rows covered by one pass of the KC loaders
   constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave in m / n
   constexpr bool A_KC = (MODE != MODE_WGRAD);     // A float4 runs along k (else along m)
   constexpr bool B_KC = (MODE == MODE_DGRAD);     // B float4 runs along k (else along n)
-  constexpr int A_LD = BM / 64, B_LD = BN / 64;   // float4 loads per thread per K-step
+  constexpr int A_LD = BM / RP, B_LD = BN / RP;   // float4 loads per thread per K-step
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+  __shared__ __attribute__((aligned(16))) float smem[2 * BKT * (LDA + LDB)];
   float* const sA = smem;
-  float* const sB = smem + 2 * BK * LDA;
+  float* const sB = smem + 2 * BKT * LDA;
 
   // XCD-aware tile order: the dispatcher places block b on XCD b%8; give each XCD a contiguous
   // range of tiles (n fastest) so blocks sharing an A row-panel share an L2.
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int lo = lane & 31, hi = lane >> 5;
-  const int kq4 = (tid & 3) * 4;
+  const int kq4 = (tid % KQ) * 4;
 
   const __amdgpu_buffer_rsrc_t rsrc_a =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
@@ -91,16 +93,16 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
   // ---- K-loop extent
   int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps, ks_begin = 0;
   if constexpr (MODE == MODE_FWD) {
-    ksteps = p.R * p.S * (p.C / BK);
+    ksteps = p.R * p.S * (p.C / BKT);
   } else if constexpr (MODE == MODE_DGRAD) {
-    ksteps = p.R * p.S * (p.K / BK);
+    ksteps = p.R * p.S * (p.K / BKT);
   } else {
     rs_fixed = blockIdx.y;
     int split = blockIdx.z;
     int P = p.N * p.OH * p.OW;
     pix0 = split * p.pix_per_split;
     pix1 = min(P, pix0 + p.pix_per_split);
-    ksteps = (max(pix1 - pix0, 0) + BK - 1) / BK;
+    ksteps = (max(pix1 - pix0, 0) + BKT - 1) / BKT;
   }
   if constexpr (MODE != MODE_WGRAD) {
     if (p.nsplit > 1) {          // split-K: this block covers K-steps [ks_begin, ksteps)
@@ -118,7 +120,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
   if constexpr (A_KC) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-      int m = m0 + (tid >> 2) + 64 * i;
+      int m = m0 + (tid / KQ) + RP * i;
       a_ok[i] = m < p.M;
       int mm = a_ok[i] ? m : 0;
       if constexpr (MODE == MODE_FWD) {
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
       int col = n0 + (u % (BN / 4)) * 4;
       b_base[i] = col < p.NG ? (unsigned)((u / (BN / 4)) * p.K + col) * 4u : OOB;
     } else if constexpr (MODE == MODE_DGRAD) {
-      int row = n0 + (tid >> 2) + 64 * i;
+      int row = n0 + (tid / KQ) + RP * i;
       b_base[i] = row < p.NG ? (unsigned)(row * p.K + kq4) * 4u : OOB;
     } else {
       int u = tid + 256 * i;
@@ -158,8 +160,8 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
 
   auto load_tile = [&](int ks) {
     if constexpr (MODE == MODE_FWD) {
-      int cpk = p.C / BK;
-      int rs = ks / cpk, c0 = (ks - rs * cpk) * BK;
+      int cpk = p.C / BKT;
+      int rs = ks / cpk, c0 = (ks - rs * cpk) * BKT;
       int r = rs / p.S, s = rs - r * p.S;
       int dy = r * p.dil, dx = s * p.dil;
       int tapoff = (dy * p.W + dx) * p.C + c0;
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
         bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         ra[i] = bufload4(rsrc_a, ok ? (unsigned)(a_base[i] + tapoff) * 4u : OOB, 0);
       }
-      unsigned so = (unsigned)(ks * BK * p.K) * 4u;
+      unsigned so = (unsigned)(ks * BKT * p.K) * 4u;
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, b_base[i], so);
       if (p.NG & 3) {   // filter rows are only dword aligned and the last quad runs into the next row
@@ -181,8 +183,8 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
         }
       }
     } else if constexpr (MODE == MODE_DGRAD) {
-      int kpk = p.K / BK;
-      int rs = ks / kpk, k0 = (ks - rs * kpk) * BK;
+      int kpk = p.K / BKT;
+      int rs = ks / kpk, k0 = (ks - rs * kpk) * BKT;
       int r = rs / p.S, s = rs - r * p.S;
       int dy = r * p.dil, dx = s * p.dil;
       if (p.stride == 1) {
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
       for (int i = 0; i < A_LD; ++i) {
         int u = tid + 256 * i;
         int kr = u / (BM / 4), m4 = u % (BM / 4);
-        int pix = pix0 + ks * BK + kr;
+        int pix = pix0 + ks * BKT + kr;
         bool ok = pix < pix1;
         int off = 0;
         if (p.R == 1 && p.S == 1 && p.stride == 1) {
@@ -231,19 +233,19 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
         int u = tid + 256 * i;
-        int pix = pix0 + ks * BK + u / (BN / 4);
+        int pix = pix0 + ks * BKT + u / (BN / 4);
         rb[i] = bufload4(rsrc_b, (pix < pix1 && b_base[i] != OOB) ? b_base[i] + (unsigned)(pix * p.K) * 4u : OOB, 0);
       }
     }
   };
 
   auto store_tile = [&](int buf) {
-    float* a = sA + buf * (BK * LDA);
-    float* b = sB + buf * (BK * LDB);
+    float* a = sA + buf * (BKT * LDA);
+    float* b = sB + buf * (BKT * LDB);
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       if constexpr (A_KC) {
-        int row = (tid >> 2) + 64 * i;
+        int row = (tid / KQ) + RP * i;
         a[(kq4 + 0) * LDA + row] = ra[i].x; a[(kq4 + 1) * LDA + row] = ra[i].y;
         a[(kq4 + 2) * LDA + row] = ra[i].z; a[(kq4 + 3) * LDA + row] = ra[i].w;
       } else {
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
       if constexpr (B_KC) {
-        int row = (tid >> 2) + 64 * i;
+        int row = (tid / KQ) + RP * i;
         b[(kq4 + 0) * LDB + row] = rb[i].x; b[(kq4 + 1) * LDB + row] = rb[i].y;
         b[(kq4 + 2) * LDB + row] = rb[i].z; b[(kq4 + 3) * LDB + row] = rb[i].w;
       } else {
@@ -280,8 +282,8 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
   for (int ks = ks_begin; ks < ksteps; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < ksteps) load_tile(ks + 1);
-    const float* a = sA + cur * (BK * LDA) + wr * (BM / 2) + lo;
-    const float* b = sB + cur * (BK * LDB) + wc * (BN / 2) + lo;
+    const float* a = sA + cur * (BKT * LDA) + wr * (BM / 2) + lo;
+    const float* b = sB + cur * (BKT * LDB) + wc * (BN / 2) + lo;
     // Software-pipelined fragments: the ds_reads of k-pair kk+1 are issued BEFORE the MFMAs of
     // k-pair kk (two register sets), pinned with sched_barrier so hipcc does not re-serialise them
     // into read -> wait -> MFMA; LDS latency is then exposed once per K-step instead of 8 times.
@@ -291,9 +293,9 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_conv_mf
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[0][j] = b[hi * LDB + j * 32];
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
+    for (int kk = 0; kk < BKT / 2; ++kk) {
       const int cs = kk & 1, ns = cs ^ 1;
-      if (kk + 1 < BK / 2) {
+      if (kk + 1 < BKT / 2) {
         const int kr = 2 * (kk + 1) + hi;
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[ns][i] = a[kr * LDA + i * 32];
@@ -717,6 +719,16 @@ static ConvArgs make_args(const mtlssl_conv_desc* d) {
   return p;
 }
 
+// Kernel configurations: tile (bm x bn) and K-step depth. The kernel template takes the K-step
+// depth as a parameter; 32-deep variants of the 128x64 and 64x64 tiles (half the barriers, twice the
+// prefetch distance) were built and measured 3-10 % SLOWER than the 16-deep ones on every layer
+// shape of config[1] (tools/bench_conv.py, round 1), so only the 16-deep ones are instantiated.
+constexpr int NCFG = 3;
+static const int CFG_BM[NCFG] = {128, 128, 64};
+static const int CFG_BN[NCFG] = {128, 64, 64};
+static const int CFG_BK[NCFG] = {16, 16, 16};
+static inline bool cfg_allowed(int c, int kc) { return kc % CFG_BK[c] == 0; }
+
 static int check_desc(const mtlssl_conv_desc* d) {
   MTLSSL_REQUIRE(d != nullptr, "conv: null descriptor");
   MTLSSL_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0 &&
@@ -731,7 +743,7 @@ static int check_desc(const mtlssl_conv_desc* d) {
 // Tile choice: the biggest tile whose grid still fills the 256 CUs without a bad tail.
 // cfg 0: 128x128, 1: 128x64, 2: 64x64.
 static int pick_tile(int64_t M, int64_t NG, int64_t zmul) {
-  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+  const int* bm = CFG_BM; const int* bn = CFG_BN;
   int best = 2;
   double best_cost = 1e30;
   for (int c = 0; c < 3; ++c) {
@@ -784,24 +796,25 @@ struct Plan { int cfg, nsplit, ks_per_split; };
 // resident queue up. A CU holding a single block (one wave per SIMD) cannot hide its own LDS /
 // barrier latencies, hence the occupancy factor. Constants fitted to tools/bench_conv.py.
 static double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block) {
-  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
-  const int resident[3] = {3, 6, 8};
-  const double base_eff[3] = {0.80, 0.76, 0.72};
+  const int resident[NCFG] = {3, 6, 8};
+  const double base_eff[NCFG] = {0.80, 0.76, 0.72};
   int64_t per_cu = cdiv(nblocks, 256);
   int64_t occ = per_cu < resident[cfg] ? per_cu : resident[cfg];
   double occ_eff = occ <= 1 ? 0.55 : (occ == 2 ? 0.80 : 1.0);
-  double step_us = bm[cfg] * bn[cfg] * 32.0 / 614e9 * 1e6 / (base_eff[cfg] * occ_eff);
-  return (double)per_cu * (ksteps_per_block + 6) * step_us;
+  double step_us = CFG_BM[cfg] * CFG_BN[cfg] * 2.0 * CFG_BK[cfg] / 614e9 * 1e6 / (base_eff[cfg] * occ_eff);
+  return (double)per_cu * (ksteps_per_block + 96 / CFG_BK[cfg]) * step_us;
 }
 
-static Plan plan_gemm(int64_t M, int64_t NG, int ksteps) {
-  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
-  Plan best{2, 1, ksteps};
+// kc = reduction channels per filter tap (C for fwd, K for dgrad), taps = R*S.
+static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc) {
+  Plan best{2, 1, taps * (kc / 16)};
   double best_t = 1e30;
-  for (int c = 0; c < 3; ++c) {
-    int64_t tiles = cdiv(M, bm[c]) * cdiv(NG, bn[c]);
+  for (int c = 0; c < NCFG; ++c) {
+    if (!cfg_allowed(c, kc)) continue;
+    int ksteps = taps * (kc / CFG_BK[c]);
+    int64_t tiles = cdiv(M, CFG_BM[c]) * cdiv(NG, CFG_BN[c]);
     for (int s = 1; s <= 8; ++s) {
-      if (s > 1 && (ksteps / s < 12 || (NG & 3))) break;   // the fold kernel is float4 over N
+      if (s > 1 && (ksteps * CFG_BK[c] / s < 192 || (NG & 3))) break;   // the fold kernel is float4 over N
       int per = (int)cdiv(ksteps, s);
       int ns = (int)cdiv(ksteps, per);
       if (ns != s) continue;
@@ -838,35 +851,34 @@ static void small_wgrad_plan(const mtlssl_conv_desc* d, int* nsplit, int* k_per_
 
 template <int MODE>
 static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st) {
-  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
-  p.tiles_m = (int)cdiv(p.M, bm[cfg]);
-  p.tiles_n = (int)cdiv(p.NG, bn[cfg]);
+  p.tiles_m = (int)cdiv(p.M, CFG_BM[cfg]);
+  p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
   switch (cfg) {
-    case 0: hipLaunchKernelGGL((k_conv_mfma<128, 128, MODE>), grid, dim3(256), 0, st, p); break;
-    case 1: hipLaunchKernelGGL((k_conv_mfma<128, 64, MODE>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((k_conv_mfma<64, 64, MODE>), grid, dim3(256), 0, st, p); break;
+    case 0: hipLaunchKernelGGL((k_conv_mfma<128, 128, MODE, 16>), grid, dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((k_conv_mfma<128, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_conv_mfma<64, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
   }
 }
 
 static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pps) {
-  const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
   int64_t P = (int64_t)d->N * d->OH * d->OW;
   int RS = d->R * d->S;
-  int ksteps = (int)cdiv(P, BK);
   double best_t = 1e30;
-  *cfg = 2; *nsplit = 1; *pps = (int)align_up(P, BK);
-  for (int c = 0; c < 3; ++c) {
-    int64_t tiles = cdiv(d->C, bm[c]) * cdiv(d->K, bn[c]) * RS;
+  *cfg = 2; *nsplit = 1; *pps = (int)align_up(P, 16);
+  for (int c = 0; c < NCFG; ++c) {
+    int bk = CFG_BK[c];
+    int ksteps = (int)cdiv(P, bk);
+    int64_t tiles = cdiv(d->C, CFG_BM[c]) * cdiv(d->K, CFG_BN[c]) * RS;
     for (int s = 1; s <= 64; ++s) {
-      if (s > 1 && ksteps / s < 8) break;
+      if (s > 1 && ksteps * bk / s < 128) break;
       int per = (int)cdiv(ksteps, s);
       int ns = (int)cdiv(ksteps, per);
       if (ns != s) continue;
       // partial tiles written + read once by the fold kernel
       double t = tile_time_us(c, tiles * ns, per) +
                  2.0 + (double)RS * d->C * d->K * 4.0 * (ns + 1) / 3.0e6;
-      if (t < best_t) { best_t = t; *cfg = c; *nsplit = ns; *pps = per * BK; }
+      if (t < best_t) { best_t = t; *cfg = c; *nsplit = ns; *pps = per * bk; }
     }
   }
 }
@@ -884,7 +896,7 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
   int64_t NG = mode == MODE_FWD ? d->K : d->C;
   int kc = mode == MODE_FWD ? d->C : d->K;
   if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : mfma_dgrad_ok(d))) return 0;
-  Plan pl = plan_gemm(M, NG, d->R * d->S * (kc / BK));
+  Plan pl = plan_gemm(M, NG, d->R * d->S, kc);
   return pl.nsplit > 1 ? align_up(M * NG * 4 * pl.nsplit, 256) : 0;
 }
 
@@ -901,7 +913,7 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
   p.M = d->N * d->OH * d->OW;
   p.NG = d->K;
   if (mfma_fwd_ok(d)) {
-    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S * (d->C / BK));
+    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S, d->C);
     if (pl.nsplit > 1 && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0};
     p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split; p.splitk_ws = (float*)workspace;
     launch_mfma<MODE_FWD>(pl.cfg, p, dim3(1, 1, pl.nsplit), S(stream));
@@ -935,7 +947,7 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   p.M = d->N * d->H * d->W;
   p.NG = d->C;
   if (mfma_dgrad_ok(d)) {
-    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S * (d->K / BK));
+    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S, d->K);
     if (pl.nsplit > 1 && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0};
     p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split; p.splitk_ws = (float*)workspace;
     launch_mfma<MODE_DGRAD>(pl.cfg, p, dim3(1, 1, pl.nsplit), S(stream));
@@ -956,10 +968,10 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
   if (!d) return -1;
   if (mode == MODE_FWD)
     return mfma_fwd_ok(d)
-               ? plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S * (d->C / BK)).cfg : -1;
+               ? plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C).cfg : -1;
   if (mode == MODE_DGRAD)
     return mfma_dgrad_ok(d)
-               ? plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S * (d->K / BK)).cfg : -1;
+               ? plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K).cfg : -1;
   if (mode == MODE_WGRAD) {
     if (!mfma_wgrad_ok(d)) return -1;
     int cfg, ns, pps;

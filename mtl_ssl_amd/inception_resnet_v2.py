@@ -100,6 +100,7 @@ class ResidualUp:
         # keep db_tmp zeroed between uses instead of a separate beta for the bias
         ops.axpby(self.db_tmp, self.ps.grad(self.b.name), self.scale, 1.0)
         self.db_tmp.zero_()
+        self.ps.grad_ready(self.w, self.b)
 
     def dgrad(self, mixed_shape, gp, mask_ref):
         epi = ops.EPI_MASK if mask_ref is not None else 0

@@ -76,6 +76,7 @@ class ConvBN:
             ps = self.ps
             ops.bn_param_grads(y, gp, ps.value(self.gamma.name), ps.value(self.beta.name),
                                ps.grad(self.gamma.name), ps.grad(self.beta.name), beta=1.0)
+            ps.grad_ready(self.gamma, self.beta)
 
     def desc(self, shape):
         d = self._desc.get(tuple(shape))
@@ -96,6 +97,7 @@ class ConvBN:
             db = self.ps.grad(self.beta.name) if (self.bn_trainable and self.gamma is None) else None
             ops.conv2d_wgrad(self.desc(x.shape), x, g, self.ps.grad(self.w.name), out_scale=self.scale,
                              dbias=db, beta=1.0)
+            self.ps.grad_ready(self.w, self.beta if db is not None else None)
 
     def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False, mask6=False):
         epi = ((ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_ACCUM if accum else 0)
@@ -154,6 +156,7 @@ class DepthwiseBN:
         if self.trainable:
             ops.depthwise_wgrad(self.desc(x.shape), x, g, self.ps.grad(self.w.name), out_scale=self.scale,
                                 beta=1.0)
+            self.ps.grad_ready(self.w)
 
     def dgrad(self, x_shape, g, mask_ref=None, mask6=False):
         epi = (ops.EPI_MASK6 if mask6 else ops.EPI_MASK) if mask_ref is not None else 0
@@ -206,6 +209,7 @@ class Conv:
         gw = self.ps.grad(self.w.name)
         ops.conv2d_wgrad(self.desc(x4.shape), x4, g4, gw.view(self.k, self.k, self.cin, self.cout),
                          dbias=self.ps.grad(self.b.name), beta=1.0)
+        self.ps.grad_ready(self.w, self.b)
 
     def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False, mask6=False):
         x4s = (x_shape[0], 1, 1, self.cin) if self.fc else tuple(x_shape)

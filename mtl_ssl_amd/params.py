@@ -118,8 +118,18 @@ class ParamStore:
         # residual scales), refreshed by ONE launch after each optimizer step (ops.fold_scales)
         self.eff = None
         self._fold_refs = {}
+        self.grad_ready_hook = None      # set by trainer.GradientReducer: called once per variable per step
         self.finalized = True
         return self
+
+    def grad_ready(self, *specs):
+        """Layers call this right after enqueueing the kernels that finalise a variable's gradient
+        for the step; the data-parallel reducer uses it to start a bucket's all-reduce while the rest
+        of backward is still running."""
+        if self.grad_ready_hook is not None:
+            for sp in specs:
+                if sp is not None and sp.trainable:
+                    self.grad_ready_hook(sp)
 
     def register_fold(self, spec, scale):
         """eff[spec] = weights[spec] * scale[channel] (channel = flat index % scale.numel());

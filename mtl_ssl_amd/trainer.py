@@ -40,34 +40,87 @@ def learning_rate_fn(optimizer_cfg):
 
 
 class GradientReducer:
-    """Cross-replica gradient sum (replaces tf.add_n on the CPU, model_deploy.py:414-444).
-    Buckets are contiguous slices of the flat gradient buffer; each is all-reduced (sum) on a side
-    stream as soon as backward has produced it. xGMI is point-to-point, so buckets are large
-    (default 64 MiB) to stay per-link bandwidth-bound rather than latency-bound."""
+    """Cross-replica gradient sum (replaces tf.add_n on the CPU, model_deploy.py:414-444),
+    overlapped with backward: buckets are contiguous, variable-aligned slices of the flat gradient
+    buffer; every layer reports `ParamStore.grad_ready(var)` when it has enqueued the kernels that
+    finalise a variable's gradient, and a bucket's all-reduce (sum) is issued on a side stream as
+    soon as its last variable has reported — behind an event on the compute stream(s), so it runs
+    while the rest of backward is still executing. xGMI is point-to-point, so buckets are large
+    (default 32 MiB) to stay per-link bandwidth-bound rather than latency-bound."""
 
-    def __init__(self, ps, bucket_bytes=64 << 20):
+    def __init__(self, ps, bucket_bytes=32 << 20):
         import torch.distributed as dist
         self.dist = dist
         self.ps = ps
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        n = ps.n_train
         per = max(bucket_bytes // 4, 1)
-        self.buckets = [(s, min(s + per, n)) for s in range(0, n, per)]
+        self.buckets, self.var_bucket, self.nvars = [], {}, []
+        start, count = 0, 0
+        for sp in ps.trainable_specs:                     # variable-aligned, >= `per` floats each
+            self.var_bucket[sp.name] = len(self.buckets)
+            count += 1
+            end = sp.offset + -(-sp.size // 64) * 64
+            if end - start >= per:
+                self.buckets.append((start, end)); self.nvars.append(count)
+                start, count = end, 0
+        if count:
+            self.buckets.append((start, ps.n_train)); self.nvars.append(count)
+        if self.buckets:
+            self.buckets[-1] = (self.buckets[-1][0], ps.n_train)
         self.stream = torch.cuda.Stream() if (self.world > 1 and ps.device.type == "cuda") else None
+        self.compute_streams = []          # extra compute streams whose work a bucket may depend on
+        self.pending, self.done, self.seen = [], [], set()
+        self.launch_order = []             # bucket ids in the order they were issued (diagnostics/tests)
+        if self.world > 1:
+            ps.grad_ready_hook = self.mark_ready
 
-    def all_reduce(self):
+    def begin_step(self):
+        self.pending = list(self.nvars)
+        self.done = [False] * len(self.buckets)
+        self.seen = set()
+        self.launch_order = []
+
+    def mark_ready(self, spec):
+        if self.world == 1 or not self.pending or spec.name in self.seen:
+            return
+        self.seen.add(spec.name)
+        b = self.var_bucket[spec.name]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        g = self.ps.grads
+        self.done[b] = True
+        self.launch_order.append(b)
+        if self.stream is None:                      # gloo / CPU path used by the unit tests
+            self.dist.all_reduce(g[s:e])
+            return
+        for cs in [torch.cuda.current_stream()] + self.compute_streams:
+            ev = torch.cuda.Event()
+            ev.record(cs)
+            self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            self.dist.all_reduce(g[s:e])
+
+    def finish(self):
+        """Issue whatever has not been reduced yet and make the compute stream wait for all of it."""
         if self.world == 1:
             return
-        g = self.ps.grads
-        if self.stream is None:                      # gloo / CPU path used by the unit tests
-            for s, e in self.buckets:
-                self.dist.all_reduce(g[s:e])
-            return
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            for s, e in self.buckets:
-                self.dist.all_reduce(g[s:e])
-        torch.cuda.current_stream().wait_stream(self.stream)
+        if not self.done:
+            self.begin_step()
+        for b in range(len(self.buckets)):
+            if not self.done[b]:
+                self._launch(b)
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.pending = []
+
+    def all_reduce(self):
+        """Non-overlapped form: reduce every bucket now."""
+        self.begin_step()
+        self.finish()
 
 
 class Trainer:
@@ -115,6 +168,7 @@ class Trainer:
         m.step = self.global_step
         self.provide(batch)
         self.ps.grads.zero_()
+        self.reducer.begin_step()
         images = m.preprocess(batch["images"])
         pd = m.predict(images)
         mtl = m._mtl
@@ -131,7 +185,7 @@ class Trainer:
 
     def apply_gradients(self):
         """trainer.py:379-427: cross-replica sum, per-variable clip_by_norm, momentum update."""
-        self.reducer.all_reduce()
+        self.reducer.finish()
         lr = self.lr_fn(self.global_step)
         ps = self.ps
         ops.sgd_momentum_clip(ps.weights, ps.grads, ps.accum, ps.var_offsets, ps.max_var_size, lr,

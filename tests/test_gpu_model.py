@@ -84,7 +84,14 @@ def test_step_losses_and_gradients_match_oracle(refine, aux, crop, pk):
     from oracle.model import Oracle
     model, tr, batch, hp = _setup(refine, aux, crop, pk)
     values = model.ps.state_dict()
+    reports = {}
+    model.ps.grad_ready_hook = lambda sp: reports.__setitem__(sp.name, reports.get(sp.name, 0) + 1)
     losses = tr.forward_backward(batch)
+    model.ps.grad_ready_hook = None
+    # every trainable variable reports "gradient final" exactly once per step (the data-parallel
+    # reducer starts a bucket's all-reduce on that signal)
+    assert reports == {sp.name: 1 for sp in model.ps.trainable_specs}, \
+        [n for n in set(reports) ^ {sp.name for sp in model.ps.trainable_specs}][:5]
     torch.cuda.synchronize()
     got = {k: float(v.item()) for k, v in losses.items()}
     ora = Oracle(hp, values)

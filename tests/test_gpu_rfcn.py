@@ -76,7 +76,14 @@ def test_rfcn_step_matches_oracle():
     assert tr.var_wd is not None                                   # L2 regularisers are configured
     batch = synthetic.make_batch(2, 160, 224, 5, seed=11, device="cuda", max_gt=4, num_windows=6)
     values = model.ps.state_dict()
+    reports = {}
+    model.ps.grad_ready_hook = lambda sp: reports.__setitem__(sp.name, reports.get(sp.name, 0) + 1)
     losses = tr.forward_backward(batch)
+    model.ps.grad_ready_hook = None
+    # every trainable variable reports "gradient final" exactly once per step (the data-parallel
+    # reducer starts a bucket's all-reduce on that signal)
+    assert reports == {sp.name: 1 for sp in model.ps.trainable_specs}, \
+        [n for n in set(reports) ^ {sp.name for sp in model.ps.trainable_specs}][:5]
     torch.cuda.synchronize()
     got = {k: float(v.item()) for k, v in losses.items()}
     hb = dict(batch)

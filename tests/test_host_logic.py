@@ -161,16 +161,32 @@ def _dp_worker(rank, world, port, out):
     from mtl_ssl_amd import trainer
     from mtl_ssl_amd.params import ParamStore
     ps = ParamStore()
-    ps.add("a/weights", (300, 7), ("truncated_normal", 0.1))
-    ps.add("b/weights", (1000,), ("zeros",))
+    names = ["a/weights", "b/weights", "b/biases", "c/weights", "d/weights", "e/weights"]
+    for n, shape in zip(names, [(300, 7), (1000,), (10,), (40, 40), (3, 3, 16, 16), (700,)]):
+        ps.add(n, shape, ("truncated_normal", 0.1))
     ps.add("c/frozen", (5,), ("zeros",), trainable=False)
     ps.finalize("cpu", seed=0)
-    red = trainer.GradientReducer(ps, bucket_bytes=4096)       # several buckets, ragged tail
-    assert len(red.buckets) > 2 and red.buckets[-1][1] == ps.n_train
+    red = trainer.GradientReducer(ps, bucket_bytes=4096)       # several variable-aligned buckets
+    assert len(red.buckets) > 2 and red.buckets[0][0] == 0 and red.buckets[-1][1] == ps.n_train
+    assert all(red.buckets[i][1] == red.buckets[i + 1][0] for i in range(len(red.buckets) - 1))
     g = torch.arange(ps.n_train, dtype=torch.float32) * (rank + 1) / world   # clone loss is scaled 1/N
     ps.grads.copy_(g)
     red.all_reduce()
-    out[rank] = ps.grads.clone().numpy()
+    res = {"flat": ps.grads.clone().numpy()}
+    # overlapped form: variables report in backward order (last created first); a bucket is reduced
+    # the moment its last variable has reported, the rest at finish()
+    ps.grads.copy_(g)
+    red.begin_step()
+    for n in reversed(names[2:]):
+        ps.grad_ready(ps.by_name[n])
+        ps.grad_ready(ps.by_name[n])                           # a repeated report is ignored
+    early = list(red.launch_order)
+    red.finish()
+    res["overlap"] = ps.grads.clone().numpy()
+    res["early"] = early
+    res["order"] = list(red.launch_order)
+    res["nb"] = len(red.buckets)
+    out[rank] = res
     dist.destroy_process_group()
 
 
@@ -182,7 +198,12 @@ def test_data_parallel_gradient_sum_gloo_world2():
     out = mgr.dict()
     port = 29500 + (os.getpid() % 1000)
     mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
-    n = len(out[0])
+    n = len(out[0]["flat"])
     expect = np.arange(n, dtype=np.float32) * (1 + 2) / 2
-    np.testing.assert_allclose(out[0], expect, rtol=1e-6)
-    np.testing.assert_array_equal(out[0], out[1])
+    for key in ("flat", "overlap"):
+        np.testing.assert_allclose(out[0][key], expect, rtol=1e-6)
+        np.testing.assert_array_equal(out[0][key], out[1][key])
+    # buckets holding only late variables were reduced before finish(), highest offsets first;
+    # every bucket exactly once overall
+    assert len(out[0]["early"]) >= 1 and out[0]["early"] == sorted(out[0]["early"], reverse=True)
+    assert sorted(out[0]["order"]) == list(range(out[0]["nb"]))
