@@ -91,6 +91,7 @@ DEFAULTS = {
     "FasterRcnnFeatureExtractor": {"first_stage_features_stride": 16, "trainable": True,
                                    "freeze_layer": "block1", "batch_norm_trainable": False},
     "KeepAspectRatioResizer": {"min_dimension": 600, "max_dimension": 1024},
+    "FixedShapeResizer": {"height": 300, "width": 300},
     "GridAnchorGenerator": {"height": 256, "width": 256, "height_stride": 16, "width_stride": 16,
                             "height_offset": 0, "width_offset": 0, "scales": [], "aspect_ratios": []},
     # protos/hyperparams.proto
@@ -118,6 +119,8 @@ DEFAULTS = {
                     "from_detection_checkpoint": False, "num_steps": 0, "startup_delay_steps": 15,
                     "bias_grad_multiplier": 0.0, "batch_queue_capacity": 600, "num_batch_queue_threads": 8,
                     "prefetch_queue_capacity": 10, "save_interval_secs": 600, "restore_box_predictor": False,
+                    "restore_mtl_refine": False, "restore_window": False, "restore_closeness": False,
+                    "restore_edgemask": False,
                     "divide_grad_by_batch": False, "optimizer": "@Optimizer"},
     # protos/optimizer.proto
     "Optimizer": {"use_moving_average": True, "moving_average_decay": 0.9999},

@@ -187,16 +187,36 @@ class FasterRCNNMetaArch:
                 l.refold()
         ops.fold_scales(self.ps)
 
+    @staticmethod
+    def resized_shape(height, width, resizer):
+        """Output size of the configured image resizer (builders/image_resizer_builder.py:36-62):
+        keep_aspect_ratio_resizer -> core/preprocessor.py:1286-1325 `_compute_new_static_size`
+        (min side to min_dimension unless that pushes the max side past max_dimension);
+        fixed_shape_resizer -> (height, width)."""
+        if resizer.has("fixed_shape_resizer"):
+            f = resizer.fixed_shape_resizer
+            return int(f.height), int(f.width)
+        r = resizer.keep_aspect_ratio_resizer
+        mn, mx = int(r.min_dimension), int(r.max_dimension)
+        large = mn / float(min(height, width))
+        new = [int(round(height * large)), int(round(width * large))]
+        if mx and max(new) > mx:
+            small = mx / float(max(height, width))
+            new = [int(round(height * small)), int(round(width * small))]
+        return new[0], new[1]
+
     def preprocess(self, inputs):
-        """faster_rcnn_meta_arch.py:479-505. Inputs must already have the resized shape (the
-        synthetic benchmark feeds 600x1024, for which keep_aspect_ratio_resizer is the identity)."""
+        """faster_rcnn_meta_arch.py:479-505: the image resizer (bilinear tf.image.resize_images,
+        align_corners=False) followed by the feature extractor's normalisation. A batch shares one
+        input size (the reference's map_fn needs a static output shape as well)."""
         if inputs.dtype != f32:
             raise ValueError("`preprocess` expects a tf.float32 tensor")
-        r = self.cfg.image_resizer.keep_aspect_ratio_resizer
-        H, W = inputs.shape[1], inputs.shape[2]
-        if min(H, W) != r.min_dimension and max(H, W) != r.max_dimension:
-            raise ValueError("inputs must be pre-resized by keep_aspect_ratio_resizer(%d,%d); got %dx%d"
-                             % (r.min_dimension, r.max_dimension, H, W))
+        if inputs.dim() != 4 or inputs.shape[-1] != 3:
+            raise ValueError("`preprocess` expects [batch, height, width, 3] inputs")
+        H, W = int(inputs.shape[1]), int(inputs.shape[2])
+        nh, nw = self.resized_shape(H, W, self.cfg.image_resizer)
+        if (nh, nw) != (H, W):
+            inputs = ops.resize_bilinear_fwd(inputs.contiguous(), nh, nw)
         return self._feature_extractor.preprocess(inputs)
 
     @staticmethod

@@ -164,3 +164,20 @@ def test_training_reduces_loss():
         first = total if first is None else first
         last = total
     assert last < first
+
+
+def test_preprocess_resizes_to_range_like_the_reference():
+    """faster_rcnn_meta_arch.py:479-505 + core/preprocessor.py:1286-1420: bilinear resize_to_range
+    (align_corners=False) then the extractor's channel-mean subtraction."""
+    from oracle import ops_torch as T
+    model, _, _, _ = _setup(False, False, 7, 1)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 120, 200, 3, generator=g) * 255.0
+    out = model.preprocess(x.cuda())
+    assert tuple(out.shape) == (2, 134, 224, 3)                 # min side 160 would give 267 > 224
+    ref = T.resize_bilinear_legacy(x, 134, 224) - torch.tensor([123.68, 116.779, 103.939])
+    assert float((out.cpu() - ref).abs().max()) < 1e-3
+    same = model.preprocess(torch.zeros(1, 160, 224, 3, device="cuda"))      # already in range: identity
+    assert tuple(same.shape) == (1, 160, 224, 3)
+    with pytest.raises(ValueError):
+        model.preprocess(torch.zeros(1, 160, 224, 3, device="cuda", dtype=torch.float64))

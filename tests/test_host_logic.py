@@ -119,6 +119,83 @@ def test_mobilenet_variables_follow_slim_names_and_trainability():
         mobilenet.FasterRCNNMobilenetV1FeatureExtractor(ParamStore(), True, first_stage_features_stride=4)
 
 
+def test_resize_to_range_shapes_match_reference_known_answers():
+    """core/preprocessor_test.py:1398-1409 testResizeToRangePreservesStaticSpatialShape."""
+    from mtl_ssl_amd import config, frcnn
+    r = config.parse_pipeline_config(
+        "model { faster_rcnn { image_resizer { keep_aspect_ratio_resizer { min_dimension: 50 max_dimension: 100 } } } }"
+    ).model.faster_rcnn.image_resizer
+    for (h, w), want in zip([(60, 40), (15, 30), (15, 50)], [(75, 50), (50, 100), (30, 100)]):
+        assert frcnn.FasterRCNNMetaArch.resized_shape(h, w, r) == want
+    r = config.parse_pipeline_config(
+        "model { faster_rcnn { image_resizer { fixed_shape_resizer { height: 320 width: 200 } } } }"
+    ).model.faster_rcnn.image_resizer
+    assert frcnn.FasterRCNNMetaArch.resized_shape(60, 40, r) == (320, 200)
+    d = _cfg("frcnn_resnet101_coco_mtl.config").model.faster_rcnn.image_resizer
+    assert frcnn.FasterRCNNMetaArch.resized_shape(600, 1024, d) == (600, 1024)       # bench inputs: identity
+    assert frcnn.FasterRCNNMetaArch.resized_shape(480, 640, d) == (600, 800)
+    assert frcnn.FasterRCNNMetaArch.resized_shape(375, 1242, d) == (309, 1024)
+
+
+def test_checkpoint_maps_follow_reference_restore_rules(tmp_path):
+    """faster_rcnn_meta_arch.py:167-205,1947-2013; models/...inception_resnet_v2...:173-248;
+    trainer.py:309-356."""
+    from mtl_ssl_amd import checkpoint, frcnn, model_builder
+    from mtl_ssl_amd.params import ParamStore
+    cfg = _cfg("frcnn_resnet101_coco_mtl.config")
+    ps = ParamStore()
+    fe = model_builder.FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP["faster_rcnn_resnet101"](
+        ps, cfg.model.faster_rcnn.feature_extractor, True)
+    frcnn.FasterRCNNMetaArch(ps, True, cfg.model.faster_rcnn, cfg.model.mtl, fe)
+    ps.finalize("cpu", seed=1)
+    # classification checkpoint: scopes stripped, first and second stage only
+    m = checkpoint.restore_map(ps, from_detection_checkpoint=False)
+    assert m["resnet_v1_101/conv1/weights"] == "FirstStageFeatureExtractor/resnet_v1_101/conv1/weights"
+    assert m["resnet_v1_101/block4/unit_3/bottleneck_v1/conv3/weights"] == \
+        "SecondStageFeatureExtractor/resnet_v1_101/block4/unit_3/bottleneck_v1/conv3/weights"
+    assert not any(v.startswith(("WindowBoxPredictor", "FirstStageBoxPredictor", "MTLClassRefiner")) for v in m.values())
+    # aux towers share the classification init (share_second_stage_init, trainer.py:337-346)
+    aux = checkpoint.mtl_init_maps(ps, cfg.model.mtl, from_detection_checkpoint=False)
+    assert len(aux) == 3
+    assert aux[0]["resnet_v1_101/block4/unit_1/bottleneck_v1/shortcut/weights"].startswith("WindowBoxPredictor/")
+    assert checkpoint.mtl_init_maps(ps, cfg.model.mtl, from_detection_checkpoint=True) == []
+    # detection checkpoint: feature extractors always, heads on request
+    d = checkpoint.restore_map(ps, True)
+    assert all(k == v for k, v in d.items())
+    assert not any(k.startswith(("SecondStageBoxPredictor", "WindowBoxPredictor")) for k in d)
+    d = checkpoint.restore_map(ps, True, restore_box_predictor=True, restore_window=True, restore_mtl_refine=True)
+    assert "SecondStageBoxPredictor/ClassPredictor/weights" in d and "MTLClassRefiner/fc1/biases" in d
+    assert any(k.startswith("WindowBoxPredictor/") for k in d) and not any(k.startswith("ClosenessBoxPredictor/") for k in d)
+    # import: shape-checked like variables_helper.get_variables_available_in_checkpoint
+    name = "FirstStageFeatureExtractor/resnet_v1_101/block2/unit_1/bottleneck_v1/conv1/weights"
+    shape = ps.by_name[name].shape
+    ck = {"resnet_v1_101/block2/unit_1/bottleneck_v1/conv1/weights": np.full(shape, 0.5, np.float32),
+          "resnet_v1_101/conv1/weights": np.zeros((3, 3, 3, 64), np.float32),      # wrong shape: skipped
+          "resnet_v1_101/logits/weights": np.zeros((1, 1, 2048, 1000), np.float32)}  # not in the model: skipped
+    done = checkpoint.assign(ps, m, ck)
+    assert done == [name] and float(ps.value(name).mean()) == 0.5
+    # save / load round trip incl. momentum slots and step
+    ps.accum.uniform_(-1, 1)
+    w0, a0 = ps.weights.clone(), ps.accum.clone()
+    path = str(tmp_path / "state.npz")
+    checkpoint.save(path, ps, global_step=1234)
+    ps.weights.zero_(); ps.accum.zero_(); ps.frozen.zero_()
+    assert checkpoint.load(path, ps) == 1234
+    for sp in ps.trainable_specs:
+        assert torch.equal(ps._view(ps.weights, sp), ps._view(w0, sp)) and torch.equal(ps._view(ps.accum, sp), ps._view(a0, sp))
+    # Inception-ResNet-v2: the second-stage `Repeat` scope is `Repeat_2` in the classification graph
+    icfg = _cfg("frcnn_inception_resnet_v2_coco_mtl.config")
+    ips = ParamStore()
+    ife = model_builder.FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP["faster_rcnn_inception_resnet_v2"](
+        ips, icfg.model.faster_rcnn.feature_extractor, True)
+    frcnn.FasterRCNNMetaArch(ips, True, icfg.model.faster_rcnn, icfg.model.mtl, ife)
+    im = checkpoint.restore_map(ips, False, inception_resnet_v2=True)
+    assert im["InceptionResnetV2/Repeat_2/block8_3/Branch_0/Conv2d_1x1/weights"] == \
+        "SecondStageFeatureExtractor/InceptionResnetV2/Repeat/block8_3/Branch_0/Conv2d_1x1/weights"
+    assert im["InceptionResnetV2/Repeat/block35_1/Conv2d_1x1/biases"] == \
+        "FirstStageFeatureExtractor/InceptionResnetV2/Repeat/block35_1/Conv2d_1x1/biases"
+
+
 def test_manual_step_learning_rate():
     from mtl_ssl_amd import trainer
     f, mom = trainer.learning_rate_fn(_cfg("smoke_resnet50_mtl.config").train_config.optimizer)
