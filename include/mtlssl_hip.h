@@ -138,6 +138,11 @@ int mtlssl_boxes_prune_outside_window(const float* boxes, int n, float win_ymin,
                                       float win_ymax, float win_xmax, int32_t* keep_idx_out,
                                       int32_t* count_out, mtlssl_stream_t stream);
 
+/* box_list_ops.clip_to_window(filter_nonoverlapping=False) (core/box_list_ops.py:102-137): the
+ * inference-time anchor clipping of faster_rcnn_meta_arch.py:583-585 (grid anchors always overlap
+ * the image, so the reference's empty-box filter never removes one). */
+int mtlssl_boxes_clip_to_window(const float* boxes, int n, float win_ymin, float win_xmin, float win_ymax,
+                                float win_xmax, float* out, mtlssl_stream_t stream);
 /* tf.gather over rows per batch item (faster_rcnn_meta_arch.py:965-976) and its gradient
  * (scatter into a zeroed buffer; indices are unique). */
 int mtlssl_gather_rows(const float* src, const int32_t* idx, float* dst, int batch, int n_src,
@@ -164,6 +169,29 @@ int mtlssl_rpn_proposals(const float* rpn_box_encodings, const float* rpn_object
                          float score_thresh, float iou_thresh, int max_proposals,
                          float* proposals_out, float* scores_out, int32_t* num_out,
                          void* workspace, mtlssl_stream_t stream);
+/* Inference post-processing: batch_multiclass_non_max_suppression (core/post_processing.py:167-312 over
+ * multiclass_non_max_suppression :25-164) as called by FasterRCNNMetaArch._postprocess_box_classifier
+ * (meta_architectures/faster_rcnn_meta_arch.py:1387-1469). boxes [B,n,q,4] (q == 1 or num_classes),
+ * scores [B,n,num_classes] with row stride scores_ld >= num_classes (already score-converted; pass
+ * the pointer to column 1 of a [B,n,num_classes+1] tensor to drop the background slot like
+ * tf.slice does at :1441-1444), num_valid int32[B] or NULL. Per class: score
+ * filter (strict >), clip to clip_window (4 floats in HOST memory; NULL = no clipping) dropping empty boxes, optional
+ * change_coordinate_frame, greedy NMS capped at max_per_class; then all classes merged, sorted by
+ * score (stable), capped at max_total and zero padded. classes_out holds 0-based class ids as floats
+ * like the reference; num_out int32[B]. The host-side check text of the reference's ValueErrors is
+ * kept in the error messages. */
+int64_t mtlssl_batch_multiclass_nms_workspace_bytes(int batch, int n, int num_classes, int max_per_class);
+int mtlssl_batch_multiclass_nms(const float* boxes, const float* scores, int scores_ld,
+                                const int32_t* num_valid, int batch, int n, int q, int num_classes,
+                                float score_thresh,
+                                float iou_thresh, int max_per_class, int max_total,
+                                const float* clip_window, int change_coordinate_frame, float* boxes_out,
+                                float* scores_out, float* classes_out, int32_t* num_out, void* workspace,
+                                mtlssl_stream_t stream);
+/* Score converters of builders/post_processing_builder.py:80-108: mode 1 = tf.nn.softmax over the last
+ * axis, mode 2 = tf.sigmoid. logits/out [rows, C]. */
+int mtlssl_score_convert(const float* logits, float* out, int64_t rows, int C, int mode,
+                         mtlssl_stream_t stream);
 /* Stand-alone pieces of the above, exposed for parity tests:
  * greedy NMS of tf.image.non_max_suppression (call site core/post_processing.py:146) on
  * boxes that are already filtered (finite scores); selected_out[max_out] int32 indices in selection order. */

@@ -368,6 +368,116 @@ static int run_nms_sorted(const NmsWs& w, const int32_t* nvalid, int batch, int 
   return check_launch("nms");
 }
 
+// box_list_ops.clip_to_window without the empty-box filter (inference-time anchor clipping).
+__global__ void k_clip_boxes(const float* boxes, int n, float wy0, float wx0, float wy1, float wx1, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Box b = load_box(boxes + (int64_t)i * 4);
+  store_box(out + (int64_t)i * 4, Box{fmaxf(fminf(b.y0, wy1), wy0), fmaxf(fminf(b.x0, wx1), wx0),
+                                       fmaxf(fminf(b.y1, wy1), wy0), fmaxf(fminf(b.x1, wx1), wx0)});
+}
+
+// ------------------------------------------------------------------------------ multiclass NMS
+// batch_multiclass_non_max_suppression (core/post_processing.py:25-312), inference post-processing.
+// Every (image, class) pair is one "batch" entry of the rank-sort / bit-mask / scan pipeline above.
+// Stage A: per (image, class, box): score filter (strict >), clip_to_window (+ drop area <= 0),
+// optional change_coordinate_frame ((v - win_min) * (1/extent), box_list_ops.py:363-390).
+__global__ void k_mc_prepare(const float* boxes, const float* scores, int scores_ld,
+                             const int32_t* num_valid, int N, int q, int C, float score_thresh, int use_clip, float wy0, float wx0,
+                             float wy1, float wx1, int change_frame, float* wboxes, float* wscores,
+                             int32_t* nvalid) {
+  int bc = blockIdx.y;
+  int b = bc / C, c = bc % C;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = false;
+  if (i < N) {
+    int nv = num_valid ? min(num_valid[b], N) : N;
+    float s = scores[((int64_t)b * N + i) * scores_ld + c];
+    Box bx = load_box(boxes + (((int64_t)b * N + i) * q + (q > 1 ? c : 0)) * 4);
+    valid = i < nv && s > score_thresh;
+    if (use_clip) {
+      bx = Box{fmaxf(fminf(bx.y0, wy1), wy0), fmaxf(fminf(bx.x0, wx1), wx0), fmaxf(fminf(bx.y1, wy1), wy0),
+               fmaxf(fminf(bx.x1, wx1), wx0)};
+      valid = valid && box_area(bx) > 0.f;
+      if (change_frame) {
+        float ih = 1.f / (wy1 - wy0), iw = 1.f / (wx1 - wx0);
+        bx = Box{(bx.y0 - wy0) * ih, (bx.x0 - wx0) * iw, (bx.y1 - wy0) * ih, (bx.x1 - wx0) * iw};
+      }
+    }
+    int64_t o = (int64_t)bc * N + i;
+    store_box(wboxes + o * 4, bx);
+    wscores[o] = valid ? s : -INFINITY;
+  }
+  unsigned long long m = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(nvalid + bc, __popcll(m));
+}
+// Stage B (after sort + NMS per (image, class)): concatenate the per-class selections in class
+// order, stable-sort by score descending (box_list_ops.sort_by_field), keep max_total, zero-pad.
+__global__ void __launch_bounds__(256)
+    k_mc_merge(const float* sboxes, const float* sscores, const int32_t* sel_rank, const int32_t* nsel,
+               int N, int C, int mpc, int max_total, float* cand_score, int32_t* cand_src,
+               float* out_boxes, float* out_scores, float* out_classes, int32_t* out_num) {
+  __shared__ int s_off[1025];
+  int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int c = 0; c < C; ++c) { s_off[c] = acc; acc += nsel[b * C + c]; }
+    s_off[C] = acc;
+  }
+  __syncthreads();
+  const int M = s_off[C];
+  float* cs = cand_score + (int64_t)b * C * mpc;
+  int32_t* cr = cand_src + (int64_t)b * C * mpc;
+  for (int t = threadIdx.x; t < C * mpc; t += 256) {
+    int c = t / mpc, k = t % mpc;
+    if (k < nsel[b * C + c]) {
+      int r = sel_rank[((int64_t)b * C + c) * mpc + k];
+      cs[s_off[c] + k] = sscores[((int64_t)b * C + c) * N + r];
+      cr[s_off[c] + k] = c * N + r;
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < max_total; t += 256) {
+    int64_t o = (int64_t)b * max_total + t;
+    store_box(out_boxes + o * 4, Box{0, 0, 0, 0});
+    out_scores[o] = 0.f;
+    out_classes[o] = 0.f;
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < M; p += 256) {
+    float sp = cs[p];
+    int rank = 0;
+    for (int j = 0; j < M; ++j) {
+      float sj = cs[j];
+      rank += (sj > sp) || (sj == sp && j < p);
+    }
+    if (rank < max_total) {
+      int src = cr[p];
+      int64_t o = (int64_t)b * max_total + rank;
+      store_box(out_boxes + o * 4, load_box(sboxes + ((int64_t)b * C * N + src) * 4));
+      out_scores[o] = sp;
+      out_classes[o] = (float)(src / N);
+    }
+  }
+  if (threadIdx.x == 0) out_num[b] = min(M, max_total);
+}
+// tf.nn.softmax / tf.sigmoid over the class axis (post_processing_builder score converters).
+__global__ void k_score_convert(const float* logits, float* out, int64_t rows, int C, int mode) {
+  int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* l = logits + r * C;
+  float* o = out + r * C;
+  if (mode == 2) {
+    for (int c = 0; c < C; ++c) o[c] = 1.f / (1.f + expf(-l[c]));
+    return;
+  }
+  float m = -INFINITY;
+  for (int c = 0; c < C; ++c) m = fmaxf(m, l[c]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += expf(l[c] - m);
+  for (int c = 0; c < C; ++c) o[c] = expf(l[c] - m) / sum;
+}
+
 // ------------------------------------------------------------------------------ target assignment
 constexpr int ASSIGN_BLOCK = 256;
 // Pass A: per-anchor column arg-max + thresholds; per-block row partials for force-match.
@@ -684,6 +794,13 @@ int mtlssl_boxes_prune_outside_window(const float* boxes, int n, float wy0, floa
   return check_launch("prune");
 }
 
+int mtlssl_boxes_clip_to_window(const float* boxes, int n, float wy0, float wx0, float wy1, float wx1,
+                                float* out, mtlssl_stream_t stream) {
+  if (!n) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_clip_boxes, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), boxes, n, wy0, wx0, wy1, wx1, out);
+  return check_launch("clip_to_window");
+}
+
 int mtlssl_gather_rows(const float* src, const int32_t* idx, float* dst, int batch, int n_src,
                        int n_idx, int row_len, mtlssl_stream_t stream) {
   if (n_idx == 0 || batch == 0) return MTLSSL_OK;
@@ -764,6 +881,78 @@ int mtlssl_nms(const float* boxes, const float* scores, int n, float iou_thresh,
   hipLaunchKernelGGL(k_emit_selected, dim3(cdiv(max_out, 256)), dim3(256), 0, st, w.sidx,
                      w.sel_rank, num_out, max_out, selected_out);
   return check_launch("nms");
+}
+
+static int64_t mc_ws_layout(int batch, int N, int C, int mpc, char* base, NmsWs* w, float** cand_score,
+                            int32_t** cand_src, int32_t** nsel) {
+  int64_t off = nms_ws_layout(batch * C, N, mpc, base, w);
+  auto take = [&](int64_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  float* a = (float*)take((int64_t)batch * C * mpc * 4);
+  int32_t* b2 = (int32_t*)take((int64_t)batch * C * mpc * 4);
+  int32_t* c2 = (int32_t*)take((int64_t)batch * C * 4);
+  if (cand_score) *cand_score = a;
+  if (cand_src) *cand_src = b2;
+  if (nsel) *nsel = c2;
+  return off;
+}
+int64_t mtlssl_batch_multiclass_nms_workspace_bytes(int batch, int n, int num_classes, int max_per_class) {
+  int mpc = max_per_class < n ? max_per_class : n;
+  return mc_ws_layout(batch, n, num_classes, mpc > 0 ? mpc : 1, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+int mtlssl_batch_multiclass_nms(const float* boxes, const float* scores, int scores_ld,
+                                const int32_t* num_valid, int batch, int n, int q, int num_classes,
+                                float score_thresh,
+                                float iou_thresh, int max_per_class, int max_total,
+                                const float* clip_window, int change_coordinate_frame, float* boxes_out,
+                                float* scores_out, float* classes_out, int32_t* num_out, void* workspace,
+                                mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(q == 1 || q == num_classes,
+                 "second dimension of boxes must be either 1 or equal to the second dimension of scores");
+  MTLSSL_REQUIRE(num_classes >= 1 && num_classes <= 1024, "batch_multiclass_nms: 1..1024 classes");
+  MTLSSL_REQUIRE(scores_ld >= num_classes, "batch_multiclass_nms: scores_ld < num_classes");
+  MTLSSL_REQUIRE(max_per_class > 0 && max_total > 0, "batch_multiclass_nms: caps must be positive");
+  MTLSSL_REQUIRE(!change_coordinate_frame || clip_window,
+                 "Coordinate frame can only be changed if clip_window is specified.");
+  MTLSSL_REQUIRE(workspace != nullptr, "batch_multiclass_nms: workspace required");
+  if (batch == 0) return MTLSSL_OK;
+  hipStream_t st = S(stream);
+  if (n == 0) {
+    (void)hipMemsetAsync(boxes_out, 0, sizeof(float) * 4 * (size_t)batch * max_total, st);
+    (void)hipMemsetAsync(scores_out, 0, sizeof(float) * (size_t)batch * max_total, st);
+    (void)hipMemsetAsync(classes_out, 0, sizeof(float) * (size_t)batch * max_total, st);
+    (void)hipMemsetAsync(num_out, 0, sizeof(int32_t) * (size_t)batch, st);
+    return MTLSSL_OK;
+  }
+  int mpc = max_per_class < n ? max_per_class : n;
+  MTLSSL_REQUIRE(mpc <= 4096, "batch_multiclass_nms: max_detections_per_class <= 4096");
+  NmsWs w;
+  float* cand_score; int32_t* cand_src; int32_t* nsel;
+  mc_ws_layout(batch, n, num_classes, mpc, (char*)workspace, &w, &cand_score, &cand_src, &nsel);
+  const int BC = batch * num_classes;
+  (void)hipMemsetAsync(w.nvalid, 0, sizeof(int32_t) * BC, st);
+  float win[4] = {0, 0, 0, 0};
+  if (clip_window) { win[0] = clip_window[0]; win[1] = clip_window[1]; win[2] = clip_window[2]; win[3] = clip_window[3]; }
+  hipLaunchKernelGGL(k_mc_prepare, dim3(cdiv(n, 256), BC), dim3(256), 0, st, boxes, scores, scores_ld, num_valid,
+                     n, q, num_classes, score_thresh, clip_window != nullptr, win[0], win[1], win[2], win[3],
+                     change_coordinate_frame, w.boxes, w.scores, w.nvalid);
+  hipLaunchKernelGGL(k_rank_sort, dim3(cdiv(n, 256), BC), dim3(256), 0, st, w.boxes, w.scores, n, w.sboxes,
+                     w.sscores, w.sidx);
+  if (int rc = run_nms_sorted(w, w.nvalid, BC, n, iou_thresh, mpc, nsel, st)) return rc;
+  hipLaunchKernelGGL(k_mc_merge, dim3(batch), dim3(256), 0, st, w.sboxes, w.sscores, w.sel_rank, nsel, n,
+                     num_classes, mpc, max_total, cand_score, cand_src, boxes_out, scores_out, classes_out,
+                     num_out);
+  return check_launch("batch_multiclass_nms");
+}
+int mtlssl_score_convert(const float* logits, float* out, int64_t rows, int C, int mode,
+                         mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(mode == 1 || mode == 2, "score_convert: mode 1 (softmax) or 2 (sigmoid)");
+  if (!rows) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_score_convert, dim3(cdiv(rows, 256)), dim3(256), 0, S(stream), logits, out, rows, C, mode);
+  return check_launch("score_convert");
 }
 
 int64_t mtlssl_assign_targets_workspace_bytes(int batch, int n, int max_gt) {

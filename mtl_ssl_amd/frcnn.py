@@ -266,8 +266,8 @@ class FasterRCNNMetaArch:
             if self._is_training and not self.cfg.first_stage_clip_window:
                 keep = ops.prune_outside_window(anchors, [0, 0, H, W]).contiguous()
                 kept = ops.gather_rows(anchors[None].contiguous(), keep)[0].contiguous()
-            else:
-                raise NotImplementedError("inference-mode anchor clipping lands with postprocess()")
+            else:       # inference (or first_stage_clip_window): clip, keep every anchor (:583-585)
+                keep, kept = None, ops.clip_to_window(anchors, [0, 0, H, W])
             self._anchors[key] = (kept, keep, anchors.shape[0])
         return self._anchors[key]
 
@@ -282,8 +282,8 @@ class FasterRCNNMetaArch:
         rpn_feat = self.rpn_conv.forward(F)
         enc_all = self.rpn_box.forward(rpn_feat).view(B, n_all, 4)
         cls_all = self.rpn_cls.forward(rpn_feat).view(B, n_all, 2)
-        enc = ops.gather_rows(enc_all, keep)
-        logits = ops.gather_rows(cls_all, keep)
+        enc = ops.gather_rows(enc_all, keep) if keep is not None else enc_all
+        logits = ops.gather_rows(cls_all, keep) if keep is not None else cls_all
         pd = {
             "rpn_box_predictor_features": rpn_feat, "rpn_features_to_crop": F,
             "image_shape": (B, H, W, 3), "rpn_box_encodings": enc,
@@ -308,22 +308,35 @@ class FasterRCNNMetaArch:
     def _box_ind(self, B, n, device):
         return (torch.arange(B * n, device=device, dtype=i32) // n).contiguous()
 
+    def _second_stage_proposals(self, props, nprop, gt, H, W):
+        """Tail of _postprocess_rpn (:1117-1132): training samples a balanced minibatch of the
+        proposals against the groundtruth; inference keeps all of them. Returns absolute boxes,
+        normalised boxes (to_normalized_coordinates = multiply by 1/H, 1/W) and the valid count."""
+        c = self.cfg
+        if self._is_training:
+            stream0 = (2 * self.step * 65536 + 1) & 0xFFFFFFFF
+            return ops.sample_proposals(props, nprop, gt["boxes_abs"], gt["num"], gt["classes_bg"],
+                                        self.max_num_proposals, c.second_stage_balance_fraction, self.seed,
+                                        stream0, 2, H, W)
+        dev = props.device
+        inv = torch.tensor([1.0 / H, 1.0 / W, 1.0 / H, 1.0 / W], dtype=f32, device=dev)
+        fwd = torch.tensor([H, W, H, W], dtype=f32, device=dev)
+        norm = ops.scale_channels(props, inv)
+        return ops.scale_channels(norm, fwd), norm, nprop       # normalized_to_image_coordinates :693
+
     def _predict_second_stage(self, pd):
         """faster_rcnn_meta_arch.py:611-719."""
         c, mtl = self.cfg, self._mtl
         B, H, W, _ = pd["image_shape"]
         F = pd["rpn_features_to_crop"]
-        gt = self._format_groundtruth_data(H, W)
+        gt = self._format_groundtruth_data(H, W) if self._is_training else None
         # _postprocess_rpn :1055-1132
         props, _scores, nprop = ops.rpn_proposals(
             pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"],
             H, W, c.first_stage_nms_score_threshold, c.first_stage_nms_iou_threshold,
             int(c.first_stage_max_proposals))
         N2 = self.max_num_proposals
-        stream0 = (2 * self.step * 65536 + 1) & 0xFFFFFFFF
-        boxes_abs, boxes_norm, num = ops.sample_proposals(
-            props, nprop, gt["boxes_abs"], gt["num"], gt["classes_bg"], N2,
-            c.second_stage_balance_fraction, self.seed, stream0, 2, H, W)
+        boxes_abs, boxes_norm, num = self._second_stage_proposals(props, nprop, gt, H, W)
         box_ind = self._box_ind(B, N2, F.device)
         flat = boxes_norm.view(B * N2, 4)
         crops, argmax = self._crop(F, flat, box_ind, True)
@@ -389,6 +402,34 @@ class FasterRCNNMetaArch:
         pd["mtl_refined_class_predictions_with_background"] = refined
         pd["_refine_in"] = net
         return pd
+
+    # ------------------------------------------------------------------ inference
+    def postprocess(self, pd):
+        """faster_rcnn_meta_arch.py:996-1053 + _postprocess_box_classifier :1387-1469: decode the
+        per-class refined boxes against the proposals, convert scores, per-class NMS, merge. With
+        `mtl.refine` the refined class predictions replace the detector's own (:1041-1044)."""
+        c = self.cfg
+        B, H, W, _ = pd["image_shape"]
+        if c.first_stage_only:
+            boxes, scores, num = ops.rpn_proposals(
+                pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"],
+                H, W, c.first_stage_nms_score_threshold, c.first_stage_nms_iou_threshold,
+                int(c.first_stage_max_proposals))
+            return {"detection_boxes": boxes, "detection_scores": scores, "num_detections": num}
+        key = "mtl_refined_class_predictions_with_background"
+        cls = pd[key] if (self._mtl.refine and key in pd) else pd["class_predictions_with_background"]
+        N, K = self.max_num_proposals, self.num_classes
+        enc = pd["refined_box_encodings"].reshape(1, B * N * K, 4).contiguous()
+        tiled = pd["proposal_boxes"].view(B, N, 1, 4).expand(B, N, K, 4).reshape(B * N * K, 4).contiguous()
+        boxes = ops.boxes_decode(enc, tiled).view(B, N, K, 4)
+        pp = c.second_stage_post_processing
+        conv = ops.score_convert(cls.reshape(B * N, K + 1).contiguous(), pp.score_converter).view(B, N, K + 1)
+        nms = pp.batch_non_max_suppression
+        ob, os_, oc, on = ops.batch_multiclass_nms(
+            boxes, conv, nms.score_threshold, nms.iou_threshold, int(nms.max_detections_per_class),
+            int(nms.max_total_detections), clip_window=[0.0, 0.0, float(H), float(W)],
+            change_coordinate_frame=True, num_valid=pd["num_proposals"], col0=1, num_classes=K)
+        return {"detection_boxes": ob, "detection_scores": os_, "detection_classes": oc, "num_detections": on}
 
     # ------------------------------------------------------------------ loss (+ d/d predictions)
     def loss(self, pd, loss_scale=1.0):

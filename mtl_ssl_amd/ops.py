@@ -269,6 +269,13 @@ def prune_outside_window(boxes, window):
     return keep[: int(cnt.item())]       # one-time host sync (anchors are static per input size)
 
 
+def clip_to_window(boxes, window):
+    out = torch.empty_like(boxes)
+    lib().boxes_clip_to_window(ptr(_chk(boxes)), boxes.shape[0], float(window[0]), float(window[1]),
+                               float(window[2]), float(window[3]), ptr(out), _stream())
+    return out
+
+
 def gather_rows(src, idx):
     B, n_src, L = src.shape
     out = torch.empty((B, idx.numel(), L), dtype=f32, device=src.device)
@@ -321,6 +328,41 @@ def nms(boxes, scores, iou_thresh, max_out):
     lib().nms(ptr(_chk(boxes)), ptr(_chk(scores)), n, float(iou_thresh), max_out, ptr(sel), ptr(num),
               ptr(ws), _stream())
     return sel, num
+
+
+def batch_multiclass_nms(boxes, scores, score_thresh, iou_thresh, max_per_class, max_total,
+                         clip_window=None, change_coordinate_frame=False, num_valid=None, col0=0,
+                         num_classes=None):
+    """core/post_processing.py:167-312. boxes [B,n,q,4], scores [B,n,Cfull]; classes are columns
+    col0 .. col0+num_classes-1 of `scores` -> (boxes [B,T,4], scores [B,T], classes [B,T] float,
+    num int32[B])."""
+    B, n, q, _ = boxes.shape
+    ld = scores.shape[2]
+    C = int(num_classes) if num_classes is not None else ld - col0
+    dev = boxes.device
+    T = int(max_total)
+    ob = torch.empty((B, T, 4), dtype=f32, device=dev)
+    os_ = torch.empty((B, T), dtype=f32, device=dev)
+    oc = torch.empty((B, T), dtype=f32, device=dev)
+    on = torch.empty((B,), dtype=i32, device=dev)
+    ws = workspace(lib().batch_multiclass_nms_workspace_bytes(B, max(n, 1), C, int(max_per_class)), "mcnms", dev)
+    win = (ctypes.c_float * 4)(*[float(v) for v in clip_window]) if clip_window is not None else None
+    lib().batch_multiclass_nms(ptr(_chk(boxes)), ptr(_chk(scores)) + 4 * col0, ld, ptr(num_valid), B, n, q, C,
+                               float(score_thresh), float(iou_thresh), int(max_per_class), T, win,
+                               1 if change_coordinate_frame else 0, ptr(ob), ptr(os_), ptr(oc), ptr(on),
+                               ptr(ws), _stream())
+    return ob, os_, oc, on
+
+
+def score_convert(logits, mode):
+    """mode: 'SOFTMAX' | 'SIGMOID' | 'IDENTITY' (builders/post_processing_builder.py:80-108)."""
+    if mode == "IDENTITY":
+        return logits
+    out = torch.empty_like(logits)
+    C = logits.shape[-1]
+    lib().score_convert(ptr(_chk(logits)), ptr(out), logits.numel() // C, C, {"SOFTMAX": 1, "SIGMOID": 2}[mode],
+                        _stream())
+    return out
 
 
 def assign_targets(anchors, gt_boxes, num_gt, gt_labels, unmatched_cls_target, matched_thresh,

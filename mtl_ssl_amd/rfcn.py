@@ -87,16 +87,13 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         c, mtl = self.cfg, self._mtl
         B, H, W, _ = pd["image_shape"]
         F = pd["rpn_features_to_crop"]
-        gt = self._format_groundtruth_data(H, W)
+        gt = self._format_groundtruth_data(H, W) if self._is_training else None
         props, _scores, nprop = ops.rpn_proposals(
             pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"],
             H, W, c.first_stage_nms_score_threshold, c.first_stage_nms_iou_threshold,
             int(c.first_stage_max_proposals))
         N2 = self.max_num_proposals
-        stream0 = (2 * self.step * 65536 + 1) & 0xFFFFFFFF
-        boxes_abs, boxes_norm, num = ops.sample_proposals(
-            props, nprop, gt["boxes_abs"], gt["num"], gt["classes_bg"], N2,
-            c.second_stage_balance_fraction, self.seed, stream0, 2, H, W)
+        boxes_abs, boxes_norm, num = self._second_stage_proposals(props, nprop, gt, H, W)
         box_ind = self._box_ind(B, N2, F.device)
         flat = boxes_norm.view(B * N2, 4)
         feat, tower_ctx = self.tower.forward(F, self._is_training)

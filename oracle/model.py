@@ -213,6 +213,76 @@ class Oracle:
             c = T.max_pool(c, hp["maxpool_kernel_size"], hp["maxpool_stride"], "VALID")
         return c
 
+    # ------------------------------------------------------------------ inference
+    def detect(self, images, post):
+        """evaluator.py:143-154 at inference: preprocess is the caller's; predict (anchors CLIPPED,
+        all proposals kept: faster_rcnn_meta_arch.py:583-585,1117-1132) -> predict_with_mtl_results
+        -> postprocess (:996-1053). Faster R-CNN heads only. `post`: dict(score_converter,
+        score_threshold, iou_threshold, max_detections_per_class, max_total_detections).
+        Returns (detection_boxes, scores, classes, num, aux)."""
+        hp, mtl = self.hp, self.hp["mtl"]
+        with torch.no_grad():
+            img = torch.as_tensor(np.asarray(images, F))
+            Bn, H, W, _ = img.shape
+            K = hp["num_classes"]
+            K1 = K + 1
+            if hp["arch"] == "mobilenet_v1":
+                Fm = self.mobilenet_trunk(img * F(2.0 / 255.0) - 1.0)
+            elif hp["arch"] == "inception_resnet_v2":
+                Fm = self.inception_trunk(img * F(2.0 / 255.0) - 1.0)
+            else:
+                Fm = self.trunk(img - torch.tensor(MEANS))
+            ast = float(hp.get("anchor_stride", 16))
+            anchors_all = B.grid_anchors(Fm.shape[1], Fm.shape[2], hp["scales"], hp["aspect_ratios"],
+                                         (256.0, 256.0), (ast, ast), (0.0, 0.0))
+            anchors, _ = B.clip_to_window(anchors_all, [0, 0, H, W], filter_nonoverlapping=False)
+            rf = self.conv(Fm, "FirstStageBoxPredictor/Conv", "relu", hp.get("first_stage_atrous_rate", 1))
+            enc = self.conv(rf, "FirstStageBoxPredictor/BoxEncodingPredictor").reshape(Bn, -1, 4)
+            obj = self.conv(rf, "FirstStageBoxPredictor/ClassPredictor").reshape(Bn, -1, 2)
+            P = hp["max_proposals"]
+            pb, _, _, pn = N.rpn_proposals(enc.numpy(), obj.numpy(), anchors, (H, W), hp["nms_score_threshold"],
+                                           hp["nms_iou_threshold"], P)
+            boxes_norm = np.stack([B.to_normalized(pb[b], H, W) for b in range(Bn)])
+            boxes_abs = np.stack([B.to_absolute(boxes_norm[b], H, W) for b in range(Bn)])
+            box_ind = np.repeat(np.arange(Bn), P)
+            crops = self.crop(Fm, boxes_norm.reshape(-1, 4), box_ind)
+            feat = self.tower(crops, "SecondStageFeatureExtractor").mean((1, 2))
+            box_enc = self.fc(feat, "SecondStageBoxPredictor/BoxEncodingPredictor").reshape(Bn * P, K, 4)
+            cls = self.fc(feat, "SecondStageBoxPredictor/ClassPredictor")
+            final = cls
+            if mtl["refine"]:
+                src = [cls]
+                if mtl["window"]:
+                    per_img = []
+                    for b in range(Bn):
+                        pbn = boxes_norm[b]
+                        ymin, xmin, ymax, xmax = pbn[:, 0], pbn[:, 1], pbn[:, 2], pbn[:, 3]
+                        ne = F(4)
+                        wins = [np.stack([ymin - ymin / ne * F(i), xmin - xmin / ne * F(i),
+                                          ymax + (F(1) - ymax) / ne * F(i), xmax + (F(1) - xmax) / ne * F(i)],
+                                         1).astype(F) for i in range(5)]
+                        ew = np.concatenate(wins, 0)
+                        ef = self.tower(self.crop(Fm, ew, np.full(len(ew), b)), "WindowBoxPredictor").mean((1, 2))
+                        ep = self.fc(ef, "WindowBoxPredictor/ClassPredictor")
+                        per_img.append(ep.reshape(5, P, K1).permute(1, 0, 2).reshape(P, 5 * K1))
+                    src.append(torch.cat(per_img, 0))
+                if mtl["closeness"]:
+                    cf = self.tower(crops, "ClosenessBoxPredictor").mean((1, 2))
+                    c3 = self.fc(cf, "ClosenessBoxPredictor/ClassPredictor").reshape(Bn, P, K1)
+                    if mtl["global_closeness"]:
+                        c3 = c3.mean(1, keepdim=True).expand(Bn, P, K1)
+                    src.append(c3.reshape(Bn * P, K1))
+                final = self.fc(torch.cat(src, 1), "MTLClassRefiner/fc1")
+                if mtl["refine_residue"]:
+                    final = final + cls
+            ob, os_, oc, on = N.postprocess_box_classifier(
+                box_enc.numpy(), final.numpy(), boxes_abs, pn, (H, W), post["score_converter"],
+                post["score_threshold"], post["iou_threshold"], post["max_detections_per_class"],
+                post["max_total_detections"])
+        aux = dict(proposal_boxes=boxes_abs, num_proposals=pn, class_predictions=final.numpy(),
+                   refined_box_encodings=box_enc.numpy())
+        return ob, os_, oc, on, aux
+
     # ------------------------------------------------------------------ one training step
     def step(self, batch, seed, step=0):
         """Returns (losses {name: float}, grads {name: ndarray}, aux dict)."""

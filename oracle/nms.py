@@ -87,7 +87,8 @@ def multiclass_nms(boxes, scores, score_thresh, iou_thresh, max_size_per_class,
 
 
 def batch_multiclass_nms(boxes, scores, score_thresh, iou_thresh, max_size_per_class,
-                         max_total_size, clip_window=None, num_valid_boxes=None):
+                         max_total_size, clip_window=None, num_valid_boxes=None,
+                         change_coordinate_frame=False):
     """object_detection/core/post_processing.py:167-312: per image NMS, zero-pad to
     max_total_size. boxes [B,N,q,4], scores [B,N,C]. Returns (boxes [B,T,4], scores [B,T],
     classes [B,T], num_detections int32[B])."""
@@ -99,7 +100,7 @@ def batch_multiclass_nms(boxes, scores, score_thresh, iou_thresh, max_size_per_c
     for i in range(Bn):
         nv = boxes.shape[1] if num_valid_boxes is None else int(num_valid_boxes[i])
         b, s, c = multiclass_nms(boxes[i, :nv], scores[i, :nv], score_thresh, iou_thresh,
-                                 max_size_per_class, max_total_size, clip_window)
+                                 max_size_per_class, max_total_size, clip_window, change_coordinate_frame)
         n = len(b)
         ob[i, :n], os_[i, :n], oc[i, :n], on[i] = b, s, c, n
     return ob, os_, oc, on
@@ -124,3 +125,31 @@ def rpn_proposals(rpn_box_encodings, rpn_objectness, anchors, image_hw,
     win = [0, 0, image_hw[0], image_hw[1]]
     return batch_multiclass_nms(dec[:, :, None, :], sc[:, :, None], score_thresh,
                                 iou_thresh, max_proposals, max_proposals, clip_window=win)
+
+
+def postprocess_box_classifier(refined_box_encodings, class_logits_with_background, proposal_boxes,
+                               num_proposals, image_hw, score_converter, score_thresh, iou_thresh,
+                               max_per_class, max_total):
+    """object_detection/meta_architectures/faster_rcnn_meta_arch.py:1387-1469
+    (_postprocess_box_classifier) + _batch_decode_boxes :1471-1512.
+    refined_box_encodings [B*N, K, 4], logits [B*N, K+1], proposal_boxes [B, N, 4] absolute."""
+    enc = np.asarray(refined_box_encodings, F)
+    lg = np.asarray(class_logits_with_background, F)
+    pb = np.asarray(proposal_boxes, F)
+    Bn, N = pb.shape[:2]
+    K = enc.shape[1]
+    tiled = np.repeat(pb[:, :, None, :], K, 2).reshape(-1, 4)
+    dec = B.decode(enc.reshape(-1, 4), tiled).reshape(Bn, N, K, 4)
+    lg = lg.reshape(Bn, N, K + 1)
+    if score_converter == "SOFTMAX":
+        m = lg.max(-1, keepdims=True)
+        e = np.exp(lg - m)
+        sc = (e / e.sum(-1, keepdims=True)).astype(F)
+    elif score_converter == "SIGMOID":
+        sc = (F(1) / (F(1) + np.exp(-lg))).astype(F)
+    else:
+        sc = lg
+    H, W = image_hw
+    return batch_multiclass_nms(dec, sc[:, :, 1:], score_thresh, iou_thresh, max_per_class, max_total,
+                                clip_window=[0, 0, H, W], num_valid_boxes=num_proposals,
+                                change_coordinate_frame=True)

@@ -21,6 +21,14 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
 
+_SHARED_BOXES = [[[0, 0, 1, 1]], [[0, 0.1, 1, 1.1]], [[0, -0.1, 1, 0.9]], [[0, 10, 1, 11]], [[0, 10.1, 1, 11.1]],
+                 [[0, 100, 1, 101]], [[0, 1000, 1, 1002]], [[0, 1000, 1, 1002.1]]]
+_SEPARATE_BOXES = [[[0, 0, 1, 1], [0, 0, 4, 5]], [[0, 0.1, 1, 1.1], [0, 0.1, 2, 1.1]],
+                   [[0, -0.1, 1, 0.9], [0, -0.1, 1, 0.9]], [[0, 10, 1, 11], [0, 10, 1, 11]],
+                   [[0, 10.1, 1, 11.1], [0, 10.1, 1, 11.1]], [[0, 100, 1, 101], [0, 100, 1, 101]],
+                   [[0, 1000, 1, 1002], [0, 999, 2, 1004]], [[0, 1000, 1, 1002.1], [0, 999, 2, 1002.7]]]
+_TWO_CLASS_SCORES = [[.9, 0.01], [.75, 0.05], [.6, 0.01], [.95, 0], [.5, 0.01], [.3, 0.01], [.01, .85], [.01, .5]]
+
 VEC = {
     # object_detection/anchor_generators/grid_anchor_generator_test.py:26-47
     "anchors_single": dict(
@@ -106,6 +114,42 @@ VEC = {
         score_thresh=0.1, iou_thresh=.5, max_output_size=4,
         exp_corners=[[0, 10, 1, 11], [0, 0, 1, 1], [0, 1000, 1, 1002], [0, 100, 1, 101]],
         exp_scores=[.95, .9, .85, .3], exp_classes=[0, 0, 1, 0]),
+    # object_detection/core/post_processing_test.py:301-568: clip window (+ change of coordinate
+    # frame), per-class cap, total cap, per-class boxes, batched with zero padding. `max_total` 0 =
+    # the reference test passes max_size_per_class only.
+    "multiclass_nms_cases": [
+        dict(name="clip_window", boxes=[[[0, 0, 10, 10]], [[1, 1, 11, 11]]], scores=[[.9], [.75]],
+             score_thresh=0.0, iou_thresh=0.5, max_per_class=100, max_total=0, clip_window=[5, 4, 8, 7],
+             change_frame=False, exp_corners=[[5, 4, 8, 7]], exp_scores=[.9], exp_classes=[0]),
+        dict(name="clip_window_change_coordinate_frame", boxes=[[[0, 0, 10, 10]], [[1, 1, 11, 11]]],
+             scores=[[.9], [.75]], score_thresh=0.0, iou_thresh=0.5, max_per_class=100, max_total=0,
+             clip_window=[5, 4, 8, 7], change_frame=True, exp_corners=[[0, 0, 1, 1]], exp_scores=[.9],
+             exp_classes=[0]),
+        dict(name="per_class_cap", boxes=_SHARED_BOXES, scores=_TWO_CLASS_SCORES, score_thresh=0.1,
+             iou_thresh=.5, max_per_class=2, max_total=0, clip_window=None, change_frame=False,
+             exp_corners=[[0, 10, 1, 11], [0, 0, 1, 1], [0, 1000, 1, 1002]], exp_scores=[.95, .9, .85],
+             exp_classes=[0, 0, 1]),
+        dict(name="total_cap", boxes=_SHARED_BOXES, scores=_TWO_CLASS_SCORES, score_thresh=0.1, iou_thresh=.5,
+             max_per_class=4, max_total=2, clip_window=None, change_frame=False,
+             exp_corners=[[0, 10, 1, 11], [0, 0, 1, 1]], exp_scores=[.95, .9], exp_classes=[0, 0]),
+        dict(name="separate_boxes", boxes=_SEPARATE_BOXES, scores=_TWO_CLASS_SCORES, score_thresh=0.1,
+             iou_thresh=.5, max_per_class=4, max_total=0, clip_window=None, change_frame=False,
+             exp_corners=[[0, 10, 1, 11], [0, 0, 1, 1], [0, 999, 2, 1004], [0, 100, 1, 101]],
+             exp_scores=[.95, .9, .85, .3], exp_classes=[0, 0, 1, 0]),
+    ],
+    "batch_multiclass_nms_cases": [
+        dict(name="batch_size_1", boxes=[_SEPARATE_BOXES], scores=[_TWO_CLASS_SCORES], score_thresh=0.1,
+             iou_thresh=.5, max_per_class=4, max_total=4,
+             exp_corners=[[[0, 10, 1, 11], [0, 0, 1, 1], [0, 999, 2, 1004], [0, 100, 1, 101]]],
+             exp_scores=[[.95, .9, .85, .3]], exp_classes=[[0, 0, 1, 0]], exp_num=[4]),
+        dict(name="batch_size_2", boxes=[_SEPARATE_BOXES[:4], _SEPARATE_BOXES[4:]],
+             scores=[_TWO_CLASS_SCORES[:4], _TWO_CLASS_SCORES[4:]], score_thresh=0.1, iou_thresh=.5,
+             max_per_class=4, max_total=4,
+             exp_corners=[[[0, 10, 1, 11], [0, 0, 1, 1], [0, 0, 0, 0], [0, 0, 0, 0]],
+                          [[0, 999, 2, 1004], [0, 10.1, 1, 11.1], [0, 100, 1, 101], [0, 0, 0, 0]]],
+             exp_scores=[[.95, .9, 0, 0], [.85, .5, .3, 0]], exp_classes=[[0, 0, 0, 0], [1, 0, 0, 0]],
+             exp_num=[2, 3]),
+    ],
     # object_detection/core/losses_test.py:97-119
     "smooth_l1": dict(
         pred=[[[2.5, 0, .4, 0], [0, 0, 0, 0], [0, 2.5, 0, .4]],

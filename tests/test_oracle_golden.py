@@ -116,6 +116,24 @@ def test_nms_known_answers(vec):
     np.testing.assert_allclose(c, m["exp_classes"])
 
 
+def test_multiclass_nms_variants_known_answers(vec):
+    """core/post_processing_test.py:301-568 through the oracle."""
+    for m in vec["multiclass_nms_cases"]:
+        b, s, c = N.multiclass_nms(np.array(m["boxes"], np.float32), np.array(m["scores"], np.float32),
+                                   m["score_thresh"], m["iou_thresh"], m["max_per_class"], m["max_total"],
+                                   m["clip_window"], m["change_frame"])
+        np.testing.assert_allclose(b, m["exp_corners"], err_msg=m["name"])
+        np.testing.assert_allclose(s, m["exp_scores"], err_msg=m["name"])
+        np.testing.assert_allclose(c, m["exp_classes"], err_msg=m["name"])
+    for m in vec["batch_multiclass_nms_cases"]:
+        ob, os_, oc, on = N.batch_multiclass_nms(np.array(m["boxes"], np.float32), np.array(m["scores"], np.float32),
+                                                 m["score_thresh"], m["iou_thresh"], m["max_per_class"], m["max_total"])
+        np.testing.assert_allclose(ob, m["exp_corners"], err_msg=m["name"])
+        np.testing.assert_allclose(os_, m["exp_scores"], err_msg=m["name"])
+        np.testing.assert_allclose(oc, m["exp_classes"], err_msg=m["name"])
+        np.testing.assert_array_equal(on, m["exp_num"])
+
+
 def test_losses_known_answers(vec):
     v = vec["smooth_l1"]
     p = torch.tensor(v["pred"])
