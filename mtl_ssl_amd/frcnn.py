@@ -174,6 +174,20 @@ class FasterRCNNMetaArch:
             return int(self.cfg.second_stage_batch_size)
         return int(self.cfg.first_stage_max_proposals)
 
+    def _aux_stream(self):
+        """Second compute stream for work that is independent of the main path (None on CPU or when
+        MTLSSL_AUX_STREAM=0)."""
+        import os
+        if self.ps.device.type != "cuda" or os.environ.get("MTLSSL_AUX_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_aux_stream_obj", None) is None:
+            self._aux_stream_obj = torch.cuda.Stream(device=self.ps.device)
+        return self._aux_stream_obj
+
+    def compute_streams(self):
+        s = getattr(self, "_aux_stream_obj", None)
+        return [s] if s is not None else []
+
     def prepare(self):
         for l in self.layers:
             l.prepare()
@@ -531,32 +545,48 @@ class FasterRCNNMetaArch:
             self.refine_fc.wgrad(pd["_refine_in"], d_ref)        # refiner input is stop_gradient (:834)
             if mtl.refine_residue and not mtl.stop_gradient_for_prediction_org:
                 ops.axpby(d_ref, d_cls, 1.0, 1.0)
+        c = self.cfg
         # main head -> tower -> crops -> dF
         feat = pd["_feat"]
         g_feat = self.box_predictor.backward(pd["_bp"], d_cls, d["refined_box_encodings"].view(feat.shape[0], -1),
                                              feat.shape)
         g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True)
-        c = self.cfg
         ops.roi_crop_pool_bwd(g_crops, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
                               pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
                               int(c.maxpool_stride), dfeat=dF)
         stop = bool(mtl.stop_gradient_for_aux_tasks)
-        if mtl.closeness:
-            cfeat = pd["_cfeat"]
-            g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat.shape)
-            gc = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop)
-            if not stop:
-                ops.roi_crop_pool_bwd(gc, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
-                                      pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
-                                      int(c.maxpool_stride), dfeat=dF)
-        if mtl.window:
-            wfeat = pd["_wfeat"]
-            g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat.shape)
-            gw = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop)
-            if not stop:
-                ops.roi_crop_pool_bwd(gw, pd["_wargmax"], F.shape, pd["_wboxes"], pd["_wbox_ind"],
-                                      int(c.initial_crop_size), int(c.maxpool_kernel_size),
-                                      int(c.maxpool_stride), dfeat=dF)
+
+        def aux_backward():
+            if mtl.closeness:
+                cfeat = pd["_cfeat"]
+                g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat.shape)
+                gc = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop)
+                if not stop:
+                    ops.roi_crop_pool_bwd(gc, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
+                                          pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
+                                          int(c.maxpool_stride), dfeat=dF)
+            if mtl.window:
+                wfeat = pd["_wfeat"]
+                g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat.shape)
+                gw = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop)
+                if not stop:
+                    ops.roi_crop_pool_bwd(gw, pd["_wargmax"], F.shape, pd["_wboxes"], pd["_wbox_ind"],
+                                          int(c.initial_crop_size), int(c.maxpool_kernel_size),
+                                          int(c.maxpool_stride), dfeat=dF)
+
+        # With stop_gradient_for_aux_tasks the aux towers' backward touches neither dF nor any
+        # tensor of the main path, so it runs on a second HIP stream, concurrently with the RPN /
+        # trunk backward below: those are small GEMMs (4 864 pixels at B=2) that cannot fill 256
+        # CUs on their own, and the aux towers' large wgrad/dgrad tiles take the idle ones. It is
+        # released only after the main tower's backward (two streams of large tiles would just
+        # time-slice), i.e. exactly when the small-GEMM phase of the main path begins.
+        side = self._aux_stream() if (stop and (mtl.closeness or mtl.window)) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                aux_backward()
+        else:
+            aux_backward()
         if mtl.edgemask:
             em_pred = pd["edgemask_predictions"]
             g = ops.resize_bilinear_bwd(d["edgemask_resized"], em_pred.shape)
@@ -579,3 +609,5 @@ class FasterRCNNMetaArch:
                                   mask6=getattr(self._feature_extractor, "output_relu6", False))
         pd["_gpF"] = gpF
         self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"])
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)

@@ -31,7 +31,8 @@ _ws_cache = {}
 def workspace(nbytes, key="default", device=None):
     """Grow-only device scratch buffers, one per key (caller-owned workspaces of the C ABI)."""
     device = device or torch.device("cuda", torch.cuda.current_device())
-    k = (key, device.index)
+    # one buffer per (purpose, device, stream): kernels on different streams may run concurrently
+    k = (key, device.index, torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(k)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -69,12 +69,14 @@ class GradientReducer:
             self.buckets[-1] = (self.buckets[-1][0], ps.n_train)
         self.stream = torch.cuda.Stream() if (self.world > 1 and ps.device.type == "cuda") else None
         self.compute_streams = []          # extra compute streams whose work a bucket may depend on
+        self.main_stream = None
         self.pending, self.done, self.seen = [], [], set()
         self.launch_order = []             # bucket ids in the order they were issued (diagnostics/tests)
         if self.world > 1:
             ps.grad_ready_hook = self.mark_ready
 
     def begin_step(self):
+        self.main_stream = torch.cuda.current_stream() if self.stream is not None else None
         self.pending = list(self.nvars)
         self.done = [False] * len(self.buckets)
         self.seen = set()
@@ -97,7 +99,10 @@ class GradientReducer:
         if self.stream is None:                      # gloo / CPU path used by the unit tests
             self.dist.all_reduce(g[s:e])
             return
-        for cs in [torch.cuda.current_stream()] + self.compute_streams:
+        # the bucket's variables may have been produced on any compute stream (main or auxiliary)
+        streams = {id(cs): cs for cs in [self.main_stream, torch.cuda.current_stream()] + self.compute_streams
+                   if cs is not None}
+        for cs in streams.values():
             ev = torch.cuda.Event()
             ev.record(cs)
             self.stream.wait_event(ev)
@@ -168,6 +173,7 @@ class Trainer:
         m.step = self.global_step
         self.provide(batch)
         self.ps.grads.zero_()
+        self.reducer.compute_streams = m.compute_streams()
         self.reducer.begin_step()
         images = m.preprocess(batch["images"])
         pd = m.predict(images)
@@ -185,6 +191,7 @@ class Trainer:
 
     def apply_gradients(self):
         """trainer.py:379-427: cross-replica sum, per-variable clip_by_norm, momentum update."""
+        self.reducer.compute_streams = self.model.compute_streams()
         self.reducer.finish()
         lr = self.lr_fn(self.global_step)
         ps = self.ps
