@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--conv-breakdown", action="store_true",
+                    help="time every conv launch (adds ~2%% to the step) and report the per-kernel table")
     a = ap.parse_args()
 
     import torch
@@ -213,7 +215,8 @@ def main():
     for _ in range(a.warmup):
         tr.step(batch)
     if not a.no_roofline:
-        ops.PROFILER = ops.ConvProfiler()
+        # live HIP-event timing of the roofline kernel (forward, 128x128 tile) inside the timed region
+        ops.PROFILER = ops.ConvProfiler(None if a.conv_breakdown else (0, 0))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -269,6 +272,7 @@ def main():
                 "launches": dom["launches"], "avg_launch_us": 1e6 * dom["seconds"] / dom["launches"],
                 "algorithmic_flop_per_launch_avg": dom["flops"] / dom["launches"],
             }
+    if prof is not None and a.conv_breakdown:
         fam_f = sum(v["flops"] for k, v in s.items() if k[1] >= 0)
         fam_t = sum(v["seconds"] for k, v in s.items() if k[1] >= 0)
         out["conv_family"] = {

@@ -77,10 +77,16 @@ class ConvProfiler:
     for the `roofline` object; off by default (PROFILER is None)."""
     MODES = ("fwd", "dgrad", "wgrad")
 
-    def __init__(self):
+    def __init__(self, only=None):
+        """only: optional (mode, tile config) — time just that kernel (two events per launch cost
+        ~1 us of stream time each; timing every conv of the step costs ~2 % of the step)."""
         self.pending = []          # (key, flops, start_event, end_event)
+        self.only = only
 
-    def begin(self):
+    def begin(self, d=None, mode=None):
+        if self.only is not None and (mode != self.only[0]
+                                      or lib().conv2d_tile_config(ctypes.byref(d), mode) != self.only[1]):
+            return None
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
@@ -108,7 +114,7 @@ PROFILER = None
 
 def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None):
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
-    t0 = PROFILER.begin() if PROFILER is not None else None
+    t0 = PROFILER.begin(d, 0) if PROFILER is not None else None
     nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 0)
     ws = workspace(nb, "splitk", x.device) if nb else None
     lib().conv2d_fwd(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(residual),
@@ -120,7 +126,7 @@ def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None):
 
 def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None):
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=f32, device=dy.device)
-    t0 = PROFILER.begin() if PROFILER is not None else None
+    t0 = PROFILER.begin(d, 1) if PROFILER is not None else None
     nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 1)
     ws = workspace(nb, "splitk", dy.device) if nb else None
     lib().conv2d_dgrad(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref),
@@ -133,7 +139,7 @@ def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None):
 def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0):
     nbytes = lib().conv2d_wgrad_workspace_bytes(ctypes.byref(d))
     ws = workspace(nbytes, "wgrad", x.device)
-    t0 = PROFILER.begin() if PROFILER is not None else None
+    t0 = PROFILER.begin(d, 2) if PROFILER is not None else None
     lib().conv2d_wgrad(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(dy)), ptr(out_scale), ptr(dw),
                        ptr(dbias), float(beta), ptr(ws), _stream())
     if t0 is not None:
