@@ -67,6 +67,11 @@ class _Lib:
             raise MtlsslError(
                 "%s not found: build it with `python -m mtl_ssl_amd.build` "
                 "(there is no CPU fallback for the product path)" % LIB_PATH)
+        # The library must bind to the SAME HIP runtime as the process that owns the device memory
+        # it is handed. PyTorch wheels bundle their own libamdhip64; loading it first makes the
+        # dynamic linker resolve this library's DT_NEEDED libamdhip64 to that copy (same soname)
+        # instead of opening /opt/rocm's as a second, uninitialised runtime.
+        import torch  # noqa: F401
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         for name, (restype, argtypes) in self.protos.items():

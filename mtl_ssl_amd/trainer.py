@@ -217,11 +217,24 @@ def train(create_tensor_dict_fn, create_model_fn, train_config, master="", task=
     here is one process per GPU over RCCL."""
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
+    import os
+    from . import checkpoint
     model = create_model_fn()
     trainer = Trainer(model, train_config, world)
+    # Resume from train_dir if a state file is there, else initialise from fine_tune_checkpoint
+    # (trainer.py:309-356; slim.learning.train restores the latest checkpoint of logdir). The
+    # container is .npz keyed by the reference's variable names (mtl_ssl_amd/checkpoint.py).
+    state = os.path.join(train_dir, "model.ckpt.npz") if train_dir else None
+    if state and os.path.exists(state):
+        trainer.global_step = checkpoint.load(state, model.ps)
+        model.prepare()
+    elif train_config.fine_tune_checkpoint and os.path.exists(str(train_config.fine_tune_checkpoint)):
+        import numpy as np
+        mtl = model_config.mtl if model_config is not None else model._mtl
+        checkpoint.init_from_checkpoint(model, np.load(str(train_config.fine_tune_checkpoint)), train_config, mtl)
     steps = num_steps if num_steps is not None else (int(train_config.num_steps) or 10)
     log = []
-    for _ in range(steps):
+    for _ in range(max(steps - trainer.global_step, 0)):
         t0 = time.time()
         losses = trainer.step(create_tensor_dict_fn())
         if trainer.global_step % log_every == 0 or trainer.global_step == steps:
@@ -233,4 +246,7 @@ def train(create_tensor_dict_fn, create_model_fn, train_config, master="", task=
             log.append({"step": trainer.global_step, "loss": total, "sec_per_step": dt})
             if is_chief:
                 print("global step %d: loss = %.4f (%.3f sec/step)" % (trainer.global_step, total, dt))
+    if state and is_chief:
+        os.makedirs(train_dir, exist_ok=True)
+        checkpoint.save(state, model.ps, trainer.global_step)
     return trainer, log

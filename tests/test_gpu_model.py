@@ -2,6 +2,8 @@
 torch-CPU autograd oracle on identical synthetic batches, weights and sampler seeds.
 Losses and gradients within 1e-3 relative fp32; assignment / sampling indices bit-exact
 (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -181,3 +183,33 @@ def test_preprocess_resizes_to_range_like_the_reference():
     assert tuple(same.shape) == (1, 160, 224, 3)
     with pytest.raises(ValueError):
         model.preprocess(torch.zeros(1, 160, 224, 3, device="cuda", dtype=torch.float64))
+
+
+def test_trainer_train_entry_point_resumes_and_fine_tunes(tmp_path):
+    """object_detection/trainer.py:217-219 `train(create_tensor_dict_fn, create_model_fn, train_config,
+    ...)`: runs, writes its state to train_dir, resumes from it, and initialises a fresh model from
+    `fine_tune_checkpoint` through restore_map (feature extractors only by default)."""
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import checkpoint, config, model_builder, synthetic, trainer
+    cfg = config.parse_pipeline_config(TINY_CONFIG % dict(refine="false", aux="false", K=5, H=160, W=224, crop=7, pk=1))
+    make = lambda: model_builder.build(cfg.model, True, "cuda", seed=3)
+    data = lambda: synthetic.make_batch(2, 160, 224, 5, seed=11, device="cuda", max_gt=4, num_windows=6)
+    d = str(tmp_path / "run")
+    tr, log = trainer.train(data, make, cfg.train_config, train_dir=d, num_steps=3, model_config=cfg.model,
+                            log_every=1)
+    assert tr.global_step == 3 and len(log) == 3 and os.path.exists(os.path.join(d, "model.ckpt.npz"))
+    w3 = tr.ps.weights.clone()
+    tr2, log2 = trainer.train(data, make, cfg.train_config, train_dir=d, num_steps=5, model_config=cfg.model,
+                              log_every=1)
+    assert tr2.global_step == 5 and [e["step"] for e in log2] == [4, 5]       # resumed at step 3
+    assert not torch.equal(tr2.ps.weights, w3)
+    # fine-tune: a detection checkpoint restores the two feature extractors but not the heads
+    cfg.train_config["fine_tune_checkpoint"] = os.path.join(d, "model.ckpt.npz")
+    cfg.train_config["from_detection_checkpoint"] = True
+    tr3, _ = trainer.train(data, lambda: model_builder.build(cfg.model, True, "cuda", seed=99), cfg.train_config,
+                           num_steps=0, model_config=cfg.model)
+    name = "FirstStageFeatureExtractor/resnet_v1_50/block3/unit_2/bottleneck_v1/conv2/weights"
+    head = "SecondStageBoxPredictor/ClassPredictor/weights"
+    assert torch.equal(tr3.ps.value(name), tr2.ps.value(name))
+    assert not torch.equal(tr3.ps.value(head), tr2.ps.value(head))
