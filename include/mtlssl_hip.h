@@ -122,6 +122,10 @@ int mtlssl_maxpool_bwd(const float* x, const float* y, const float* dy, float* d
 /* tf.reduce_mean over H,W (core/box_predictor.py:469-471) and its gradient. */
 int mtlssl_spatial_mean_fwd(const float* x, float* y, int N, int HW, int C, mtlssl_stream_t s);
 int mtlssl_spatial_mean_bwd(const float* dy, float* dx, int N, int HW, int C, mtlssl_stream_t s);
+/* The same fused with the activation gradient of the averaged tensor `act` [N,HW,C] (the tower output
+ * is a ReLU / ReLU6 output): dx = (0 < act (< 6)) ? dy/HW : 0. */
+int mtlssl_spatial_mean_bwd_masked(const float* dy, const float* act, float* dx, int N, int HW, int C,
+                                   int relu6, mtlssl_stream_t stream);
 
 /* ------------------------------------------------------------------ detection family */
 

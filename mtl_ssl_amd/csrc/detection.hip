@@ -677,6 +677,107 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Fast path of the balanced sampler for batch_size <= 512: the rank of an element only matters if
+// it is below the class cap, so only elements whose hash priority is under a per-class threshold
+// (chosen for ~4x the cap, doubled on a shortfall) become candidates; every element that precedes a
+// candidate in (priority, index) order is itself a candidate, hence ranks among candidates are the
+// true ranks. One block per image; O(n) + O(candidates^2 / 1024) instead of O(n^2 / 256) per block.
+constexpr int BS_CAP = 8192;
+__global__ void __launch_bounds__(1024)
+    k_balanced_sample_fast(const float* indicator, const float* labels, int n, int batch_size,
+                           int max_pos, uint32_t seed, uint32_t stream0, uint32_t stream_stride,
+                           float* sampled) {
+  __shared__ uint32_t c_pri[BS_CAP];
+  __shared__ int c_idx[BS_CAP];
+  __shared__ unsigned char c_cl[BS_CAP];
+  __shared__ int s_cnt[6];     // 0 npos, 1 nneg, 2 ncand, 3 below_pos, 4 below_neg
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint32_t stream = stream0 + stream_stride * (uint32_t)b;
+  const float* ind = indicator + (int64_t)b * n;
+  const float* lab = labels + (int64_t)b * n;
+  float* out = sampled + (int64_t)b * n;
+  if (tid < 6) s_cnt[tid] = 0;
+  __syncthreads();
+  int lp = 0, ln = 0;
+  for (int i = tid; i < n; i += 1024) {
+    bool id = ind[i] != 0.f, lb = lab[i] != 0.f;
+    lp += id && lb;
+    ln += id && !lb;
+  }
+  lp = wave_sum_i(lp); ln = wave_sum_i(ln);
+  if ((tid & 63) == 0) { atomicAdd(&s_cnt[0], lp); atomicAdd(&s_cnt[1], ln); }
+  __syncthreads();
+  const int npos = s_cnt[0], nneg = s_cnt[1];
+  const int sel_pos = min(npos, max_pos);
+  const int cap_pos = max_pos, cap_neg = batch_size - sel_pos;
+  const int need_pos = min(npos, max(cap_pos, 0)), need_neg = min(nneg, max(cap_neg, 0));
+  auto thr0 = [](int need, int nc) -> uint32_t {
+    if (need <= 0) return 0u;
+    if ((int64_t)nc <= 4ll * need + 64) return 0xFFFFFFFFu;
+    double f = (4.0 * need + 64.0) / (double)nc;
+    return (uint32_t)(f * 4294967295.0);
+  };
+  uint32_t tp = thr0(need_pos, npos), tn = thr0(need_neg, nneg);
+  bool ok = false;
+  for (int iter = 0; iter < 40 && !ok; ++iter) {
+    __syncthreads();
+    if (tid < 3) s_cnt[2 + tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+      bool id = ind[i] != 0.f, lb = lab[i] != 0.f;
+      int cl = id ? (lb ? 1 : 2) : 0;
+      out[i] = 0.f;
+      if (!cl) continue;
+      if ((cl == 1 && need_pos <= 0) || (cl == 2 && need_neg <= 0)) continue;
+      uint32_t pi = sampler_priority(seed, stream, (uint32_t)i);
+      if (pi <= (cl == 1 ? tp : tn)) {
+        atomicAdd(&s_cnt[2 + cl], 1);
+        int slot = atomicAdd(&s_cnt[2], 1);
+        if (slot < BS_CAP) { c_pri[slot] = pi; c_idx[slot] = i; c_cl[slot] = (unsigned char)cl; }
+      }
+    }
+    __syncthreads();
+    const bool short_p = s_cnt[3] < need_pos, short_n = s_cnt[4] < need_neg, over = s_cnt[2] > BS_CAP;
+    ok = !short_p && !short_n && !over;
+    if (!ok) {
+      if (over && !short_p && !short_n) { tp = tp / 2; tn = tn / 2; }      // pathological: shrink both
+      if (short_p) tp = tp > 0x7FFFFFFFu ? 0xFFFFFFFFu : tp * 2u + 1u;
+      if (short_n) tn = tn > 0x7FFFFFFFu ? 0xFFFFFFFFu : tn * 2u + 1u;
+    }
+  }
+  __syncthreads();
+  if (ok) {
+    const int nc = s_cnt[2];
+    for (int p = tid; p < nc; p += 1024) {
+      const uint32_t pi = c_pri[p];
+      const int i = c_idx[p];
+      const int cl = c_cl[p];
+      int rank = 0;
+      for (int j = 0; j < nc; ++j) {
+        uint32_t pj = c_pri[j];
+        rank += (c_cl[j] == cl) && (pj < pi || (pj == pi && c_idx[j] < i));
+      }
+      if (rank < (cl == 1 ? cap_pos : cap_neg)) out[i] = 1.f;
+    }
+    return;
+  }
+  // unreachable in practice (the thresholds could not be balanced): exact O(n^2) ranking in-block
+  for (int i = tid; i < n; i += 1024) {
+    bool id = ind[i] != 0.f, lb = lab[i] != 0.f;
+    int cl = id ? (lb ? 1 : 2) : 0;
+    if (!cl) continue;
+    uint32_t pi = sampler_priority(seed, stream, (uint32_t)i);
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      bool idj = ind[j] != 0.f, lbj = lab[j] != 0.f;
+      int clj = idj ? (lbj ? 1 : 2) : 0;
+      uint32_t pj = sampler_priority(seed, stream, (uint32_t)j);
+      rank += (clj == cl) && (pj < pi || (pj == pi && j < i));
+    }
+    out[i] = (rank < (cl == 1 ? cap_pos : cap_neg)) ? 1.f : 0.f;
+  }
+}
+
 // One block per image: detector-assign valid proposals, balanced-sample, compact, pad.
 constexpr int SP_MAX = 1024;
 __global__ void __launch_bounds__(256)
@@ -995,6 +1096,11 @@ int mtlssl_balanced_sample(const float* indicator, const float* labels, int batc
                            uint32_t stream_stride, float* sampled, mtlssl_stream_t stream) {
   if (n == 0 || batch == 0) return MTLSSL_OK;
   int max_pos = (int)(positive_fraction * batch_size);
+  if (batch_size <= 512 && n > 2048) {
+    hipLaunchKernelGGL(k_balanced_sample_fast, dim3(batch), dim3(1024), 0, S(stream), indicator, labels, n,
+                       batch_size, max_pos, seed, stream0, stream_stride, sampled);
+    return check_launch("balanced_sample");
+  }
   hipLaunchKernelGGL(k_balanced_sample, dim3(cdiv(n, 256), batch), dim3(256), 0, S(stream),
                      indicator, labels, n, batch_size, max_pos, seed, stream0, stream_stride,
                      sampled);

@@ -304,6 +304,25 @@ __global__ void k_spatial_mean_bwd(const float* dy, float* dx, int HW, int C, in
   dx[i] = dy[n * C + c] / (float)HW;
 }
 
+// Same, fused with the ReLU / ReLU6 gradient of the tensor that was averaged (the second-stage
+// tower's output): dx = act in linear range ? dy/HW : 0. float4 over channels.
+__global__ void k_spatial_mean_bwd_masked(const float* dy, const float* act, float* dx, int HW, int C4,
+                                          int relu6, int64_t total4) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  int c4 = i % C4;
+  int64_t n = i / ((int64_t)HW * C4);
+  float4 g = reinterpret_cast<const float4*>(dy)[n * C4 + c4];
+  float4 a = reinterpret_cast<const float4*>(act)[i];
+  const float inv = (float)HW;
+  float4 o;
+  o.x = (a.x > 0.f && (!relu6 || a.x < 6.f)) ? g.x / inv : 0.f;
+  o.y = (a.y > 0.f && (!relu6 || a.y < 6.f)) ? g.y / inv : 0.f;
+  o.z = (a.z > 0.f && (!relu6 || a.z < 6.f)) ? g.z / inv : 0.f;
+  o.w = (a.w > 0.f && (!relu6 || a.w < 6.f)) ? g.w / inv : 0.f;
+  reinterpret_cast<float4*>(dx)[i] = o;
+}
+
 // ------------------------------------------------------------------------------ losses
 __global__ void k_smooth_l1(const float* pred, const float* target, const float* row_scale,
                             int rows, int cs, float sigma2, float* row_loss, float* dpred) {
@@ -564,6 +583,16 @@ int mtlssl_spatial_mean_bwd(const float* dy, float* dx, int N, int HW, int C, mt
   hipLaunchKernelGGL(k_spatial_mean_bwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), dy, dx, HW,
                      C, total);
   return check_launch("spatial_mean_bwd");
+}
+
+int mtlssl_spatial_mean_bwd_masked(const float* dy, const float* act, float* dx, int N, int HW, int C,
+                                   int relu6, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(C % 4 == 0, "spatial_mean_bwd_masked: C must be a multiple of 4");
+  int64_t total4 = (int64_t)N * HW * (C / 4);
+  if (!total4) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_spatial_mean_bwd_masked, dim3(cdiv(total4, 256)), dim3(256), 0, S(stream), dy, act, dx,
+                     HW, C / 4, relu6, total4);
+  return check_launch("spatial_mean_bwd_masked");
 }
 
 int mtlssl_smooth_l1_fwd_bwd(const float* pred, const float* target, const float* row_scale,

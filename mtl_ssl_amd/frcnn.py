@@ -63,7 +63,9 @@ class MaskRCNNBoxPredictor:
             out["box"] = self.box.forward(pooled)
         return out
 
-    def backward(self, pred, d_class, d_box, feat_shape, need_feat_grad=True):
+    def backward(self, pred, d_class, d_box, feat_shape, need_feat_grad=True, mask_ref=None, mask6=False):
+        """Returns dL/d(feat); with mask_ref (= feat, an activation output) the activation gradient
+        is fused in, i.e. the result is dL/d(pre-activation of feat)."""
         pooled = pred["pooled"]
         self.cls.wgrad(pooled, d_class)
         if d_box is not None:
@@ -73,7 +75,7 @@ class MaskRCNNBoxPredictor:
         dp = self.cls.dgrad(pooled.shape, d_class)
         if d_box is not None:
             self.box.dgrad(pooled.shape, d_box, out=dp, accum=True)
-        return ops.spatial_mean_bwd(dp, feat_shape)
+        return ops.spatial_mean_bwd(dp, feat_shape, mask_ref, mask6)
 
 
 class FasterRCNNMetaArch:
@@ -548,9 +550,10 @@ class FasterRCNNMetaArch:
         c = self.cfg
         # main head -> tower -> crops -> dF
         feat = pd["_feat"]
+        m6 = getattr(self.tower, "out_relu6", False)
         g_feat = self.box_predictor.backward(pd["_bp"], d_cls, d["refined_box_encodings"].view(feat.shape[0], -1),
-                                             feat.shape)
-        g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True)
+                                             feat.shape, mask_ref=feat, mask6=m6)
+        g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True, masked=True)
         ops.roi_crop_pool_bwd(g_crops, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
                               pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
                               int(c.maxpool_stride), dfeat=dF)
@@ -559,16 +562,18 @@ class FasterRCNNMetaArch:
         def aux_backward():
             if mtl.closeness:
                 cfeat = pd["_cfeat"]
-                g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat.shape)
-                gc = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop)
+                g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat.shape,
+                                                      mask_ref=cfeat, mask6=m6)
+                gc = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop, masked=True)
                 if not stop:
                     ops.roi_crop_pool_bwd(gc, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
                                           pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
                                           int(c.maxpool_stride), dfeat=dF)
             if mtl.window:
                 wfeat = pd["_wfeat"]
-                g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat.shape)
-                gw = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop)
+                g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat.shape,
+                                                   mask_ref=wfeat, mask6=m6)
+                gw = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop, masked=True)
                 if not stop:
                     ops.roi_crop_pool_bwd(gw, pd["_wargmax"], F.shape, pd["_wboxes"], pd["_wbox_ind"],
                                           int(c.initial_crop_size), int(c.maxpool_kernel_size),

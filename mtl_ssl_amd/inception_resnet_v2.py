@@ -267,9 +267,9 @@ class InceptionTower:
         out = self.conv_7b.forward(x)
         return out, ((c7, ctxs, x) if save else None)
 
-    def backward(self, g_out, out, ctx, need_input_grad):
+    def backward(self, g_out, out, ctx, need_input_grad, masked=False):
         c7, ctxs, pre7b = ctx
-        gp = ops.relu_bwd(out, g_out)
+        gp = g_out if masked else ops.relu_bwd(out, g_out)
         self.conv_7b.wgrad(pre7b, gp)
         gp = self.conv_7b.dgrad(pre7b.shape, gp)                # Block8 has no activation: no mask
         for i in range(len(self.blocks) - 1, -1, -1):

@@ -67,9 +67,11 @@ class MobilenetTower:
         a13 = self.pw13.forward(d13)
         return a13, ((crops, d12, a12, d13) if save else None)
 
-    def backward(self, g_out, out, ctx, need_input_grad):
+    out_relu6 = True
+
+    def backward(self, g_out, out, ctx, need_input_grad, masked=False):
         crops, d12, a12, d13 = ctx
-        gp = ops.relu6_bwd(out, g_out)
+        gp = g_out if masked else ops.relu6_bwd(out, g_out)
         self.pw13.bn_grad(out, gp)
         self.pw13.wgrad(d13, gp)
         g = self.pw13.dgrad(d13.shape, gp)

@@ -246,10 +246,17 @@ def spatial_mean_fwd(x):
     return y
 
 
-def spatial_mean_bwd(dy, shape):
+def spatial_mean_bwd(dy, shape, mask_ref=None, mask6=False):
+    """mask_ref: the averaged activation; when given the ReLU (ReLU6) gradient is fused in."""
     N, H, W, C = shape
-    dx = torch.empty(shape, dtype=f32, device=dy.device)
+    dx = torch.empty(tuple(shape), dtype=f32, device=dy.device)
+    if mask_ref is not None and C % 4 == 0:
+        lib().spatial_mean_bwd_masked(ptr(_chk(dy)), ptr(_chk(mask_ref)), ptr(dx), N, H * W, C, 1 if mask6 else 0,
+                                      _stream())
+        return dx
     lib().spatial_mean_bwd(ptr(_chk(dy)), ptr(dx), N, H * W, C, _stream())
+    if mask_ref is not None:
+        return (relu6_bwd if mask6 else relu_bwd)(mask_ref, dx, out=dx)
     return dx
 
 

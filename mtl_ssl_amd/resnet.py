@@ -33,9 +33,10 @@ class BoxClassifierTower:
             ctxs.append(c)
         return x, (ctxs if save else None)
 
-    def backward(self, g_out, out, ctxs, need_input_grad):
-        """g_out: dL/d(out) (post-ReLU). Returns dL/d(crops) or None."""
-        gp = ops.relu_bwd(out, g_out)
+    def backward(self, g_out, out, ctxs, need_input_grad, masked=False):
+        """g_out: dL/d(out) (post-ReLU), or dL/d(pre-activation) when `masked`. Returns
+        dL/d(crops) or None."""
+        gp = g_out if masked else ops.relu_bwd(out, g_out)
         units = self.stack.units
         for i in range(len(units) - 1, -1, -1):
             first = i == 0

@@ -229,18 +229,21 @@ def test_matcher_golden_via_assign(ops, vec):
     assert r["match"][3] == 1                      # forced: best anchor for gt1
 
 
-@pytest.mark.parametrize("n", [100, 5000, 14453])
-def test_balanced_sample_bit_exact(ops, n):
-    rng = np.random.RandomState(n)
-    ind = (rng.rand(2, n) > 0.2).astype(np.float32)
-    lab = (rng.rand(2, n) > (0.999 if n > 1000 else 0.7)).astype(np.float32)
+@pytest.mark.parametrize("n,bs", [(100, 256), (5000, 256), (14453, 256), (50400, 256), (14453, 64),
+                                  (29554, 512), (5000, 2000)])
+def test_balanced_sample_bit_exact(ops, n, bs):
+    rng = np.random.RandomState(n + bs)
+    ind = (rng.rand(3, n) > 0.2).astype(np.float32)
+    lab = (rng.rand(3, n) > (0.999 if n > 1000 else 0.7)).astype(np.float32)
     lab[1] = (rng.rand(n) > 0.5)                      # many positives in image 1
-    out = ops.balanced_sample(cu(ind), cu(lab), 256, 0.5, 1234, 10, 2).cpu().numpy()
-    for b in range(2):
+    ind[2] = (rng.rand(n) > 0.995)                    # fewer candidates than the batch size in image 2
+    out = ops.balanced_sample(cu(ind), cu(lab), bs, 0.5, 1234, 10, 2).cpu().numpy()
+    for b in range(3):
         prio = A.hash_priority(1234, n, stream=10 + 2 * b)
-        ref = A.balanced_subsample(ind[b] > 0, 256, lab[b] > 0, 0.5, prio)
+        ref = A.balanced_subsample(ind[b] > 0, bs, lab[b] > 0, 0.5, prio)
         np.testing.assert_array_equal(out[b] > 0, ref)
-        assert out[b].sum() <= 256
+        assert out[b].sum() <= bs
+        assert set(np.unique(out[b])) <= {0.0, 1.0}
 
 
 def test_sample_proposals_vs_oracle(ops):
