@@ -213,3 +213,41 @@ def test_trainer_train_entry_point_resumes_and_fine_tunes(tmp_path):
     head = "SecondStageBoxPredictor/ClassPredictor/weights"
     assert torch.equal(tr3.ps.value(name), tr2.ps.value(name))
     assert not torch.equal(tr3.ps.value(head), tr2.ps.value(head))
+
+
+def test_step_with_an_image_without_groundtruth_matches_oracle():
+    """Ragged / empty groundtruth: image 1 carries no boxes at all (every anchor and proposal is a
+    negative, its localisation and closeness terms vanish), image 0 carries the maximum the padding
+    allows. core/target_assigner.py:99-213 with zero groundtruth rows -> all matches -1."""
+    from oracle.model import Oracle
+    model, tr, batch, hp = _setup(True, True, 14, 2)
+    K = 5
+    batch = dict(batch)
+    for key, shape in (("groundtruth_boxes", (0, 4)), ("groundtruth_classes", (0, K)),
+                       ("groundtruth_closeness", (0, K + 1))):
+        lst = list(batch[key])
+        lst[1] = np.zeros(shape, np.float32)
+        batch[key] = lst
+    em = list(batch["groundtruth_edgemask"])
+    em[1] = np.stack([np.zeros((64, 64), np.float32), np.ones((64, 64), np.float32)])
+    batch["groundtruth_edgemask"] = em
+    values = model.ps.state_dict()
+    losses = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    got = {k: float(v.item()) for k, v in losses.items()}
+    ref, rgrads, aux_o = Oracle(hp, values).step(_host_batch(batch), seed=model.seed, step=0)
+    pd = tr._pd
+    np.testing.assert_array_equal(pd["_rpn_targets"]["match"].cpu().numpy(), aux_o["rpn_match"])
+    assert (pd["_rpn_targets"]["match"][1].cpu().numpy() == -1).all()
+    np.testing.assert_array_equal(pd["_det_targets"]["match"].cpu().numpy(), aux_o["det_match"])
+    np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux_o["num_proposals"])
+    for k in ref:
+        assert np.isfinite(got[k]) and abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
+    l2 = []
+    for name, gv in model.ps.grads_dict().items():
+        r = rgrads.get(name)
+        if r is None:
+            assert np.abs(gv).max() == 0, name
+            continue
+        l2.append(np.linalg.norm((gv - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-12))
+    assert max(l2) < 5e-3 and np.median(l2) < 1e-3
