@@ -37,6 +37,9 @@ def _inception_resnet_v2(ps, fe_cfg, is_training):
 
 FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP = {
     "faster_rcnn_inception_resnet_v2": _inception_resnet_v2,
+    # builders/model_builder.py:64-65 registers this name with the SAME Inception-ResNet-v2 class
+    # (paper configs model61/62/91/92 use it)
+    "faster_rcnn_inception_v2": _inception_resnet_v2,
     "frcnn_mobilenet_v1": _mobilenet,
     "faster_rcnn_resnet50": _resnet("resnet_v1_50"),
     "faster_rcnn_resnet101": _resnet("resnet_v1_101"),

@@ -196,6 +196,35 @@ def test_checkpoint_maps_follow_reference_restore_rules(tmp_path):
         "FirstStageFeatureExtractor/InceptionResnetV2/Repeat/block35_1/Conv2d_1x1/biases"
 
 
+REF_CONFIGS = "/root/reference/object_detection/configs/test"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference tree only exists in the authoring container")
+def test_every_paper_config_of_the_reference_builds():
+    """All 18 pipeline configs of the reference (ResNet-101 / MobileNet-v1 / 'faster_rcnn_inception_v2'
+    = the Inception-ResNet-v2 class, Faster R-CNN and R-FCN heads) parse unchanged and build their
+    full variable set through the plugin registry."""
+    from mtl_ssl_amd import config, frcnn, model_builder, rfcn
+    from mtl_ssl_amd.params import ParamStore
+    names = sorted(f for f in os.listdir(REF_CONFIGS) if f.endswith(".config"))
+    assert len(names) == 18
+    kinds = set()
+    for f in names:
+        cfg = config.parse_pipeline_config(open(os.path.join(REF_CONFIGS, f)).read())
+        fr = cfg.model.faster_rcnn
+        ps = ParamStore()
+        fe = model_builder.FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP[fr.feature_extractor.type](
+            ps, fr.feature_extractor, True)
+        arch = rfcn.RFCNMetaArch if fr.second_stage_box_predictor.has("rfcn_box_predictor") else frcnn.FasterRCNNMetaArch
+        arch(ps, True, fr, cfg.model.mtl, fe)
+        assert len(ps.specs) > 100 and any(s.trainable for s in ps.specs)
+        from mtl_ssl_amd import trainer
+        f_lr, mom = trainer.learning_rate_fn(cfg.train_config.optimizer)
+        assert f_lr(0) > 0 and mom == 0.9
+        kinds.add((fr.feature_extractor.type, arch.__name__))
+    assert len(kinds) >= 4, kinds
+
+
 def test_manual_step_learning_rate():
     from mtl_ssl_amd import trainer
     f, mom = trainer.learning_rate_fn(_cfg("smoke_resnet50_mtl.config").train_config.optimizer)
