@@ -54,12 +54,20 @@ def test_concat_and_slice_channels(ops):
         ops.slice_channels(cat, 144, 8)
 
 
-def test_inception_resnet_v2_step_matches_oracle():
+@pytest.mark.parametrize("stride", [16, 8])
+def test_inception_resnet_v2_step_matches_oracle(stride):
     import bench
     from mtl_ssl_amd import config, inception_resnet_v2, model_builder, synthetic, trainer
     from oracle.model import Oracle
-    cfg = config.parse_pipeline_config(
-        open(os.path.join(ROOT, "configs", "smoke_inception_resnet_v2_mtl.config")).read())
+    text = open(os.path.join(ROOT, "configs", "smoke_inception_resnet_v2_mtl.config")).read()
+    if stride == 8:
+        # the atrous variant of samples/configs/faster_rcnn_inception_resnet_v2_atrous_*.config:
+        # stride-1 Mixed_6a, rate-2 block17s, anchors every 8 px, atrous RPN conv
+        text = text.replace("first_stage_features_stride: 16", "first_stage_features_stride: 8")
+        text = text.replace("height_stride: 16 width_stride: 16", "height_stride: 8 width_stride: 8")
+        text = text.replace("first_stage_nms_score_threshold", "first_stage_atrous_rate: 2\n    first_stage_nms_score_threshold", 1)
+    cfg = config.parse_pipeline_config(text)
+    assert int(cfg.model.faster_rcnn.first_stage_atrous_rate) == (2 if stride == 8 else 1)
     model = model_builder.build(cfg.model, True, "cuda", seed=3)
     fe = model._feature_extractor
     assert isinstance(fe, inception_resnet_v2.FasterRCNNInceptionResnetV2FeatureExtractor)
@@ -92,7 +100,7 @@ def test_inception_resnet_v2_step_matches_oracle():
     hb["images"] = batch["images"].cpu().numpy()
     ref, rgrads, aux = Oracle(bench.hyper_params_for_oracle(cfg), values).step(hb, seed=model.seed, step=0)
     pd = tr._pd
-    assert tuple(pd["rpn_features_to_crop"].shape) == (2, 10, 14, 1088)
+    assert tuple(pd["rpn_features_to_crop"].shape) == ((2, 10, 14, 1088) if stride == 16 else (2, 20, 28, 1088))
     np.testing.assert_allclose(pd["rpn_features_to_crop"].cpu().numpy(), aux["features"], rtol=1e-3, atol=1e-4)
     np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
     np.testing.assert_array_equal(pd["_rpn_targets"]["match"].cpu().numpy(), aux["rpn_match"])
