@@ -108,6 +108,8 @@ def hbm_kernels(tr, iters=10):
 
     F = pd["rpn_features_to_crop"]
     B, Hf, Wf, C = F.shape
+    if not c.has("initial_crop_size"):        # R-FCN: no crop_and_resize stage (position-sensitive pooling)
+        return res
     crop = int(c.initial_crop_size)
     pk, pst = int(c.maxpool_kernel_size), int(c.maxpool_stride)
     boxes = pd["proposal_boxes_normalized"].reshape(-1, 4).contiguous()
@@ -242,6 +244,8 @@ def main():
     value = B * world * a.steps / dt
     default_cfg = os.path.basename(a.config) == "frcnn_resnet101_coco_mtl.config"
     fe_type = cfg.model.faster_rcnn.feature_extractor.type
+    if cfg.model.faster_rcnn.second_stage_box_predictor.has("rfcn_box_predictor"):
+        fe_type = "R-FCN " + fe_type
     out = {
         "metric": "images/sec training, Faster R-CNN ResNet-101 + aux heads" if default_cfg
                   else "images/sec training, %s + aux heads" % fe_type,
