@@ -1,0 +1,94 @@
+"""Size-independent properties of the whole training step at BASELINE.json configs[1]'s FULL size
+(Faster R-CNN ResNet-101 + 3 aux heads + refine, 2 x 600x1024, 90 classes, 256 second-stage ROIs,
+1 280 refine ROIs per image) — sizes the CPU oracle cannot reach in test time."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", "frcnn_resnet101_coco_mtl.config")).read())
+    model = model_builder.build(cfg.model, True, "cuda", seed=0)
+    tr = trainer.Trainer(model, cfg.train_config, 1)
+    batch = tr.stage_batch(synthetic.make_batch(2, 600, 1024, 90, seed=1234, device="cuda"))
+    return cfg, model, tr, batch
+
+
+def test_full_size_step_invariants_and_determinism(setup):
+    cfg, model, tr, batch = setup
+    fr = cfg.model.faster_rcnn
+    losses = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    pd = tr._pd
+    l1 = {k: float(v.item()) for k, v in losses.items()}
+    g1 = model.ps.grads.clone()
+    assert len(l1) == 8 and all(np.isfinite(v) and v >= 0 for v in l1.values()), l1
+    # shapes of the reference's prediction_dict at this configuration
+    assert tuple(pd["rpn_features_to_crop"].shape) == (2, 38, 64, 1024)
+    assert pd["anchors"].shape[0] == 14453 and pd["_n_all"] == 29184
+    assert tuple(pd["refined_box_encodings"].shape) == (512, 90, 4)
+    assert tuple(pd["expand_window_class_predictions"].shape) == (2, 5, 256, 91)
+    assert tuple(pd["mtl_refined_class_predictions_with_background"].shape) == (512, 91)
+    # integer work: sampler budgets and match codes
+    samp = pd["_rpn_targets"]["sampled"].cpu().numpy()
+    match = pd["_rpn_targets"]["match"].cpu().numpy()
+    assert samp.shape == (2, 14453) and (samp.sum(1) == int(fr.first_stage_minibatch_size)).all()
+    pos = ((match >= 0) & (samp > 0)).sum(1)
+    assert (pos <= int(fr.first_stage_minibatch_size) // 2).all() and (pos > 0).all()
+    assert set(np.unique(match)) <= set(range(-2, 20))
+    nump = pd["num_proposals"].cpu().numpy()
+    assert (nump > 0).all() and (nump <= 256).all()
+    dm = pd["_det_targets"]["match"].cpu().numpy()
+    assert dm.shape == (2, 256)
+    # every trainable variable received a finite gradient, the frozen ones none
+    gd = model.ps.grads_dict()
+    assert all(np.isfinite(v).all() for v in gd.values())
+    dead = [n for n, v in gd.items() if not np.any(v)]
+    if (dm >= 0).any():
+        assert not dead, dead[:5]
+    else:
+        # a randomly initialised RPN may propose nothing that overlaps a groundtruth box by 0.5: then
+        # the box-regression and closeness terms (and only those) are exactly zero, like in the reference
+        assert all(n.startswith(("SecondStageBoxPredictor/BoxEncodingPredictor", "ClosenessBoxPredictor/"))
+                   for n in dead), dead[:5]
+        assert l1["second_stage_localization_loss"] == 0.0 and l1["closeness_classification_loss"] == 0.0
+    # same weights, same batch, same step counter -> same integer decisions and (up to the order of
+    # fp32 atomic adds in the ROI-crop / max-pool backward) the same floats
+    losses2 = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    pd2 = tr._pd
+    np.testing.assert_array_equal(pd2["_rpn_targets"]["sampled"].cpu().numpy(), samp)
+    np.testing.assert_array_equal(pd2["_det_targets"]["match"].cpu().numpy(), dm)
+    np.testing.assert_array_equal(pd2["proposal_boxes"].cpu().numpy(), pd["proposal_boxes"].cpu().numpy())
+    for k, v in losses2.items():
+        assert abs(float(v.item()) - l1[k]) <= 1e-6 * max(abs(l1[k]), 1.0), k
+    rel = float((model.ps.grads - g1).norm() / g1.norm())
+    assert rel < 1e-5, rel
+
+
+def test_full_size_training_reduces_the_loss_and_keeps_the_fold_consistent(setup):
+    cfg, model, tr, batch = setup
+    first = None
+    for i in range(6):
+        losses = tr.step(batch)
+        total = float(sum(v.item() for v in losses.values()))
+        assert np.isfinite(total)
+        first = total if first is None else first
+    assert total < first, (first, total)
+    # the batched fold keeps every shadow filter equal to weight * BN scale after the updates
+    l = model.tower.stack.units[2].conv3
+    want = model.ps.value(l.w.name) * l.scale
+    assert float((l.w_eff - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    # the sampler draws a different minibatch at a different step
+    s5 = tr._pd["_rpn_targets"]["sampled"].cpu().numpy()
+    tr.forward_backward(batch)
+    assert (tr._pd["_rpn_targets"]["sampled"].cpu().numpy() != s5).any()
