@@ -1,0 +1,170 @@
+"""PASCAL-VOC style detection evaluation: mAP at a matching IoU, CorLoc.
+
+Restates the reference's numpy evaluator — utils/object_detection_evaluation.py:43-294
+(ObjectDetectionEvaluation), utils/per_image_evaluation.py:28-281 (tp/fp labelling with "difficult"
+boxes, CorLoc) and utils/metrics.py:21-127 (precision/recall, VOC-devkit average precision) — as a
+small array-oriented module. Host-side numpy: the evaluator is outside the training hot path and
+consumes the arrays `FasterRCNNMetaArch.postprocess` returns (after `.cpu()`).
+"""
+import numpy as np
+
+
+def iou_matrix(a, b):
+    """utils/np_box_ops.py:25-78: pairwise IoU of [N,4] and [M,4] boxes (ymin,xmin,ymax,xmax)."""
+    a, b = np.asarray(a, np.float64).reshape(-1, 4), np.asarray(b, np.float64).reshape(-1, 4)
+    ih = np.maximum(0.0, np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0]))
+    iw = np.maximum(0.0, np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1]))
+    inter = ih * iw
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+
+def precision_recall(scores, labels, num_gt):
+    """metrics.compute_precision_recall (utils/metrics.py:21-67)."""
+    scores, labels = np.asarray(scores), np.asarray(labels)
+    if labels.dtype != bool or labels.ndim != 1:
+        raise ValueError("labels must be single dimension bool numpy array")
+    if scores.ndim != 1:
+        raise ValueError("scores must be single dimension numpy array")
+    if num_gt < labels.sum():
+        raise ValueError("Number of true positives must be smaller than num_gt.")
+    if len(scores) != len(labels):
+        raise ValueError("scores and labels must be of the same size.")
+    if num_gt == 0:
+        return None, None
+    order = np.argsort(scores)[::-1]
+    tp = labels[order].astype(int)
+    ctp, cfp = np.cumsum(tp), np.cumsum(1 - tp)
+    return ctp.astype(float) / (ctp + cfp), ctp.astype(float) / num_gt
+
+
+def average_precision(precision, recall):
+    """metrics.compute_average_precision (utils/metrics.py:70-127): area under the
+    monotonically-decreasing envelope of the precision/recall curve (VOC devkit, all points)."""
+    if precision is None:
+        if recall is not None:
+            raise ValueError("If precision is None, recall must also be None")
+        return np.nan
+    precision, recall = np.asarray(precision, float), np.asarray(recall, float)
+    if len(precision) != len(recall):
+        raise ValueError("precision and recall must be of the same size.")
+    if not precision.size:
+        return 0.0
+    if precision.min() < 0 or precision.max() > 1:
+        raise ValueError("Precision must be in the range of [0, 1].")
+    if recall.min() < 0 or recall.max() > 1:
+        raise ValueError("recall must be in the range of [0, 1].")
+    if np.any(np.diff(recall) < 0):
+        raise ValueError("recall must be a non-decreasing array")
+    r = np.concatenate([[0.0], recall, [1.0]])
+    p = np.concatenate([[0.0], precision, [0.0]])
+    p = np.maximum.accumulate(p[::-1])[::-1]
+    idx = np.where(r[1:] != r[:-1])[0] + 1
+    return float(np.sum((r[idx] - r[idx - 1]) * p[idx]))
+
+
+class PascalDetectionEvaluator:
+    """ObjectDetectionEvaluation with the 'default' subset: boxes flagged difficult are neither
+    counted as groundtruth nor do detections matched to them count as true or false positives."""
+
+    def __init__(self, num_classes, matching_iou_threshold=0.5, max_detections_per_class=10000):
+        self.K, self.thr, self.cap = int(num_classes), float(matching_iou_threshold), int(max_detections_per_class)
+        self.clear()
+
+    def clear(self):
+        self.gt = {}
+        self.seen = set()
+        self.num_gt = np.zeros(self.K, int)
+        self.num_gt_imgs = np.zeros(self.K, int)
+        self.scores = [[] for _ in range(self.K)]
+        self.labels = [[] for _ in range(self.K)]
+        self.correct_imgs = np.zeros(self.K)
+
+    def add_single_ground_truth_image_info(self, image_key, boxes, class_labels, is_difficult=None):
+        if image_key in self.gt:
+            return
+        boxes = np.asarray(boxes, float).reshape(-1, 4)
+        cls = np.asarray(class_labels, int).reshape(-1)
+        diff = np.zeros(len(cls), bool) if is_difficult is None else np.asarray(is_difficult, bool).reshape(-1)
+        self.gt[image_key] = (boxes, cls, diff)
+        for c in range(self.K):
+            self.num_gt[c] += int(np.sum((cls == c) & ~diff))
+            self.num_gt_imgs[c] += int(np.any(cls == c))
+
+    def add_single_detected_image_info(self, image_key, boxes, scores, class_labels):
+        boxes = np.asarray(boxes, float).reshape(-1, 4)
+        scores = np.asarray(scores, float).reshape(-1)
+        cls = np.asarray(class_labels, int).reshape(-1)
+        if not (len(boxes) == len(scores) == len(cls)):
+            raise ValueError("detected_boxes, detected_scores and detected_class_labels should all have same "
+                             "lengths. Got[%d, %d, %d]" % (len(boxes), len(scores), len(cls)))
+        if image_key in self.seen:
+            return
+        self.seen.add(image_key)
+        gb, gc, gd = self.gt.get(image_key, (np.zeros((0, 4)), np.zeros(0, int), np.zeros(0, bool)))
+        valid = (boxes[:, 0] < boxes[:, 2]) & (boxes[:, 1] < boxes[:, 3])       # _remove_invalid_boxes
+        boxes, scores, cls = boxes[valid], scores[valid], cls[valid]
+        for c in range(self.K):
+            db, ds = boxes[cls == c], scores[cls == c]
+            s, lab = self._tp_fp(db, ds, gb[gc == c], gd[gc == c])
+            self.scores[c].append(s)
+            self.labels[c].append(lab)
+            # CorLoc: the top-scoring detection of the class hits any groundtruth box of the class
+            if len(db) and np.any(gc == c):
+                top = int(np.argmax(ds))
+                self.correct_imgs[c] += float(iou_matrix(db[top:top + 1], gb[gc == c]).max() >= self.thr)
+
+    def _tp_fp(self, db, ds, gb, gdiff):
+        """per_image_evaluation.py:233-281: detections in descending score order; each takes its
+        best-IoU groundtruth box; a box can be claimed once; matches to difficult boxes are dropped."""
+        if not len(db):
+            return np.zeros(0, float), np.zeros(0, bool)
+        order = np.argsort(ds)[::-1][: self.cap]
+        db, ds = db[order], ds[order]
+        if not len(gb):
+            return ds, np.zeros(len(ds), bool)
+        iou = iou_matrix(db, gb)
+        best = iou.argmax(1)
+        taken = np.zeros(len(gb), bool)
+        tp = np.zeros(len(ds), bool)
+        drop = np.zeros(len(ds), bool)
+        for i, g in enumerate(best):
+            if iou[i, g] >= self.thr:
+                if gdiff[g]:
+                    drop[i] = True
+                elif not taken[g]:
+                    tp[i] = taken[g] = True
+        return ds[~drop], tp[~drop]
+
+    def evaluate(self):
+        """Returns dict(ap_per_class, mean_ap, precisions, recalls, corloc_per_class, mean_corloc)."""
+        ap = np.full(self.K, np.nan)
+        precisions, recalls = [], []
+        for c in range(self.K):
+            if self.num_gt[c] == 0:
+                continue
+            s = np.concatenate(self.scores[c]) if self.scores[c] else np.zeros(0)
+            lab = np.concatenate(self.labels[c]) if self.labels[c] else np.zeros(0, bool)
+            p, r = precision_recall(s, lab, self.num_gt[c])
+            precisions.append(p)
+            recalls.append(r)
+            ap[c] = average_precision(p, r)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            corloc = np.where(self.num_gt_imgs == 0, np.nan, self.correct_imgs / np.maximum(self.num_gt_imgs, 1))
+        return dict(ap_per_class=ap, mean_ap=float(np.nanmean(ap)) if np.any(~np.isnan(ap)) else float("nan"),
+                    precisions=precisions, recalls=recalls, corloc_per_class=corloc,
+                    mean_corloc=float(np.nanmean(corloc)) if np.any(~np.isnan(corloc)) else float("nan"))
+
+
+def evaluate_detections(detections, groundtruth, num_classes, image_hw=None, matching_iou_threshold=0.5):
+    """Convenience wrapper for `postprocess` outputs: detections = dict of arrays (detection_boxes
+    [B,T,4] normalised, detection_scores [B,T], detection_classes [B,T] 0-based, num_detections [B]);
+    groundtruth = list of (boxes [G,4] normalised, classes [G] 0-based[, difficult [G]])."""
+    ev = PascalDetectionEvaluator(num_classes, matching_iou_threshold)
+    for i, g in enumerate(groundtruth):
+        ev.add_single_ground_truth_image_info(i, g[0], g[1], g[2] if len(g) > 2 else None)
+        n = int(detections["num_detections"][i])
+        ev.add_single_detected_image_info(i, detections["detection_boxes"][i][:n], detections["detection_scores"][i][:n],
+                                          detections["detection_classes"][i][:n])
+    return ev.evaluate()

@@ -150,6 +150,28 @@ VEC = {
              exp_scores=[[.95, .9, 0, 0], [.85, .5, .3, 0]], exp_classes=[[0, 0, 0, 0], [1, 0, 0, 0]],
              exp_num=[2, 3]),
     ],
+    # object_detection/utils/metrics_test.py:27-86 and per_image_evaluation_test.py:25-140
+    "eval_metrics": dict(
+        pr=dict(num_gt=10, scores=[0.4, 0.3, 0.6, 0.2, 0.7, 0.1], labels=[0, 1, 1, 0, 0, 1],
+                cum_tp=[0, 1, 1, 2, 2, 3]),
+        ap=dict(precision=[0.8, 0.76, 0.9, 0.65, 0.7, 0.5, 0.55, 0], recall=[0.3, 0.3, 0.4, 0.4, 0.45, 0.45, 0.5, 0.5],
+                processed_precision=[0.9, 0.9, 0.9, 0.7, 0.7, 0.55, 0.55, 0],
+                recall_interval=[0.3, 0, 0.1, 0, 0.05, 0, 0.05, 0]),
+        corloc=dict(num_gt_imgs=[100, 0, 0, 1, 1], correct=[10, 0, 1, 0, 0], expected=[0.1, None, None, 0, 0]),
+        tp_fp=[
+            dict(det=[[0, 0, 1, 1], [0, 0, 2, 2], [0, 0, 3, 3]], scores=[0.6, 0.8, 0.5],
+                 gt=[[0, 0, 1, 1], [0, 0, 10, 10]], difficult=[False, True], thr=0.5,
+                 exp_scores=[0.8, 0.6, 0.5], exp_labels=[False, True, False]),
+            dict(det=[[0, 0, 1, 1], [0, 0, 2, 2], [0, 0, 3, 3]], scores=[0.6, 0.8, 0.5],
+                 gt=[[0, 0, 1, 1], [0, 0, 10, 10]], difficult=[True, False], thr=0.5,
+                 exp_scores=[0.8, 0.5], exp_labels=[False, False]),
+            dict(det=[[0, 0, 1, 1], [0, 0, 2, 2], [0, 0, 3, 3]], scores=[0.6, 0.8, 0.5],
+                 gt=[[100, 100, 105, 105]], difficult=[False], thr=0.5,
+                 exp_scores=[0.8, 0.6, 0.5], exp_labels=[False, False, False]),
+            dict(det=[[0, 0, 1, 1], [0, 0, 2, 2], [0, 0, 3, 3]], scores=[0.6, 0.8, 0.5],
+                 gt=[[0, 0, 1, 1]], difficult=[False], thr=0.1,
+                 exp_scores=[0.8, 0.6, 0.5], exp_labels=[True, False, False]),
+        ]),
     # object_detection/core/losses_test.py:97-119
     "smooth_l1": dict(
         pred=[[[2.5, 0, .4, 0], [0, 0, 0, 0], [0, 2.5, 0, .4]],
@@ -245,6 +267,51 @@ def main():
         out["nms_out_scores_%d" % int(thr * 10)] = res.get_field("scores")
     np.savez_compressed(os.path.join(HERE, "np_box_golden.npz"), **out)
     print("wrote", len(VEC), "vector groups and", len(out), "arrays")
+
+    # --- the reference's own evaluator (utils/per_image_evaluation.py + utils/metrics.py; the
+    # aggregation loop of utils/object_detection_evaluation.py:160-287 is replayed here because that
+    # module imports pycocotools, which is absent) on a seeded synthetic detection set
+    np.bool, np.float = bool, float              # numpy<1.24 aliases used by metrics.py:41,93
+    from object_detection.utils import metrics, per_image_evaluation
+    K, n_img = 4, 12
+    pie = per_image_evaluation.PerImageEvaluation(K, 0.5, nms_iou_threshold=1.0, nms_max_output_boxes=10000)
+    ev = {"K": np.array(K), "n_img": np.array(n_img)}
+    scores_pc, labels_pc = [[] for _ in range(K)], [[] for _ in range(K)]
+    num_gt, num_gt_imgs, correct = np.zeros(K, int), np.zeros(K, int), np.zeros(K)
+    for i in range(n_img):
+        G = int(rng.randint(0, 6))
+        gb = rand_boxes(G, 1.0 * 64) / 64.0 if G else np.zeros((0, 4), np.float32)
+        gc = rng.randint(0, K, G)
+        gd = rng.rand(G) < 0.25
+        D = int(rng.randint(0, 15))
+        db = rand_boxes(D, 64.0) / 64.0 if D else np.zeros((0, 4), np.float32)
+        dc = rng.randint(0, K, D)
+        for j in range(min(G, D)):               # make some detections overlap their groundtruth
+            if rng.rand() < 0.7:
+                db[j] = gb[j] + rng.uniform(-0.02, 0.02, 4).astype(np.float32)
+                dc[j] = gc[j]
+        if D > 2:
+            db[D - 1] = [0.5, 0.5, 0.5, 0.7]     # an invalid (zero-height) box is dropped
+        ds = (rng.permutation(64)[:D].astype(np.float64) + 1) / 64.0    # distinct scores
+        for k, v in (("gb", gb), ("gc", gc), ("gd", gd), ("db", db), ("ds", ds), ("dc", dc)):
+            ev["%s_%d" % (k, i)] = np.asarray(v)
+        sc_l, tp_l, cor = pie.compute_object_detection_metrics(
+            db.astype(float), ds, dc, gb.astype(float), gc, gd)
+        for c in range(K):
+            scores_pc[c].append(sc_l[c]); labels_pc[c].append(tp_l[c])
+            num_gt[c] += int(np.sum((gc == c) & ~gd)); num_gt_imgs[c] += int(np.any(gc == c))
+        correct += cor
+    ap = np.full(K, np.nan)
+    for c in range(K):
+        if num_gt[c] == 0:
+            continue
+        p, r = metrics.compute_precision_recall(np.concatenate(scores_pc[c]), np.concatenate(labels_pc[c]), num_gt[c])
+        ap[c] = metrics.compute_average_precision(p, r)
+        ev["precision_%d" % c], ev["recall_%d" % c] = p, r
+    ev["ap"], ev["mean_ap"] = ap, np.nanmean(ap)
+    ev["corloc"] = metrics.compute_cor_loc(num_gt_imgs, correct)
+    np.savez_compressed(os.path.join(HERE, "eval_golden.npz"), **ev)
+    print("wrote eval golden: AP", ap, "mAP", ev["mean_ap"], "corloc", ev["corloc"])
 
 
 if __name__ == "__main__":
