@@ -120,7 +120,7 @@ DEFAULTS = {
                     "bias_grad_multiplier": 0.0, "batch_queue_capacity": 600, "num_batch_queue_threads": 8,
                     "prefetch_queue_capacity": 10, "save_interval_secs": 600, "restore_box_predictor": False,
                     "restore_mtl_refine": False, "restore_window": False, "restore_closeness": False,
-                    "restore_edgemask": False,
+                    "restore_edgemask": False, "data_augmentation_options": [],
                     "divide_grad_by_batch": False, "optimizer": "@Optimizer"},
     # protos/optimizer.proto
     "Optimizer": {"use_moving_average": True, "moving_average_decay": 0.9999},

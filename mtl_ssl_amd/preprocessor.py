@@ -1,0 +1,66 @@
+"""Training-time data augmentation of the paper configs: every one of the
+reference's pipeline configs enables exactly `random_horizontal_flip`.
+
+Restates core/preprocessor.py:145-168 (flip_boxes) and :239-345 (random_horizontal_flip with the
+fork's extra window boxes and edge masks) on host numpy arrays — the input pipeline is host-side in
+the reference too (queue runners feeding the graph, trainer.py:47-98).
+"""
+import numpy as np
+
+
+def flip_boxes(boxes):
+    """Left-right flip of normalised [ymin, xmin, ymax, xmax] boxes: xmin' = 1 - xmax, xmax' = 1 - xmin."""
+    b = np.asarray(boxes, np.float32).reshape(-1, 4)
+    one = np.float32(1.0)
+    return np.stack([b[:, 0], one - b[:, 3], b[:, 2], one - b[:, 1]], 1)
+
+
+def random_horizontal_flip(image, boxes, window_boxes=None, edgemask=None, rng=None, do_flip=None,
+                           reference_edgemask_axis=True):
+    """image [H,W,3]; boxes [N,4] normalised; window_boxes [Wn,4]; edgemask [2,h,w] (fg, weight).
+
+    The flip happens with probability 0.5 (`uniform > 0.5`) and only if the image has boxes
+    (preprocessor.py:300-304). The reference passes the [2,h,w] edge mask to
+    tf.image.flip_left_right, which treats it as [height=2, width=h, channels=w] and therefore
+    reverses the mask ROWS, not its columns (:340-342); `reference_edgemask_axis=True` reproduces
+    that, False mirrors the columns like the image."""
+    image = np.asarray(image)
+    boxes = np.asarray(boxes, np.float32).reshape(-1, 4)
+    if do_flip is None:
+        rng = rng if rng is not None else np.random
+        do_flip = float(rng.uniform()) > 0.5
+    do_flip = bool(do_flip) and boxes.size > 0
+    out = [image[:, ::-1].copy() if do_flip else image, flip_boxes(boxes) if do_flip else boxes]
+    if window_boxes is not None:
+        wb = np.asarray(window_boxes, np.float32).reshape(-1, 4)
+        out.append(flip_boxes(wb) if do_flip else wb)
+    if edgemask is not None:
+        em = np.asarray(edgemask)
+        if do_flip:
+            em = em[:, ::-1].copy() if reference_edgemask_axis else em[:, :, ::-1].copy()
+        out.append(em)
+    return tuple(out)
+
+
+def preprocess(example, data_augmentation_options, rng=None):
+    """core/preprocessor.py:1905-2048 `preprocess(tensor_dict, preprocess_options)` for the options
+    the reference's configs use. `example`: one image's dict with the fields of
+    mtl_ssl_amd.synthetic.make_batch (unbatched): image, groundtruth_boxes, window_boxes,
+    groundtruth_edgemask (class / closeness labels are flip-invariant)."""
+    ex = dict(example)
+    for opt in data_augmentation_options:
+        kinds = [k for k in opt.keys()] if hasattr(opt, "keys") else [opt]
+        for kind in kinds:
+            if kind != "random_horizontal_flip":
+                raise ValueError("data augmentation %r is not supported (the reference's configs only "
+                                 "use random_horizontal_flip)" % kind)
+            res = random_horizontal_flip(ex["image"], ex["groundtruth_boxes"], ex.get("window_boxes"),
+                                         ex.get("groundtruth_edgemask"), rng)
+            ex["image"], ex["groundtruth_boxes"] = res[0], res[1]
+            i = 2
+            if ex.get("window_boxes") is not None:
+                ex["window_boxes"] = res[i]
+                i += 1
+            if ex.get("groundtruth_edgemask") is not None:
+                ex["groundtruth_edgemask"] = res[i]
+    return ex

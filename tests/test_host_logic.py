@@ -313,3 +313,34 @@ def test_data_parallel_gradient_sum_gloo_world2():
     # every bucket exactly once overall
     assert len(out[0]["early"]) >= 1 and out[0]["early"] == sorted(out[0]["early"], reverse=True)
     assert sorted(out[0]["order"]) == list(range(out[0]["nb"]))
+
+
+def test_random_horizontal_flip_known_answers_and_fork_extras():
+    """core/preprocessor_test.py:63-66,181-184,357-383 (boxes after mirroring) + the fork's window
+    boxes and its edge-mask axis quirk (core/preprocessor.py:340-342)."""
+    from mtl_ssl_amd import config, preprocessor
+    boxes = np.array([[0.0, 0.25, 0.75, 1.0], [0.25, 0.5, 0.75, 1.0]], np.float32)
+    np.testing.assert_allclose(preprocessor.flip_boxes(boxes), [[0.0, 0.0, 0.75, 0.75], [0.25, 0.0, 0.75, 0.5]])
+    img = np.arange(2 * 3 * 3, dtype=np.float32).reshape(2, 3, 3)
+    wins = np.array([[0.1, 0.0, 0.2, 0.4]], np.float32)
+    em = np.arange(2 * 4 * 4, dtype=np.float32).reshape(2, 4, 4)
+    i2, b2, w2, e2 = preprocessor.random_horizontal_flip(img, boxes, wins, em, do_flip=True)
+    np.testing.assert_array_equal(i2, img[:, ::-1])
+    np.testing.assert_allclose(w2, [[0.1, 0.6, 0.2, 1.0]])
+    np.testing.assert_array_equal(e2, em[:, ::-1])                      # rows reversed, like the reference
+    e3 = preprocessor.random_horizontal_flip(img, boxes, wins, em, do_flip=True, reference_edgemask_axis=False)[3]
+    np.testing.assert_array_equal(e3, em[:, :, ::-1])
+    same = preprocessor.random_horizontal_flip(img, boxes, wins, em, do_flip=False)
+    assert same[0] is not None and np.array_equal(same[0], img) and np.array_equal(same[1], boxes)
+    # no boxes -> never flipped (:302-304)
+    noflip = preprocessor.random_horizontal_flip(img, np.zeros((0, 4), np.float32), do_flip=True)
+    np.testing.assert_array_equal(noflip[0], img)
+    # ~half of the draws flip; driven by the parsed config options
+    cfg = _cfg("frcnn_resnet101_coco_mtl.config")
+    rng = np.random.RandomState(0)
+    ex = dict(image=img, groundtruth_boxes=boxes, window_boxes=wins, groundtruth_edgemask=em)
+    flips = sum(not np.array_equal(preprocessor.preprocess(ex, cfg.train_config.data_augmentation_options, rng)["image"], img)
+                for _ in range(400))
+    assert 150 < flips < 250
+    with pytest.raises(ValueError, match="not supported"):
+        preprocessor.preprocess(ex, [{"random_crop_image": {}}])
