@@ -301,7 +301,10 @@ int mtlssl_reduce_sum(const float* x, int n, float scale, float* out, mtlssl_str
  *   g <- g * min(1, clip/||g||_2) per variable; acc <- momentum*acc + g; w <- w - lr*acc.
  * The parameters live in one flat buffer; var_offsets int32[num_vars+1] (device) delimits the
  * variables (offsets in floats, multiples of 4); max_var_size = largest variable (floats).
- * norms_ws: float[num_vars] workspace. */
+ * norms_ws: workspace of mtlssl_sgd_workspace_bytes(num_vars, max_var_size) bytes (per-variable
+ * norms + per-chunk partial sums: the norm is reduced in a fixed order, so replicas that apply the
+ * same reduced gradient stay bit-identical). */
+int64_t mtlssl_sgd_workspace_bytes(int num_vars, int64_t max_var_size);
 int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              const int32_t* var_offsets, int num_vars, int64_t total,
                              int64_t max_var_size, float lr, float momentum, float clip_norm,

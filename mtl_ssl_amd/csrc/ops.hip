@@ -382,18 +382,19 @@ __global__ void __launch_bounds__(1024) k_reduce_sum(const float* x, int n, floa
 }
 
 // ------------------------------------------------------------------------------ optimizer
-// Per-variable sum of squares: grid (chunks_per_var, num_vars); partials folded with atomics
-// into norms_ws (zeroed first). Integer-free float atomics -> order-dependent in the last
-// bits only; the clip factor tolerates that (documented in DESIGN.md).
+// Per-variable sum of squares: grid (chunks_per_var, num_vars).
 constexpr int NORM_CHUNK = 1 << 16;
+// Partial sums of squares per (variable, 64k-float chunk), written to part[v * chunks + chunk]; the
+// fold below adds them in chunk order, so the norm — and with it the clip factor and the updated
+// weights — is bit-reproducible (data-parallel replicas must stay bit-identical after the update).
 __global__ void __launch_bounds__(256)
     k_var_sumsq(const float* g, const float* w, const float* var_wd, const int32_t* off,
-                float gscale, float* norms) {
+                float gscale, int chunks, float* part) {
   int v = blockIdx.y;
   const float wd = var_wd ? var_wd[v] : 0.f;
   int64_t lo = off[v], hi = off[v + 1];
   int64_t s = lo + (int64_t)blockIdx.x * NORM_CHUNK;
-  if (s >= hi) return;
+  if (s >= hi) return;                      // part[] was zeroed
   int64_t e = s + NORM_CHUNK < hi ? s + NORM_CHUNK : hi;
   float acc = 0.f;
   for (int64_t i = s + threadIdx.x * 4; i < e; i += 256 * 4) {
@@ -409,7 +410,14 @@ __global__ void __launch_bounds__(256)
   __shared__ float sw[4];
   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(norms + v, sw[0] + sw[1] + sw[2] + sw[3]);
+  if (threadIdx.x == 0) part[(int64_t)v * chunks + blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ void k_var_norm_fold(const float* part, int chunks, int num_vars, float* norms) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= num_vars) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[(int64_t)v * chunks + c];
+  norms[v] = s;
 }
 __global__ void __launch_bounds__(256)
     k_momentum_update(float* w, const float* g, float* acc, const int32_t* off, int num_vars,
@@ -616,6 +624,10 @@ int mtlssl_reduce_sum(const float* x, int n, float scale, float* out, mtlssl_str
   return check_launch("reduce_sum");
 }
 
+int64_t mtlssl_sgd_workspace_bytes(int num_vars, int64_t max_var_size) {
+  int64_t chunks = cdiv(max_var_size > 0 ? max_var_size : 1, NORM_CHUNK);
+  return (int64_t)sizeof(float) * num_vars * (1 + chunks);
+}
 int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              const int32_t* var_offsets, int num_vars, int64_t total,
                              int64_t max_var_size, float lr, float momentum, float clip_norm,
@@ -627,12 +639,15 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
   hipStream_t st = S(stream);
   if (clip_norm > 0.f) {
     MTLSSL_REQUIRE(norms_ws != nullptr, "sgd: norms workspace required when clipping");
-    if (hipMemsetAsync(norms_ws, 0, sizeof(float) * num_vars, st) != hipSuccess)
-      return check_launch("sgd memset");
-    // the largest variable decides the chunk count; empty chunks exit immediately
+    // the largest variable decides the chunk count; empty chunks stay zero
     int chunks = (int)cdiv(max_var_size > 0 ? max_var_size : total, NORM_CHUNK);
+    float* part = norms_ws + num_vars;
+    if (hipMemsetAsync(part, 0, sizeof(float) * (size_t)num_vars * chunks, st) != hipSuccess)
+      return check_launch("sgd memset");
     hipLaunchKernelGGL(k_var_sumsq, dim3(chunks, num_vars), dim3(256), 0, st, grads, weights,
-                       var_weight_decay, var_offsets, grad_scale, norms_ws);
+                       var_weight_decay, var_offsets, grad_scale, chunks, part);
+    hipLaunchKernelGGL(k_var_norm_fold, dim3(cdiv(num_vars, 256)), dim3(256), 0, st, (const float*)part, chunks,
+                       num_vars, norms_ws);
   }
   hipLaunchKernelGGL(k_momentum_update, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads,
                      accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
