@@ -193,16 +193,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if rank == 0:
         ge.build()
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if world > 1 else 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        # RCCL ("nccl") needs one device per rank; MTLSSL_DIST_BACKEND=gloo lets the whole multi-rank
+        # code path be exercised on a single GPU (debugging only, not a performance configuration)
+        backend = os.environ.get("MTLSSL_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
     else:
         torch.cuda.set_device(0)
     from mtl_ssl_amd import config, model_builder, ops, synthetic, trainer
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     cfg = config.parse_pipeline_config(open(a.config).read())
     B = int(cfg.train_config.batch_size)                     # per-GPU batch (weak scaling)
     K = int(cfg.model.faster_rcnn.num_classes)
