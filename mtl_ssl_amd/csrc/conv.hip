@@ -12,6 +12,8 @@
 // K-step's global loads are issued before the current step's MFMAs (register prefetch, double
 // buffered LDS, one barrier per step). Frozen BatchNorm is folded into the weights by the caller,
 // so the epilogue is bias(+residual)(+ReLU) and the backward needs only ReLU masks.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mtlssl {
@@ -45,6 +47,8 @@ struct ConvArgs {
   int nsplit;            // wgrad: splits of the pixel range; fwd/dgrad: splits of the K loop
   int ks_per_split;      // fwd/dgrad split-K: K-steps per split
   int pix_per_split;     // wgrad
+  int tile_m0;           // first tile row covered by this launch (tail launches start past 0)
+  int ws_m0;             // first GEMM row held by the split-K workspace of this launch
 };
 
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
@@ -78,7 +82,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3
     int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+  const int tile_m = bid / p.tiles_n + p.tile_m0, tile_n = bid % p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
@@ -320,7 +324,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3
   if constexpr (MODE == MODE_WGRAD)
     outp += ((int64_t)blockIdx.z * (p.R * p.S) + rs_fixed) * (int64_t)p.M * p.NG;
   const bool raw = (MODE != MODE_WGRAD) && p.nsplit > 1;   // split-K partial: epilogue runs later
-  if (raw) outp = p.splitk_ws + (int64_t)blockIdx.z * (int64_t)p.M * p.NG;
+  if (raw) outp = p.splitk_ws + (int64_t)blockIdx.z * (int64_t)(p.M - p.ws_m0) * p.NG;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -337,7 +341,7 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3
         const int64_t o = (int64_t)row * ldo + col;
         float v = acc[i][j][e];
         if (raw) {
-          outp[o] = v;
+          outp[(int64_t)(row - p.ws_m0) * ldo + col] = v;
           continue;
         }
         if constexpr (MODE == MODE_FWD) {
@@ -790,7 +794,10 @@ __global__ void k_splitk_epilogue(ConvArgs p) {
 
 // Launch plan for fwd/dgrad: tile config + K split, from a per-CU MFMA time model (a CU retires
 // one 32-deep block-step of an bm x bn tile in bm*bn*32 / 614 GFLOP/s; blocks beyond 256 queue).
-struct Plan { int cfg, nsplit, ks_per_split; };
+// tail_rows > 0: the last `tail_rows` tile rows are a second launch whose K loop is split
+// `tail_nsplit` ways (wave quantisation: T tiles on S resident slots leave T mod S tiles that would
+// run a whole tile time at low occupancy; split along K they finish in 1/tail_nsplit of it).
+struct Plan { int cfg, nsplit, ks_per_split, tail_rows, tail_nsplit, tail_ks; };
 // Time model shared by the planners (microseconds). A CU retires one 16-deep K-step of a
 // bm x bn tile in bm*bn*32 FLOP / 614 GFLOP/s (fp32 MFMA peak per CU); blocks beyond what is
 // resident queue up. A CU holding a single block (one wave per SIMD) cannot hide its own LDS /
@@ -805,14 +812,27 @@ static double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block) {
   return (double)per_cu * (ksteps_per_block + 96 / CFG_BK[cfg]) * step_us;
 }
 
+static bool tail_split_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MTLSSL_TAIL_SPLIT");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
 // kc = reduction channels per filter tap (C for fwd, K for dgrad), taps = R*S.
 static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc) {
-  Plan best{2, 1, taps * (kc / 16)};
+  const int resident[NCFG] = {3, 6, 8};
+  Plan best{2, 1, taps * (kc / 16), 0, 1, 0};
   double best_t = 1e30;
+  static int force = -2;
+  if (force == -2) { const char* e = getenv("MTLSSL_FORCE_CFG"); force = e ? atoi(e) : -1; }
   for (int c = 0; c < NCFG; ++c) {
     if (!cfg_allowed(c, kc)) continue;
+    if (force >= 0 && c != force) continue;
     int ksteps = taps * (kc / CFG_BK[c]);
-    int64_t tiles = cdiv(M, CFG_BM[c]) * cdiv(NG, CFG_BN[c]);
+    const int64_t tiles_m = cdiv(M, CFG_BM[c]), tiles_n = cdiv(NG, CFG_BN[c]);
+    int64_t tiles = tiles_m * tiles_n;
     for (int s = 1; s <= 8; ++s) {
       if (s > 1 && (ksteps * CFG_BK[c] / s < 192 || (NG & 3))) break;   // the fold kernel is float4 over N
       int per = (int)cdiv(ksteps, s);
@@ -820,7 +840,24 @@ static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc) {
       if (ns != s) continue;
       double t = tile_time_us(c, tiles * ns, per);
       if (ns > 1) t += 3.0 + (double)M * NG * 4.0 * (ns + 2) / 3.0e6;    // fold kernel: launch + traffic
-      if (t < best_t) { best_t = t; best = Plan{c, ns, per}; }
+      if (t < best_t) { best_t = t; best = Plan{c, ns, per, 0, 1, 0}; }
+    }
+    // Un-split main launch on a whole number of waves + K-split launch of the remaining tile rows.
+    const int64_t slots = 256 * resident[c];
+    const int64_t R = tiles % slots;
+    if (tail_split_enabled() && !(NG & 3) && tiles >= slots && R > 0 && ksteps >= 32) {
+      int64_t rows = cdiv(R, tiles_n);
+      int64_t tail_tiles = rows * tiles_n;
+      int ns = (int)(slots / tail_tiles);
+      if (ns > 8) ns = 8;
+      if (ns > ksteps / 16) ns = ksteps / 16;
+      if (ns >= 2 && rows < tiles_m) {
+        int per = (int)cdiv(ksteps, ns);
+        ns = (int)cdiv(ksteps, per);
+        double t = tile_time_us(c, tiles - tail_tiles, ksteps) + tile_time_us(c, tail_tiles * ns, per) +
+                   8.0 + (double)rows * CFG_BM[c] * NG * 4.0 * (ns + 2) / 3.0e6;   // 2 more launches + fold traffic
+        if (t < best_t) { best_t = t; best = Plan{c, 1, ksteps, (int)rows, ns, per}; }
+      }
     }
   }
   return best;
@@ -850,8 +887,8 @@ static void small_wgrad_plan(const mtlssl_conv_desc* d, int* nsplit, int* k_per_
 }
 
 template <int MODE>
-static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st) {
-  p.tiles_m = (int)cdiv(p.M, CFG_BM[cfg]);
+static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st, int tile_rows = -1) {
+  p.tiles_m = tile_rows >= 0 ? tile_rows : (int)cdiv(p.M, CFG_BM[cfg]);
   p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
   switch (cfg) {
@@ -859,6 +896,36 @@ static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st) {
     case 1: hipLaunchKernelGGL((k_conv_mfma<128, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
     default: hipLaunchKernelGGL((k_conv_mfma<64, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
   }
+}
+
+// fwd / dgrad according to a Plan: plain, split-K + fold, or main launch + K-split tail launch + fold
+// of the tail rows.
+template <int MODE>
+static void launch_planned(const Plan& pl, ConvArgs& p, float* ws, hipStream_t st) {
+  p.splitk_ws = ws;
+  if (pl.tail_rows == 0) {
+    p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split;
+    launch_mfma<MODE>(pl.cfg, p, dim3(1, 1, pl.nsplit), st);
+    if (pl.nsplit > 1)
+      hipLaunchKernelGGL(k_splitk_epilogue<MODE>, dim3(cdiv((int64_t)p.M * p.NG / 4, 256)), dim3(256), 0, st, p);
+    return;
+  }
+  const int rows_total = (int)cdiv(p.M, CFG_BM[pl.cfg]);
+  const int rows_main = rows_total - pl.tail_rows;
+  p.nsplit = 1; p.ks_per_split = 0; p.tile_m0 = 0; p.ws_m0 = 0;
+  launch_mfma<MODE>(pl.cfg, p, dim3(1, 1, 1), st, rows_main);
+  ConvArgs q = p;
+  q.tile_m0 = rows_main;
+  q.ws_m0 = rows_main * CFG_BM[pl.cfg];
+  q.nsplit = pl.tail_nsplit; q.ks_per_split = pl.tail_ks;
+  launch_mfma<MODE>(pl.cfg, q, dim3(1, 1, pl.tail_nsplit), st, pl.tail_rows);
+  ConvArgs f = q;                       // fold: the tail rows as a matrix of their own
+  const int64_t off = (int64_t)q.ws_m0 * p.NG;
+  f.M = p.M - q.ws_m0;
+  f.out = p.out + off;
+  if (p.residual) f.residual = p.residual + off;
+  if (p.mask) f.mask = p.mask + off;
+  hipLaunchKernelGGL(k_splitk_epilogue<MODE>, dim3(cdiv((int64_t)f.M * f.NG / 4, 256)), dim3(256), 0, st, f);
 }
 
 static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pps) {
@@ -897,6 +964,10 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
   int kc = mode == MODE_FWD ? d->C : d->K;
   if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : mfma_dgrad_ok(d))) return 0;
   Plan pl = plan_gemm(M, NG, d->R * d->S, kc);
+  if (pl.tail_rows > 0) {
+    int64_t m_tail0 = (cdiv(M, CFG_BM[pl.cfg]) - pl.tail_rows) * CFG_BM[pl.cfg];
+    return align_up((M - m_tail0) * NG * 4 * pl.tail_nsplit, 256);
+  }
   return pl.nsplit > 1 ? align_up(M * NG * 4 * pl.nsplit, 256) : 0;
 }
 
@@ -914,12 +985,8 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
   p.NG = d->K;
   if (mfma_fwd_ok(d)) {
     Plan pl = plan_gemm(p.M, p.NG, d->R * d->S, d->C);
-    if (pl.nsplit > 1 && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0};
-    p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split; p.splitk_ws = (float*)workspace;
-    launch_mfma<MODE_FWD>(pl.cfg, p, dim3(1, 1, pl.nsplit), S(stream));
-    if (pl.nsplit > 1)
-      hipLaunchKernelGGL(k_splitk_epilogue<MODE_FWD>, dim3(cdiv((int64_t)p.M * p.NG / 4, 256)), dim3(256), 0,
-                         S(stream), p);
+    if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
+    launch_planned<MODE_FWD>(pl, p, (float*)workspace, S(stream));
   } else if (is_pointwise(d)) {
     GemmArgs g{x, w, y, bias, residual, nullptr, p.M, d->K, d->C, epi, 0};
     hipLaunchKernelGGL(k_gemm_small<GM_FWD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, S(stream), g);
@@ -948,12 +1015,8 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   p.NG = d->C;
   if (mfma_dgrad_ok(d)) {
     Plan pl = plan_gemm(p.M, p.NG, d->R * d->S, d->K);
-    if (pl.nsplit > 1 && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0};
-    p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split; p.splitk_ws = (float*)workspace;
-    launch_mfma<MODE_DGRAD>(pl.cfg, p, dim3(1, 1, pl.nsplit), S(stream));
-    if (pl.nsplit > 1)
-      hipLaunchKernelGGL(k_splitk_epilogue<MODE_DGRAD>, dim3(cdiv((int64_t)p.M * p.NG / 4, 256)), dim3(256), 0,
-                         S(stream), p);
+    if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
+    launch_planned<MODE_DGRAD>(pl, p, (float*)workspace, S(stream));
   } else if (is_pointwise(d)) {
     GemmArgs g{dy, w, dx, nullptr, residual, mask_ref, p.M, d->C, d->K, epi, 0};
     hipLaunchKernelGGL(k_gemm_small<GM_DGRAD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, S(stream), g);

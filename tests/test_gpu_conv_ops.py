@@ -50,6 +50,8 @@ CONV_CASES = [
     (4, 8, 8, 2080, 192, 1, 1, 1, "SAME"),       # block8 1x1 in
     (4, 8, 8, 448, 2080, 1, 1, 1, "SAME"),       # block8 1x1 up (ragged N = 2080)
     (3, 8, 8, 192, 224, (1, 3), 1, 1, "SAME"),   # block8 1x3
+    # 784 tiles of 128x128 on 768 resident slots: main launch + K-split tail launch + fold (fwd and dgrad)
+    (512, 7, 7, 512, 512, 1, 1, 1, "SAME"),
 ]
 
 
