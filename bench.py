@@ -280,8 +280,12 @@ def main():
                 "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": dom["flops"] / dom["seconds"] / FP32_MFMA_PEAK, "traffic": pmc_traffic(default_cfg),
                 "kernel": "mtlssl::k_conv_mfma<128,128,0> (implicit-GEMM conv forward)",
-                "launches": dom["launches"], "avg_launch_us": 1e6 * dom["seconds"] / dom["launches"],
-                "algorithmic_flop_per_launch_avg": dom["flops"] / dom["launches"],
+                # calls of mtlssl_conv2d_fwd that ran this kernel; some make two launches of it (whole
+                # waves + a K-split tail), so the per-launch average divides by the dispatch count —
+                # that is the number rocprofv3's per-kernel average reports
+                "calls": dom["launches"], "launches": dom["dispatches"],
+                "avg_launch_us": 1e6 * dom["seconds"] / dom["dispatches"],
+                "algorithmic_flop_per_launch_avg": dom["flops"] / dom["dispatches"],
             }
     if prof is not None and a.conv_breakdown:
         fam_f = sum(v["flops"] for k, v in s.items() if k[1] >= 0)

@@ -76,6 +76,10 @@ int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d);
  * 0: k_conv_mfma<128,128,mode>, 1: <128,64,mode>, 2: <64,64,mode>, -1: direct (non-MFMA) path.
  * For profiling attribution only. */
 int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode);
+/* Number of launches of the implicit-GEMM kernel one call makes for this problem (2 when the planner
+ * splits off a K-split tail launch) — lets a profiler relate per-call timings to
+ * per-dispatch kernel traces. */
+int mtlssl_conv2d_num_dispatches(const mtlssl_conv_desc* d, int mode);
 int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,
                         const float* out_scale, float* dw, float* dbias, float beta,
                         void* workspace, mtlssl_stream_t stream);

@@ -1045,6 +1045,15 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
   return -1;
 }
 
+int mtlssl_conv2d_num_dispatches(const mtlssl_conv_desc* d, int mode) {
+  if (!d) return 0;
+  if (mode == MODE_FWD && mfma_fwd_ok(d))
+    return plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C).tail_rows > 0 ? 2 : 1;
+  if (mode == MODE_DGRAD && mfma_dgrad_ok(d))
+    return plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K).tail_rows > 0 ? 2 : 1;
+  return 1;
+}
+
 int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
   if (!d) return 256;
   int64_t bias_part = align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256);

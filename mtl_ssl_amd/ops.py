@@ -96,14 +96,17 @@ class ConvProfiler:
         e.record()
         cfg = lib().conv2d_tile_config(ctypes.byref(d), mode)
         flops = 2.0 * d.N * d.OH * d.OW * d.K * d.C * d.R * d.S
-        self.pending.append(((self.MODES[mode], cfg), flops, start, e))
+        self.pending.append(((self.MODES[mode], cfg), flops, start, e,
+                             lib().conv2d_num_dispatches(ctypes.byref(d), mode)))
 
     def summary(self):
-        """{(mode, cfg): dict(launches, seconds, flops)} — call after torch.cuda.synchronize()."""
+        """{(mode, cfg): dict(launches, dispatches, seconds, flops)} — call after
+        torch.cuda.synchronize(). launches = calls; dispatches = launches of the MFMA kernel."""
         out = {}
-        for key, flops, s, e in self.pending:
-            r = out.setdefault(key, {"launches": 0, "seconds": 0.0, "flops": 0.0})
+        for key, flops, s, e, nd in self.pending:
+            r = out.setdefault(key, {"launches": 0, "dispatches": 0, "seconds": 0.0, "flops": 0.0})
             r["launches"] += 1
+            r["dispatches"] += nd
             r["seconds"] += s.elapsed_time(e) * 1e-3
             r["flops"] += flops
         return out
