@@ -1,0 +1,108 @@
+"""CPU tests of the TensorFlow-free TFRecord / tf.Example input path (mtl_ssl_amd/input_reader.py):
+CRC-32C known answers (RFC 3720 B.4), record framing incl. corruption detection, the protobuf wire
+codec against hand-assembled Example bytes (packed and unpacked lists), and the decoder's field
+contract (data_decoders/tf_example_decoder.py:34-124, trainer.py:100-156)."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from mtl_ssl_amd import input_reader as R
+
+
+def test_crc32c_known_answers():
+    assert R.crc32c(b"123456789") == 0xE3069283
+    assert R.crc32c(bytes(32)) == 0x8A9136AA
+    assert R.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert R.crc32c(bytes(range(32))) == 0x46DD794E
+    assert R.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    c = R.crc32c(b"abc")
+    assert R.masked_crc(b"abc") == ((((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF)
+
+
+def test_tfrecord_framing_round_trip_and_corruption(tmp_path):
+    recs = [b"", b"x", os.urandom(1000), b"tail"]
+    p = str(tmp_path / "a.record")
+    R.write_tfrecord(p, recs)
+    assert list(R.read_tfrecord(p, verify=True)) == recs
+    assert os.path.getsize(p) == sum(16 + len(r) for r in recs)          # 8 + 4 + payload + 4
+    raw = bytearray(open(p, "rb").read())
+    raw[16 + 17 + 12 + 5] ^= 0x40                                       # flip a payload bit of record 2
+    open(p, "wb").write(bytes(raw))
+    assert len(list(R.read_tfrecord(p))) == 4                           # unverified read still frames
+    with pytest.raises(IOError, match="CRC"):
+        list(R.read_tfrecord(p, verify=True))
+    open(p, "wb").write(bytes(raw[:-3]))
+    with pytest.raises(IOError, match="truncated"):
+        list(R.read_tfrecord(p))
+
+
+def test_example_wire_format_against_hand_assembled_bytes():
+    # Example{features{feature{key:"a" value{int64_list{value:[1]}}}}}, packed like TF's serializer
+    want = bytes.fromhex("0a0c0a0a0a016112051a030a0101")
+    assert R.serialize_example({"a": np.array([1], np.int64)}) == want
+    assert R.parse_example(want)["a"].tolist() == [1]
+    # the same list unpacked (field 1, varint wire type) and a negative value (10-byte varint)
+    unpacked = bytes.fromhex("0a0b0a090a016112041a020801")
+    assert R.parse_example(unpacked)["a"].tolist() == [1]
+    neg = R.serialize_example({"n": np.array([-2, 300], np.int64)})
+    assert R.parse_example(neg)["n"].tolist() == [-2, 300]
+    # floats: packed little-endian fp32; unpacked fixed32 entries
+    fl = R.serialize_example({"f": np.array([0.5, -1.25], np.float32)})
+    assert bytes.fromhex("0000003f") in fl and R.parse_example(fl)["f"].tolist() == [0.5, -1.25]
+    unp = bytes.fromhex("0a130a110a0166120c120a0d0000003f0d0000a0bf")
+    assert R.parse_example(unp)["f"].tolist() == [0.5, -1.25]
+    # bytes lists, several features, unknown top-level fields ignored
+    ex = R.serialize_example({"s": [b"ab", "cd"], "z": b"\x00\xff", "k": np.arange(200, dtype=np.int64)})
+    got = R.parse_example(ex + bytes.fromhex("1001"))
+    assert got["s"] == [b"ab", b"cd"] and got["z"] == [b"\x00\xff"] and got["k"].tolist() == list(range(200))
+
+
+def _png(img):
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, format="PNG")
+    return b.getvalue()
+
+
+def test_decoder_contract_and_batches(tmp_path):
+    K = 3
+    rng = np.random.RandomState(0)
+    recs = []
+    for i in range(4):
+        img = rng.randint(0, 256, (12, 16, 3)).astype(np.uint8)
+        em = rng.rand(2, 4, 4).astype(np.float32)
+        feats = {
+            "image/encoded": _png(img), "image/format": b"png", "image/filename": "img%d.png" % i,
+            "image/source_id": str(i), "image/height": np.array([12]), "image/width": np.array([16]),
+            "image/object/bbox/ymin": np.array([0.1, 0.2], np.float32), "image/object/bbox/xmin": np.array([0.0, 0.5], np.float32),
+            "image/object/bbox/ymax": np.array([0.6, 0.9], np.float32), "image/object/bbox/xmax": np.array([0.4, 1.0], np.float32),
+            "image/object/class/label": np.array([1, 3], np.int64), "image/object/difficult": np.array([0, 1], np.int64),
+            "image/window/bbox/ymin": np.array([0.0], np.float32), "image/window/bbox/xmin": np.array([0.25], np.float32),
+            "image/window/bbox/ymax": np.array([1.0], np.float32), "image/window/bbox/xmax": np.array([0.75], np.float32),
+            "image/window/labels/text": [b"0.5 0.25 0 0.25"],
+            "image/object/closeness/text": [b"0 1 0 0", b"0 0.5 0 0.5"],
+            "image/edgemask/masks": em.reshape(-1), "image/edgemask/height": np.array([4]), "image/edgemask/width": np.array([4]),
+        }
+        recs.append(R.serialize_example(feats))
+    p = str(tmp_path / "train.record")
+    R.write_tfrecord(p, recs)
+    ex = R.decode_example(next(R.read_tfrecord(p, verify=True)), K)
+    assert ex["image"].shape == (12, 16, 3) and ex["image"].dtype == np.float32 and ex["image"].max() <= 255
+    np.testing.assert_allclose(ex["groundtruth_boxes"], [[0.1, 0.0, 0.6, 0.4], [0.2, 0.5, 0.9, 1.0]])
+    np.testing.assert_array_equal(ex["groundtruth_classes"], [[1, 0, 0], [0, 0, 1]])      # 1-based labels
+    assert ex["groundtruth_difficult"].tolist() == [False, True] and ex["filename"] == "img0.png"
+    np.testing.assert_allclose(ex["window_classes"], [[0.5, 0.25, 0, 0.25]])
+    np.testing.assert_allclose(ex["groundtruth_closeness"], [[0, 1, 0, 0], [0, 0.5, 0, 0.5]])
+    assert ex["groundtruth_edgemask"].shape == (2, 4, 4)
+    from mtl_ssl_amd import config
+    opts = config.parse_pipeline_config(
+        "train_config { data_augmentation_options { random_horizontal_flip { } } }").train_config.data_augmentation_options
+    bs = list(R.batches([p], K, 2, opts, np.random.RandomState(1)))
+    assert len(bs) == 2 and tuple(bs[0]["images"].shape) == (2, 12, 16, 3)
+    for b in bs:
+        assert set(b) >= {"images", "groundtruth_boxes", "groundtruth_classes", "groundtruth_closeness", "window_boxes",
+                          "window_classes", "groundtruth_edgemask"}
+        for g in b["groundtruth_boxes"]:             # flipped or not, boxes stay normalised and ordered
+            assert (g[:, 1] <= g[:, 3]).all() and g.min() >= 0 and g.max() <= 1
