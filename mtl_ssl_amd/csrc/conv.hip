@@ -727,10 +727,12 @@ static ConvArgs make_args(const mtlssl_conv_desc* d) {
 // depth as a parameter; 32-deep variants of the 128x64 and 64x64 tiles (half the barriers, twice the
 // prefetch distance) were built and measured 3-10 % SLOWER than the 16-deep ones on every layer
 // shape of config[1] (tools/bench_conv.py, round 1), so only the 16-deep ones are instantiated.
-constexpr int NCFG = 4;
-static const int CFG_BM[NCFG] = {128, 128, 64, 128};
-static const int CFG_BN[NCFG] = {128, 64, 64, 192};     // 128x192: Inception's 192 / 384 / 1536-wide layers
-static const int CFG_BK[NCFG] = {16, 16, 16, 16};
+// A 128x192 tile (for Inception's 192 / 2080-wide layers) was built and measured too: 88 TFLOP/s where
+// the 128x128 and 64x64 tiles reach 115-128 on the same layers (154 VGPRs, 42 KB LDS), so it is out.
+constexpr int NCFG = 3;
+static const int CFG_BM[NCFG] = {128, 128, 64};
+static const int CFG_BN[NCFG] = {128, 64, 64};
+static const int CFG_BK[NCFG] = {16, 16, 16};
 static inline bool cfg_allowed(int c, int kc) { return kc % CFG_BK[c] == 0; }
 
 static int check_desc(const mtlssl_conv_desc* d) {
@@ -803,8 +805,8 @@ struct Plan { int cfg, nsplit, ks_per_split, tail_rows, tail_nsplit, tail_ks; };
 // resident queue up. A CU holding a single block (one wave per SIMD) cannot hide its own LDS /
 // barrier latencies, hence the occupancy factor. Constants fitted to tools/bench_conv.py.
 static double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block) {
-  const int resident[NCFG] = {3, 6, 8, 3};
-  const double base_eff[NCFG] = {0.80, 0.76, 0.72, 0.80};
+  const int resident[NCFG] = {3, 6, 8};
+  const double base_eff[NCFG] = {0.80, 0.76, 0.72};
   int64_t per_cu = cdiv(nblocks, 256);
   int64_t occ = per_cu < resident[cfg] ? per_cu : resident[cfg];
   double occ_eff = occ <= 1 ? 0.55 : (occ == 2 ? 0.80 : 1.0);
@@ -822,7 +824,7 @@ static bool tail_split_enabled() {
 }
 // kc = reduction channels per filter tap (C for fwd, K for dgrad), taps = R*S.
 static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc) {
-  const int resident[NCFG] = {3, 6, 8, 3};
+  const int resident[NCFG] = {3, 6, 8};
   Plan best{2, 1, taps * (kc / 16), 0, 1, 0};
   double best_t = 1e30;
   static int force = -2;
@@ -894,7 +896,6 @@ static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st, int ti
   switch (cfg) {
     case 0: hipLaunchKernelGGL((k_conv_mfma<128, 128, MODE, 16>), grid, dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((k_conv_mfma<128, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
-    case 3: hipLaunchKernelGGL((k_conv_mfma<128, 192, MODE, 16>), grid, dim3(256), 0, st, p); break;
     default: hipLaunchKernelGGL((k_conv_mfma<64, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
   }
 }

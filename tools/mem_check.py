@@ -1,0 +1,29 @@
+"""Memory footprint / leak check of the default bench configuration: allocated and reserved bytes
+after warm-up and after N more steps. Usage: python tools/mem_check.py [steps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g  # noqa: E402
+
+g.build()
+from mtl_ssl_amd import config, model_builder, synthetic, trainer  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+cfg = config.parse_pipeline_config(open(os.path.join(os.path.dirname(__file__), "..", "configs", "frcnn_resnet101_coco_mtl.config")).read())
+model = model_builder.build(cfg.model, True, "cuda", seed=0)
+tr = trainer.Trainer(model, cfg.train_config, 1)
+batch = tr.stage_batch(synthetic.make_batch(2, 600, 1024, 90, seed=1234, device="cuda"))
+for _ in range(3):
+    tr.step(batch)
+torch.cuda.synchronize()
+a0, r0 = torch.cuda.memory_allocated(), torch.cuda.memory_reserved()
+for i in range(steps):
+    losses = tr.step(batch)
+torch.cuda.synchronize()
+a1, r1, peak = torch.cuda.memory_allocated(), torch.cuda.memory_reserved(), torch.cuda.max_memory_allocated()
+print("allocated %.2f -> %.2f GB, reserved %.2f -> %.2f GB, peak allocated %.2f GB, loss %.3f" % (
+    a0 / 1e9, a1 / 1e9, r0 / 1e9, r1 / 1e9, peak / 1e9, float(sum(v.item() for v in losses.values()))))
+assert a1 <= a0 * 1.01 + 1e6 and r1 <= r0 * 1.05 + 1e6, "memory grows across steps"
