@@ -70,7 +70,9 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3
   constexpr bool B_KC = (MODE == MODE_DGRAD);     // B float4 runs along k (else along n)
   constexpr int A_LD = BM / RP, B_LD = BN / RP;   // float4 loads per thread per K-step
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  __shared__ __attribute__((aligned(16))) float smem[2 * BKT * (LDA + LDB)];
+  constexpr int LDT = 36;                          // epilogue staging: floats per row of a 32x32 tile
+  constexpr int SMEM_OPS = 2 * BKT * (LDA + LDB), SMEM_EPI = 4 * 32 * LDT;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_OPS > SMEM_EPI ? SMEM_OPS : SMEM_EPI];
   float* const sA = smem;
   float* const sB = smem + 2 * BKT * LDA;
 
@@ -325,6 +327,58 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3
     outp += ((int64_t)blockIdx.z * (p.R * p.S) + rs_fixed) * (int64_t)p.M * p.NG;
   const bool raw = (MODE != MODE_WGRAD) && p.nsplit > 1;   // split-K partial: epilogue runs later
   if (raw) outp = p.splitk_ws + (int64_t)blockIdx.z * (int64_t)(p.M - p.ws_m0) * p.NG;
+  if (!(p.NG & 3)) {
+    // Coalesced epilogue: each wave transposes its 32x32 accumulator tiles through a private LDS
+    // patch (the operand buffers are free after the last K-step's barrier) so that a lane holds 4
+    // consecutive columns: 4 ds_read_b128 + 4 global 16-byte stores per tile instead of 64 scalar
+    // stores, and the bias / residual / mask / accumulate operands come in as 16-byte loads too.
+    float* tile = smem + wid * (32 * LDT);                 // LDT: 16-byte aligned rows, conflict-light
+    const int r_in = lane >> 3, c4 = (lane & 7) * 4;      // this lane's row (mod 8) and first column in the tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hi) * LDT + lo] = acc[i][j][e];
+        const int col = n0 + wc * (BN / 2) + j * 32 + c4;
+        floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == MODE_FWD)
+          if ((p.epi & MTLSSL_EPI_BIAS) && col < p.NG && !raw) bv = *reinterpret_cast<const floatx4*>(p.bias + col);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int rt = r_in + 8 * k;
+          floatx4 v = *reinterpret_cast<const floatx4*>(tile + rt * LDT + c4);
+          const int row = m0 + wr * (BM / 2) + i * 32 + rt;
+          if (row >= p.M || col >= p.NG) continue;
+          if (raw) {
+            *reinterpret_cast<floatx4*>(outp + (int64_t)(row - p.ws_m0) * ldo + col) = v;
+            continue;
+          }
+          const int64_t o = (int64_t)row * ldo + col;
+          if constexpr (MODE == MODE_FWD) {
+            v += bv;
+            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (p.epi & MTLSSL_EPI_RELU) v[q] = fmaxf(v[q], 0.f);
+              if (p.epi & MTLSSL_EPI_RELU6) v[q] = fminf(fmaxf(v[q], 0.f), 6.f);
+              if (p.epi & MTLSSL_EPI_TANH) v[q] = tanhf(v[q]);
+            }
+          } else if constexpr (MODE == MODE_DGRAD) {
+            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
+            if (p.epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const floatx4*>(outp + o);
+            if (p.epi & MASK_ANY) {
+              floatx4 mk = *reinterpret_cast<const floatx4*>(p.mask + o);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = act_mask(v[q], mk[q], p.epi);
+            }
+          }
+          *reinterpret_cast<floatx4*>(outp + o) = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
