@@ -14,6 +14,9 @@
 // so the epilogue is bias(+residual)(+ReLU) and the backward needs only ReLU masks.
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace mtlssl {
@@ -868,6 +871,27 @@ static double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block) {
   return (double)per_cu * (ksteps_per_block + 96 / CFG_BK[cfg]) * step_us;
 }
 
+// Tile choices measured by the caller's autotuner (mtlssl_conv2d_force_config): key = GEMM shape +
+// mode; the time-model planner still picks the K split / tail split for the forced tile.
+struct TunedKey {
+  int mode; int64_t M, NG; int taps, kc;
+  bool operator==(const TunedKey& o) const { return mode == o.mode && M == o.M && NG == o.NG && taps == o.taps && kc == o.kc; }
+};
+struct TunedHash {
+  size_t operator()(const TunedKey& k) const {
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t v : {(uint64_t)k.mode, (uint64_t)k.M, (uint64_t)k.NG, (uint64_t)k.taps, (uint64_t)k.kc}) { h ^= v; h *= 1099511628211ull; }
+    return (size_t)h;
+  }
+};
+static std::unordered_map<TunedKey, int, TunedHash>& tuned_map() { static std::unordered_map<TunedKey, int, TunedHash> m; return m; }
+static std::mutex& tuned_mutex() { static std::mutex m; return m; }
+static int tuned_cfg(int mode, int64_t M, int64_t NG, int taps, int kc) {
+  std::lock_guard<std::mutex> g(tuned_mutex());
+  auto it = tuned_map().find(TunedKey{mode, M, NG, taps, kc});
+  return it == tuned_map().end() ? -1 : it->second;
+}
+
 static bool tail_split_enabled() {
   static int v = -1;
   if (v < 0) {
@@ -877,12 +901,14 @@ static bool tail_split_enabled() {
   return v != 0;
 }
 // kc = reduction channels per filter tap (C for fwd, K for dgrad), taps = R*S.
-static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc) {
+static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int mode) {
   const int resident[NCFG] = {3, 6, 8};
   Plan best{2, 1, taps * (kc / 16), 0, 1, 0};
   double best_t = 1e30;
-  static int force = -2;
-  if (force == -2) { const char* e = getenv("MTLSSL_FORCE_CFG"); force = e ? atoi(e) : -1; }
+  static int env_force = -2;
+  if (env_force == -2) { const char* e = getenv("MTLSSL_FORCE_CFG"); env_force = e ? atoi(e) : -1; }
+  int force = env_force >= 0 ? env_force : tuned_cfg(mode, M, NG, taps, kc);
+  if (force >= NCFG || (force >= 0 && !cfg_allowed(force, kc))) force = -1;
   for (int c = 0; c < NCFG; ++c) {
     if (!cfg_allowed(c, kc)) continue;
     if (force >= 0 && c != force) continue;
@@ -989,7 +1015,9 @@ static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pp
   int RS = d->R * d->S;
   double best_t = 1e30;
   *cfg = 2; *nsplit = 1; *pps = (int)align_up(P, 16);
+  const int force = tuned_cfg(MODE_WGRAD, d->C, d->K, RS, (int)(P > 0x7fffffff ? 0x7fffffff : P));
   for (int c = 0; c < NCFG; ++c) {
+    if (force >= 0 && force < NCFG && c != force) continue;
     int bk = CFG_BK[c];
     int ksteps = (int)cdiv(P, bk);
     int64_t tiles = cdiv(d->C, CFG_BM[c]) * cdiv(d->K, CFG_BN[c]) * RS;
@@ -1019,7 +1047,7 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
   int64_t NG = mode == MODE_FWD ? d->K : d->C;
   int kc = mode == MODE_FWD ? d->C : d->K;
   if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : mfma_dgrad_ok(d))) return 0;
-  Plan pl = plan_gemm(M, NG, d->R * d->S, kc);
+  Plan pl = plan_gemm(M, NG, d->R * d->S, kc, mode);
   if (pl.tail_rows > 0) {
     int64_t m_tail0 = (cdiv(M, CFG_BM[pl.cfg]) - pl.tail_rows) * CFG_BM[pl.cfg];
     return align_up((M - m_tail0) * NG * 4 * pl.tail_nsplit, 256);
@@ -1040,7 +1068,7 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
   p.M = d->N * d->OH * d->OW;
   p.NG = d->K;
   if (mfma_fwd_ok(d)) {
-    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S, d->C);
+    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S, d->C, MODE_FWD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
     launch_planned<MODE_FWD>(pl, p, (float*)workspace, S(stream));
   } else if (is_pointwise(d)) {
@@ -1070,7 +1098,7 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   p.M = d->N * d->H * d->W;
   p.NG = d->C;
   if (mfma_dgrad_ok(d)) {
-    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S, d->K);
+    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S, d->K, MODE_DGRAD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
     launch_planned<MODE_DGRAD>(pl, p, (float*)workspace, S(stream));
   } else if (is_pointwise(d)) {
@@ -1087,10 +1115,10 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
   if (!d) return -1;
   if (mode == MODE_FWD)
     return mfma_fwd_ok(d)
-               ? plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C).cfg : -1;
+               ? plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C, MODE_FWD).cfg : -1;
   if (mode == MODE_DGRAD)
     return mfma_dgrad_ok(d)
-               ? plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K).cfg : -1;
+               ? plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K, MODE_DGRAD).cfg : -1;
   if (mode == MODE_WGRAD) {
     if (!mfma_wgrad_ok(d)) return -1;
     int cfg, ns, pps;
@@ -1100,12 +1128,27 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
   return -1;
 }
 
+int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg) {
+  MTLSSL_REQUIRE(d != nullptr && mode >= MODE_FWD && mode <= MODE_WGRAD, "force_config: bad arguments");
+  MTLSSL_REQUIRE(cfg < NCFG, "force_config: tile configuration out of range");
+  TunedKey k;
+  if (mode == MODE_FWD) k = TunedKey{mode, (int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C};
+  else if (mode == MODE_DGRAD) k = TunedKey{mode, (int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K};
+  else {
+    int64_t P = (int64_t)d->N * d->OH * d->OW;
+    k = TunedKey{mode, d->C, d->K, d->R * d->S, (int)(P > 0x7fffffff ? 0x7fffffff : P)};
+  }
+  std::lock_guard<std::mutex> g(tuned_mutex());
+  if (cfg < 0) tuned_map().erase(k); else tuned_map()[k] = cfg;
+  return MTLSSL_OK;
+}
+
 int mtlssl_conv2d_num_dispatches(const mtlssl_conv_desc* d, int mode) {
   if (!d) return 0;
   if (mode == MODE_FWD && mfma_fwd_ok(d))
-    return plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C).tail_rows > 0 ? 2 : 1;
+    return plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C, MODE_FWD).tail_rows > 0 ? 2 : 1;
   if (mode == MODE_DGRAD && mfma_dgrad_ok(d))
-    return plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K).tail_rows > 0 ? 2 : 1;
+    return plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K, MODE_DGRAD).tail_rows > 0 ? 2 : 1;
   return 1;
 }
 

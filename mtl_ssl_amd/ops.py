@@ -5,6 +5,7 @@ returns torch CUDA tensors whose storage is handed to the HIP kernels as raw poi
 Names follow the reference operators they replace (see include/mtlssl_hip.h).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -114,9 +115,51 @@ class ConvProfiler:
 
 PROFILER = None
 
+# ---- tile autotuning: the first time a (problem, mode) is seen, each tile configuration is timed
+# on the caller's tensors (scratch outputs) and the winner pinned in the library's plan registry
+# (mtlssl_conv2d_force_config) if it beats the time-model planner's own choice by > 5 %.
+AUTOTUNE = os.environ.get("MTLSSL_AUTOTUNE", "1") != "0"
+_tuned = {}
+
+
+def _autotune(d, mode, run):
+    key = (mode, d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.OH, d.OW, d.stride, d.dilation, d.pad_t, d.pad_l)
+    if key in _tuned:
+        return
+    _tuned[key] = None
+    L, ref = lib(), ctypes.byref(d)
+    default = L.conv2d_tile_config(ref, mode)
+    if default < 0:                                   # not on the MFMA path
+        return
+    times = {}
+    for cfg in (0, 1, 2):
+        L.conv2d_force_config(ref, mode, cfg)
+        if L.conv2d_tile_config(ref, mode) != cfg:    # this tile is not available for the problem
+            continue
+        run()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(4):
+            run()
+        e.record()
+        e.synchronize()
+        times[cfg] = s.elapsed_time(e)
+    L.conv2d_force_config(ref, mode, -1)
+    best = min(times, key=times.get)
+    if best != default and times[best] < 0.95 * times.get(default, float("inf")):
+        L.conv2d_force_config(ref, mode, best)
+    _tuned[key] = (default, best, times)
+
 
 def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None):
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
+    if AUTOTUNE and PROFILER is None:
+        def run():
+            nb_ = lib().conv2d_workspace_bytes(ctypes.byref(d), 0)
+            ws_ = workspace(nb_, "splitk", x.device) if nb_ else None
+            lib().conv2d_fwd(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(residual), ptr(y), epilogue,
+                             ptr(ws_), _stream())
+        _autotune(d, 0, run)
     t0 = PROFILER.begin(d, 0) if PROFILER is not None else None
     nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 0)
     ws = workspace(nb, "splitk", x.device) if nb else None
@@ -129,6 +172,14 @@ def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None):
 
 def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None):
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=f32, device=dy.device)
+    if AUTOTUNE and PROFILER is None:
+        def run():                                    # scratch output; no accumulate into it
+            tmp = workspace(4 * d.N * d.H * d.W * d.C, "tune_out", dy.device)
+            nb_ = lib().conv2d_workspace_bytes(ctypes.byref(d), 1)
+            ws_ = workspace(nb_, "splitk", dy.device) if nb_ else None
+            lib().conv2d_dgrad(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref), ptr(tmp),
+                               epilogue & ~EPI_ACCUM, ptr(ws_), _stream())
+        _autotune(d, 1, run)
     t0 = PROFILER.begin(d, 1) if PROFILER is not None else None
     nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 1)
     ws = workspace(nb, "splitk", dy.device) if nb else None
@@ -140,6 +191,14 @@ def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None):
 
 
 def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0):
+    if AUTOTUNE and PROFILER is None:
+        def run():                                    # scratch filter gradient, beta = 0
+            tmp = workspace(4 * d.R * d.S * d.C * d.K, "tune_out", x.device)
+            nb_ = lib().conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+            ws_ = workspace(nb_, "wgrad", x.device)
+            lib().conv2d_wgrad(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(dy)), ptr(out_scale), ptr(tmp), None, 0.0,
+                               ptr(ws_), _stream())
+        _autotune(d, 2, run)
     nbytes = lib().conv2d_wgrad_workspace_bytes(ctypes.byref(d))
     ws = workspace(nbytes, "wgrad", x.device)
     t0 = PROFILER.begin(d, 2) if PROFILER is not None else None
