@@ -288,12 +288,28 @@ __global__ void __launch_bounds__(64) k_nms_scan(const unsigned long long* mask,
     int base = nsel - __popcll(sel);
     if ((sel >> lane) & 1ull) sel_rank[(int64_t)b * max_out + base + __popcll(sel & ((1ull << lane) - 1))] = row;
     if (nsel < max_out) {
-      unsigned long long rem = sel;
-      while (rem) {
-        int j = __ffsll((long long)rem) - 1;
-        rem &= rem - 1;
-        const unsigned long long* rowp = mk + (int64_t)(c * 64 + j) * nchunks;
-        for (int w = c + 1 + lane; w < nch; w += 64) s_remv[w] |= rowp[w];
+      // fold the selected rows into the removed set: per word, the loads of up to 8 selected rows
+      // are issued together (independent addresses) and OR-ed in registers before the LDS update,
+      // instead of one dependent global load + LDS read-modify-write per row
+      for (int w = c + 1 + lane; w < nch; w += 64) {
+        unsigned long long rem = sel, accw = 0;
+        while (rem) {
+          unsigned long long v[8];
+          int cnt = 0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            v[u] = 0;
+            if (rem) {
+              int j = __ffsll((long long)rem) - 1;
+              rem &= rem - 1;
+              v[u] = mk[(int64_t)(c * 64 + j) * nchunks + w];
+              ++cnt;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) accw |= v[u];
+        }
+        s_remv[w] |= accw;
       }
     }
     __syncthreads();
