@@ -166,6 +166,34 @@ def test_rpn_proposals_full_size_vs_oracle(ops):
     np.testing.assert_allclose(b.cpu().numpy(), rb, rtol=1e-4, atol=1e-2)
 
 
+def test_rpn_proposals_degenerate_inputs(ops):
+    """Edge cases: no candidate survives the score filter in one image, every box collapses on the
+    window edge (zero area after clipping) in the other, fewer candidates than max_proposals."""
+    rng = np.random.RandomState(3)
+    anchors = rand_boxes(rng, 50, 100, 100, 8.0)
+    enc = np.zeros((3, 50, 4), np.float32)
+    logit = np.zeros((3, 50, 2), np.float32)
+    logit[0, :, 0] = 20.0                                   # image 0: fg score ~2e-9 < threshold
+    logit[1, :, 1] = 5.0
+    enc[1, :, 1] = 1e4                                      # image 1: centres pushed far outside -> clipped to zero area
+    logit[2, :, 1] = np.linspace(0, 3, 50)                  # image 2: 50 candidates, 300 requested
+    b, s, num = ops.rpn_proposals(cu(enc), cu(logit), cu(anchors), 100, 100, 1e-6, 0.7, 300)
+    rb, rs, _, rn = N.rpn_proposals(enc, logit, anchors, (100, 100), 1e-6, 0.7, 300)
+    assert num.cpu().tolist() == rn.tolist() and rn[0] == 0 and rn[1] == 0 and 0 < rn[2] <= 50
+    np.testing.assert_allclose(b.cpu().numpy(), rb, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(s.cpu().numpy(), rs, rtol=1e-5, atol=1e-7)
+    assert float(b[:2].abs().sum()) == 0 and float(s[:2].abs().sum()) == 0      # zero padded
+    # sampling from an empty proposal set: nothing selected, everything zero padded
+    gts = np.tile(np.array([[10, 10, 60, 60]], np.float32), (3, 1, 1))
+    labels = np.zeros((3, 1, 4), np.float32); labels[:, 0, 1] = 1
+    ob, on, n2 = ops.sample_proposals(b, num, cu(gts), cu(np.ones(3, np.int32)), cu(labels), 16, 0.25, 5, 1, 2, 100, 100)
+    assert n2.cpu().tolist()[:2] == [0, 0] and 0 < int(n2[2]) <= 16
+    assert float(ob[:2].abs().sum()) == 0 and float(on[:2].abs().sum()) == 0
+    rbx, rnx, _ = L.sample_box_classifier_batch(rb, rn, [g for g in gts], [l for l in labels], 16, 0.25, 5)
+    np.testing.assert_array_equal(n2.cpu().numpy(), rnx)
+    np.testing.assert_allclose(ob.cpu().numpy(), rbx, rtol=1e-5, atol=1e-4)
+
+
 def _assign_case(rng, n, G, B_=2, H=600, W=1024):
     anchors = rand_boxes(rng, n, H, W, 16.0)
     gts, ngt = np.zeros((B_, max(G, 1), 4), np.float32), np.zeros((B_,), np.int32)
