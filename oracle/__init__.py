@@ -13,8 +13,14 @@ Parity pinning status (see DESIGN.md "Oracle"):
   * anchors, box coder, arg-max matcher, target assigner, SmoothL1, softmax-CE,
     multiclass NMS, RPN post-processing, meta-arch losses: pinned against the
     reference unit tests' known-answer vectors (tests/golden/reference_vectors.json).
-  * crop_and_resize, legacy bilinear resize, conv SAME padding, frozen BN, momentum,
-    aux-head losses (window / closeness / edgemask / refine): **parity unpinned** — the
+  * multiclass / batched NMS variants (clip window, coordinate-frame change, per-class and
+    total caps, zero padding) and position-sensitive ROI pooling: pinned against the known
+    answers of `core/post_processing_test.py:301-568` and `utils/ops_test.py:711-898`;
+    conv SAME vs `conv2d_same` padding against `slim/nets/resnet_v1_test.py:72-111`.
+  * crop_and_resize (beyond what the PS-RoI known answers exercise), legacy bilinear resize,
+    depthwise / separable convolutions, TF-'SAME' average pooling, inference-mode BatchNorm
+    (with or without trainable gamma/beta), momentum, aux-head losses (window / closeness /
+    edgemask / refine), the inference path `Oracle.detect`: **parity unpinned** — the
     reference delegates these to TensorFlow 1.7 kernels that are not in the tree and
     has no tests for the aux heads; the restatement follows TF 1.7's documented
     semantics.
