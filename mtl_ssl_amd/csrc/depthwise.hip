@@ -86,12 +86,14 @@ __global__ void k_dw_dgrad(DwArgs p) {
   reinterpret_cast<floatx4*>(p.out)[i] = acc;
 }
 
-// dw[r,s,c] partials: block = 64 channel-quads... grid (C/4/64 rounded, chunks); each block reduces
-// a contiguous range of output pixels for its channels; partials [chunk][R*S][C].
-__global__ void __launch_bounds__(256) k_dw_wgrad_partial(DwArgs p, int pix_per_chunk, float* part) {
+// dw[r,s,c] partials. Block = CQ channel quads x PL pixel lanes (CQ = min(C/4, 64), PL = 256/CQ, so
+// the narrow early layers — 32 channels x 150k pixels — still use every lane); grid (C/4/CQ, chunks);
+// each block reduces a contiguous range of output pixels; partials [chunk][R*S][C].
+__global__ void __launch_bounds__(256) k_dw_wgrad_partial(DwArgs p, int pix_per_chunk, int CQ, float* part) {
   const int C4 = p.C / 4;
-  int c4 = blockIdx.x * 64 + (threadIdx.x & 63);
-  int sub = threadIdx.x >> 6;                       // 4 pixel lanes per block
+  const int PL = 256 / CQ;
+  const int cq = threadIdx.x % CQ, sub = threadIdx.x / CQ;
+  const int c4 = blockIdx.x * CQ + cq;
   int chunk = blockIdx.y;
   int64_t P = (int64_t)p.N * p.OH * p.OW;
   int64_t p0 = (int64_t)chunk * pix_per_chunk, p1 = p0 + pix_per_chunk < P ? p0 + pix_per_chunk : P;
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(256) k_dw_wgrad_partial(DwArgs p, int pix_per_
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
   if (c4 < C4) {
-    for (int64_t pix = p0 + sub; pix < p1; pix += 4) {
+    for (int64_t pix = p0 + sub; pix < p1; pix += PL) {
       int ow = pix % p.OW;
       int64_t t = pix / p.OW;
       int oh = t % p.OH, n = t / p.OH;
@@ -118,12 +120,13 @@ __global__ void __launch_bounds__(256) k_dw_wgrad_partial(DwArgs p, int pix_per_
       }
     }
   }
-  __shared__ floatx4 red[4][64];
+  __shared__ floatx4 red[256];
   for (int k = 0; k < 9; ++k) {
-    red[sub][threadIdx.x & 63] = acc[k];
+    red[threadIdx.x] = acc[k];
     __syncthreads();
     if (sub == 0 && c4 < C4) {
-      floatx4 v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      floatx4 v = red[cq];
+      for (int l = 1; l < PL; ++l) v += red[l * CQ + cq];          // fixed order: deterministic
       *reinterpret_cast<floatx4*>(part + ((int64_t)chunk * 9 + k) * p.C + c4 * 4) = v;
     }
     __syncthreads();
@@ -231,7 +234,9 @@ int mtlssl_depthwise_wgrad(const mtlssl_conv_desc* d, const float* x, const floa
   int chunks = (int)(cdiv(P, 256) < DW_MAX_CHUNKS ? cdiv(P, 256) : DW_MAX_CHUNKS);
   int ppc = (int)cdiv(P, chunks);
   chunks = (int)cdiv(P, ppc);
-  hipLaunchKernelGGL(k_dw_wgrad_partial, dim3(cdiv(a.C / 4, 64), chunks), dim3(256), 0, S(stream), a, ppc,
+  int CQ = 64;                                     // channel quads per block: a power of two <= 64
+  while (CQ > 1 && CQ / 2 >= a.C / 4) CQ /= 2;
+  hipLaunchKernelGGL(k_dw_wgrad_partial, dim3(cdiv(a.C / 4, CQ), chunks), dim3(256), 0, S(stream), a, ppc, CQ,
                      (float*)workspace);
   int total = 9 * a.C;
   hipLaunchKernelGGL(k_dw_wgrad_fold, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), (const float*)workspace,
