@@ -155,6 +155,7 @@ class FasterRCNNMetaArch:
                                      fc=True)
             self.layers.append(self.refine_fc)
         self._anchors = {}
+        self._consts = {}
         self._gt = None
         self._window = None
         self._edgemask = None
@@ -312,8 +313,12 @@ class FasterRCNNMetaArch:
     def _format_groundtruth_data(self, H, W):
         """faster_rcnn_meta_arch.py:1218-1266: absolute boxes (+ bg-padded classes)."""
         if "boxes_abs" not in self._gt:
-            scale = torch.tensor([H, W, H, W], dtype=f32, device=self.ps.device)
-            self._gt["boxes_abs"] = (self._gt["boxes_norm"] * scale).contiguous()
+            # constants are created once: a host->device torch.tensor() is a synchronising copy, which
+            # would make the launch thread wait for the whole previous step every iteration
+            key = ("hw_scale", H, W)
+            if key not in self._consts:
+                self._consts[key] = torch.tensor([H, W, H, W], dtype=f32, device=self.ps.device)
+            self._gt["boxes_abs"] = ops.scale_channels(self._gt["boxes_norm"].contiguous(), self._consts[key])
         return self._gt
 
     def _crop(self, F, boxes_norm_flat, box_ind, want_argmax):
@@ -462,7 +467,11 @@ class FasterRCNNMetaArch:
         # ---- _loss_rpn :1591-1668
         anchors = pd["anchors"]
         n = anchors.shape[0]
-        um = torch.zeros((1,), dtype=f32, device=dev)
+        if "um" not in self._consts:
+            K1_ = self.num_classes + 1
+            self._consts["um"] = torch.zeros((1,), dtype=f32, device=dev)
+            self._consts["um2"] = torch.tensor([1.0] + [0.0] * (K1_ - 1), dtype=f32, device=dev)
+        um = self._consts["um"]
         tg = ops.assign_targets(anchors, gt["boxes_abs"], gt["num"], None, um, 0.7, 0.3, True)
         cls_t = tg["cls_targets"].view(B, n)
         sampled = ops.balanced_sample(tg["cls_weights"], cls_t, int(c.first_stage_minibatch_size),
@@ -479,8 +488,7 @@ class FasterRCNNMetaArch:
         pd["_rpn_targets"] = dict(tg, sampled=sampled)
         # ---- _loss_box_classifier :1670-1793
         N2, K, K1 = self.max_num_proposals, self.num_classes, self.num_classes + 1
-        um2 = torch.zeros((K1,), dtype=f32, device=dev)
-        um2[0] = 1
+        um2 = self._consts["um2"]
         dt = ops.assign_targets(pd["proposal_boxes"], gt["boxes_abs"], gt["num"], gt["classes_bg"], um2,
                                 0.5, 0.5, False, gt_extra=gt["closeness"] if mtl.closeness else None)
         cls_s, loc_s2, clo_s = ops.detector_loss_scales(
