@@ -3,7 +3,7 @@
 THIS PACKAGE IS TEST INFRASTRUCTURE. It is a CPU restatement (numpy fp32 for the
 detection maths, torch-CPU fp32 for convolutions) of the reference algorithm, used
 only as the *checker*: `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg
-of `bench.py` may import it. Nothing under `mtl_ssl_amd/` (the product) imports it.
+of `bench.py` may import it. Nothing under `mtl_ssl_amd/` (the product) imports it (tests/test_abi.py enforces this).
 
 Parity pinning status (see DESIGN.md "Oracle"):
   * boxes (area/intersection/iou/ioa/clip/prune/change-frame), greedy NMS: pinned against

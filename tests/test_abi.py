@@ -36,3 +36,14 @@ def test_header_cites_reference_for_every_family():
                    "argmax_matcher.py", "target_assigner.py", "balanced_positive_negative_sampler.py",
                    "faster_rcnn_meta_arch.py", "losses.py", "learning.py"):
         assert needle in text, needle
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's
+    cpu_baseline leg may import it."""
+    import re
+    pkg = os.path.join(ROOT, "mtl_ssl_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
