@@ -22,13 +22,14 @@ SOURCES = {
     "ops.hip": ["-ffp-contract=off"],   # ROI max-pool arg-max must not flip on fma rounding
     "conv.hip": [],
     "glue.hip": ["-ffp-contract=off"],
-    "depthwise.hip": [], "pool_concat.hip": [],
+    "depthwise.hip": [], "pool_concat.hip": [], "winograd.hip": [],
 }
 
 
 def _digest(path, flags):
     h = hashlib.sha256()
-    for f in (path, os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "mtlssl_hip.h")):
+    for f in (path, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_mfma.h"),
+              os.path.join(HERE, "..", "include", "mtlssl_hip.h")):
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(flags).encode())

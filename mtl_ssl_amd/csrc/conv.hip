@@ -17,406 +17,10 @@
 #include <mutex>
 #include <unordered_map>
 
-#include "common.h"
+#include "conv_mfma.h"
 
 namespace mtlssl {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
-// ReLU / ReLU6 backward: pass the gradient where the activation was in its linear range.
-__device__ __forceinline__ float act_mask(float g, float y, int epi) {
-  bool on = y > 0.f && (!(epi & MTLSSL_EPI_MASK6) || y < 6.f);
-  return on ? g : 0.f;
-}
-constexpr int MASK_ANY = MTLSSL_EPI_MASK | MTLSSL_EPI_MASK6;
-constexpr int BK = 16;
-
-struct ConvArgs {
-  const float* a;        // fwd: x     dgrad: dy    wgrad: x
-  const float* b;        // fwd: w     dgrad: w     wgrad: dy
-  float* out;            // fwd: y     dgrad: dx    wgrad: workspace partials
-  const float* bias;     // fwd
-  const float* residual; // fwd / dgrad
-  const float* mask;     // dgrad
-  float* splitk_ws;      // fwd/dgrad split-K partials [nsplit][M][NG]
-  int N, H, W, C, K, R, S, OH, OW, stride, dil, pt, pl;
-  int M;                 // GEMM rows
-  int NG;                // GEMM cols
-  int epi;
-  int tiles_m, tiles_n;
-  unsigned a_bytes, b_bytes;   // extents of the a / b tensors (buffer-load range checks)
-  int nsplit;            // wgrad: splits of the pixel range; fwd/dgrad: splits of the K loop
-  int ks_per_split;      // fwd/dgrad split-K: K-steps per split
-  int pix_per_split;     // wgrad
-  int tile_m0;           // first tile row covered by this launch (tail launches start past 0)
-  int ws_m0;             // first GEMM row held by the split-K workspace of this launch
-};
-
-typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ floatx4 bufload4(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset,
-                                            unsigned soffset) {
-  // raw buffer load: an offset beyond num_records returns zeros, which is exactly the zero
-  // padding / ragged-tile semantics the gathers need — no branches around the loads.
-  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
-}
-
-template <int BM, int BN, int MODE, int BKT>
-__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3) : 4)) k_conv_mfma(ConvArgs p) {
-  constexpr int LDA = BM + 4, LDB = BN + 4;
-  constexpr int KQ = BKT / 4;                     // float4 quads along k per tile row
-  constexpr int RP = 256 / KQ;                    // tile rows covered by one pass of the KC loaders
-  constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave in m / n
-  constexpr bool A_KC = (MODE != MODE_WGRAD);     // A float4 runs along k (else along m)
-  constexpr bool B_KC = (MODE == MODE_DGRAD);     // B float4 runs along k (else along n)
-  constexpr int A_LD = BM / RP, B_LD = BN / RP;   // float4 loads per thread per K-step
-  constexpr unsigned OOB = 0xFFFFFFF0u;
-  constexpr int LDT = 36;                          // epilogue staging: floats per row of a 32x32 tile
-  constexpr int SMEM_OPS = 2 * BKT * (LDA + LDB), SMEM_EPI = 4 * 32 * LDT;
-  __shared__ __attribute__((aligned(16))) float smem[SMEM_OPS > SMEM_EPI ? SMEM_OPS : SMEM_EPI];
-  float* const sA = smem;
-  float* const sB = smem + 2 * BKT * LDA;
-
-  // XCD-aware tile order: the dispatcher places block b on XCD b%8; give each XCD a contiguous
-  // range of tiles (n fastest) so blocks sharing an A row-panel share an L2.
-  int nwg = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
-    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int tile_m = bid / p.tiles_n + p.tile_m0, tile_n = bid % p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;
-  const int lo = lane & 31, hi = lane >> 5;
-  const int kq4 = (tid % KQ) * 4;
-
-  const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_b =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
-
-  // ---- K-loop extent
-  int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps, ks_begin = 0;
-  if constexpr (MODE == MODE_FWD) {
-    ksteps = p.R * p.S * (p.C / BKT);
-  } else if constexpr (MODE == MODE_DGRAD) {
-    ksteps = p.R * p.S * (p.K / BKT);
-  } else {
-    rs_fixed = blockIdx.y;
-    int split = blockIdx.z;
-    int P = p.N * p.OH * p.OW;
-    pix0 = split * p.pix_per_split;
-    pix1 = min(P, pix0 + p.pix_per_split);
-    ksteps = (max(pix1 - pix0, 0) + BKT - 1) / BKT;
-  }
-  if constexpr (MODE != MODE_WGRAD) {
-    if (p.nsplit > 1) {          // split-K: this block covers K-steps [ks_begin, ksteps)
-      ks_begin = blockIdx.z * p.ks_per_split;
-      ksteps = min(ksteps, ks_begin + p.ks_per_split);
-    }
-  }
-
-  // ---- per-thread gather state (32-bit element offsets; the host guarantees < 2^30 elements)
-  // KC loaders: thread -> (row = tid/4 + 64*i, 4 consecutive k at kq4)
-  // MC loaders: thread -> float4 unit u = tid + 256*i of the [16][B?/4] tile
-  int a_base[A_LD], a_y[A_LD], a_x[A_LD], a_n[A_LD];
-  bool a_ok[A_LD];
-  unsigned b_base[B_LD];
-  if constexpr (A_KC) {
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      int m = m0 + (tid / KQ) + RP * i;
-      a_ok[i] = m < p.M;
-      int mm = a_ok[i] ? m : 0;
-      if constexpr (MODE == MODE_FWD) {
-        int ow = mm % p.OW, t = mm / p.OW;
-        a_x[i] = ow * p.stride - p.pl;
-        a_y[i] = (t % p.OH) * p.stride - p.pt;
-        a_n[i] = t / p.OH;
-        a_base[i] = ((a_n[i] * p.H + a_y[i]) * p.W + a_x[i]) * p.C + kq4;
-      } else {
-        int iw = mm % p.W, t = mm / p.W;
-        a_x[i] = iw + p.pl;
-        a_y[i] = (t % p.H) + p.pt;
-        a_n[i] = t / p.H;
-        a_base[i] = ((a_n[i] * p.OH + a_y[i]) * p.OW + a_x[i]) * p.K + kq4;   // stride-1 form
-      }
-    }
-  }
-  // Ragged N (channel counts that are not a multiple of the tile): columns >= NG get the
-  // out-of-range offset, so their LDS image is zero and the epilogue skips them.
-#pragma unroll
-  for (int i = 0; i < B_LD; ++i) {
-    if constexpr (MODE == MODE_FWD) {
-      int u = tid + 256 * i;
-      int col = n0 + (u % (BN / 4)) * 4;
-      b_base[i] = col < p.NG ? (unsigned)((u / (BN / 4)) * p.K + col) * 4u : OOB;
-    } else if constexpr (MODE == MODE_DGRAD) {
-      int row = n0 + (tid / KQ) + RP * i;
-      b_base[i] = row < p.NG ? (unsigned)(row * p.K + kq4) * 4u : OOB;
-    } else {
-      int u = tid + 256 * i;
-      int col = n0 + (u % (BN / 4)) * 4;
-      b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
-    }
-  }
-
-  floatx4 ra[A_LD], rb[B_LD];
-
-  auto load_tile = [&](int ks) {
-    if constexpr (MODE == MODE_FWD) {
-      int cpk = p.C / BKT;
-      int rs = ks / cpk, c0 = (ks - rs * cpk) * BKT;
-      int r = rs / p.S, s = rs - r * p.S;
-      int dy = r * p.dil, dx = s * p.dil;
-      int tapoff = (dy * p.W + dx) * p.C + c0;
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i) {
-        int ih = a_y[i] + dy, iw = a_x[i] + dx;
-        bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        ra[i] = bufload4(rsrc_a, ok ? (unsigned)(a_base[i] + tapoff) * 4u : OOB, 0);
-      }
-      unsigned so = (unsigned)(ks * BKT * p.K) * 4u;
-#pragma unroll
-      for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, b_base[i], so);
-      if (p.NG & 3) {   // filter rows are only dword aligned and the last quad runs into the next row
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-          int left = p.NG - (n0 + ((tid + 256 * i) % (BN / 4)) * 4);
-#pragma unroll
-          for (int e = 1; e < 4; ++e) rb[i][e] = e < left ? rb[i][e] : 0.f;
-        }
-      }
-    } else if constexpr (MODE == MODE_DGRAD) {
-      int kpk = p.K / BKT;
-      int rs = ks / kpk, k0 = (ks - rs * kpk) * BKT;
-      int r = rs / p.S, s = rs - r * p.S;
-      int dy = r * p.dil, dx = s * p.dil;
-      if (p.stride == 1) {
-        int tapoff = k0 - (dy * p.OW + dx) * p.K;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-          int oh = a_y[i] - dy, ow = a_x[i] - dx;
-          bool ok = a_ok[i] && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
-          ra[i] = bufload4(rsrc_a, ok ? (unsigned)(a_base[i] + tapoff) * 4u : OOB, 0);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-          int ny = a_y[i] - dy, nx = a_x[i] - dx;
-          bool ok = a_ok[i] && ny >= 0 && nx >= 0 && (ny % p.stride == 0) && (nx % p.stride == 0);
-          int oh = ny / p.stride, ow = nx / p.stride;
-          ok = ok && oh < p.OH && ow < p.OW;
-          int off = ((a_n[i] * p.OH + oh) * p.OW + ow) * p.K + k0 + kq4;
-          ra[i] = bufload4(rsrc_a, ok ? (unsigned)off * 4u : OOB, 0);
-        }
-      }
-      unsigned so = (unsigned)(rs * p.C * p.K + k0) * 4u;
-#pragma unroll
-      for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, b_base[i], so);
-    } else {
-      int r = rs_fixed / p.S, s = rs_fixed - r * p.S;
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i) {
-        int u = tid + 256 * i;
-        int kr = u / (BM / 4), m4 = u % (BM / 4);
-        int pix = pix0 + ks * BKT + kr;
-        bool ok = pix < pix1;
-        int off = 0;
-        if (p.R == 1 && p.S == 1 && p.stride == 1) {
-          off = pix * p.C;
-        } else {
-          int ow = pix % p.OW, t = pix / p.OW;
-          int oh = t % p.OH, n = t / p.OH;
-          int ih = oh * p.stride - p.pt + r * p.dil, iw = ow * p.stride - p.pl + s * p.dil;
-          ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-          off = ((n * p.H + ih) * p.W + iw) * p.C;
-        }
-        ok = ok && (m0 + m4 * 4) < p.M;
-        ra[i] = bufload4(rsrc_a, ok ? (unsigned)(off + m0 + m4 * 4) * 4u : OOB, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < B_LD; ++i) {
-        int u = tid + 256 * i;
-        int pix = pix0 + ks * BKT + u / (BN / 4);
-        rb[i] = bufload4(rsrc_b, (pix < pix1 && b_base[i] != OOB) ? b_base[i] + (unsigned)(pix * p.K) * 4u : OOB, 0);
-      }
-    }
-  };
-
-  auto store_tile = [&](int buf) {
-    float* a = sA + buf * (BKT * LDA);
-    float* b = sB + buf * (BKT * LDB);
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-      if constexpr (A_KC) {
-        int row = (tid / KQ) + RP * i;
-        a[(kq4 + 0) * LDA + row] = ra[i].x; a[(kq4 + 1) * LDA + row] = ra[i].y;
-        a[(kq4 + 2) * LDA + row] = ra[i].z; a[(kq4 + 3) * LDA + row] = ra[i].w;
-      } else {
-        int u = tid + 256 * i;
-        *reinterpret_cast<floatx4*>(a + (u / (BM / 4)) * LDA + (u % (BM / 4)) * 4) = ra[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_LD; ++i) {
-      if constexpr (B_KC) {
-        int row = (tid / KQ) + RP * i;
-        b[(kq4 + 0) * LDB + row] = rb[i].x; b[(kq4 + 1) * LDB + row] = rb[i].y;
-        b[(kq4 + 2) * LDB + row] = rb[i].z; b[(kq4 + 3) * LDB + row] = rb[i].w;
-      } else {
-        int u = tid + 256 * i;
-        *reinterpret_cast<floatx4*>(b + (u / (BN / 4)) * LDB + (u % (BN / 4)) * 4) = rb[i];
-      }
-    }
-  };
-
-  floatx16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  if (ksteps > ks_begin) {
-    load_tile(ks_begin);
-    store_tile(ks_begin & 1);
-  }
-  __syncthreads();
-  for (int ks = ks_begin; ks < ksteps; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < ksteps) load_tile(ks + 1);
-    const float* a = sA + cur * (BKT * LDA) + wr * (BM / 2) + lo;
-    const float* b = sB + cur * (BKT * LDB) + wc * (BN / 2) + lo;
-    // Software-pipelined fragments: the ds_reads of k-pair kk+1 are issued BEFORE the MFMAs of
-    // k-pair kk (two register sets), pinned with sched_barrier so hipcc does not re-serialise them
-    // into read -> wait -> MFMA; LDS latency is then exposed once per K-step instead of 8 times.
-    float fa[2][TM], fb[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = a[hi * LDA + i * 32];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = b[hi * LDB + j * 32];
-#pragma unroll
-    for (int kk = 0; kk < BKT / 2; ++kk) {
-      const int cs = kk & 1, ns = cs ^ 1;
-      if (kk + 1 < BKT / 2) {
-        const int kr = 2 * (kk + 1) + hi;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[ns][i] = a[kr * LDA + i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[ns][j] = b[kr * LDB + j * 32];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cs][i], fb[cs][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (ks + 1 < ksteps) store_tile(cur ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue. MFMA C/D map: lane l, reg e -> row (e&3) + 8*(e>>2) + 4*(l>>5), col l&31.
-  const int ldo = p.NG;
-  float* outp = p.out;
-  if constexpr (MODE == MODE_WGRAD)
-    outp += ((int64_t)blockIdx.z * (p.R * p.S) + rs_fixed) * (int64_t)p.M * p.NG;
-  const bool raw = (MODE != MODE_WGRAD) && p.nsplit > 1;   // split-K partial: epilogue runs later
-  if (raw) outp = p.splitk_ws + (int64_t)blockIdx.z * (int64_t)(p.M - p.ws_m0) * p.NG;
-  if (!(p.NG & 3)) {
-    // Coalesced epilogue: each wave transposes its 32x32 accumulator tiles through a private LDS
-    // patch (the operand buffers are free after the last K-step's barrier) so that a lane holds 4
-    // consecutive columns: 4 ds_read_b128 + 4 global 16-byte stores per tile instead of 64 scalar
-    // stores, and the bias / residual / mask / accumulate operands come in as 16-byte loads too.
-    float* tile = smem + wid * (32 * LDT);                 // LDT: 16-byte aligned rows, conflict-light
-    const int r_in = lane >> 3, c4 = (lane & 7) * 4;      // this lane's row (mod 8) and first column in the tile
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hi) * LDT + lo] = acc[i][j][e];
-        const int col = n0 + wc * (BN / 2) + j * 32 + c4;
-        floatx4 bv = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == MODE_FWD)
-          if ((p.epi & MTLSSL_EPI_BIAS) && col < p.NG && !raw) bv = *reinterpret_cast<const floatx4*>(p.bias + col);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int rt = r_in + 8 * k;
-          floatx4 v = *reinterpret_cast<const floatx4*>(tile + rt * LDT + c4);
-          const int row = m0 + wr * (BM / 2) + i * 32 + rt;
-          if (row >= p.M || col >= p.NG) continue;
-          if (raw) {
-            *reinterpret_cast<floatx4*>(outp + (int64_t)(row - p.ws_m0) * ldo + col) = v;
-            continue;
-          }
-          const int64_t o = (int64_t)row * ldo + col;
-          if constexpr (MODE == MODE_FWD) {
-            v += bv;
-            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              if (p.epi & MTLSSL_EPI_RELU) v[q] = fmaxf(v[q], 0.f);
-              if (p.epi & MTLSSL_EPI_RELU6) v[q] = fminf(fmaxf(v[q], 0.f), 6.f);
-              if (p.epi & MTLSSL_EPI_TANH) v[q] = tanhf(v[q]);
-            }
-          } else if constexpr (MODE == MODE_DGRAD) {
-            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
-            if (p.epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const floatx4*>(outp + o);
-            if (p.epi & MASK_ANY) {
-              floatx4 mk = *reinterpret_cast<const floatx4*>(p.mask + o);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = act_mask(v[q], mk[q], p.epi);
-            }
-          }
-          *reinterpret_cast<floatx4*>(outp + o) = v;
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wc * (BN / 2) + j * 32 + lo;
-      const bool col_ok = col < p.NG;
-      float bv = 0.f;
-      if constexpr (MODE == MODE_FWD)
-        if ((p.epi & MTLSSL_EPI_BIAS) && col_ok) bv = p.bias[col];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        if (row >= p.M || !col_ok) continue;
-        const int64_t o = (int64_t)row * ldo + col;
-        float v = acc[i][j][e];
-        if (raw) {
-          outp[(int64_t)(row - p.ws_m0) * ldo + col] = v;
-          continue;
-        }
-        if constexpr (MODE == MODE_FWD) {
-          v += bv;
-          if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
-          if (p.epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
-          if (p.epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
-          if (p.epi & MTLSSL_EPI_TANH) v = tanhf(v);
-        } else if constexpr (MODE == MODE_DGRAD) {
-          if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
-          if (p.epi & MTLSSL_EPI_ACCUM) v += outp[o];
-          if (p.epi & MASK_ANY) v = act_mask(v, p.mask[o], p.epi);
-        }
-        outp[o] = v;
-      }
-    }
-  }
-}
 
 // wgrad split-K fold: dw = beta*dw + scale[k] * sum_split ws[split]; float4 over k.
 __global__ void k_wgrad_reduce(const float* ws, int nsplit, int64_t total4, int K,
@@ -780,16 +384,6 @@ static ConvArgs make_args(const mtlssl_conv_desc* d) {
   return p;
 }
 
-// Kernel configurations: tile (bm x bn) and K-step depth. The kernel template takes the K-step
-// depth as a parameter; 32-deep variants of the 128x64 and 64x64 tiles (half the barriers, twice the
-// prefetch distance) were built and measured 3-10 % SLOWER than the 16-deep ones on every layer
-// shape of config[1] (tools/bench_conv.py, round 1), so only the 16-deep ones are instantiated.
-// A 128x192 tile (for Inception's 192 / 2080-wide layers) was built and measured too: 88 TFLOP/s where
-// the 128x128 and 64x64 tiles reach 115-128 on the same layers (154 VGPRs, 42 KB LDS), so it is out.
-constexpr int NCFG = 3;
-static const int CFG_BM[NCFG] = {128, 128, 64};
-static const int CFG_BN[NCFG] = {128, 64, 64};
-static const int CFG_BK[NCFG] = {16, 16, 16};
 static inline bool cfg_allowed(int c, int kc) { return kc % CFG_BK[c] == 0; }
 
 static int check_desc(const mtlssl_conv_desc* d) {
@@ -857,38 +451,33 @@ __global__ void k_splitk_epilogue(ConvArgs p) {
 // `tail_nsplit` ways (wave quantisation: T tiles on S resident slots leave T mod S tiles that would
 // run a whole tile time at low occupancy; split along K they finish in 1/tail_nsplit of it).
 struct Plan { int cfg, nsplit, ks_per_split, tail_rows, tail_nsplit, tail_ks; };
-// Time model shared by the planners (microseconds). A CU retires one 16-deep K-step of a
-// bm x bn tile in bm*bn*32 FLOP / 614 GFLOP/s (fp32 MFMA peak per CU); blocks beyond what is
-// resident queue up. A CU holding a single block (one wave per SIMD) cannot hide its own LDS /
-// barrier latencies, hence the occupancy factor. Constants fitted to tools/bench_conv.py.
-static double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block) {
-  const int resident[NCFG] = {3, 6, 8};
-  const double base_eff[NCFG] = {0.80, 0.76, 0.72};
-  int64_t per_cu = cdiv(nblocks, 256);
-  int64_t occ = per_cu < resident[cfg] ? per_cu : resident[cfg];
-  double occ_eff = occ <= 1 ? 0.55 : (occ == 2 ? 0.80 : 1.0);
-  double step_us = CFG_BM[cfg] * CFG_BN[cfg] * 2.0 * CFG_BK[cfg] / 614e9 * 1e6 / (base_eff[cfg] * occ_eff);
-  return (double)per_cu * (ksteps_per_block + 96 / CFG_BK[cfg]) * step_us;
-}
-
 // Tile choices measured by the caller's autotuner (mtlssl_conv2d_force_config): key = GEMM shape +
 // mode; the time-model planner still picks the K split / tail split for the forced tile.
 struct TunedKey {
-  int mode; int64_t M, NG; int taps, kc;
-  bool operator==(const TunedKey& o) const { return mode == o.mode && M == o.M && NG == o.NG && taps == o.taps && kc == o.kc; }
+  int mode; int64_t M, NG; int taps, kc, hw;   // hw: map height << 16 | width (tells conv geometries with one GEMM shape apart)
+  bool operator==(const TunedKey& o) const {
+    return mode == o.mode && M == o.M && NG == o.NG && taps == o.taps && kc == o.kc && hw == o.hw;
+  }
 };
 struct TunedHash {
   size_t operator()(const TunedKey& k) const {
     uint64_t h = 1469598103934665603ull;
-    for (uint64_t v : {(uint64_t)k.mode, (uint64_t)k.M, (uint64_t)k.NG, (uint64_t)k.taps, (uint64_t)k.kc}) { h ^= v; h *= 1099511628211ull; }
+    for (uint64_t v : {(uint64_t)k.mode, (uint64_t)k.M, (uint64_t)k.NG, (uint64_t)k.taps, (uint64_t)k.kc, (uint64_t)k.hw}) { h ^= v; h *= 1099511628211ull; }
     return (size_t)h;
   }
 };
 static std::unordered_map<TunedKey, int, TunedHash>& tuned_map() { static std::unordered_map<TunedKey, int, TunedHash> m; return m; }
 static std::mutex& tuned_mutex() { static std::mutex m; return m; }
-static int tuned_cfg(int mode, int64_t M, int64_t NG, int taps, int kc) {
+static TunedKey make_key(const mtlssl_conv_desc* d, int mode) {
+  const int hw = (d->H << 16) | (d->W & 0xffff);
+  if (mode == MODE_FWD) return TunedKey{mode, (int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C, hw};
+  if (mode == MODE_DGRAD) return TunedKey{mode, (int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K, hw};
+  int64_t P = (int64_t)d->N * d->OH * d->OW;
+  return TunedKey{mode, d->C, d->K, d->R * d->S, (int)(P > 0x7fffffff ? 0x7fffffff : P), hw};
+}
+static int tuned_cfg(const mtlssl_conv_desc* d, int mode) {
   std::lock_guard<std::mutex> g(tuned_mutex());
-  auto it = tuned_map().find(TunedKey{mode, M, NG, taps, kc});
+  auto it = tuned_map().find(make_key(d, mode));
   return it == tuned_map().end() ? -1 : it->second;
 }
 
@@ -901,13 +490,13 @@ static bool tail_split_enabled() {
   return v != 0;
 }
 // kc = reduction channels per filter tap (C for fwd, K for dgrad), taps = R*S.
-static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int mode) {
+static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double* t_out = nullptr) {
   const int resident[NCFG] = {3, 6, 8};
   Plan best{2, 1, taps * (kc / 16), 0, 1, 0};
   double best_t = 1e30;
   static int env_force = -2;
   if (env_force == -2) { const char* e = getenv("MTLSSL_FORCE_CFG"); env_force = e ? atoi(e) : -1; }
-  int force = env_force >= 0 ? env_force : tuned_cfg(mode, M, NG, taps, kc);
+  int force = env_force >= 0 ? env_force : tuned;
   if (force >= NCFG || (force >= 0 && !cfg_allowed(force, kc))) force = -1;
   for (int c = 0; c < NCFG; ++c) {
     if (!cfg_allowed(c, kc)) continue;
@@ -942,7 +531,14 @@ static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int mode) {
       }
     }
   }
+  if (t_out) *t_out = best_t;
   return best;
+}
+// Direct-path plan of a fwd / dgrad problem.
+static Plan plan_dir(const mtlssl_conv_desc* d, int mode, double* t_out = nullptr) {
+  const int64_t M = mode == MODE_FWD ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W;
+  return plan_gemm(M, mode == MODE_FWD ? d->K : d->C, d->R * d->S, mode == MODE_FWD ? d->C : d->K,
+                   tuned_cfg(d, mode), t_out);
 }
 
 constexpr int COLSUM_MAX_PARTS = 64;
@@ -1010,12 +606,12 @@ static void launch_planned(const Plan& pl, ConvArgs& p, float* ws, hipStream_t s
   hipLaunchKernelGGL(k_splitk_epilogue<MODE>, dim3(cdiv((int64_t)f.M * f.NG / 4, 256)), dim3(256), 0, st, f);
 }
 
-static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pps) {
+static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pps, double* t_out = nullptr) {
   int64_t P = (int64_t)d->N * d->OH * d->OW;
   int RS = d->R * d->S;
   double best_t = 1e30;
   *cfg = 2; *nsplit = 1; *pps = (int)align_up(P, 16);
-  const int force = tuned_cfg(MODE_WGRAD, d->C, d->K, RS, (int)(P > 0x7fffffff ? 0x7fffffff : P));
+  const int force = tuned_cfg(d, MODE_WGRAD);
   for (int c = 0; c < NCFG; ++c) {
     if (force >= 0 && force < NCFG && c != force) continue;
     int bk = CFG_BK[c];
@@ -1032,6 +628,36 @@ static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pp
       if (t < best_t) { best_t = t; *cfg = c; *nsplit = ns; *pps = per * bk; }
     }
   }
+  if (t_out) *t_out = best_t;
+}
+
+// Direct or Winograd F(4x4,3x3)? MTLSSL_WINOGRAD: 0 never, 1 (default) by the plan registry, else by
+// the time models; 2 every eligible problem. Registry codes WINO_CFG0 + tile select Winograd with that
+// GEMM tile; codes 0..NCFG-1 pin the direct path.
+constexpr int WINO_CFG0 = 4;
+static int wino_env() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MTLSSL_WINOGRAD");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+static bool choose_wino(const mtlssl_conv_desc* d, int mode, int* tile) {
+  const int env = wino_env();
+  if (env == 0 || !wino_eligible(d, mode)) return false;
+  if (mode == MODE_FWD ? !mfma_fwd_ok(d) : (mode == MODE_DGRAD ? !mfma_dgrad_ok(d) : !mfma_wgrad_ok(d))) return false;
+  const int force = tuned_cfg(d, mode);
+  int model_tile;
+  const double tw = wino_time_us(d, mode, &model_tile);
+  if (force >= WINO_CFG0 && force < WINO_CFG0 + NCFG) { *tile = force - WINO_CFG0; return true; }
+  *tile = model_tile;
+  if (env == 2) return true;
+  if (force >= 0) return false;
+  double td;
+  if (mode == MODE_WGRAD) { int c, ns, pps; wgrad_plan(d, &c, &ns, &pps, &td); }
+  else plan_dir(d, mode, &td);
+  return tw < td;
 }
 
 }  // namespace mtlssl
@@ -1045,9 +671,10 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
   if (mode == MODE_WGRAD) return mtlssl_conv2d_wgrad_workspace_bytes(d);
   int64_t M = mode == MODE_FWD ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W;
   int64_t NG = mode == MODE_FWD ? d->K : d->C;
-  int kc = mode == MODE_FWD ? d->C : d->K;
   if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : mfma_dgrad_ok(d))) return 0;
-  Plan pl = plan_gemm(M, NG, d->R * d->S, kc, mode);
+  int wt;
+  if (choose_wino(d, mode, &wt)) return wino_workspace_bytes(d, mode);
+  Plan pl = plan_dir(d, mode);
   if (pl.tail_rows > 0) {
     int64_t m_tail0 = (cdiv(M, CFG_BM[pl.cfg]) - pl.tail_rows) * CFG_BM[pl.cfg];
     return align_up((M - m_tail0) * NG * 4 * pl.tail_nsplit, 256);
@@ -1067,8 +694,11 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
   p.b_bytes = (unsigned)((int64_t)d->R * d->S * d->C * d->K * 4);
   p.M = d->N * d->OH * d->OW;
   p.NG = d->K;
-  if (mfma_fwd_ok(d)) {
-    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S, d->C, MODE_FWD);
+  int wt;
+  if (workspace && choose_wino(d, MODE_FWD, &wt)) {
+    wino_fwd(d, wt, x, w, bias, residual, y, epi, workspace, S(stream));
+  } else if (mfma_fwd_ok(d)) {
+    Plan pl = plan_dir(d, MODE_FWD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
     launch_planned<MODE_FWD>(pl, p, (float*)workspace, S(stream));
   } else if (is_pointwise(d)) {
@@ -1097,8 +727,11 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   p.b_bytes = (unsigned)((int64_t)d->R * d->S * d->C * d->K * 4);
   p.M = d->N * d->H * d->W;
   p.NG = d->C;
-  if (mfma_dgrad_ok(d)) {
-    Plan pl = plan_gemm(p.M, p.NG, d->R * d->S, d->K, MODE_DGRAD);
+  int wt;
+  if (workspace && choose_wino(d, MODE_DGRAD, &wt)) {
+    wino_dgrad(d, wt, dy, w, residual, mask_ref, dx, epi, workspace, S(stream));
+  } else if (mfma_dgrad_ok(d)) {
+    Plan pl = plan_dir(d, MODE_DGRAD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
     launch_planned<MODE_DGRAD>(pl, p, (float*)workspace, S(stream));
   } else if (is_pointwise(d)) {
@@ -1112,32 +745,22 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
 }
 
 int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
-  if (!d) return -1;
-  if (mode == MODE_FWD)
-    return mfma_fwd_ok(d)
-               ? plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C, MODE_FWD).cfg : -1;
-  if (mode == MODE_DGRAD)
-    return mfma_dgrad_ok(d)
-               ? plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K, MODE_DGRAD).cfg : -1;
+  if (!d || mode < MODE_FWD || mode > MODE_WGRAD) return -1;
+  if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : (mode == MODE_DGRAD ? mfma_dgrad_ok(d) : mfma_wgrad_ok(d)))) return -1;
+  int wt;
+  if (choose_wino(d, mode, &wt)) return WINO_CFG0 + wt;
   if (mode == MODE_WGRAD) {
-    if (!mfma_wgrad_ok(d)) return -1;
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);
     return cfg;
   }
-  return -1;
+  return plan_dir(d, mode).cfg;
 }
 
 int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg) {
   MTLSSL_REQUIRE(d != nullptr && mode >= MODE_FWD && mode <= MODE_WGRAD, "force_config: bad arguments");
-  MTLSSL_REQUIRE(cfg < NCFG, "force_config: tile configuration out of range");
-  TunedKey k;
-  if (mode == MODE_FWD) k = TunedKey{mode, (int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C};
-  else if (mode == MODE_DGRAD) k = TunedKey{mode, (int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K};
-  else {
-    int64_t P = (int64_t)d->N * d->OH * d->OW;
-    k = TunedKey{mode, d->C, d->K, d->R * d->S, (int)(P > 0x7fffffff ? 0x7fffffff : P)};
-  }
+  MTLSSL_REQUIRE(cfg < WINO_CFG0 + NCFG && cfg != NCFG, "force_config: tile configuration out of range");
+  TunedKey k = make_key(d, mode);
   std::lock_guard<std::mutex> g(tuned_mutex());
   if (cfg < 0) tuned_map().erase(k); else tuned_map()[k] = cfg;
   return MTLSSL_OK;
@@ -1145,10 +768,9 @@ int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg) {
 
 int mtlssl_conv2d_num_dispatches(const mtlssl_conv_desc* d, int mode) {
   if (!d) return 0;
-  if (mode == MODE_FWD && mfma_fwd_ok(d))
-    return plan_gemm((int64_t)d->N * d->OH * d->OW, d->K, d->R * d->S, d->C, MODE_FWD).tail_rows > 0 ? 2 : 1;
-  if (mode == MODE_DGRAD && mfma_dgrad_ok(d))
-    return plan_gemm((int64_t)d->N * d->H * d->W, d->C, d->R * d->S, d->K, MODE_DGRAD).tail_rows > 0 ? 2 : 1;
+  int wt;
+  if ((mode == MODE_FWD && mfma_fwd_ok(d)) || (mode == MODE_DGRAD && mfma_dgrad_ok(d)))
+    return !choose_wino(d, mode, &wt) && plan_dir(d, mode).tail_rows > 0 ? 2 : 1;
   return 1;
 }
 
@@ -1162,7 +784,8 @@ int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
     small_wgrad_plan(d, &ns, &kps);
     return bias_part + align_up((int64_t)ns * d->C * d->K * 4, 256);
   }
-  int cfg, ns, pps;
+  int cfg, ns, pps, wt;
+  if (choose_wino(d, MODE_WGRAD, &wt)) return bias_part + wino_workspace_bytes(d, MODE_WGRAD);
   wgrad_plan(d, &cfg, &ns, &pps);
   return bias_part + align_up((int64_t)ns * d->R * d->S * d->C * d->K * 4, 256);
 }
@@ -1179,7 +802,10 @@ int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* 
   int64_t P = (int64_t)d->N * d->OH * d->OW;
   MTLSSL_REQUIRE(workspace != nullptr, "conv_wgrad: workspace required");
   float* ws_main = (float*)((char*)workspace + align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256));
-  if (mfma_wgrad_ok(d)) {
+  int wt;
+  if (choose_wino(d, MODE_WGRAD, &wt)) {
+    wino_wgrad(d, wt, x, dy, out_scale, dw, beta, ws_main, st);
+  } else if (mfma_wgrad_ok(d)) {
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);
     p.out = ws_main;

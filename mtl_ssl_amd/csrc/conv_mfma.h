@@ -1,0 +1,462 @@
+// Tile engine of the NHWC fp32 convolution family (see conv.hip for the description): ConvArgs, the
+// implicit-GEMM MFMA kernel body with its three gather modes, the kernel wrappers and the tile /
+// time-model tables shared by conv.hip (direct path) and winograd.hip (Winograd-domain GEMM stacks).
+#pragma once
+#include "common.h"
+
+namespace mtlssl {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+// ReLU / ReLU6 backward: pass the gradient where the activation was in its linear range.
+__device__ __forceinline__ float act_mask(float g, float y, int epi) {
+  bool on = y > 0.f && (!(epi & MTLSSL_EPI_MASK6) || y < 6.f);
+  return on ? g : 0.f;
+}
+constexpr int MASK_ANY = MTLSSL_EPI_MASK | MTLSSL_EPI_MASK6;
+constexpr int BK = 16;
+
+struct ConvArgs {
+  const float* a;        // fwd: x     dgrad: dy    wgrad: x
+  const float* b;        // fwd: w     dgrad: w     wgrad: dy
+  float* out;            // fwd: y     dgrad: dx    wgrad: workspace partials
+  const float* bias;     // fwd
+  const float* residual; // fwd / dgrad
+  const float* mask;     // dgrad
+  float* splitk_ws;      // fwd/dgrad split-K partials [nsplit][M][NG]
+  int N, H, W, C, K, R, S, OH, OW, stride, dil, pt, pl;
+  int M;                 // GEMM rows
+  int NG;                // GEMM cols
+  int epi;
+  int tiles_m, tiles_n;
+  unsigned a_bytes, b_bytes;   // extents of the a / b tensors (buffer-load range checks)
+  int nsplit;            // wgrad: splits of the pixel range; fwd/dgrad: splits of the K loop
+  int ks_per_split;      // fwd/dgrad split-K: K-steps per split
+  int pix_per_split;     // wgrad
+  int tile_m0;           // first tile row covered by this launch (tail launches start past 0)
+  int ws_m0;             // first GEMM row held by the split-K workspace of this launch
+  int64_t a_bs, b_bs, o_bs;   // batched launches: element strides between the planes of a / b / out
+};
+
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ floatx4 bufload4(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset,
+                                            unsigned soffset) {
+  // raw buffer load: an offset beyond num_records returns zeros, which is exactly the zero
+  // padding / ragged-tile semantics the gathers need — no branches around the loads.
+  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+}
+
+// BATCH: the launch is a stack of gridDim.y independent GEMMs (the Winograd-domain products);
+// blockIdx.y selects the operand / output planes `a_bs` / `b_bs` / `o_bs` elements apart.
+template <int BM, int BN, int MODE, int BKT, bool BATCH>
+__device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int KQ = BKT / 4;                     // float4 quads along k per tile row
+  constexpr int RP = 256 / KQ;                    // tile rows covered by one pass of the KC loaders
+  constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave in m / n
+  constexpr bool A_KC = (MODE != MODE_WGRAD);     // A float4 runs along k (else along m)
+  constexpr bool B_KC = (MODE == MODE_DGRAD);     // B float4 runs along k (else along n)
+  constexpr int A_LD = BM / RP, B_LD = BN / RP;   // float4 loads per thread per K-step
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  constexpr int LDT = 36;                          // epilogue staging: floats per row of a 32x32 tile
+  constexpr int SMEM_OPS = 2 * BKT * (LDA + LDB), SMEM_EPI = 4 * 32 * LDT;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_OPS > SMEM_EPI ? SMEM_OPS : SMEM_EPI];
+  float* const sA = smem;
+  float* const sB = smem + 2 * BKT * LDA;
+
+  // XCD-aware tile order: the dispatcher places block b on XCD b%8; give each XCD a contiguous
+  // range of tiles (n fastest) so blocks sharing an A row-panel share an L2.
+  int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tile_m = bid / p.tiles_n + p.tile_m0, tile_n = bid % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int kq4 = (tid % KQ) * 4;
+
+  if constexpr (BATCH) {
+    p.a += (int64_t)blockIdx.y * p.a_bs;
+    p.b += (int64_t)blockIdx.y * p.b_bs;
+    if constexpr (MODE != MODE_WGRAD) p.out += (int64_t)blockIdx.y * p.o_bs;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
+
+  // ---- K-loop extent
+  int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps, ks_begin = 0;
+  if constexpr (MODE == MODE_FWD) {
+    ksteps = p.R * p.S * (p.C / BKT);
+  } else if constexpr (MODE == MODE_DGRAD) {
+    ksteps = p.R * p.S * (p.K / BKT);
+  } else {
+    rs_fixed = BATCH ? 0 : blockIdx.y;
+    int split = blockIdx.z;
+    int P = p.N * p.OH * p.OW;
+    pix0 = split * p.pix_per_split;
+    pix1 = min(P, pix0 + p.pix_per_split);
+    ksteps = (max(pix1 - pix0, 0) + BKT - 1) / BKT;
+  }
+  if constexpr (MODE != MODE_WGRAD) {
+    if (p.nsplit > 1) {          // split-K: this block covers K-steps [ks_begin, ksteps)
+      ks_begin = blockIdx.z * p.ks_per_split;
+      ksteps = min(ksteps, ks_begin + p.ks_per_split);
+    }
+  }
+
+  // ---- per-thread gather state (32-bit element offsets; the host guarantees < 2^30 elements)
+  // KC loaders: thread -> (row = tid/4 + 64*i, 4 consecutive k at kq4)
+  // MC loaders: thread -> float4 unit u = tid + 256*i of the [16][B?/4] tile
+  int a_base[A_LD], a_y[A_LD], a_x[A_LD], a_n[A_LD];
+  bool a_ok[A_LD];
+  unsigned b_base[B_LD];
+  if constexpr (A_KC) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      int m = m0 + (tid / KQ) + RP * i;
+      a_ok[i] = m < p.M;
+      int mm = a_ok[i] ? m : 0;
+      if constexpr (MODE == MODE_FWD) {
+        int ow = mm % p.OW, t = mm / p.OW;
+        a_x[i] = ow * p.stride - p.pl;
+        a_y[i] = (t % p.OH) * p.stride - p.pt;
+        a_n[i] = t / p.OH;
+        a_base[i] = ((a_n[i] * p.H + a_y[i]) * p.W + a_x[i]) * p.C + kq4;
+      } else {
+        int iw = mm % p.W, t = mm / p.W;
+        a_x[i] = iw + p.pl;
+        a_y[i] = (t % p.H) + p.pt;
+        a_n[i] = t / p.H;
+        a_base[i] = ((a_n[i] * p.OH + a_y[i]) * p.OW + a_x[i]) * p.K + kq4;   // stride-1 form
+      }
+    }
+  }
+  // Ragged N (channel counts that are not a multiple of the tile): columns >= NG get the
+  // out-of-range offset, so their LDS image is zero and the epilogue skips them.
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    if constexpr (MODE == MODE_FWD) {
+      int u = tid + 256 * i;
+      int col = n0 + (u % (BN / 4)) * 4;
+      b_base[i] = col < p.NG ? (unsigned)((u / (BN / 4)) * p.K + col) * 4u : OOB;
+    } else if constexpr (MODE == MODE_DGRAD) {
+      int row = n0 + (tid / KQ) + RP * i;
+      b_base[i] = row < p.NG ? (unsigned)(row * p.K + kq4) * 4u : OOB;
+    } else {
+      int u = tid + 256 * i;
+      int col = n0 + (u % (BN / 4)) * 4;
+      b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
+    }
+  }
+
+  floatx4 ra[A_LD], rb[B_LD];
+
+  auto load_tile = [&](int ks) {
+    if constexpr (MODE == MODE_FWD) {
+      int cpk = p.C / BKT;
+      int rs = ks / cpk, c0 = (ks - rs * cpk) * BKT;
+      int r = rs / p.S, s = rs - r * p.S;
+      int dy = r * p.dil, dx = s * p.dil;
+      int tapoff = (dy * p.W + dx) * p.C + c0;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        int ih = a_y[i] + dy, iw = a_x[i] + dx;
+        bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        ra[i] = bufload4(rsrc_a, ok ? (unsigned)(a_base[i] + tapoff) * 4u : OOB, 0);
+      }
+      unsigned so = (unsigned)(ks * BKT * p.K) * 4u;
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, b_base[i], so);
+      if (p.NG & 3) {   // filter rows are only dword aligned and the last quad runs into the next row
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+          int left = p.NG - (n0 + ((tid + 256 * i) % (BN / 4)) * 4);
+#pragma unroll
+          for (int e = 1; e < 4; ++e) rb[i][e] = e < left ? rb[i][e] : 0.f;
+        }
+      }
+    } else if constexpr (MODE == MODE_DGRAD) {
+      int kpk = p.K / BKT;
+      int rs = ks / kpk, k0 = (ks - rs * kpk) * BKT;
+      int r = rs / p.S, s = rs - r * p.S;
+      int dy = r * p.dil, dx = s * p.dil;
+      if (p.stride == 1) {
+        int tapoff = k0 - (dy * p.OW + dx) * p.K;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+          int oh = a_y[i] - dy, ow = a_x[i] - dx;
+          bool ok = a_ok[i] && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
+          ra[i] = bufload4(rsrc_a, ok ? (unsigned)(a_base[i] + tapoff) * 4u : OOB, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+          int ny = a_y[i] - dy, nx = a_x[i] - dx;
+          bool ok = a_ok[i] && ny >= 0 && nx >= 0 && (ny % p.stride == 0) && (nx % p.stride == 0);
+          int oh = ny / p.stride, ow = nx / p.stride;
+          ok = ok && oh < p.OH && ow < p.OW;
+          int off = ((a_n[i] * p.OH + oh) * p.OW + ow) * p.K + k0 + kq4;
+          ra[i] = bufload4(rsrc_a, ok ? (unsigned)off * 4u : OOB, 0);
+        }
+      }
+      unsigned so = (unsigned)(rs * p.C * p.K + k0) * 4u;
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, b_base[i], so);
+    } else {
+      int r = rs_fixed / p.S, s = rs_fixed - r * p.S;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) {
+        int u = tid + 256 * i;
+        int kr = u / (BM / 4), m4 = u % (BM / 4);
+        int pix = pix0 + ks * BKT + kr;
+        bool ok = pix < pix1;
+        int off = 0;
+        if (p.R == 1 && p.S == 1 && p.stride == 1) {
+          off = pix * p.C;
+        } else {
+          int ow = pix % p.OW, t = pix / p.OW;
+          int oh = t % p.OH, n = t / p.OH;
+          int ih = oh * p.stride - p.pt + r * p.dil, iw = ow * p.stride - p.pl + s * p.dil;
+          ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          off = ((n * p.H + ih) * p.W + iw) * p.C;
+        }
+        ok = ok && (m0 + m4 * 4) < p.M;
+        ra[i] = bufload4(rsrc_a, ok ? (unsigned)(off + m0 + m4 * 4) * 4u : OOB, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) {
+        int u = tid + 256 * i;
+        int pix = pix0 + ks * BKT + u / (BN / 4);
+        rb[i] = bufload4(rsrc_b, (pix < pix1 && b_base[i] != OOB) ? b_base[i] + (unsigned)(pix * p.K) * 4u : OOB, 0);
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    float* a = sA + buf * (BKT * LDA);
+    float* b = sB + buf * (BKT * LDB);
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      if constexpr (A_KC) {
+        int row = (tid / KQ) + RP * i;
+        a[(kq4 + 0) * LDA + row] = ra[i].x; a[(kq4 + 1) * LDA + row] = ra[i].y;
+        a[(kq4 + 2) * LDA + row] = ra[i].z; a[(kq4 + 3) * LDA + row] = ra[i].w;
+      } else {
+        int u = tid + 256 * i;
+        *reinterpret_cast<floatx4*>(a + (u / (BM / 4)) * LDA + (u % (BM / 4)) * 4) = ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      if constexpr (B_KC) {
+        int row = (tid / KQ) + RP * i;
+        b[(kq4 + 0) * LDB + row] = rb[i].x; b[(kq4 + 1) * LDB + row] = rb[i].y;
+        b[(kq4 + 2) * LDB + row] = rb[i].z; b[(kq4 + 3) * LDB + row] = rb[i].w;
+      } else {
+        int u = tid + 256 * i;
+        *reinterpret_cast<floatx4*>(b + (u / (BN / 4)) * LDB + (u % (BN / 4)) * 4) = rb[i];
+      }
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (ksteps > ks_begin) {
+    load_tile(ks_begin);
+    store_tile(ks_begin & 1);
+  }
+  __syncthreads();
+  for (int ks = ks_begin; ks < ksteps; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < ksteps) load_tile(ks + 1);
+    const float* a = sA + cur * (BKT * LDA) + wr * (BM / 2) + lo;
+    const float* b = sB + cur * (BKT * LDB) + wc * (BN / 2) + lo;
+    // Software-pipelined fragments: the ds_reads of k-pair kk+1 are issued BEFORE the MFMAs of
+    // k-pair kk (two register sets), pinned with sched_barrier so hipcc does not re-serialise them
+    // into read -> wait -> MFMA; LDS latency is then exposed once per K-step instead of 8 times.
+    float fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = a[hi * LDA + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = b[hi * LDB + j * 32];
+#pragma unroll
+    for (int kk = 0; kk < BKT / 2; ++kk) {
+      const int cs = kk & 1, ns = cs ^ 1;
+      if (kk + 1 < BKT / 2) {
+        const int kr = 2 * (kk + 1) + hi;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[ns][i] = a[kr * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[ns][j] = b[kr * LDB + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cs][i], fb[cs][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ks + 1 < ksteps) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue. MFMA C/D map: lane l, reg e -> row (e&3) + 8*(e>>2) + 4*(l>>5), col l&31.
+  const int ldo = p.NG;
+  float* outp = p.out;
+  if constexpr (MODE == MODE_WGRAD)
+    outp += ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (int64_t)p.M * p.NG;
+  const bool raw = (MODE != MODE_WGRAD) && p.nsplit > 1;   // split-K partial: epilogue runs later
+  if (raw) outp = p.splitk_ws + (int64_t)blockIdx.z * (int64_t)(p.M - p.ws_m0) * p.NG;
+  if (!(p.NG & 3)) {
+    // Coalesced epilogue: each wave transposes its 32x32 accumulator tiles through a private LDS
+    // patch (the operand buffers are free after the last K-step's barrier) so that a lane holds 4
+    // consecutive columns: 4 ds_read_b128 + 4 global 16-byte stores per tile instead of 64 scalar
+    // stores, and the bias / residual / mask / accumulate operands come in as 16-byte loads too.
+    float* tile = smem + wid * (32 * LDT);                 // LDT: 16-byte aligned rows, conflict-light
+    const int r_in = lane >> 3, c4 = (lane & 7) * 4;      // this lane's row (mod 8) and first column in the tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hi) * LDT + lo] = acc[i][j][e];
+        const int col = n0 + wc * (BN / 2) + j * 32 + c4;
+        floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == MODE_FWD)
+          if ((p.epi & MTLSSL_EPI_BIAS) && col < p.NG && !raw) bv = *reinterpret_cast<const floatx4*>(p.bias + col);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int rt = r_in + 8 * k;
+          floatx4 v = *reinterpret_cast<const floatx4*>(tile + rt * LDT + c4);
+          const int row = m0 + wr * (BM / 2) + i * 32 + rt;
+          if (row >= p.M || col >= p.NG) continue;
+          if (raw) {
+            *reinterpret_cast<floatx4*>(outp + (int64_t)(row - p.ws_m0) * ldo + col) = v;
+            continue;
+          }
+          const int64_t o = (int64_t)row * ldo + col;
+          if constexpr (MODE == MODE_FWD) {
+            v += bv;
+            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (p.epi & MTLSSL_EPI_RELU) v[q] = fmaxf(v[q], 0.f);
+              if (p.epi & MTLSSL_EPI_RELU6) v[q] = fminf(fmaxf(v[q], 0.f), 6.f);
+              if (p.epi & MTLSSL_EPI_TANH) v[q] = tanhf(v[q]);
+            }
+          } else if constexpr (MODE == MODE_DGRAD) {
+            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
+            if (p.epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const floatx4*>(outp + o);
+            if (p.epi & MASK_ANY) {
+              floatx4 mk = *reinterpret_cast<const floatx4*>(p.mask + o);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = act_mask(v[q], mk[q], p.epi);
+            }
+          }
+          *reinterpret_cast<floatx4*>(outp + o) = v;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wc * (BN / 2) + j * 32 + lo;
+      const bool col_ok = col < p.NG;
+      float bv = 0.f;
+      if constexpr (MODE == MODE_FWD)
+        if ((p.epi & MTLSSL_EPI_BIAS) && col_ok) bv = p.bias[col];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        if (row >= p.M || !col_ok) continue;
+        const int64_t o = (int64_t)row * ldo + col;
+        float v = acc[i][j][e];
+        if (raw) {
+          outp[(int64_t)(row - p.ws_m0) * ldo + col] = v;
+          continue;
+        }
+        if constexpr (MODE == MODE_FWD) {
+          v += bv;
+          if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
+          if (p.epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
+          if (p.epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+          if (p.epi & MTLSSL_EPI_TANH) v = tanhf(v);
+        } else if constexpr (MODE == MODE_DGRAD) {
+          if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
+          if (p.epi & MTLSSL_EPI_ACCUM) v += outp[o];
+          if (p.epi & MASK_ANY) v = act_mask(v, p.mask[o], p.epi);
+        }
+        outp[o] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int MODE, int BKT>
+__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3) : 4)) k_conv_mfma(ConvArgs p) {
+  conv_mfma_body<BM, BN, MODE, BKT, false>(p);
+}
+// The same tile engine over a stack of plain GEMMs (1x1 "convolutions"): the 36 Winograd-domain
+// products of F(4x4,3x3). A kernel of its own so that profiles tell the two apart.
+template <int BM, int BN, int MODE>
+__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_wino_gemm(ConvArgs p) {
+  conv_mfma_body<BM, BN, MODE, 16, true>(p);
+}
+
+// Tile configurations (bm x bn, 16-deep K-step) shared by the planners. The kernel template takes the
+// K-step depth as a parameter; 32-deep variants of the 128x64 and 64x64 tiles (half the barriers, twice
+// the prefetch distance) were built and measured 3-10 % SLOWER than the 16-deep ones on every layer
+// shape of config[1] (tools/bench_conv.py, round 1), so only the 16-deep ones are instantiated.
+// A 128x192 tile (for Inception's 192 / 2080-wide layers) was built and measured too: 88 TFLOP/s where
+// the 128x128 and 64x64 tiles reach 115-128 on the same layers (154 VGPRs, 42 KB LDS), so it is out.
+constexpr int NCFG = 3;
+static const int CFG_BM[NCFG] = {128, 128, 64};
+static const int CFG_BN[NCFG] = {128, 64, 64};
+static const int CFG_BK[NCFG] = {16, 16, 16};
+
+// Time model shared by the planners (microseconds). A CU retires one 16-deep K-step of a
+// bm x bn tile in bm*bn*32 FLOP / 614 GFLOP/s (fp32 MFMA peak per CU); blocks beyond what is
+// resident queue up. A CU holding a single block (one wave per SIMD) cannot hide its own LDS /
+// barrier latencies, hence the occupancy factor. Constants fitted to tools/bench_conv.py.
+static inline double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block) {
+  const int resident[NCFG] = {3, 6, 8};
+  const double base_eff[NCFG] = {0.80, 0.76, 0.72};
+  int64_t per_cu = cdiv(nblocks, 256);
+  int64_t occ = per_cu < resident[cfg] ? per_cu : resident[cfg];
+  double occ_eff = occ <= 1 ? 0.55 : (occ == 2 ? 0.80 : 1.0);
+  double step_us = CFG_BM[cfg] * CFG_BN[cfg] * 2.0 * CFG_BK[cfg] / 614e9 * 1e6 / (base_eff[cfg] * occ_eff);
+  return (double)per_cu * (ksteps_per_block + 96 / CFG_BK[cfg]) * step_us;
+}
+
+// ---- Winograd F(4x4,3x3) path (winograd.hip), behind the same entry points as the direct one.
+// mode: MODE_FWD / MODE_DGRAD / MODE_WGRAD; tile: GEMM tile configuration 0..NCFG-1.
+bool wino_eligible(const mtlssl_conv_desc* d, int mode);
+double wino_time_us(const mtlssl_conv_desc* d, int mode, int* tile);
+int64_t wino_workspace_bytes(const mtlssl_conv_desc* d, int mode);
+void wino_fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* w, const float* bias,
+              const float* residual, float* y, int epi, void* workspace, hipStream_t st);
+void wino_dgrad(const mtlssl_conv_desc* d, int tile, const float* dy, const float* w, const float* residual,
+                const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st);
+void wino_wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float* dy, const float* out_scale,
+                float* dw, float beta, void* workspace, hipStream_t st);
+
+}  // namespace mtlssl
