@@ -22,7 +22,9 @@ namespace {
 
 constexpr int WP = 36;   // Winograd-domain points of F(4x4,3x3)
 
-__device__ __forceinline__ void bt6(const float* d, float* o) {   // o = B^T d
+// 1-D transforms; T is float or floatx4 (four channels at once).
+template <typename T>
+__device__ __forceinline__ void bt6(const T* d, T* o) {   // o = B^T d
   o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
   o[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
   o[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
@@ -30,24 +32,27 @@ __device__ __forceinline__ void bt6(const float* d, float* o) {   // o = B^T d
   o[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
   o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
 }
-__device__ __forceinline__ void at4(const float* m, float* o) {   // o = A^T m
-  float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+template <typename T>
+__device__ __forceinline__ void at4(const T* m, T* o) {   // o = A^T m
+  T s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
   o[0] = m[0] + s12 + s34;
   o[1] = d12 + 2.f * d34;
   o[2] = s12 + 4.f * s34;
   o[3] = d12 + 8.f * d34 + m[5];
 }
-__device__ __forceinline__ void a6(const float* y, float* o) {    // o = A y
-  float s02 = y[0] + y[2], s13 = y[1] + y[3];
+template <typename T>
+__device__ __forceinline__ void a6(const T* y, T* o) {    // o = A y
+  T s02 = y[0] + y[2], s13 = y[1] + y[3];
   o[0] = y[0];
   o[1] = s02 + s13;
   o[2] = s02 - s13;
-  float e = y[0] + 4.f * y[2], f = 2.f * y[1] + 8.f * y[3];
+  T e = y[0] + 4.f * y[2], f = 2.f * y[1] + 8.f * y[3];
   o[3] = e + f;
   o[4] = e - f;
   o[5] = y[3];
 }
-__device__ __forceinline__ void g6(const float* g, float* o) {    // o = G g
+template <typename T>
+__device__ __forceinline__ void g6(const T* g, T* o) {    // o = G g
   const float c6 = 1.f / 6.f, c12 = 1.f / 12.f, c24 = 1.f / 24.f;
   o[0] = 0.25f * g[0];
   o[1] = -c6 * (g[0] + g[1] + g[2]);
@@ -56,7 +61,8 @@ __device__ __forceinline__ void g6(const float* g, float* o) {    // o = G g
   o[4] = c24 * g[0] - c12 * g[1] + c6 * g[2];
   o[5] = g[2];
 }
-__device__ __forceinline__ void gt3(const float* u, float* o) {   // o = G^T u
+template <typename T>
+__device__ __forceinline__ void gt3(const T* u, T* o) {   // o = G^T u
   const float c6 = 1.f / 6.f, c12 = 1.f / 12.f, c24 = 1.f / 24.f;
   o[0] = 0.25f * u[0] - c6 * (u[1] + u[2]) + c24 * (u[3] + u[4]);
   o[1] = c6 * (u[2] - u[1]) + c12 * (u[3] - u[4]);
@@ -67,209 +73,227 @@ struct WinoGeom {
   int N, H, W, th, tw;
   int64_t T;            // N * th * tw tiles
 };
+// Thread -> (tile t, channel group) of a [T][C] plane, channels fastest. VT = floatx4: four channels per
+// thread, a wave touches 1 KB of contiguous memory per access (C % 16 == 0 on this path, so a quad never
+// straddles a row) — the wide problems; VT = float: one channel per thread, four times the threads —
+// the narrow ones (a block3 unit has 320 tiles x 256 channels), which are latency- not bandwidth-bound.
+struct TileIdx { int64_t t; int c, n, ty, tx; bool ok; };
+template <typename VT>
+__device__ __forceinline__ TileIdx tile_index(const WinoGeom& g, int C) {
+  constexpr int VW = sizeof(VT) / 4;
+  TileIdx r;
+  const int cq = C / VW;
+  int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x;
+  r.ok = idx < g.T * cq;
+  r.c = (int)(idx % cq) * VW;
+  r.t = idx / cq;
+  r.tx = (int)(r.t % g.tw);
+  int64_t q = r.t / g.tw;
+  r.ty = (int)(q % g.th);
+  r.n = (int)(q / g.th);
+  return r;
+}
+__device__ __forceinline__ float act_fwd(float v, int epi) {
+  if (epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
+  if (epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+  if (epi & MTLSSL_EPI_TANH) v = tanhf(v);
+  return v;
+}
+__device__ __forceinline__ floatx4 act_fwd(floatx4 v, int epi) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], epi);
+  return v;
+}
+__device__ __forceinline__ float mask_bwd(float g, float y, int epi) { return act_mask(g, y, epi); }
+__device__ __forceinline__ floatx4 mask_bwd(floatx4 g, floatx4 y, int epi) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) g[q] = act_mask(g[q], y[q], epi);
+  return g;
+}
 
 // Filter transform U[xi][c][k] = (G g G^T)[xi] of w[r][s][c][k]; flip = 1 takes g[2-r][2-s] (the
 // dgrad filter; its [C][K] layout is what the tile engine's dgrad mode reads as B[n][k]).
 __global__ void __launch_bounds__(256) k_wino_filter(const float* w, float* U, int64_t CK, int flip) {
-  int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * 4;
   if (i >= CK) return;
-  float g[3][3], t[6][3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
-      g[r][s] = w[(int64_t)(rr * 3 + ss) * CK + i];
-    }
+  floatx4 t[6][3];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {           // columns: t = G g
-    float col[3] = {g[0][s], g[1][s], g[2][s]}, o[6];
+    floatx4 col[3], o[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
+      col[r] = *reinterpret_cast<const floatx4*>(w + (int64_t)(rr * 3 + ss) * CK + i);
+    }
     g6(col, o);
 #pragma unroll
     for (int a = 0; a < 6; ++a) t[a][s] = o[a];
   }
 #pragma unroll
   for (int a = 0; a < 6; ++a) {           // rows: U = t G^T
-    float o[6];
+    floatx4 o[6];
     g6(t[a], o);
 #pragma unroll
-    for (int b = 0; b < 6; ++b) U[(int64_t)(a * 6 + b) * CK + i] = o[b];
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<floatx4*>(U + (int64_t)(a * 6 + b) * CK + i) = o[b];
   }
 }
 
 // Input transform V[xi][t][c] = (B^T d B)[xi] of the 6x6 patch of tile t (origin 4*ty-1, 4*tx-1,
-// zero outside the map). One thread per (tile, channel), channel fastest: a wave reads / writes
-// 256 contiguous bytes per access.
+// zero outside the map). The patch is streamed a column at a time (24 registers), the column-transformed
+// 6x6 is held (144), then rows are transformed and stored plane by plane.
+template <typename VT>
 __global__ void __launch_bounds__(256) k_wino_input(const float* in, float* V, WinoGeom g, int C) {
-  int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x;
-  if (idx >= g.T * C) return;
-  int c = (int)(idx % C);
-  int64_t t = idx / C;
-  int tx = (int)(t % g.tw);
-  int64_t q = t / g.tw;
-  int ty = (int)(q % g.th), n = (int)(q / g.th);
-  const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-  float d[6][6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    int iy = y0 + i;
-    bool oky = (unsigned)iy < (unsigned)g.H;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      int ix = x0 + j;
-      bool ok = oky && (unsigned)ix < (unsigned)g.W;
-      d[i][j] = ok ? in[(((int64_t)n * g.H + iy) * g.W + ix) * C + c] : 0.f;
-    }
-  }
-  float tmp[6][6];
+  const TileIdx ix = tile_index<VT>(g, C);
+  if (!ix.ok) return;
+  const int y0 = 4 * ix.ty - 1, x0 = 4 * ix.tx - 1;
+  const float* base = in + ((int64_t)ix.n * g.H * g.W) * C + ix.c;
+  VT tmp[6][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]}, o[6];
+    const int x = x0 + j;
+    const bool okx = (unsigned)x < (unsigned)g.W;
+    VT col[6], o[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int y = y0 + i;
+      const bool ok = okx && (unsigned)y < (unsigned)g.H;
+      col[i] = ok ? *reinterpret_cast<const VT*>(base + ((int64_t)y * g.W + x) * C) : VT{};
+    }
     bt6(col, o);
 #pragma unroll
     for (int i = 0; i < 6; ++i) tmp[i][j] = o[i];
   }
   const int64_t plane = g.T * C;
-  float* vp = V + t * C + c;
+  float* vp = V + ix.t * C + ix.c;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    float o[6];
+    VT o[6];
     bt6(tmp[i], o);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) vp[(int64_t)(i * 6 + j) * plane] = o[j];
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<VT*>(vp + (int64_t)(i * 6 + j) * plane) = o[j];
   }
 }
 
 // Output-gradient transform for the filter gradient: dM[xi][t][k] = (A dY A^T)[xi] of the 4x4
 // tile of dY (zero outside the map).
+template <typename VT>
 __global__ void __launch_bounds__(256) k_wino_dy(const float* dy, float* dM, WinoGeom g, int K) {
-  int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x;
-  if (idx >= g.T * K) return;
-  int k = (int)(idx % K);
-  int64_t t = idx / K;
-  int tx = (int)(t % g.tw);
-  int64_t q = t / g.tw;
-  int ty = (int)(q % g.th), n = (int)(q / g.th);
-  float y[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int oy = 4 * ty + i;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int ox = 4 * tx + j;
-      bool ok = oy < g.H && ox < g.W;
-      y[i][j] = ok ? dy[(((int64_t)n * g.H + oy) * g.W + ox) * K + k] : 0.f;
-    }
-  }
-  float tmp[6][4];
+  const TileIdx ix = tile_index<VT>(g, K);
+  if (!ix.ok) return;
+  const float* base = dy + ((int64_t)ix.n * g.H * g.W) * K + ix.c;
+  VT tmp[6][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float col[4] = {y[0][j], y[1][j], y[2][j], y[3][j]}, o[6];
+    const int x = 4 * ix.tx + j;
+    VT col[4], o[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = 4 * ix.ty + i;
+      const bool ok = y < g.H && x < g.W;
+      col[i] = ok ? *reinterpret_cast<const VT*>(base + ((int64_t)y * g.W + x) * K) : VT{};
+    }
     a6(col, o);
 #pragma unroll
     for (int i = 0; i < 6; ++i) tmp[i][j] = o[i];
   }
   const int64_t plane = g.T * K;
-  float* mp = dM + t * K + k;
+  float* mp = dM + ix.t * K + ix.c;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    float o[6];
+    VT o[6];
     a6(tmp[i], o);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) mp[(int64_t)(i * 6 + j) * plane] = o[j];
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<VT*>(mp + (int64_t)(i * 6 + j) * plane) = o[j];
   }
 }
 
 // Output transform Y = A^T m A of Mb[xi][t][k] + the epilogue of the direct kernel (forward:
 // bias / residual / ReLU / ReLU6 / tanh; dgrad: residual / accumulate / activation mask).
-template <int MODE>
+template <int MODE, typename VT>
 __global__ void __launch_bounds__(256) k_wino_output(const float* Mb, float* out, WinoGeom g, int K,
                                                      const float* bias, const float* residual,
                                                      const float* mask, int epi) {
-  int64_t idx = blockIdx.x * (int64_t)256 + threadIdx.x;
-  if (idx >= g.T * K) return;
-  int k = (int)(idx % K);
-  int64_t t = idx / K;
-  int tx = (int)(t % g.tw);
-  int64_t q = t / g.tw;
-  int ty = (int)(q % g.th), n = (int)(q / g.th);
+  const TileIdx ix = tile_index<VT>(g, K);
+  if (!ix.ok) return;
   const int64_t plane = g.T * K;
-  const float* mp = Mb + t * K + k;
-  float m[6][6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) m[i][j] = mp[(int64_t)(i * 6 + j) * plane];
-  float tmp[4][6];
+  const float* mp = Mb + ix.t * K + ix.c;
+  VT tmp[4][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]}, o[4];
+    VT col[6], o[4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const VT*>(mp + (int64_t)(i * 6 + j) * plane);
     at4(col, o);
 #pragma unroll
     for (int i = 0; i < 4; ++i) tmp[i][j] = o[i];
   }
-  float bv = 0.f;
+  VT bv{};
   if constexpr (MODE == MODE_FWD)
-    if (epi & MTLSSL_EPI_BIAS) bv = bias[k];
+    if (epi & MTLSSL_EPI_BIAS) bv = *reinterpret_cast<const VT*>(bias + ix.c);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float o[4];
+    VT o[4];
     at4(tmp[i], o);
-    int oy = 4 * ty + i;
+    const int oy = 4 * ix.ty + i;
     if (oy >= g.H) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int ox = 4 * tx + j;
+      const int ox = 4 * ix.tx + j;
       if (ox >= g.W) continue;
-      const int64_t off = (((int64_t)n * g.H + oy) * g.W + ox) * K + k;
-      float v = o[j];
+      const int64_t off = (((int64_t)ix.n * g.H + oy) * g.W + ox) * K + ix.c;
+      VT v = o[j];
       if constexpr (MODE == MODE_FWD) {
         v += bv;
-        if (epi & MTLSSL_EPI_RESIDUAL) v += residual[off];
-        if (epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
-        if (epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
-        if (epi & MTLSSL_EPI_TANH) v = tanhf(v);
+        if (epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const VT*>(residual + off);
+        v = act_fwd(v, epi);
       } else {
-        if (epi & MTLSSL_EPI_RESIDUAL) v += residual[off];
-        if (epi & MTLSSL_EPI_ACCUM) v += out[off];
-        if (epi & MASK_ANY) v = act_mask(v, mask[off], epi);
+        if (epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const VT*>(residual + off);
+        if (epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const VT*>(out + off);
+        if (epi & MASK_ANY) v = mask_bwd(v, *reinterpret_cast<const VT*>(mask + off), epi);
       }
-      out[off] = v;
+      *reinterpret_cast<VT*>(out + off) = v;
     }
   }
 }
 
 // Filter-gradient back-transform: dw[r][s][c][k] = beta*dw + scale[k] * (G^T (sum_split dU) G)[r][s].
+// Two (c,k) pairs per thread; the split loop is outermost so that the 36 plane loads of one split are
+// independent and in flight together.
 __global__ void __launch_bounds__(256) k_wino_wgrad_out(const float* dU, int nsplit, int64_t CK, int K,
                                                         const float* scale, float* dw, float beta) {
-  int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  typedef float floatx2 __attribute__((ext_vector_type(2)));
+  int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * 2;
   if (i >= CK) return;
-  float u[6][6];
+  floatx2 u[6][6];
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      float s = 0.f;
-      for (int z = 0; z < nsplit; ++z) s += dU[((int64_t)z * WP + a * 6 + b) * CK + i];
-      u[a][b] = s;
-    }
-  float t[3][6];
+    for (int b = 0; b < 6; ++b) u[a][b] = *reinterpret_cast<const floatx2*>(dU + (int64_t)(a * 6 + b) * CK + i);
+  for (int z = 1; z < nsplit; ++z) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b)
+        u[a][b] += *reinterpret_cast<const floatx2*>(dU + ((int64_t)z * WP + a * 6 + b) * CK + i);
+  }
+  floatx2 t[3][6];
 #pragma unroll
   for (int b = 0; b < 6; ++b) {
-    float col[6] = {u[0][b], u[1][b], u[2][b], u[3][b], u[4][b], u[5][b]}, o[3];
+    floatx2 col[6] = {u[0][b], u[1][b], u[2][b], u[3][b], u[4][b], u[5][b]}, o[3];
     gt3(col, o);
 #pragma unroll
     for (int r = 0; r < 3; ++r) t[r][b] = o[r];
   }
-  float sc = scale ? scale[i % K] : 1.f;
+  floatx2 sc = {1.f, 1.f};
+  if (scale) sc = *reinterpret_cast<const floatx2*>(scale + i % K);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    float o[3];
+    floatx2 o[3];
     gt3(t[r], o);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      float v = o[s] * sc;
-      float* p = dw + (int64_t)(r * 3 + s) * CK + i;
+      floatx2 v = o[s] * sc;
+      floatx2* p = reinterpret_cast<floatx2*>(dw + (int64_t)(r * 3 + s) * CK + i);
       *p = beta != 0.f ? beta * *p + v : v;
     }
   }
@@ -281,6 +305,31 @@ WinoGeom geom(const mtlssl_conv_desc* d) {
   g.th = (int)cdiv(d->H, 4); g.tw = (int)cdiv(d->W, 4);
   g.T = (int64_t)d->N * g.th * g.tw;
   return g;
+}
+
+// Wide planes: four channels per thread; narrow ones: one (more threads in flight).
+bool wide(int64_t T, int C) { return T * C / 4 >= 131072; }
+void run_input(const float* in, float* V, const WinoGeom& g, int C, hipStream_t st) {
+  if (wide(g.T, C))
+    hipLaunchKernelGGL(k_wino_input<floatx4>, dim3(cdiv(g.T * C / 4, 256)), dim3(256), 0, st, in, V, g, C);
+  else
+    hipLaunchKernelGGL(k_wino_input<float>, dim3(cdiv(g.T * C, 256)), dim3(256), 0, st, in, V, g, C);
+}
+void run_dy(const float* dy, float* dM, const WinoGeom& g, int K, hipStream_t st) {
+  if (wide(g.T, K))
+    hipLaunchKernelGGL(k_wino_dy<floatx4>, dim3(cdiv(g.T * K / 4, 256)), dim3(256), 0, st, dy, dM, g, K);
+  else
+    hipLaunchKernelGGL(k_wino_dy<float>, dim3(cdiv(g.T * K, 256)), dim3(256), 0, st, dy, dM, g, K);
+}
+template <int MODE>
+void run_output(const float* Mb, float* out, const WinoGeom& g, int K, const float* bias, const float* residual,
+                const float* mask, int epi, hipStream_t st) {
+  if (wide(g.T, K))
+    hipLaunchKernelGGL((k_wino_output<MODE, floatx4>), dim3(cdiv(g.T * K / 4, 256)), dim3(256), 0, st, Mb, out, g, K,
+                       bias, residual, mask, epi);
+  else
+    hipLaunchKernelGGL((k_wino_output<MODE, float>), dim3(cdiv(g.T * K, 256)), dim3(256), 0, st, Mb, out, g, K,
+                       bias, residual, mask, epi);
 }
 
 template <int MODE>
@@ -389,16 +438,15 @@ void wino_fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* 
   float* U = (float*)workspace;
   float* V = (float*)((char*)U + align_up(WP * CK * 4, 256));
   float* Mb = (float*)((char*)V + align_up((int64_t)WP * g.T * d->C * 4, 256));
-  hipLaunchKernelGGL(k_wino_filter, dim3(cdiv(CK, 256)), dim3(256), 0, st, w, U, CK, 0);
-  hipLaunchKernelGGL(k_wino_input, dim3(cdiv(g.T * d->C, 256)), dim3(256), 0, st, x, V, g, d->C);
+  hipLaunchKernelGGL(k_wino_filter, dim3(cdiv(CK / 4, 256)), dim3(256), 0, st, w, U, CK, 0);
+  run_input(x, V, g, d->C, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = U; p.out = Mb;
   p.M = (int)g.T; p.NG = d->K;
   p.a_bytes = (unsigned)(g.T * d->C * 4); p.b_bytes = (unsigned)(CK * 4);
   p.a_bs = g.T * d->C; p.b_bs = CK; p.o_bs = g.T * d->K;
   launch_gemm<MODE_FWD>(tile, p, 1, st);
-  hipLaunchKernelGGL(k_wino_output<MODE_FWD>, dim3(cdiv(g.T * d->K, 256)), dim3(256), 0, st, (const float*)Mb, y,
-                     g, d->K, bias, residual, (const float*)nullptr, epi);
+  run_output<MODE_FWD>(Mb, y, g, d->K, bias, residual, nullptr, epi, st);
 }
 
 void wino_dgrad(const mtlssl_conv_desc* d, int tile, const float* dy, const float* w, const float* residual,
@@ -408,16 +456,15 @@ void wino_dgrad(const mtlssl_conv_desc* d, int tile, const float* dy, const floa
   float* U = (float*)workspace;
   float* V = (float*)((char*)U + align_up(WP * CK * 4, 256));               // transformed dy [36][T][K]
   float* Mb = (float*)((char*)V + align_up((int64_t)WP * g.T * d->K * 4, 256));   // [36][T][C]
-  hipLaunchKernelGGL(k_wino_filter, dim3(cdiv(CK, 256)), dim3(256), 0, st, w, U, CK, 1);
-  hipLaunchKernelGGL(k_wino_input, dim3(cdiv(g.T * d->K, 256)), dim3(256), 0, st, dy, V, g, d->K);
+  hipLaunchKernelGGL(k_wino_filter, dim3(cdiv(CK / 4, 256)), dim3(256), 0, st, w, U, CK, 1);
+  run_input(dy, V, g, d->K, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = U; p.out = Mb;
   p.M = (int)g.T; p.NG = d->C;
   p.a_bytes = (unsigned)(g.T * d->K * 4); p.b_bytes = (unsigned)(CK * 4);
   p.a_bs = g.T * d->K; p.b_bs = CK; p.o_bs = g.T * d->C;
   launch_gemm<MODE_DGRAD>(tile, p, 1, st);
-  hipLaunchKernelGGL(k_wino_output<MODE_DGRAD>, dim3(cdiv(g.T * d->C, 256)), dim3(256), 0, st, (const float*)Mb,
-                     dx, g, d->C, (const float*)nullptr, residual, mask_ref, epi);
+  run_output<MODE_DGRAD>(Mb, dx, g, d->C, nullptr, residual, mask_ref, epi, st);
 }
 
 void wino_wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float* dy, const float* out_scale,
@@ -429,15 +476,15 @@ void wino_wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float
   float* dU = (float*)((char*)dM + align_up((int64_t)WP * g.T * d->K * 4, 256));  // [ns][36][C][K]
   int ns, pps;
   wgrad_split(d, tile, &ns, &pps);
-  hipLaunchKernelGGL(k_wino_input, dim3(cdiv(g.T * d->C, 256)), dim3(256), 0, st, x, V, g, d->C);
-  hipLaunchKernelGGL(k_wino_dy, dim3(cdiv(g.T * d->K, 256)), dim3(256), 0, st, dy, dM, g, d->K);
+  run_input(x, V, g, d->C, st);
+  run_dy(dy, dM, g, d->K, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = dM; p.out = dU;
   p.M = d->C; p.NG = d->K; p.nsplit = ns; p.pix_per_split = pps;
   p.a_bytes = (unsigned)(g.T * d->C * 4); p.b_bytes = (unsigned)(g.T * d->K * 4);
   p.a_bs = g.T * d->C; p.b_bs = g.T * d->K;
   launch_gemm<MODE_WGRAD>(tile, p, ns, st);
-  hipLaunchKernelGGL(k_wino_wgrad_out, dim3(cdiv(CK, 256)), dim3(256), 0, st, (const float*)dU, ns, CK, d->K,
+  hipLaunchKernelGGL(k_wino_wgrad_out, dim3(cdiv(CK / 2, 256)), dim3(256), 0, st, (const float*)dU, ns, CK, d->K,
                      out_scale, dw, beta);
 }
 
