@@ -73,13 +73,16 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
  * workspace: mtlssl_conv2d_wgrad_workspace_bytes(d) bytes. */
 int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d);
 /* Which kernel instantiation a call will use: mode 0 fwd / 1 dgrad / 2 wgrad ->
- * 0: k_conv_mfma<128,128,mode>, 1: <128,64,mode>, 2: <64,64,mode>, -1: direct (non-MFMA) path.
+ * 0: k_conv_mfma<128,128,mode>, 1: <128,64,mode>, 2: <64,64,mode>, -1: direct (non-MFMA) path;
+ * 4..6: Winograd F(4x4,3x3) (3x3 / stride 1 / SAME layers) with the GEMM stack on tile 0..2.
  * For profiling attribution only. */
 int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode);
-/* Autotuning hook: pin the tile configuration (0: 128x128, 1: 128x64, 2: 64x64; < 0 clears) the
- * planner uses for this problem and mode; the K split / tail split is still planned for that tile.
- * The caller times the candidates on its own tensors (mtl_ssl_amd/ops.py does at first use). The
- * registry is process-wide and thread-safe. */
+/* Autotuning hook: pin the algorithm + tile configuration (0: 128x128, 1: 128x64, 2: 64x64 direct
+ * implicit GEMM; 4/5/6: Winograd F(4x4,3x3) with that GEMM tile, ignored for problems outside its
+ * domain; < 0 clears) the planner uses for this problem and mode; the K split / tail split is still
+ * planned for that tile. The caller times the candidates on its own tensors (mtl_ssl_amd/ops.py does
+ * at first use, or takes them from its committed plan table). The registry is process-wide and
+ * thread-safe. Workspace sizes follow the pinned choice: query mtlssl_conv2d_workspace_bytes after. */
 int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg);
 /* Number of launches of the implicit-GEMM kernel one call makes for this problem (2 when the planner
  * splits off a K-split tail launch) — lets a profiler relate per-call timings to
