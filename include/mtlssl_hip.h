@@ -84,6 +84,11 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode);
  * at first use, or takes them from its committed plan table). The registry is process-wide and
  * thread-safe. Workspace sizes follow the pinned choice: query mtlssl_conv2d_workspace_bytes after. */
 int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg);
+/* Algorithm policy for the 3x3 / stride-1 / SAME layers: 0 = always the direct implicit GEMM, 1 = by the
+ * plan registry, else by the time models (default; the MTLSSL_WINOGRAD environment variable sets the
+ * initial value), 2 = Winograd F(4x4,3x3) for every eligible problem. Returns the previous mode; a mode
+ * outside 0..2 only queries. Process-wide. */
+int mtlssl_conv2d_set_winograd(int mode);
 /* Number of launches of the implicit-GEMM kernel one call makes for this problem (2 when the planner
  * splits off a K-split tail launch) — lets a profiler relate per-call timings to
  * per-dispatch kernel traces. */

@@ -14,6 +14,7 @@
 // so the epilogue is bias(+residual)(+ReLU) and the backward needs only ReLU masks.
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -635,11 +636,17 @@ static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pp
 // the time models; 2 every eligible problem. Registry codes WINO_CFG0 + tile select Winograd with that
 // GEMM tile; codes 0..NCFG-1 pin the direct path.
 constexpr int WINO_CFG0 = 4;
+static std::atomic<int>& wino_mode_ref() {
+  static std::atomic<int> v{-1};
+  return v;
+}
 static int wino_env() {
-  static int v = -1;
+  int v = wino_mode_ref().load();
   if (v < 0) {
     const char* e = getenv("MTLSSL_WINOGRAD");
     v = e ? atoi(e) : 1;
+    if (v < 0 || v > 2) v = 1;
+    wino_mode_ref().store(v);
   }
   return v;
 }
@@ -764,6 +771,12 @@ int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg) {
   std::lock_guard<std::mutex> g(tuned_mutex());
   if (cfg < 0) tuned_map().erase(k); else tuned_map()[k] = cfg;
   return MTLSSL_OK;
+}
+
+int mtlssl_conv2d_set_winograd(int mode) {
+  const int prev = wino_env();
+  if (mode >= 0 && mode <= 2) wino_mode_ref().store(mode);
+  return prev;
 }
 
 int mtlssl_conv2d_num_dispatches(const mtlssl_conv_desc* d, int mode) {

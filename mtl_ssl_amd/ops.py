@@ -166,6 +166,12 @@ def force_conv_config(d, mode, cfg):
     return lib().conv2d_tile_config(ctypes.byref(d), mode)
 
 
+def set_winograd(mode):
+    """0: direct convolution only, 1: plan registry / time model (default), 2: Winograd F(4x4,3x3) for every
+    eligible 3x3 stride-1 layer. Returns the previous mode (mode=-1 only queries)."""
+    return lib().conv2d_set_winograd(int(mode))
+
+
 def _autotune(d, mode, run):
     key = _plan_key(d, mode)
     if key in _tuned:

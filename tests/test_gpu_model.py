@@ -81,10 +81,25 @@ def _host_batch(batch):
     return hb
 
 
+@pytest.fixture
+def conv_algorithm(request):
+    """Pin the 3x3 stride-1 layers to the direct implicit GEMM (0) or to Winograd F(4x4,3x3) (2) for one
+    test; back to the plan registry's choice afterwards."""
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import ops
+    ops.set_winograd(request.param)
+    yield request.param
+    ops.set_winograd(1)
+
+
+@pytest.mark.parametrize("conv_algorithm", [0, 2], indirect=True, ids=["direct", "winograd"])
 @pytest.mark.parametrize("refine,aux,crop,pk", [(True, True, 14, 2), (False, False, 7, 1)])
-def test_step_losses_and_gradients_match_oracle(refine, aux, crop, pk):
+def test_step_losses_and_gradients_match_oracle(refine, aux, crop, pk, conv_algorithm):
     from oracle.model import Oracle
+    from mtl_ssl_amd import ops
     model, tr, batch, hp = _setup(refine, aux, crop, pk)
+    assert ops.set_winograd(-1) == conv_algorithm
     values = model.ps.state_dict()
     reports = {}
     model.ps.grad_ready_hook = lambda sp: reports.__setitem__(sp.name, reports.get(sp.name, 0) + 1)
