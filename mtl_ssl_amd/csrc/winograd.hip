@@ -113,17 +113,18 @@ __device__ __forceinline__ floatx4 mask_bwd(floatx4 g, floatx4 y, int epi) {
 
 // Filter transform U[xi][c][k] = (G g G^T)[xi] of w[r][s][c][k]; flip = 1 takes g[2-r][2-s] (the
 // dgrad filter; its [C][K] layout is what the tile engine's dgrad mode reads as B[n][k]).
+template <typename VT>
 __global__ void __launch_bounds__(256) k_wino_filter(const float* w, float* U, int64_t CK, int flip) {
-  int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * 4;
+  int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * (sizeof(VT) / 4);
   if (i >= CK) return;
-  floatx4 t[6][3];
+  VT t[6][3];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {           // columns: t = G g
-    floatx4 col[3], o[6];
+    VT col[3], o[6];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
-      col[r] = *reinterpret_cast<const floatx4*>(w + (int64_t)(rr * 3 + ss) * CK + i);
+      col[r] = *reinterpret_cast<const VT*>(w + (int64_t)(rr * 3 + ss) * CK + i);
     }
     g6(col, o);
 #pragma unroll
@@ -131,10 +132,10 @@ __global__ void __launch_bounds__(256) k_wino_filter(const float* w, float* U, i
   }
 #pragma unroll
   for (int a = 0; a < 6; ++a) {           // rows: U = t G^T
-    floatx4 o[6];
+    VT o[6];
     g6(t[a], o);
 #pragma unroll
-    for (int b = 0; b < 6; ++b) *reinterpret_cast<floatx4*>(U + (int64_t)(a * 6 + b) * CK + i) = o[b];
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<VT*>(U + (int64_t)(a * 6 + b) * CK + i) = o[b];
   }
 }
 
@@ -257,43 +258,43 @@ __global__ void __launch_bounds__(256) k_wino_output(const float* Mb, float* out
 }
 
 // Filter-gradient back-transform: dw[r][s][c][k] = beta*dw + scale[k] * (G^T (sum_split dU) G)[r][s].
-// Two (c,k) pairs per thread; the split loop is outermost so that the 36 plane loads of one split are
-// independent and in flight together.
+// The split loop is outermost so that the 36 plane loads of one split are independent and in flight
+// together. VT = float2: two (c,k) pairs per thread (wide filters), float: one (narrow ones).
+template <typename VT>
 __global__ void __launch_bounds__(256) k_wino_wgrad_out(const float* dU, int nsplit, int64_t CK, int K,
                                                         const float* scale, float* dw, float beta) {
-  typedef float floatx2 __attribute__((ext_vector_type(2)));
-  int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * 2;
+  int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * (sizeof(VT) / 4);
   if (i >= CK) return;
-  floatx2 u[6][6];
+  VT u[6][6];
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int b = 0; b < 6; ++b) u[a][b] = *reinterpret_cast<const floatx2*>(dU + (int64_t)(a * 6 + b) * CK + i);
+    for (int b = 0; b < 6; ++b) u[a][b] = *reinterpret_cast<const VT*>(dU + (int64_t)(a * 6 + b) * CK + i);
   for (int z = 1; z < nsplit; ++z) {
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int b = 0; b < 6; ++b)
-        u[a][b] += *reinterpret_cast<const floatx2*>(dU + ((int64_t)z * WP + a * 6 + b) * CK + i);
+        u[a][b] += *reinterpret_cast<const VT*>(dU + ((int64_t)z * WP + a * 6 + b) * CK + i);
   }
-  floatx2 t[3][6];
+  VT t[3][6];
 #pragma unroll
   for (int b = 0; b < 6; ++b) {
-    floatx2 col[6] = {u[0][b], u[1][b], u[2][b], u[3][b], u[4][b], u[5][b]}, o[3];
+    VT col[6] = {u[0][b], u[1][b], u[2][b], u[3][b], u[4][b], u[5][b]}, o[3];
     gt3(col, o);
 #pragma unroll
     for (int r = 0; r < 3; ++r) t[r][b] = o[r];
   }
-  floatx2 sc = {1.f, 1.f};
-  if (scale) sc = *reinterpret_cast<const floatx2*>(scale + i % K);
+  VT sc;
+  if (scale) sc = *reinterpret_cast<const VT*>(scale + i % K);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    floatx2 o[3];
+    VT o[3];
     gt3(t[r], o);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      floatx2 v = o[s] * sc;
-      floatx2* p = reinterpret_cast<floatx2*>(dw + (int64_t)(r * 3 + s) * CK + i);
+      VT v = scale ? o[s] * sc : o[s];
+      VT* p = reinterpret_cast<VT*>(dw + (int64_t)(r * 3 + s) * CK + i);
       *p = beta != 0.f ? beta * *p + v : v;
     }
   }
@@ -309,6 +310,12 @@ WinoGeom geom(const mtlssl_conv_desc* d) {
 
 // Wide planes: four channels per thread; narrow ones: one (more threads in flight).
 bool wide(int64_t T, int C) { return T * C / 4 >= 131072; }
+void run_filter(const float* w, float* U, int64_t CK, int flip, hipStream_t st) {
+  if (CK >= 262144)
+    hipLaunchKernelGGL(k_wino_filter<floatx4>, dim3(cdiv(CK / 4, 256)), dim3(256), 0, st, w, U, CK, flip);
+  else
+    hipLaunchKernelGGL(k_wino_filter<float>, dim3(cdiv(CK, 256)), dim3(256), 0, st, w, U, CK, flip);
+}
 void run_input(const float* in, float* V, const WinoGeom& g, int C, hipStream_t st) {
   if (wide(g.T, C))
     hipLaunchKernelGGL(k_wino_input<floatx4>, dim3(cdiv(g.T * C / 4, 256)), dim3(256), 0, st, in, V, g, C);
@@ -438,7 +445,7 @@ void wino_fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* 
   float* U = (float*)workspace;
   float* V = (float*)((char*)U + align_up(WP * CK * 4, 256));
   float* Mb = (float*)((char*)V + align_up((int64_t)WP * g.T * d->C * 4, 256));
-  hipLaunchKernelGGL(k_wino_filter, dim3(cdiv(CK / 4, 256)), dim3(256), 0, st, w, U, CK, 0);
+  run_filter(w, U, CK, 0, st);
   run_input(x, V, g, d->C, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = U; p.out = Mb;
@@ -456,7 +463,7 @@ void wino_dgrad(const mtlssl_conv_desc* d, int tile, const float* dy, const floa
   float* U = (float*)workspace;
   float* V = (float*)((char*)U + align_up(WP * CK * 4, 256));               // transformed dy [36][T][K]
   float* Mb = (float*)((char*)V + align_up((int64_t)WP * g.T * d->K * 4, 256));   // [36][T][C]
-  hipLaunchKernelGGL(k_wino_filter, dim3(cdiv(CK / 4, 256)), dim3(256), 0, st, w, U, CK, 1);
+  run_filter(w, U, CK, 1, st);
   run_input(dy, V, g, d->K, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = U; p.out = Mb;
@@ -484,8 +491,13 @@ void wino_wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float
   p.a_bytes = (unsigned)(g.T * d->C * 4); p.b_bytes = (unsigned)(g.T * d->K * 4);
   p.a_bs = g.T * d->C; p.b_bs = g.T * d->K;
   launch_gemm<MODE_WGRAD>(tile, p, ns, st);
-  hipLaunchKernelGGL(k_wino_wgrad_out, dim3(cdiv(CK / 2, 256)), dim3(256), 0, st, (const float*)dU, ns, CK, d->K,
-                     out_scale, dw, beta);
+  typedef float floatx2 __attribute__((ext_vector_type(2)));
+  if (CK >= 262144)
+    hipLaunchKernelGGL(k_wino_wgrad_out<floatx2>, dim3(cdiv(CK / 2, 256)), dim3(256), 0, st, (const float*)dU, ns, CK,
+                       d->K, out_scale, dw, beta);
+  else
+    hipLaunchKernelGGL(k_wino_wgrad_out<float>, dim3(cdiv(CK, 256)), dim3(256), 0, st, (const float*)dU, ns, CK, d->K,
+                       out_scale, dw, beta);
 }
 
 }  // namespace mtlssl
