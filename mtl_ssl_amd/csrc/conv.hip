@@ -632,10 +632,12 @@ static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pp
   if (t_out) *t_out = best_t;
 }
 
-// Direct or Winograd F(4x4,3x3)? MTLSSL_WINOGRAD: 0 never, 1 (default) by the plan registry, else by
-// the time models; 2 every eligible problem. Registry codes WINO_CFG0 + tile select Winograd with that
-// GEMM tile; codes 0..NCFG-1 pin the direct path.
+// Direct or Winograd? MTLSSL_WINOGRAD / mtlssl_conv2d_set_winograd: 0 never, 1 (default) by the plan
+// registry, else by the time models; 2 every eligible problem. Registry codes WINO_CFG0 + 4*variant + tile
+// select a Winograd variant (0: F(4x4,3x3), 1: whole-7-span) with that GEMM tile; codes 0..NCFG-1 pin the
+// direct path.
 constexpr int WINO_CFG0 = 4;
+struct WinoChoice { int variant, tile; };
 static std::atomic<int>& wino_mode_ref() {
   static std::atomic<int> v{-1};
   return v;
@@ -650,17 +652,24 @@ static int wino_env() {
   }
   return v;
 }
-static bool choose_wino(const mtlssl_conv_desc* d, int mode, int* tile) {
+static bool choose_wino(const mtlssl_conv_desc* d, int mode, WinoChoice* wc) {
   const int env = wino_env();
-  if (env == 0 || !wino_eligible(d, mode)) return false;
+  if (env == 0 || !wino_eligible(d, WINO_F43)) return false;     // F43's domain contains M7's
   if (mode == MODE_FWD ? !mfma_fwd_ok(d) : (mode == MODE_DGRAD ? !mfma_dgrad_ok(d) : !mfma_wgrad_ok(d))) return false;
   const int force = tuned_cfg(d, mode);
-  int model_tile;
-  const double tw = wino_time_us(d, mode, &model_tile);
-  if (force >= WINO_CFG0 && force < WINO_CFG0 + NCFG) { *tile = force - WINO_CFG0; return true; }
-  *tile = model_tile;
+  if (force >= WINO_CFG0) {
+    const int variant = (force - WINO_CFG0) / 4, tile = (force - WINO_CFG0) % 4;
+    if (variant < WINO_VARIANTS && tile < NCFG && wino_eligible(d, variant)) { *wc = WinoChoice{variant, tile}; return true; }
+  }
+  double tw = 1e30;
+  for (int v = 0; v < WINO_VARIANTS; ++v) {
+    if (!wino_eligible(d, v)) continue;
+    int tile;
+    double t = wino_time_us(d, v, mode, &tile);
+    if (t < tw) { tw = t; *wc = WinoChoice{v, tile}; }
+  }
   if (env == 2) return true;
-  if (force >= 0) return false;
+  if (force >= 0 && force < NCFG) return false;
   double td;
   if (mode == MODE_WGRAD) { int c, ns, pps; wgrad_plan(d, &c, &ns, &pps, &td); }
   else plan_dir(d, mode, &td);
@@ -679,8 +688,8 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
   int64_t M = mode == MODE_FWD ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W;
   int64_t NG = mode == MODE_FWD ? d->K : d->C;
   if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : mfma_dgrad_ok(d))) return 0;
-  int wt;
-  if (choose_wino(d, mode, &wt)) return wino_workspace_bytes(d, mode);
+  WinoChoice wc;
+  if (choose_wino(d, mode, &wc)) return wino_workspace_bytes(d, wc.variant, mode);
   Plan pl = plan_dir(d, mode);
   if (pl.tail_rows > 0) {
     int64_t m_tail0 = (cdiv(M, CFG_BM[pl.cfg]) - pl.tail_rows) * CFG_BM[pl.cfg];
@@ -701,9 +710,9 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
   p.b_bytes = (unsigned)((int64_t)d->R * d->S * d->C * d->K * 4);
   p.M = d->N * d->OH * d->OW;
   p.NG = d->K;
-  int wt;
-  if (workspace && choose_wino(d, MODE_FWD, &wt)) {
-    wino_fwd(d, wt, x, w, bias, residual, y, epi, workspace, S(stream));
+  WinoChoice wc;
+  if (workspace && choose_wino(d, MODE_FWD, &wc)) {
+    wino_fwd(d, wc.variant, wc.tile, x, w, bias, residual, y, epi, workspace, S(stream));
   } else if (mfma_fwd_ok(d)) {
     Plan pl = plan_dir(d, MODE_FWD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
@@ -734,9 +743,9 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   p.b_bytes = (unsigned)((int64_t)d->R * d->S * d->C * d->K * 4);
   p.M = d->N * d->H * d->W;
   p.NG = d->C;
-  int wt;
-  if (workspace && choose_wino(d, MODE_DGRAD, &wt)) {
-    wino_dgrad(d, wt, dy, w, residual, mask_ref, dx, epi, workspace, S(stream));
+  WinoChoice wc;
+  if (workspace && choose_wino(d, MODE_DGRAD, &wc)) {
+    wino_dgrad(d, wc.variant, wc.tile, dy, w, residual, mask_ref, dx, epi, workspace, S(stream));
   } else if (mfma_dgrad_ok(d)) {
     Plan pl = plan_dir(d, MODE_DGRAD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
@@ -754,8 +763,8 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
 int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
   if (!d || mode < MODE_FWD || mode > MODE_WGRAD) return -1;
   if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : (mode == MODE_DGRAD ? mfma_dgrad_ok(d) : mfma_wgrad_ok(d)))) return -1;
-  int wt;
-  if (choose_wino(d, mode, &wt)) return WINO_CFG0 + wt;
+  WinoChoice wc;
+  if (choose_wino(d, mode, &wc)) return WINO_CFG0 + 4 * wc.variant + wc.tile;
   if (mode == MODE_WGRAD) {
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);
@@ -766,7 +775,8 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
 
 int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg) {
   MTLSSL_REQUIRE(d != nullptr && mode >= MODE_FWD && mode <= MODE_WGRAD, "force_config: bad arguments");
-  MTLSSL_REQUIRE(cfg < WINO_CFG0 + NCFG && cfg != NCFG, "force_config: tile configuration out of range");
+  MTLSSL_REQUIRE(cfg < WINO_CFG0 + 4 * WINO_VARIANTS && (cfg < 0 || cfg % 4 < NCFG),
+                 "force_config: tile configuration out of range");
   TunedKey k = make_key(d, mode);
   std::lock_guard<std::mutex> g(tuned_mutex());
   if (cfg < 0) tuned_map().erase(k); else tuned_map()[k] = cfg;
@@ -781,9 +791,9 @@ int mtlssl_conv2d_set_winograd(int mode) {
 
 int mtlssl_conv2d_num_dispatches(const mtlssl_conv_desc* d, int mode) {
   if (!d) return 0;
-  int wt;
+  WinoChoice wc;
   if ((mode == MODE_FWD && mfma_fwd_ok(d)) || (mode == MODE_DGRAD && mfma_dgrad_ok(d)))
-    return !choose_wino(d, mode, &wt) && plan_dir(d, mode).tail_rows > 0 ? 2 : 1;
+    return !choose_wino(d, mode, &wc) && plan_dir(d, mode).tail_rows > 0 ? 2 : 1;
   return 1;
 }
 
@@ -797,8 +807,9 @@ int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
     small_wgrad_plan(d, &ns, &kps);
     return bias_part + align_up((int64_t)ns * d->C * d->K * 4, 256);
   }
-  int cfg, ns, pps, wt;
-  if (choose_wino(d, MODE_WGRAD, &wt)) return bias_part + wino_workspace_bytes(d, MODE_WGRAD);
+  int cfg, ns, pps;
+  WinoChoice wc;
+  if (choose_wino(d, MODE_WGRAD, &wc)) return bias_part + wino_workspace_bytes(d, wc.variant, MODE_WGRAD);
   wgrad_plan(d, &cfg, &ns, &pps);
   return bias_part + align_up((int64_t)ns * d->R * d->S * d->C * d->K * 4, 256);
 }
@@ -815,9 +826,9 @@ int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* 
   int64_t P = (int64_t)d->N * d->OH * d->OW;
   MTLSSL_REQUIRE(workspace != nullptr, "conv_wgrad: workspace required");
   float* ws_main = (float*)((char*)workspace + align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256));
-  int wt;
-  if (choose_wino(d, MODE_WGRAD, &wt)) {
-    wino_wgrad(d, wt, x, dy, out_scale, dw, beta, ws_main, st);
+  WinoChoice wc;
+  if (choose_wino(d, MODE_WGRAD, &wc)) {
+    wino_wgrad(d, wc.variant, wc.tile, x, dy, out_scale, dw, beta, ws_main, st);
   } else if (mfma_wgrad_ok(d)) {
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);

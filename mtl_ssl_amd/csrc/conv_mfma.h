@@ -447,16 +447,18 @@ static inline double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block
   return (double)per_cu * (ksteps_per_block + 96 / CFG_BK[cfg]) * step_us;
 }
 
-// ---- Winograd F(4x4,3x3) path (winograd.hip), behind the same entry points as the direct one.
+// ---- Winograd path (winograd.hip), behind the same entry points as the direct one.
+// variant: tile specification (F(4x4,3x3) for any map; the whole-7-span F(4,3)+F(3,3) for 7k x 7k maps);
 // mode: MODE_FWD / MODE_DGRAD / MODE_WGRAD; tile: GEMM tile configuration 0..NCFG-1.
-bool wino_eligible(const mtlssl_conv_desc* d, int mode);
-double wino_time_us(const mtlssl_conv_desc* d, int mode, int* tile);
-int64_t wino_workspace_bytes(const mtlssl_conv_desc* d, int mode);
-void wino_fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* w, const float* bias,
+enum { WINO_F43 = 0, WINO_M7 = 1, WINO_VARIANTS = 2 };
+bool wino_eligible(const mtlssl_conv_desc* d, int variant);
+double wino_time_us(const mtlssl_conv_desc* d, int variant, int mode, int* tile);
+int64_t wino_workspace_bytes(const mtlssl_conv_desc* d, int variant, int mode);
+void wino_fwd(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* w, const float* bias,
               const float* residual, float* y, int epi, void* workspace, hipStream_t st);
-void wino_dgrad(const mtlssl_conv_desc* d, int tile, const float* dy, const float* w, const float* residual,
-                const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st);
-void wino_wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float* dy, const float* out_scale,
-                float* dw, float beta, void* workspace, hipStream_t st);
+void wino_dgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* dy, const float* w,
+                const float* residual, const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st);
+void wino_wgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* dy,
+                const float* out_scale, float* dw, float beta, void* workspace, hipStream_t st);
 
 }  // namespace mtlssl

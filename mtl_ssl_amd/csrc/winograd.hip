@@ -1,72 +1,102 @@
-// Winograd F(4x4,3x3) path of the NHWC fp32 convolution family for gfx950 (MI355X).
+// Winograd minimal-filtering path of the NHWC fp32 convolution family for gfx950 (MI355X).
 //
 // The 3x3 / stride-1 / SAME convolutions of the detector (slim/nets/resnet_utils.py:77-122 conv2d_same
 // with stride 1; the 3x3 of every bottleneck unit, slim/nets/resnet_v1.py:110-111) are 45 % of the
-// training step's direct-convolution FLOPs. Lavin & Gray's minimal filtering algorithm computes a
-// 4x4 output tile from a 6x6 input patch with 36 multiplies per (c, k) pair instead of 144:
+// training step's direct-convolution FLOPs. Lavin & Gray's minimal filtering algorithm computes an
+// O x O output tile from an I x I input patch with P x P multiplies per (c, k) pair instead of 9 O^2:
 //
 //     Y = A^T [ (G g G^T) . (B^T d B) ] A          (forward, and dgrad with the flipped filter)
 //     dg = G^T [ (A dY A^T) . (B^T d B) ] G         (filter gradient)
 //
-// so the convolution becomes 36 independent GEMMs [tiles x Cin] x [Cin x Cout] in the transformed
+// so the convolution becomes P^2 independent GEMMs [tiles x Cin] x [Cin x Cout] in the transformed
 // domain — run here as ONE launch of the MFMA tile engine (conv_mfma.h, k_wino_gemm: blockIdx.y is the
-// Winograd point) — between two HBM-bound transform kernels. On the 7x7 maps of the second stage the
-// tiles cover 8x8, so the multiply count drops 3.06x (not 4x); the transformed operands are 2.9x the
-// size of the activations, all of which the 8 TB/s HBM absorbs in a fraction of the GEMM time saved.
-// fp32 throughout; the transform constants are exact binary fractions except the 1/6, 1/12, 1/24 of G.
+// Winograd point) — between two HBM-bound transform kernels. Two tile specifications:
+//
+//   F43 : F(4x4,3x3), P = 6, I = 6, O = 4 (points 0, +-1, +-2, inf): 36 multiplies per 16 outputs. Any map.
+//   M7  : a whole 7-wide span as F(4,3) (+) F(3,3) side by side, P = 11, I = 9, O = 7: 121 multiplies per 49
+//         outputs. The second stage runs on 7x7 ROI maps, which F43 has to cover with 2x2 tiles = 8x8
+//         (144 multiplies, a quarter of them for outputs that are thrown away); M7 covers 7 exactly.
+//         F(3,3) uses the points 0, +-1, 2, inf.
+//
+// The transforms are generated from the specification's constant matrices (loops fully unrolled, zero
+// coefficients dropped at compile time). fp32 throughout; the matrices are exact in binary except the
+// 1/6, 1/12, 1/24 (F43) and 1/6, 1/3, 2/3 (F33) entries of G.
 #include "conv_mfma.h"
 
 namespace mtlssl {
 
 namespace {
 
-constexpr int WP = 36;   // Winograd-domain points of F(4x4,3x3)
+// ---- tile specifications. bt: P x I, at: O x P, g: P x 3 (Cook-Toom, scaled as in Lavin & Gray).
+struct F43 {
+  static constexpr int P = 6, I = 6, O = 4;
+  static constexpr float bt(int a, int i) {
+    constexpr float t[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                               {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+    return t[a][i];
+  }
+  static constexpr float at(int u, int a) {
+    constexpr float t[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    return t[u][a];
+  }
+  static constexpr float g(int a, int r) {
+    constexpr float t[6][3] = {{1.f / 4, 0, 0}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                               {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0, 0, 1}};
+    return t[a][r];
+  }
+};
+struct F33 {   // F(3,3): 5 points, 5 inputs, 3 outputs — only as the second segment of M7
+  static constexpr float bt(int a, int i) {
+    constexpr float t[5][5] = {{2, -1, -2, 1, 0}, {0, -2, -1, 1, 0}, {0, 2, -3, 1, 0}, {0, -1, 0, 1, 0}, {0, 2, -1, -2, 1}};
+    return t[a][i];
+  }
+  static constexpr float at(int u, int a) {
+    constexpr float t[3][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 0}, {0, 1, 1, 4, 1}};
+    return t[u][a];
+  }
+  static constexpr float g(int a, int r) {
+    constexpr float t[5][3] = {{1.f / 2, 0, 0}, {-1.f / 2, -1.f / 2, -1.f / 2}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                               {1.f / 6, 1.f / 3, 2.f / 3}, {0, 0, 1}};
+    return t[a][r];
+  }
+};
+struct M7 {    // outputs 0..3 from patch 0..5 via F43, outputs 4..6 from patch 4..8 via F33
+  static constexpr int P = 11, I = 9, O = 7;
+  static constexpr float bt(int a, int i) {
+    return a < 6 ? (i < 6 ? F43::bt(a, i) : 0.f) : (i >= 4 ? F33::bt(a - 6, i - 4) : 0.f);
+  }
+  static constexpr float at(int u, int a) {
+    return u < 4 ? (a < 6 ? F43::at(u, a) : 0.f) : (a >= 6 ? F33::at(u - 4, a - 6) : 0.f);
+  }
+  static constexpr float g(int a, int r) { return a < 6 ? F43::g(a, r) : F33::g(a - 6, r); }
+};
 
-// 1-D transforms; T is float or floatx4 (four channels at once).
-template <typename T>
-__device__ __forceinline__ void bt6(const T* d, T* o) {   // o = B^T d
-  o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-  o[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
-  o[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
-  o[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-  o[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-  o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+// o[0..NO) = M[NO x NI] * d[0..NI) with compile-time coefficients; KIND selects the matrix.
+enum { XF_BT, XF_AT, XF_A, XF_G, XF_GT };
+template <typename S, int KIND>
+__host__ __device__ constexpr float coef(int o, int i) {
+  return KIND == XF_BT ? S::bt(o, i) : KIND == XF_AT ? S::at(o, i) : KIND == XF_A ? S::at(i, o)
+         : KIND == XF_G ? S::g(o, i) : S::g(i, o);
 }
-template <typename T>
-__device__ __forceinline__ void at4(const T* m, T* o) {   // o = A^T m
-  T s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-  o[0] = m[0] + s12 + s34;
-  o[1] = d12 + 2.f * d34;
-  o[2] = s12 + 4.f * s34;
-  o[3] = d12 + 8.f * d34 + m[5];
-}
-template <typename T>
-__device__ __forceinline__ void a6(const T* y, T* o) {    // o = A y
-  T s02 = y[0] + y[2], s13 = y[1] + y[3];
-  o[0] = y[0];
-  o[1] = s02 + s13;
-  o[2] = s02 - s13;
-  T e = y[0] + 4.f * y[2], f = 2.f * y[1] + 8.f * y[3];
-  o[3] = e + f;
-  o[4] = e - f;
-  o[5] = y[3];
-}
-template <typename T>
-__device__ __forceinline__ void g6(const T* g, T* o) {    // o = G g
-  const float c6 = 1.f / 6.f, c12 = 1.f / 12.f, c24 = 1.f / 24.f;
-  o[0] = 0.25f * g[0];
-  o[1] = -c6 * (g[0] + g[1] + g[2]);
-  o[2] = -c6 * (g[0] - g[1] + g[2]);
-  o[3] = c24 * g[0] + c12 * g[1] + c6 * g[2];
-  o[4] = c24 * g[0] - c12 * g[1] + c6 * g[2];
-  o[5] = g[2];
-}
-template <typename T>
-__device__ __forceinline__ void gt3(const T* u, T* o) {   // o = G^T u
-  const float c6 = 1.f / 6.f, c12 = 1.f / 12.f, c24 = 1.f / 24.f;
-  o[0] = 0.25f * u[0] - c6 * (u[1] + u[2]) + c24 * (u[3] + u[4]);
-  o[1] = c6 * (u[2] - u[1]) + c12 * (u[3] - u[4]);
-  o[2] = -c6 * (u[1] + u[2]) + c6 * (u[3] + u[4]) + u[5];
+template <typename S, int KIND, int NO, int NI, typename VT>
+__device__ __forceinline__ void xform(const VT* d, VT* o) {
+#pragma unroll
+  for (int a = 0; a < NO; ++a) {
+    VT acc{};
+    bool first = true;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float c = coef<S, KIND>(a, i);
+      if (c != 0.f) {
+        if (first) acc = (c == 1.f) ? d[i] : c * d[i];
+        else if (c == 1.f) acc = acc + d[i];
+        else if (c == -1.f) acc = acc - d[i];
+        else acc = acc + c * d[i];
+        first = false;
+      }
+    }
+    o[a] = acc;
+  }
 }
 
 struct WinoGeom {
@@ -76,7 +106,8 @@ struct WinoGeom {
 // Thread -> (tile t, channel group) of a [T][C] plane, channels fastest. VT = floatx4: four channels per
 // thread, a wave touches 1 KB of contiguous memory per access (C % 16 == 0 on this path, so a quad never
 // straddles a row) — the wide problems; VT = float: one channel per thread, four times the threads —
-// the narrow ones (a block3 unit has 320 tiles x 256 channels), which are latency- not bandwidth-bound.
+// the narrow ones (a block3 unit has 320 tiles x 256 channels), which are latency- not bandwidth-bound,
+// and M7, whose 11x11 working set does not fit the registers four channels wide.
 struct TileIdx { int64_t t; int c, n, ty, tx; bool ok; };
 template <typename VT>
 __device__ __forceinline__ TileIdx tile_index(const WinoGeom& g, int C) {
@@ -113,136 +144,140 @@ __device__ __forceinline__ floatx4 mask_bwd(floatx4 g, floatx4 y, int epi) {
 
 // Filter transform U[xi][c][k] = (G g G^T)[xi] of w[r][s][c][k]; flip = 1 takes g[2-r][2-s] (the
 // dgrad filter; its [C][K] layout is what the tile engine's dgrad mode reads as B[n][k]).
-template <typename VT>
+template <typename S, typename VT>
 __global__ void __launch_bounds__(256) k_wino_filter(const float* w, float* U, int64_t CK, int flip) {
+  constexpr int P = S::P;
   int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * (sizeof(VT) / 4);
   if (i >= CK) return;
-  VT t[6][3];
+  VT t[P][3];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {           // columns: t = G g
-    VT col[3], o[6];
+    VT col[3], o[P];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
       col[r] = *reinterpret_cast<const VT*>(w + (int64_t)(rr * 3 + ss) * CK + i);
     }
-    g6(col, o);
+    xform<S, XF_G, P, 3>(col, o);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) t[a][s] = o[a];
+    for (int a = 0; a < P; ++a) t[a][s] = o[a];
   }
 #pragma unroll
-  for (int a = 0; a < 6; ++a) {           // rows: U = t G^T
-    VT o[6];
-    g6(t[a], o);
+  for (int a = 0; a < P; ++a) {           // rows: U = t G^T
+    VT o[P];
+    xform<S, XF_G, P, 3>(t[a], o);
 #pragma unroll
-    for (int b = 0; b < 6; ++b) *reinterpret_cast<VT*>(U + (int64_t)(a * 6 + b) * CK + i) = o[b];
+    for (int b = 0; b < P; ++b) *reinterpret_cast<VT*>(U + (int64_t)(a * P + b) * CK + i) = o[b];
   }
 }
 
-// Input transform V[xi][t][c] = (B^T d B)[xi] of the 6x6 patch of tile t (origin 4*ty-1, 4*tx-1,
-// zero outside the map). The patch is streamed a column at a time (24 registers), the column-transformed
-// 6x6 is held (144), then rows are transformed and stored plane by plane.
-template <typename VT>
+// Input transform V[xi][t][c] = (B^T d B)[xi] of the I x I patch of tile t (origin O*ty-1, O*tx-1,
+// zero outside the map). The patch is streamed a column at a time, the column-transformed P x I block is
+// held in registers, then rows are transformed and stored plane by plane.
+template <typename S, typename VT>
 __global__ void __launch_bounds__(256) k_wino_input(const float* in, float* V, WinoGeom g, int C) {
+  constexpr int P = S::P, I = S::I;
   const TileIdx ix = tile_index<VT>(g, C);
   if (!ix.ok) return;
-  const int y0 = 4 * ix.ty - 1, x0 = 4 * ix.tx - 1;
+  const int y0 = S::O * ix.ty - 1, x0 = S::O * ix.tx - 1;
   const float* base = in + ((int64_t)ix.n * g.H * g.W) * C + ix.c;
-  VT tmp[6][6];
+  VT tmp[P][I];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < I; ++j) {
     const int x = x0 + j;
     const bool okx = (unsigned)x < (unsigned)g.W;
-    VT col[6], o[6];
+    VT col[I], o[P];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < I; ++i) {
       const int y = y0 + i;
       const bool ok = okx && (unsigned)y < (unsigned)g.H;
       col[i] = ok ? *reinterpret_cast<const VT*>(base + ((int64_t)y * g.W + x) * C) : VT{};
     }
-    bt6(col, o);
+    xform<S, XF_BT, P, I>(col, o);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) tmp[i][j] = o[i];
+    for (int a = 0; a < P; ++a) tmp[a][j] = o[a];
   }
   const int64_t plane = g.T * C;
   float* vp = V + ix.t * C + ix.c;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    VT o[6];
-    bt6(tmp[i], o);
+  for (int a = 0; a < P; ++a) {
+    VT o[P];
+    xform<S, XF_BT, P, I>(tmp[a], o);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<VT*>(vp + (int64_t)(i * 6 + j) * plane) = o[j];
+    for (int b = 0; b < P; ++b) *reinterpret_cast<VT*>(vp + (int64_t)(a * P + b) * plane) = o[b];
   }
 }
 
-// Output-gradient transform for the filter gradient: dM[xi][t][k] = (A dY A^T)[xi] of the 4x4
+// Output-gradient transform for the filter gradient: dM[xi][t][k] = (A dY A^T)[xi] of the O x O
 // tile of dY (zero outside the map).
-template <typename VT>
+template <typename S, typename VT>
 __global__ void __launch_bounds__(256) k_wino_dy(const float* dy, float* dM, WinoGeom g, int K) {
+  constexpr int P = S::P, O = S::O;
   const TileIdx ix = tile_index<VT>(g, K);
   if (!ix.ok) return;
   const float* base = dy + ((int64_t)ix.n * g.H * g.W) * K + ix.c;
-  VT tmp[6][4];
+  VT tmp[P][O];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int x = 4 * ix.tx + j;
-    VT col[4], o[6];
+  for (int j = 0; j < O; ++j) {
+    const int x = O * ix.tx + j;
+    VT col[O], o[P];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int y = 4 * ix.ty + i;
+    for (int i = 0; i < O; ++i) {
+      const int y = O * ix.ty + i;
       const bool ok = y < g.H && x < g.W;
       col[i] = ok ? *reinterpret_cast<const VT*>(base + ((int64_t)y * g.W + x) * K) : VT{};
     }
-    a6(col, o);
+    xform<S, XF_A, P, O>(col, o);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) tmp[i][j] = o[i];
+    for (int a = 0; a < P; ++a) tmp[a][j] = o[a];
   }
   const int64_t plane = g.T * K;
   float* mp = dM + ix.t * K + ix.c;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    VT o[6];
-    a6(tmp[i], o);
+  for (int a = 0; a < P; ++a) {
+    VT o[P];
+    xform<S, XF_A, P, O>(tmp[a], o);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<VT*>(mp + (int64_t)(i * 6 + j) * plane) = o[j];
+    for (int b = 0; b < P; ++b) *reinterpret_cast<VT*>(mp + (int64_t)(a * P + b) * plane) = o[b];
   }
 }
 
 // Output transform Y = A^T m A of Mb[xi][t][k] + the epilogue of the direct kernel (forward:
 // bias / residual / ReLU / ReLU6 / tanh; dgrad: residual / accumulate / activation mask).
-template <int MODE, typename VT>
+template <typename S, int MODE, typename VT>
 __global__ void __launch_bounds__(256) k_wino_output(const float* Mb, float* out, WinoGeom g, int K,
                                                      const float* bias, const float* residual,
                                                      const float* mask, int epi) {
+  constexpr int P = S::P, O = S::O;
   const TileIdx ix = tile_index<VT>(g, K);
   if (!ix.ok) return;
   const int64_t plane = g.T * K;
   const float* mp = Mb + ix.t * K + ix.c;
-  VT tmp[4][6];
+  VT tmp[O][P];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    VT col[6], o[4];
+  for (int b = 0; b < P; ++b) {
+    VT col[P], o[O];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const VT*>(mp + (int64_t)(i * 6 + j) * plane);
-    at4(col, o);
+    for (int a = 0; a < P; ++a) col[a] = *reinterpret_cast<const VT*>(mp + (int64_t)(a * P + b) * plane);
+    xform<S, XF_AT, O, P>(col, o);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tmp[i][j] = o[i];
+    for (int u = 0; u < O; ++u) tmp[u][b] = o[u];
   }
   VT bv{};
   if constexpr (MODE == MODE_FWD)
     if (epi & MTLSSL_EPI_BIAS) bv = *reinterpret_cast<const VT*>(bias + ix.c);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    VT o[4];
-    at4(tmp[i], o);
-    const int oy = 4 * ix.ty + i;
+  for (int u = 0; u < O; ++u) {
+    VT o[O];
+    xform<S, XF_AT, O, P>(tmp[u], o);
+    const int oy = O * ix.ty + u;
     if (oy >= g.H) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ox = 4 * ix.tx + j;
+    for (int v_ = 0; v_ < O; ++v_) {
+      const int ox = O * ix.tx + v_;
       if (ox >= g.W) continue;
       const int64_t off = (((int64_t)ix.n * g.H + oy) * g.W + ox) * K + ix.c;
-      VT v = o[j];
+      VT v = o[v_];
       if constexpr (MODE == MODE_FWD) {
         v += bv;
         if (epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const VT*>(residual + off);
@@ -258,39 +293,42 @@ __global__ void __launch_bounds__(256) k_wino_output(const float* Mb, float* out
 }
 
 // Filter-gradient back-transform: dw[r][s][c][k] = beta*dw + scale[k] * (G^T (sum_split dU) G)[r][s].
-// The split loop is outermost so that the 36 plane loads of one split are independent and in flight
+// The split loop is outermost so that the P^2 plane loads of one split are independent and in flight
 // together. VT = float2: two (c,k) pairs per thread (wide filters), float: one (narrow ones).
-template <typename VT>
+template <typename S, typename VT>
 __global__ void __launch_bounds__(256) k_wino_wgrad_out(const float* dU, int nsplit, int64_t CK, int K,
                                                         const float* scale, float* dw, float beta) {
+  constexpr int P = S::P;
   int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * (sizeof(VT) / 4);
   if (i >= CK) return;
-  VT u[6][6];
+  VT u[P][P];
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
+  for (int a = 0; a < P; ++a)
 #pragma unroll
-    for (int b = 0; b < 6; ++b) u[a][b] = *reinterpret_cast<const VT*>(dU + (int64_t)(a * 6 + b) * CK + i);
+    for (int b = 0; b < P; ++b) u[a][b] = *reinterpret_cast<const VT*>(dU + (int64_t)(a * P + b) * CK + i);
   for (int z = 1; z < nsplit; ++z) {
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < P; ++a)
 #pragma unroll
-      for (int b = 0; b < 6; ++b)
-        u[a][b] += *reinterpret_cast<const VT*>(dU + ((int64_t)z * WP + a * 6 + b) * CK + i);
+      for (int b = 0; b < P; ++b)
+        u[a][b] += *reinterpret_cast<const VT*>(dU + ((int64_t)z * (P * P) + a * P + b) * CK + i);
   }
-  VT t[3][6];
+  VT t[3][P];
 #pragma unroll
-  for (int b = 0; b < 6; ++b) {
-    VT col[6] = {u[0][b], u[1][b], u[2][b], u[3][b], u[4][b], u[5][b]}, o[3];
-    gt3(col, o);
+  for (int b = 0; b < P; ++b) {
+    VT col[P], o[3];
+#pragma unroll
+    for (int a = 0; a < P; ++a) col[a] = u[a][b];
+    xform<S, XF_GT, 3, P>(col, o);
 #pragma unroll
     for (int r = 0; r < 3; ++r) t[r][b] = o[r];
   }
-  VT sc;
+  VT sc{};
   if (scale) sc = *reinterpret_cast<const VT*>(scale + i % K);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     VT o[3];
-    gt3(t[r], o);
+    xform<S, XF_GT, 3, P>(t[r], o);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       VT v = scale ? o[s] * sc : o[s];
@@ -300,50 +338,84 @@ __global__ void __launch_bounds__(256) k_wino_wgrad_out(const float* dU, int nsp
   }
 }
 
+// ---- host side
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+template <typename S>
 WinoGeom geom(const mtlssl_conv_desc* d) {
   WinoGeom g;
   g.N = d->N; g.H = d->H; g.W = d->W;
-  g.th = (int)cdiv(d->H, 4); g.tw = (int)cdiv(d->W, 4);
+  g.th = (int)cdiv(d->H, S::O); g.tw = (int)cdiv(d->W, S::O);
   g.T = (int64_t)d->N * g.th * g.tw;
   return g;
 }
 
-// Wide planes: four channels per thread; narrow ones: one (more threads in flight).
-bool wide(int64_t T, int C) { return T * C / 4 >= 131072; }
+// Wide planes: four channels per thread; narrow ones: one (more threads in flight). M7 is scalar only.
+template <typename S> constexpr bool can_vec() { return S::P <= 6; }
+inline bool wide(int64_t T, int C) { return T * C / 4 >= 131072; }
+
+template <typename S>
 void run_filter(const float* w, float* U, int64_t CK, int flip, hipStream_t st) {
-  if (CK >= 262144)
-    hipLaunchKernelGGL(k_wino_filter<floatx4>, dim3(cdiv(CK / 4, 256)), dim3(256), 0, st, w, U, CK, flip);
-  else
-    hipLaunchKernelGGL(k_wino_filter<float>, dim3(cdiv(CK, 256)), dim3(256), 0, st, w, U, CK, flip);
+  if constexpr (can_vec<S>()) {
+    if (CK >= 262144) {
+      hipLaunchKernelGGL((k_wino_filter<S, floatx4>), dim3(cdiv(CK / 4, 256)), dim3(256), 0, st, w, U, CK, flip);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_wino_filter<S, float>), dim3(cdiv(CK, 256)), dim3(256), 0, st, w, U, CK, flip);
 }
+template <typename S>
 void run_input(const float* in, float* V, const WinoGeom& g, int C, hipStream_t st) {
-  if (wide(g.T, C))
-    hipLaunchKernelGGL(k_wino_input<floatx4>, dim3(cdiv(g.T * C / 4, 256)), dim3(256), 0, st, in, V, g, C);
-  else
-    hipLaunchKernelGGL(k_wino_input<float>, dim3(cdiv(g.T * C, 256)), dim3(256), 0, st, in, V, g, C);
+  if constexpr (can_vec<S>()) {
+    if (wide(g.T, C)) {
+      hipLaunchKernelGGL((k_wino_input<S, floatx4>), dim3(cdiv(g.T * C / 4, 256)), dim3(256), 0, st, in, V, g, C);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_wino_input<S, float>), dim3(cdiv(g.T * C, 256)), dim3(256), 0, st, in, V, g, C);
 }
+template <typename S>
 void run_dy(const float* dy, float* dM, const WinoGeom& g, int K, hipStream_t st) {
-  if (wide(g.T, K))
-    hipLaunchKernelGGL(k_wino_dy<floatx4>, dim3(cdiv(g.T * K / 4, 256)), dim3(256), 0, st, dy, dM, g, K);
-  else
-    hipLaunchKernelGGL(k_wino_dy<float>, dim3(cdiv(g.T * K, 256)), dim3(256), 0, st, dy, dM, g, K);
+  if constexpr (can_vec<S>()) {
+    if (wide(g.T, K)) {
+      hipLaunchKernelGGL((k_wino_dy<S, floatx4>), dim3(cdiv(g.T * K / 4, 256)), dim3(256), 0, st, dy, dM, g, K);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_wino_dy<S, float>), dim3(cdiv(g.T * K, 256)), dim3(256), 0, st, dy, dM, g, K);
 }
-template <int MODE>
+template <typename S, int MODE>
 void run_output(const float* Mb, float* out, const WinoGeom& g, int K, const float* bias, const float* residual,
                 const float* mask, int epi, hipStream_t st) {
-  if (wide(g.T, K))
-    hipLaunchKernelGGL((k_wino_output<MODE, floatx4>), dim3(cdiv(g.T * K / 4, 256)), dim3(256), 0, st, Mb, out, g, K,
-                       bias, residual, mask, epi);
-  else
-    hipLaunchKernelGGL((k_wino_output<MODE, float>), dim3(cdiv(g.T * K, 256)), dim3(256), 0, st, Mb, out, g, K,
-                       bias, residual, mask, epi);
+  if constexpr (can_vec<S>()) {
+    if (wide(g.T, K)) {
+      hipLaunchKernelGGL((k_wino_output<S, MODE, floatx4>), dim3(cdiv(g.T * K / 4, 256)), dim3(256), 0, st, Mb, out,
+                         g, K, bias, residual, mask, epi);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_wino_output<S, MODE, float>), dim3(cdiv(g.T * K, 256)), dim3(256), 0, st, Mb, out, g, K, bias,
+                     residual, mask, epi);
+}
+template <typename S>
+void run_wgrad_out(const float* dU, int ns, int64_t CK, int K, const float* scale, float* dw, float beta,
+                   hipStream_t st) {
+  if constexpr (can_vec<S>()) {
+    if (CK >= 262144) {
+      hipLaunchKernelGGL((k_wino_wgrad_out<S, floatx2>), dim3(cdiv(CK / 2, 256)), dim3(256), 0, st, dU, ns, CK, K,
+                         scale, dw, beta);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_wino_wgrad_out<S, float>), dim3(cdiv(CK, 256)), dim3(256), 0, st, dU, ns, CK, K, scale, dw,
+                     beta);
 }
 
 template <int MODE>
-void launch_gemm(int cfg, ConvArgs& p, int nz, hipStream_t st) {
+void launch_gemm(int cfg, ConvArgs& p, int planes, int nz, hipStream_t st) {
   p.tiles_m = (int)cdiv(p.M, CFG_BM[cfg]);
   p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
-  dim3 grid(p.tiles_m * p.tiles_n, WP, nz);
+  dim3 grid(p.tiles_m * p.tiles_n, planes, nz);
   switch (cfg) {
     case 0: hipLaunchKernelGGL((k_wino_gemm<128, 128, MODE>), grid, dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((k_wino_gemm<128, 64, MODE>), grid, dim3(256), 0, st, p); break;
@@ -351,7 +423,7 @@ void launch_gemm(int cfg, ConvArgs& p, int nz, hipStream_t st) {
   }
 }
 
-// The stack of 36 GEMMs as a 1x1 "convolution" over a [1, 1, T] map for the tile engine.
+// The stack of P^2 GEMMs as a 1x1 "convolution" over a [1, 1, T] map for the tile engine.
 ConvArgs gemm_args(int64_t T, int C, int K) {
   ConvArgs p;
   memset(&p, 0, sizeof(p));
@@ -361,143 +433,172 @@ ConvArgs gemm_args(int64_t T, int C, int K) {
   return p;
 }
 
-// Filter-gradient GEMM stack: split the tile range when 36 * tiles does not fill the chip.
-void wgrad_split(const mtlssl_conv_desc* d, int cfg, int* nsplit, int* pps) {
-  WinoGeom g = geom(d);
-  int64_t tiles = cdiv(d->C, CFG_BM[cfg]) * cdiv(d->K, CFG_BN[cfg]) * WP;
-  int64_t ksteps = cdiv(g.T, 16);
+// Filter-gradient GEMM stack: split the tile range when planes * tiles does not fill the chip.
+void wgrad_split(int64_t T, int planes, int C, int K, int cfg, int* nsplit, int* pps) {
+  int64_t tiles = cdiv(C, CFG_BM[cfg]) * cdiv(K, CFG_BN[cfg]) * planes;
+  int64_t ksteps = cdiv(T, 16);
   double best = 1e30;
-  *nsplit = 1; *pps = (int)align_up(g.T, 16);
+  *nsplit = 1; *pps = (int)align_up(T, 16);
   for (int s = 1; s <= 16; ++s) {
     if (s > 1 && ksteps * 16 / s < 128) break;
     int64_t per = cdiv(ksteps, s);
     int64_t ns = cdiv(ksteps, per);
     if (ns != s) continue;
-    double t = tile_time_us(cfg, tiles * ns, (int)per) + (double)WP * d->C * d->K * 4.0 * ns / 3.0e6;
+    double t = tile_time_us(cfg, tiles * ns, (int)per) + (double)planes * C * K * 4.0 * ns / 3.0e6;
     if (t < best) { best = t; *nsplit = (int)ns; *pps = (int)(per * 16); }
   }
 }
 
-int best_tile(int64_t rows, int64_t cols, int ksteps, double* t_out) {
+int best_tile(int64_t rows, int64_t cols, int planes, int ksteps, double* t_out) {
   int best = 2;
   double bt = 1e30;
   for (int c = 0; c < NCFG; ++c) {
-    double t = tile_time_us(c, cdiv(rows, CFG_BM[c]) * cdiv(cols, CFG_BN[c]) * WP, ksteps);
+    double t = tile_time_us(c, cdiv(rows, CFG_BM[c]) * cdiv(cols, CFG_BN[c]) * planes, ksteps);
     if (t < bt) { bt = t; best = c; }
   }
   if (t_out) *t_out = bt;
   return best;
 }
 
-}  // namespace
-
-bool wino_eligible(const mtlssl_conv_desc* d, int mode) {
-  (void)mode;
+template <typename S>
+bool eligible(const mtlssl_conv_desc* d) {
   if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->dilation == 1 && d->pad_t == 1 && d->pad_l == 1 &&
         d->OH == d->H && d->OW == d->W))
     return false;
   if (d->C % 16 || d->K % 16 || d->C < 32 || d->K < 32) return false;
-  WinoGeom g = geom(d);
+  if (S::O == 7 && (d->H % 7 || d->W % 7)) return false;      // whole 7-spans only
+  WinoGeom g = geom<S>(d);
   int64_t widest = d->C > d->K ? d->C : d->K;
   return g.T * widest < (1ll << 30);   // 32-bit offsets inside one Winograd plane
 }
 
 // Time model (microseconds): the GEMM stack on the tile engine + the transform traffic at ~4 TB/s
-// (scalar 4-byte accesses, 36 planes) + the extra launches.
-double wino_time_us(const mtlssl_conv_desc* d, int mode, int* tile) {
-  WinoGeom g = geom(d);
+// + the extra launches.
+template <typename S>
+double time_us(const mtlssl_conv_desc* d, int mode, int* tile) {
+  constexpr int PL = S::P * S::P;
+  WinoGeom g = geom<S>(d);
   double tg;
   int cfg;
   const double px = (double)d->N * d->H * d->W;
   double bytes;
   if (mode == MODE_WGRAD) {
-    cfg = best_tile(d->C, d->K, (int)cdiv(g.T, 16), &tg);
+    cfg = best_tile(d->C, d->K, PL, (int)cdiv(g.T, 16), &tg);
     int ns, pps;
-    wgrad_split(d, cfg, &ns, &pps);
-    tg = tile_time_us(cfg, cdiv(d->C, CFG_BM[cfg]) * cdiv(d->K, CFG_BN[cfg]) * WP * ns, pps / 16);
-    bytes = 4.0 * (px * (d->C + d->K) + 2.0 * WP * g.T * (d->C + d->K) + (double)WP * d->C * d->K * (ns + 1));
+    wgrad_split(g.T, PL, d->C, d->K, cfg, &ns, &pps);
+    tg = tile_time_us(cfg, cdiv(d->C, CFG_BM[cfg]) * cdiv(d->K, CFG_BN[cfg]) * PL * ns, pps / 16);
+    bytes = 4.0 * (px * (d->C + d->K) + 2.0 * PL * g.T * (d->C + d->K) + (double)PL * d->C * d->K * (ns + 1));
   } else {
     int cin = mode == MODE_FWD ? d->C : d->K, cout = mode == MODE_FWD ? d->K : d->C;
-    cfg = best_tile(g.T, cout, cin / 16, &tg);
-    bytes = 4.0 * (px * (cin + cout) + 2.0 * WP * g.T * (cin + cout) + 2.0 * WP * d->C * d->K);
+    cfg = best_tile(g.T, cout, PL, cin / 16, &tg);
+    bytes = 4.0 * (px * (cin + cout) + 2.0 * PL * g.T * (cin + cout) + 2.0 * PL * d->C * d->K);
   }
   if (tile) *tile = cfg;
   return tg + bytes / 4.0e6 + 12.0;
 }
 
-int64_t wino_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
-  WinoGeom g = geom(d);
-  int64_t planes = align_up((int64_t)WP * g.T * d->C * 4, 256) + align_up((int64_t)WP * g.T * d->K * 4, 256);
+template <typename S>
+int64_t workspace_bytes(const mtlssl_conv_desc* d, int mode) {
+  constexpr int PL = S::P * S::P;
+  WinoGeom g = geom<S>(d);
+  int64_t planes = align_up((int64_t)PL * g.T * d->C * 4, 256) + align_up((int64_t)PL * g.T * d->K * 4, 256);
   if (mode == MODE_WGRAD) {
-    int ns = 1, pps, cfg;
-    // the split depends on the tile; size for the largest split any tile would ask for
-    int64_t mx = 1;
-    for (cfg = 0; cfg < NCFG; ++cfg) { wgrad_split(d, cfg, &ns, &pps); if (ns > mx) mx = ns; }
-    return planes + align_up(mx * WP * d->C * d->K * 4, 256);
+    int ns = 1, pps;
+    int64_t mx = 1;    // the split depends on the tile; size for the largest split any tile would ask for
+    for (int cfg = 0; cfg < NCFG; ++cfg) { wgrad_split(g.T, PL, d->C, d->K, cfg, &ns, &pps); if (ns > mx) mx = ns; }
+    return planes + align_up(mx * PL * d->C * d->K * 4, 256);
   }
-  return planes + align_up((int64_t)WP * d->C * d->K * 4, 256);
+  return planes + align_up((int64_t)PL * d->C * d->K * 4, 256);
 }
 
-void wino_fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* w, const float* bias,
-              const float* residual, float* y, int epi, void* workspace, hipStream_t st) {
-  WinoGeom g = geom(d);
+template <typename S>
+void fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* w, const float* bias,
+         const float* residual, float* y, int epi, void* workspace, hipStream_t st) {
+  constexpr int PL = S::P * S::P;
+  WinoGeom g = geom<S>(d);
   const int64_t CK = (int64_t)d->C * d->K;
   float* U = (float*)workspace;
-  float* V = (float*)((char*)U + align_up(WP * CK * 4, 256));
-  float* Mb = (float*)((char*)V + align_up((int64_t)WP * g.T * d->C * 4, 256));
-  run_filter(w, U, CK, 0, st);
-  run_input(x, V, g, d->C, st);
+  float* V = (float*)((char*)U + align_up(PL * CK * 4, 256));
+  float* Mb = (float*)((char*)V + align_up((int64_t)PL * g.T * d->C * 4, 256));
+  run_filter<S>(w, U, CK, 0, st);
+  run_input<S>(x, V, g, d->C, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = U; p.out = Mb;
   p.M = (int)g.T; p.NG = d->K;
   p.a_bytes = (unsigned)(g.T * d->C * 4); p.b_bytes = (unsigned)(CK * 4);
   p.a_bs = g.T * d->C; p.b_bs = CK; p.o_bs = g.T * d->K;
-  launch_gemm<MODE_FWD>(tile, p, 1, st);
-  run_output<MODE_FWD>(Mb, y, g, d->K, bias, residual, nullptr, epi, st);
+  launch_gemm<MODE_FWD>(tile, p, PL, 1, st);
+  run_output<S, MODE_FWD>(Mb, y, g, d->K, bias, residual, nullptr, epi, st);
 }
 
-void wino_dgrad(const mtlssl_conv_desc* d, int tile, const float* dy, const float* w, const float* residual,
-                const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st) {
-  WinoGeom g = geom(d);
+template <typename S>
+void dgrad(const mtlssl_conv_desc* d, int tile, const float* dy, const float* w, const float* residual,
+           const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st) {
+  constexpr int PL = S::P * S::P;
+  WinoGeom g = geom<S>(d);
   const int64_t CK = (int64_t)d->C * d->K;
   float* U = (float*)workspace;
-  float* V = (float*)((char*)U + align_up(WP * CK * 4, 256));               // transformed dy [36][T][K]
-  float* Mb = (float*)((char*)V + align_up((int64_t)WP * g.T * d->K * 4, 256));   // [36][T][C]
-  run_filter(w, U, CK, 1, st);
-  run_input(dy, V, g, d->K, st);
+  float* V = (float*)((char*)U + align_up(PL * CK * 4, 256));                     // transformed dy [P^2][T][K]
+  float* Mb = (float*)((char*)V + align_up((int64_t)PL * g.T * d->K * 4, 256));   // [P^2][T][C]
+  run_filter<S>(w, U, CK, 1, st);
+  run_input<S>(dy, V, g, d->K, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = U; p.out = Mb;
   p.M = (int)g.T; p.NG = d->C;
   p.a_bytes = (unsigned)(g.T * d->K * 4); p.b_bytes = (unsigned)(CK * 4);
   p.a_bs = g.T * d->K; p.b_bs = CK; p.o_bs = g.T * d->C;
-  launch_gemm<MODE_DGRAD>(tile, p, 1, st);
-  run_output<MODE_DGRAD>(Mb, dx, g, d->C, nullptr, residual, mask_ref, epi, st);
+  launch_gemm<MODE_DGRAD>(tile, p, PL, 1, st);
+  run_output<S, MODE_DGRAD>(Mb, dx, g, d->C, nullptr, residual, mask_ref, epi, st);
 }
 
-void wino_wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float* dy, const float* out_scale,
-                float* dw, float beta, void* workspace, hipStream_t st) {
-  WinoGeom g = geom(d);
+template <typename S>
+void wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float* dy, const float* out_scale,
+           float* dw, float beta, void* workspace, hipStream_t st) {
+  constexpr int PL = S::P * S::P;
+  WinoGeom g = geom<S>(d);
   const int64_t CK = (int64_t)d->C * d->K;
-  float* V = (float*)workspace;                                             // [36][T][C]
-  float* dM = (float*)((char*)V + align_up((int64_t)WP * g.T * d->C * 4, 256));   // [36][T][K]
-  float* dU = (float*)((char*)dM + align_up((int64_t)WP * g.T * d->K * 4, 256));  // [ns][36][C][K]
+  float* V = (float*)workspace;                                                   // [P^2][T][C]
+  float* dM = (float*)((char*)V + align_up((int64_t)PL * g.T * d->C * 4, 256));   // [P^2][T][K]
+  float* dU = (float*)((char*)dM + align_up((int64_t)PL * g.T * d->K * 4, 256));  // [ns][P^2][C][K]
   int ns, pps;
-  wgrad_split(d, tile, &ns, &pps);
-  run_input(x, V, g, d->C, st);
-  run_dy(dy, dM, g, d->K, st);
+  wgrad_split(g.T, PL, d->C, d->K, tile, &ns, &pps);
+  run_input<S>(x, V, g, d->C, st);
+  run_dy<S>(dy, dM, g, d->K, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = dM; p.out = dU;
   p.M = d->C; p.NG = d->K; p.nsplit = ns; p.pix_per_split = pps;
   p.a_bytes = (unsigned)(g.T * d->C * 4); p.b_bytes = (unsigned)(g.T * d->K * 4);
   p.a_bs = g.T * d->C; p.b_bs = g.T * d->K;
-  launch_gemm<MODE_WGRAD>(tile, p, ns, st);
-  typedef float floatx2 __attribute__((ext_vector_type(2)));
-  if (CK >= 262144)
-    hipLaunchKernelGGL(k_wino_wgrad_out<floatx2>, dim3(cdiv(CK / 2, 256)), dim3(256), 0, st, (const float*)dU, ns, CK,
-                       d->K, out_scale, dw, beta);
-  else
-    hipLaunchKernelGGL(k_wino_wgrad_out<float>, dim3(cdiv(CK, 256)), dim3(256), 0, st, (const float*)dU, ns, CK, d->K,
-                       out_scale, dw, beta);
+  launch_gemm<MODE_WGRAD>(tile, p, PL, ns, st);
+  run_wgrad_out<S>(dU, ns, CK, d->K, out_scale, dw, beta, st);
+}
+
+}  // namespace
+
+// variant: WINO_F43 / WINO_M7
+bool wino_eligible(const mtlssl_conv_desc* d, int variant) {
+  return variant == WINO_M7 ? eligible<M7>(d) : eligible<F43>(d);
+}
+double wino_time_us(const mtlssl_conv_desc* d, int variant, int mode, int* tile) {
+  return variant == WINO_M7 ? time_us<M7>(d, mode, tile) : time_us<F43>(d, mode, tile);
+}
+int64_t wino_workspace_bytes(const mtlssl_conv_desc* d, int variant, int mode) {
+  return variant == WINO_M7 ? workspace_bytes<M7>(d, mode) : workspace_bytes<F43>(d, mode);
+}
+void wino_fwd(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* w, const float* bias,
+              const float* residual, float* y, int epi, void* workspace, hipStream_t st) {
+  if (variant == WINO_M7) fwd<M7>(d, tile, x, w, bias, residual, y, epi, workspace, st);
+  else fwd<F43>(d, tile, x, w, bias, residual, y, epi, workspace, st);
+}
+void wino_dgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* dy, const float* w,
+                const float* residual, const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st) {
+  if (variant == WINO_M7) dgrad<M7>(d, tile, dy, w, residual, mask_ref, dx, epi, workspace, st);
+  else dgrad<F43>(d, tile, dy, w, residual, mask_ref, dx, epi, workspace, st);
+}
+void wino_wgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* dy,
+                const float* out_scale, float* dw, float beta, void* workspace, hipStream_t st) {
+  if (variant == WINO_M7) wgrad<M7>(d, tile, x, dy, out_scale, dw, beta, workspace, st);
+  else wgrad<F43>(d, tile, x, dy, out_scale, dw, beta, workspace, st);
 }
 
 }  // namespace mtlssl

@@ -38,11 +38,22 @@ CASES = [
 ]
 
 
+CASES_M7 = [
+    # maps whose sides are multiples of 7: the whole-7-span specification (F(4,3) + F(3,3) per span)
+    (32, 7, 7, 512, 512),           # block4 unit on ROI crops: one 7x7 tile per map
+    (3, 14, 14, 64, 96),            # 2x2 spans per map (initial_crop_size 14 before the max-pool)
+    (5, 7, 21, 32, 48),             # 1x3 spans, narrow channels
+    (130, 7, 7, 128, 256),          # > 128 maps: two GEMM row tiles, the second ragged
+]
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2])
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", [(c, "f43") for c in CASES] + [(c, "m7") for c in CASES_M7],
+                         ids=lambda cv: "%s-%s" % (cv[1], "x".join(map(str, cv[0]))))
 def test_winograd_matches_oracle_and_direct(ops, case, tile):
-    N, H, W, C, K = case
-    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    (N, H, W, C, K), variant = case
+    wino_cfg = (ops.WINO_CFG0 if variant == "f43" else ops.WINO7_CFG0) + tile
+    g = torch.Generator().manual_seed(hash(case[0]) % 2**31)
     x = torch.randn(N, H, W, C, generator=g)
     w = torch.randn(3, 3, C, K, generator=g) / np.sqrt(9 * C)
     bias = torch.randn(K, generator=g)
@@ -56,7 +67,7 @@ def test_winograd_matches_oracle_and_direct(ops, case, tile):
     mref, addend, prev = (torch.randn(x.shape, generator=g) for _ in range(3))
     scale = torch.rand(K, generator=g) + 0.5
     outs = {}
-    for name, cfg in (("direct", 2), ("winograd", ops.WINO_CFG0 + tile)):
+    for name, cfg in (("direct", 2), ("winograd", wino_cfg)):
         for mode in (0, 1, 2):
             assert ops.force_conv_config(d, mode, cfg) == cfg
         y = ops.conv2d_fwd(d, xd, wd, bias.cuda(), res.cuda(), ops.EPI_BIAS | ops.EPI_RESIDUAL | ops.EPI_RELU)
@@ -92,10 +103,17 @@ def test_winograd_not_offered_outside_its_domain(ops):
         d = ops.conv_desc(shape, wshape, stride, dil, pad)
         for mode in (0, 1, 2):
             assert ops.force_conv_config(d, mode, ops.WINO_CFG0) < ops.WINO_CFG0
+            assert ops.force_conv_config(d, mode, ops.WINO7_CFG0) < ops.WINO_CFG0
             ops.force_conv_config(d, mode, -1)
+    # the whole-7-span specification needs map sides that are multiples of 7; F(4x4,3x3) takes the rest
+    d = ops.conv_desc((2, 38, 64, 64), (3, 3, 64, 64), 1, 1, "SAME")
+    for mode in (0, 1, 2):
+        assert ops.force_conv_config(d, mode, ops.WINO7_CFG0 + 1) < ops.WINO7_CFG0
+        ops.force_conv_config(d, mode, -1)
 
 
-def test_winograd_full_size_round_trip(ops):
+@pytest.mark.parametrize("wino_cfg", [4, 8], ids=["f43", "m7"])
+def test_winograd_full_size_round_trip(ops, wino_cfg):
     """Size-independent properties at config[1]'s largest 3x3 (block4 on 2560 ROI crops): linearity of
     the forward, and <conv(x), gy> == <x, dgrad(gy)> == <w, wgrad(x, gy)> (adjointness ties the three
     Winograd pipelines to each other)."""
@@ -106,7 +124,7 @@ def test_winograd_full_size_round_trip(ops):
     gy = torch.randn(2560, 7, 7, 512, device="cuda", generator=g)
     d = ops.conv_desc(x.shape, w.shape, 1, 1, "SAME")
     for mode in (0, 1, 2):
-        assert ops.force_conv_config(d, mode, ops.WINO_CFG0) == ops.WINO_CFG0
+        assert ops.force_conv_config(d, mode, wino_cfg) == wino_cfg
     y = ops.conv2d_fwd(d, x, w)
     lhs = ops.conv2d_fwd(d, 0.5 * x + x2, w)
     rhs = 0.5 * y + ops.conv2d_fwd(d, x2, w)

@@ -14,7 +14,8 @@ from mtl_ssl_amd import ops  # noqa: E402
 
 SHAPES = [(2560, 7, 7, 512, 512), (512, 7, 7, 512, 512), (128, 7, 7, 512, 512), (2, 38, 64, 256, 256),
           (2, 75, 128, 128, 128), (2, 150, 256, 64, 64), (2, 38, 64, 1024, 512), (2, 38, 64, 512, 512)]
-print("%-26s %-6s %10s %10s %10s %10s   best" % ("N,H,W,C,K", "mode", "direct us", "wino0 us", "wino1 us", "wino2 us"))
+print("%-26s %-6s %10s %10s %10s %10s %10s %10s %10s   best" % ("N,H,W,C,K", "mode", "direct us", "f43/0 us", "f43/1 us", "f43/2 us",
+                                                          "m7/0 us", "m7/1 us", "m7/2 us"))
 for N, H, W, C, K in SHAPES:
     x = torch.randn(N, H, W, C, device="cuda")
     w = torch.randn(3, 3, C, K, device="cuda") / (9 * C) ** 0.5
@@ -25,7 +26,7 @@ for N, H, W, C, K in SHAPES:
             2: lambda: ops.conv2d_wgrad(d, x, gy, dw)}
     for mode in (0, 1, 2):
         row = []
-        for cfg in (-1, 4, 5, 6):
+        for cfg in (-1, 4, 5, 6, 8, 9, 10):
             if cfg < 0:                      # best direct tile
                 best = 1e30
                 for c in (0, 1, 2):
@@ -51,5 +52,8 @@ for N, H, W, C, K in SHAPES:
             e.record(); e.synchronize()
             row.append(s.elapsed_time(e) * 100)
         ops.force_conv_config(d, mode, -1)
-        print("%-26s %-6s %10.1f %10.1f %10.1f %10.1f   %s" % ((N, H, W, C, K), ("fwd", "dgrad", "wgrad")[mode], *row,
-                                                              "winograd x%.2f" % (row[0] / min(row[1:])) if min(row[1:]) < row[0] else "direct"))
+        import math
+        best = min(v for v in row[1:] if not math.isnan(v))
+        print("%-26s %-6s %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f   %s" % (
+            (N, H, W, C, K), ("fwd", "dgrad", "wgrad")[mode], *row,
+            "winograd x%.2f" % (row[0] / best) if best < row[0] else "direct"))
