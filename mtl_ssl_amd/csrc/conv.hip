@@ -492,7 +492,7 @@ static bool tail_split_enabled() {
 }
 // kc = reduction channels per filter tap (C for fwd, K for dgrad), taps = R*S.
 static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double* t_out = nullptr) {
-  const int resident[NCFG] = {3, 6, 8};
+  const int* resident = CFG_RESIDENT;
   Plan best{2, 1, taps * (kc / 16), 0, 1, 0};
   double best_t = 1e30;
   static int env_force = -2;
@@ -573,7 +573,8 @@ static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st, int ti
   switch (cfg) {
     case 0: hipLaunchKernelGGL((k_conv_mfma<128, 128, MODE, 16>), grid, dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((k_conv_mfma<128, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((k_conv_mfma<64, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((k_conv_mfma<64, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_conv_mfma<256, 128, MODE, 16>), grid, dim3(512), 0, st, p); break;
   }
 }
 

@@ -53,16 +53,18 @@ __device__ __forceinline__ floatx4 bufload4(__amdgpu_buffer_rsrc_t rsrc, unsigne
 // blockIdx.y selects the operand / output planes `a_bs` / `b_bs` / `o_bs` elements apart.
 template <int BM, int BN, int MODE, int BKT, bool BATCH>
 __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
+  // 4 wavefronts (2x2) per block; the 256-row tile has 8 (4x2) so that a wave's tile stays 64x64
+  constexpr int NW = BM > 128 ? 8 : 4, NT = 64 * NW, WR = NW / 2;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int KQ = BKT / 4;                     // float4 quads along k per tile row
-  constexpr int RP = 256 / KQ;                    // tile rows covered by one pass of the KC loaders
-  constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave in m / n
+  constexpr int RP = NT / KQ;                     // tile rows covered by one pass of the KC loaders
+  constexpr int TM = BM / (32 * WR), TN = BN / 64;   // 32x32 MFMA tiles per wave in m / n
   constexpr bool A_KC = (MODE != MODE_WGRAD);     // A float4 runs along k (else along m)
   constexpr bool B_KC = (MODE == MODE_DGRAD);     // B float4 runs along k (else along n)
   constexpr int A_LD = BM / RP, B_LD = BN / RP;   // float4 loads per thread per K-step
   constexpr unsigned OOB = 0xFFFFFFF0u;
   constexpr int LDT = 36;                          // epilogue staging: floats per row of a 32x32 tile
-  constexpr int SMEM_OPS = 2 * BKT * (LDA + LDB), SMEM_EPI = 4 * 32 * LDT;
+  constexpr int SMEM_OPS = 2 * BKT * (LDA + LDB), SMEM_EPI = NW * 32 * LDT;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_OPS > SMEM_EPI ? SMEM_OPS : SMEM_EPI];
   float* const sA = smem;
   float* const sB = smem + 2 * BKT * LDA;
@@ -145,14 +147,14 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < B_LD; ++i) {
     if constexpr (MODE == MODE_FWD) {
-      int u = tid + 256 * i;
+      int u = tid + NT * i;
       int col = n0 + (u % (BN / 4)) * 4;
       b_base[i] = col < p.NG ? (unsigned)((u / (BN / 4)) * p.K + col) * 4u : OOB;
     } else if constexpr (MODE == MODE_DGRAD) {
       int row = n0 + (tid / KQ) + RP * i;
       b_base[i] = row < p.NG ? (unsigned)(row * p.K + kq4) * 4u : OOB;
     } else {
-      int u = tid + 256 * i;
+      int u = tid + NT * i;
       int col = n0 + (u % (BN / 4)) * 4;
       b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
     }
@@ -179,7 +181,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
       if (p.NG & 3) {   // filter rows are only dword aligned and the last quad runs into the next row
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
-          int left = p.NG - (n0 + ((tid + 256 * i) % (BN / 4)) * 4);
+          int left = p.NG - (n0 + ((tid + NT * i) % (BN / 4)) * 4);
 #pragma unroll
           for (int e = 1; e < 4; ++e) rb[i][e] = e < left ? rb[i][e] : 0.f;
         }
@@ -215,7 +217,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
       int r = rs_fixed / p.S, s = rs_fixed - r * p.S;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
-        int u = tid + 256 * i;
+        int u = tid + NT * i;
         int kr = u / (BM / 4), m4 = u % (BM / 4);
         int pix = pix0 + ks * BKT + kr;
         bool ok = pix < pix1;
@@ -234,7 +236,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
       }
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
-        int u = tid + 256 * i;
+        int u = tid + NT * i;
         int pix = pix0 + ks * BKT + u / (BN / 4);
         rb[i] = bufload4(rsrc_b, (pix < pix1 && b_base[i] != OOB) ? b_base[i] + (unsigned)(pix * p.K) * 4u : OOB, 0);
       }
@@ -251,7 +253,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
         a[(kq4 + 0) * LDA + row] = ra[i].x; a[(kq4 + 1) * LDA + row] = ra[i].y;
         a[(kq4 + 2) * LDA + row] = ra[i].z; a[(kq4 + 3) * LDA + row] = ra[i].w;
       } else {
-        int u = tid + 256 * i;
+        int u = tid + NT * i;
         *reinterpret_cast<floatx4*>(a + (u / (BM / 4)) * LDA + (u % (BM / 4)) * 4) = ra[i];
       }
     }
@@ -262,7 +264,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
         b[(kq4 + 0) * LDB + row] = rb[i].x; b[(kq4 + 1) * LDB + row] = rb[i].y;
         b[(kq4 + 2) * LDB + row] = rb[i].z; b[(kq4 + 3) * LDB + row] = rb[i].w;
       } else {
-        int u = tid + 256 * i;
+        int u = tid + NT * i;
         *reinterpret_cast<floatx4*>(b + (u / (BN / 4)) * LDB + (u % (BN / 4)) * 4) = rb[i];
       }
     }
@@ -284,7 +286,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
   for (int ks = ks_begin; ks < ksteps; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < ksteps) load_tile(ks + 1);
-    const float* a = sA + cur * (BKT * LDA) + wr * (BM / 2) + lo;
+    const float* a = sA + cur * (BKT * LDA) + wr * (BM / WR) + lo;
     const float* b = sB + cur * (BKT * LDB) + wc * (BN / 2) + lo;
     // Software-pipelined fragments: the ds_reads of k-pair kk+1 are issued BEFORE the MFMAs of
     // k-pair kk (two register sets), pinned with sched_barrier so hipcc does not re-serialise them
@@ -344,7 +346,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
         for (int k = 0; k < 4; ++k) {
           const int rt = r_in + 8 * k;
           floatx4 v = *reinterpret_cast<const floatx4*>(tile + rt * LDT + c4);
-          const int row = m0 + wr * (BM / 2) + i * 32 + rt;
+          const int row = m0 + wr * (BM / WR) + i * 32 + rt;
           if (row >= p.M || col >= p.NG) continue;
           if (raw) {
             *reinterpret_cast<floatx4*>(outp + (int64_t)(row - p.ws_m0) * ldo + col) = v;
@@ -386,7 +388,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
         if ((p.epi & MTLSSL_EPI_BIAS) && col_ok) bv = p.bias[col];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        const int row = m0 + wr * (BM / WR) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
         if (row >= p.M || !col_ok) continue;
         const int64_t o = (int64_t)row * ldo + col;
         float v = acc[i][j][e];
@@ -412,13 +414,15 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
 }
 
 template <int BM, int BN, int MODE, int BKT>
-__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3) : 4)) k_conv_mfma(ConvArgs p) {
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3) : 4))
+k_conv_mfma(ConvArgs p) {
   conv_mfma_body<BM, BN, MODE, BKT, false>(p);
 }
 // The same tile engine over a stack of plain GEMMs (1x1 "convolutions"): the 36 Winograd-domain
 // products of F(4x4,3x3). A kernel of its own so that profiles tell the two apart.
 template <int BM, int BN, int MODE>
-__global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_wino_gemm(ConvArgs p) {
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN >= 128 * 128 ? 3 : 4))
+k_wino_gemm(ConvArgs p) {
   conv_mfma_body<BM, BN, MODE, 16, true>(p);
 }
 
@@ -428,20 +432,26 @@ __global__ void __launch_bounds__(256, (BM * BN >= 128 * 128 ? 3 : 4)) k_wino_ge
 // shape of config[1] (tools/bench_conv.py, round 1), so only the 16-deep ones are instantiated.
 // A 128x192 tile (for Inception's 192 / 2080-wide layers) was built and measured too: 88 TFLOP/s where
 // the 128x128 and 64x64 tiles reach 115-128 on the same layers (154 VGPRs, 42 KB LDS), so it is out.
-constexpr int NCFG = 3;
-static const int CFG_BM[NCFG] = {128, 128, 64};
-static const int CFG_BN[NCFG] = {128, 64, 64};
-static const int CFG_BK[NCFG] = {16, 16, 16};
+// The 256x128 tile keeps the 64x64 wave tile (same registers per wave) with 8 wavefronts per block: a
+// quarter less operand staging per MAC. It wins on the pixel-reduction (wgrad) GEMMs (+3 %: 133 -> 137
+// TFLOP/s) and on the short-K wide-N forward layers (1x1 512->2048 on 2560 ROIs: 113 -> 123.5), loses
+// elsewhere (tools/bench_tiles.py) — a candidate for the measured plan table, not a default.
+constexpr int NCFG = 4;
+static const int CFG_BM[NCFG] = {128, 128, 64, 256};
+static const int CFG_BN[NCFG] = {128, 64, 64, 128};
+static const int CFG_BK[NCFG] = {16, 16, 16, 16};
+static const int CFG_THREADS[NCFG] = {256, 256, 256, 512};
+static const int CFG_RESIDENT[NCFG] = {3, 6, 8, 2};      // blocks a CU holds
 
 // Time model shared by the planners (microseconds). A CU retires one 16-deep K-step of a
 // bm x bn tile in bm*bn*32 FLOP / 614 GFLOP/s (fp32 MFMA peak per CU); blocks beyond what is
 // resident queue up. A CU holding a single block (one wave per SIMD) cannot hide its own LDS /
 // barrier latencies, hence the occupancy factor. Constants fitted to tools/bench_conv.py.
 static inline double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block) {
-  const int resident[NCFG] = {3, 6, 8};
-  const double base_eff[NCFG] = {0.80, 0.76, 0.72};
+  const double base_eff[NCFG] = {0.80, 0.76, 0.72, 0.78};
   int64_t per_cu = cdiv(nblocks, 256);
-  int64_t occ = per_cu < resident[cfg] ? per_cu : resident[cfg];
+  int64_t occ = per_cu < CFG_RESIDENT[cfg] ? per_cu : CFG_RESIDENT[cfg];
+  if (cfg == 3) occ *= 2;                                  // 8 waves per block
   double occ_eff = occ <= 1 ? 0.55 : (occ == 2 ? 0.80 : 1.0);
   double step_us = CFG_BM[cfg] * CFG_BN[cfg] * 2.0 * CFG_BK[cfg] / 614e9 * 1e6 / (base_eff[cfg] * occ_eff);
   return (double)per_cu * (ksteps_per_block + 96 / CFG_BK[cfg]) * step_us;

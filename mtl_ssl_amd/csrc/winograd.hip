@@ -419,7 +419,8 @@ void launch_gemm(int cfg, ConvArgs& p, int planes, int nz, hipStream_t st) {
   switch (cfg) {
     case 0: hipLaunchKernelGGL((k_wino_gemm<128, 128, MODE>), grid, dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((k_wino_gemm<128, 64, MODE>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((k_wino_gemm<64, 64, MODE>), grid, dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((k_wino_gemm<64, 64, MODE>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_wino_gemm<256, 128, MODE>), grid, dim3(512), 0, st, p); break;
   }
 }
 

@@ -146,7 +146,8 @@ def save_plans(path=_PLAN_FILE):
         if val is not None:
             plans[",".join(str(v) for v in key)] = val[1] if val[1] != val[0] else -1
     json.dump({"comment": "mode,N,H,W,C,K,R,S,OH,OW,stride,dilation,pad_t,pad_l -> forced tile "
-                          "(0: 128x128, 1: 128x64, 2: 64x64; 4-6: Winograd F(4x4,3x3) with GEMM tile 0-2; 8-10: whole-7-span Winograd with GEMM tile 0-2; "
+                          "(0: 128x128, 1: 128x64, 2: 64x64, 3: 256x128; 4-7: Winograd F(4x4,3x3) with GEMM tile 0-3; 8-11: whole-7-span Winograd with GEMM "
+                          "tile 0-3; "
                           "-1: keep the planner's choice); "
                           "measured on MI355X",
                "plans": dict(sorted(plans.items()))}, open(path, "w"), indent=0)
@@ -161,8 +162,8 @@ WINO7_CFG0 = 8         # tile codes WINO7_CFG0 + t: whole-7-span Winograd (maps 
 
 
 def force_conv_config(d, mode, cfg):
-    """Pin the algorithm / tile of one (problem, mode) — 0..2 direct tiles, 4..6 Winograd F(4x4,3x3),
-    8..10 whole-7-span Winograd, -1 back to the planner — and keep the autotuner away from it."""
+    """Pin the algorithm / tile of one (problem, mode) — 0..3 direct tiles, 4..7 Winograd F(4x4,3x3),
+    8..11 whole-7-span Winograd, -1 back to the planner — and keep the autotuner away from it."""
     _tuned[_plan_key(d, mode)] = None
     lib().conv2d_force_config(ctypes.byref(d), mode, int(cfg))
     return lib().conv2d_tile_config(ctypes.byref(d), mode)
@@ -191,7 +192,7 @@ def _autotune(d, mode, run):
     if not AUTOTUNE:
         return
     times = {}
-    for cfg in (0, 1, 2, 4, 5, 6, 8, 9, 10):
+    for cfg in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
         L.conv2d_force_config(ref, mode, cfg)
         if L.conv2d_tile_config(ref, mode) != cfg:    # this tile is not available for the problem
             continue

@@ -102,6 +102,48 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     assert relerr(dw, 2 * wr.grad * scale) < 1e-4
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", [
+    (3, 19, 23, 64, 160, 3, 1, 1, "SAME"),           # ragged M (1311 rows) and N (160) for every tile
+    (2, 14, 15, 128, 128, 3, 2, 1, "RESNET_SAME"),   # strided gather
+    (300, 1, 1, 512, 272, 1, 1, 1, "VALID"),         # FC-shaped, N one quad past 256+...
+    (5, 7, 7, 272, 512, 1, 1, 1, "SAME"),            # wgrad M = C = 272: ragged rows of the 256-row tile
+])
+def test_every_direct_tile_matches_oracle(ops, case, tile):
+    """Each implicit-GEMM tile (128x128, 128x64, 64x64, 256x128 with 8 wavefronts) pinned through the plan
+    registry, all three modes with their epilogues."""
+    N, H, W, C, K, R, stride, dil, padding = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(N, H, W, C, generator=g)
+    w = torch.randn(R, R, C, K, generator=g) / np.sqrt(R * R * C)
+    bias = torch.randn(K, generator=g)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = T.conv2d_same(xr, wr, stride, dil) if padding == "RESNET_SAME" else T.conv2d(xr, wr, stride, dil, padding)
+    res = torch.randn(yr.shape, generator=g)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    d = ops.conv_desc(x.shape, w.shape, stride, dil, padding)
+    ops.set_winograd(0)
+    try:
+        for mode in (0, 1, 2):
+            assert ops.force_conv_config(d, mode, tile) == tile
+        xd, wd, gyd = x.cuda(), w.cuda(), gy.cuda()
+        y = ops.conv2d_fwd(d, xd, wd, bias.cuda(), res.cuda(), ops.EPI_BIAS | ops.EPI_RESIDUAL | ops.EPI_RELU)
+        assert relerr(y, torch.relu(yr + bias + res)) < 1e-4
+        mref, addend, prev = (torch.randn(x.shape, generator=g) for _ in range(3))
+        dx = prev.cuda().clone()
+        ops.conv2d_dgrad(d, gyd, wd, addend.cuda(), mref.cuda(), ops.EPI_RESIDUAL | ops.EPI_MASK | ops.EPI_ACCUM, out=dx)
+        assert relerr(dx, (xr.grad + addend + prev) * (mref > 0)) < 1e-4
+        scale = torch.rand(K, generator=g) + 0.5
+        dw = torch.ones(w.shape).cuda()
+        ops.conv2d_wgrad(d, xd, gyd, dw, out_scale=scale.cuda(), beta=1.0)
+        assert relerr(dw, 1 + wr.grad * scale) < 1e-4
+    finally:
+        ops.set_winograd(1)
+        for mode in (0, 1, 2):
+            ops.force_conv_config(d, mode, -1)
+
+
 def test_conv_same_padding_matches_reference_known_answer(ops):
     """Known answers of slim/nets/resnet_v1_test.py:72-111 (testConv2DSameEven): x[i,j] = i+j on
     4x4, w[i,j] = i+j on 3x3; SAME stride 1, conv2d_same stride 2 (== subsample of the former)

@@ -47,7 +47,7 @@ CASES_M7 = [
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", [(c, "f43") for c in CASES] + [(c, "m7") for c in CASES_M7],
                          ids=lambda cv: "%s-%s" % (cv[1], "x".join(map(str, cv[0]))))
 def test_winograd_matches_oracle_and_direct(ops, case, tile):
