@@ -677,6 +677,117 @@ static bool choose_wino(const mtlssl_conv_desc* d, int mode, WinoChoice* wc) {
   return tw < td;
 }
 
+// ---- stride-2 dgrad by input parity. dX[ih][iw] only receives the taps r with (ih + pt - r) even, so
+// the stride-2 gather wastes 3 of 4 K-steps on all-zero operand tiles (20-22 TFLOP/s on Inception's
+// Mixed_6a / Mixed_7a reductions). Each parity class (ih%2, iw%2) is an ordinary stride-1 dgrad of dY with
+// the sub-filter W[r0+2j][s0+2l] and pad (a, b) = ((py+pt-r0)/2, (px+pl-s0)/2):
+//     dX[2u+py][2v+px] = sum_{j,l,k} dY[u + a - j][v + b - l][k] * W[r0+2j][s0+2l][c][k]
+// so the engine runs four dense problems on a quarter of the rows each (9 taps in total instead of 36);
+// the results go through a compact buffer and are interleaved into dX by a kernel that applies the epilogue.
+struct ParityProblem { int py, px, Hs, Ws, r0, s0, Rs, Ss, a, b; };
+static bool parity_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MTLSSL_DGRAD_PARITY"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+static bool parity_ok(const mtlssl_conv_desc* d) {
+  return parity_enabled() && d->stride == 2 && d->dilation == 1 && mfma_dgrad_ok(d) && d->R * d->S > 1 &&
+         d->H >= 2 && d->W >= 2;
+}
+static ParityProblem parity_problem(const mtlssl_conv_desc* d, int py, int px) {
+  ParityProblem q;
+  q.py = py; q.px = px;
+  q.Hs = (d->H - py + 1) / 2; q.Ws = (d->W - px + 1) / 2;
+  q.r0 = (py + d->pad_t) & 1; q.s0 = (px + d->pad_l) & 1;
+  q.Rs = d->R > q.r0 ? (d->R - q.r0 + 1) / 2 : 0;
+  q.Ss = d->S > q.s0 ? (d->S - q.s0 + 1) / 2 : 0;
+  q.a = (py + d->pad_t - q.r0) / 2; q.b = (px + d->pad_l - q.s0) / 2;
+  return q;
+}
+// Wsub[j][l][c][k] = W[r0+2j][s0+2l][c][k]
+__global__ void k_parity_filter(const float* w, float* ws, int S, int r0, int s0, int Ss, int64_t CK4) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= CK4) return;
+  int jl = blockIdx.y, j = jl / Ss, l = jl - j * Ss;
+  reinterpret_cast<floatx4*>(ws)[(int64_t)jl * CK4 + i] =
+      reinterpret_cast<const floatx4*>(w)[(int64_t)((r0 + 2 * j) * S + s0 + 2 * l) * CK4 + i];
+}
+// dX[n][2u+py][2v+px][c] = epilogue(tmp[n][u][v][c]); tmp == nullptr: the class has no taps (zeros).
+__global__ void k_parity_scatter(const float* tmp, float* dx, const float* residual, const float* mask, int epi,
+                                 int H, int W, int C4, int Hs, int Ws, int py, int px, int64_t total4) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  int c4 = (int)(i % C4);
+  int64_t t = i / C4;
+  int v = (int)(t % Ws);
+  t /= Ws;
+  int u = (int)(t % Hs), n = (int)(t / Hs);
+  floatx4 val = tmp ? reinterpret_cast<const floatx4*>(tmp)[i] : floatx4{0.f, 0.f, 0.f, 0.f};
+  const int64_t o = ((((int64_t)n * H + 2 * u + py) * W + 2 * v + px) * C4 + c4);
+  if (epi & MTLSSL_EPI_RESIDUAL) val += reinterpret_cast<const floatx4*>(residual)[o];
+  if (epi & MTLSSL_EPI_ACCUM) val += reinterpret_cast<const floatx4*>(dx)[o];
+  if (epi & MASK_ANY) {
+    floatx4 mk = reinterpret_cast<const floatx4*>(mask)[o];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) val[e] = act_mask(val[e], mk[e], epi);
+  }
+  reinterpret_cast<floatx4*>(dx)[o] = val;
+}
+static Plan parity_plan(const mtlssl_conv_desc* d, const ParityProblem& q) {
+  int forced = tuned_cfg(d, MODE_DGRAD);
+  return plan_gemm((int64_t)d->N * q.Hs * q.Ws, d->C, q.Rs * q.Ss, d->K, forced >= 0 && forced < NCFG ? forced : -1);
+}
+static int64_t parity_split_bytes(const mtlssl_conv_desc* d, const ParityProblem& q) {
+  if (q.Rs == 0 || q.Ss == 0) return 0;
+  Plan pl = parity_plan(d, q);
+  const int64_t M = (int64_t)d->N * q.Hs * q.Ws;
+  if (pl.tail_rows > 0) {
+    int64_t m_tail0 = (cdiv(M, CFG_BM[pl.cfg]) - pl.tail_rows) * CFG_BM[pl.cfg];
+    return align_up((M - m_tail0) * d->C * 4 * pl.tail_nsplit, 256);
+  }
+  return pl.nsplit > 1 ? align_up(M * d->C * 4 * pl.nsplit, 256) : 0;
+}
+// workspace: [sub-filter: R*S*C*K floats][compact result of one class][split-K partials of one class]
+static int64_t parity_workspace_bytes(const mtlssl_conv_desc* d) {
+  int64_t wsub = align_up((int64_t)d->R * d->S * d->C * d->K * 4, 256);
+  int64_t tmp = align_up((int64_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) * d->C * 4, 256);
+  int64_t split = 0;
+  for (int c = 0; c < 4; ++c) {
+    int64_t b = parity_split_bytes(d, parity_problem(d, c >> 1, c & 1));
+    if (b > split) split = b;
+  }
+  return wsub + tmp + split;
+}
+static void parity_dgrad(const mtlssl_conv_desc* d, const float* dy, const float* w, const float* residual,
+                         const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st) {
+  const int64_t CK = (int64_t)d->C * d->K;
+  float* wsub = (float*)workspace;
+  float* tmp = (float*)((char*)wsub + align_up((int64_t)d->R * d->S * CK * 4, 256));
+  float* split = (float*)((char*)tmp + align_up((int64_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) * d->C * 4, 256));
+  for (int c = 0; c < 4; ++c) {
+    ParityProblem q = parity_problem(d, c >> 1, c & 1);
+    if (q.Hs == 0 || q.Ws == 0) continue;
+    const int64_t M = (int64_t)d->N * q.Hs * q.Ws;
+    const bool taps = q.Rs > 0 && q.Ss > 0;
+    if (taps) {
+      hipLaunchKernelGGL(k_parity_filter, dim3(cdiv(CK / 4, 256), q.Rs * q.Ss), dim3(256), 0, st, w, wsub, d->S, q.r0,
+                         q.s0, q.Ss, CK / 4);
+      ConvArgs p;
+      memset(&p, 0, sizeof(p));
+      p.N = d->N; p.H = q.Hs; p.W = q.Ws; p.C = d->C; p.K = d->K; p.R = q.Rs; p.S = q.Ss;
+      p.OH = d->OH; p.OW = d->OW; p.stride = 1; p.dil = 1; p.pt = q.a; p.pl = q.b;
+      p.a = dy; p.b = wsub; p.out = tmp; p.epi = 0;
+      p.a_bytes = (unsigned)((int64_t)d->N * d->OH * d->OW * d->K * 4);
+      p.b_bytes = (unsigned)((int64_t)q.Rs * q.Ss * CK * 4);
+      p.M = (int)M; p.NG = d->C;
+      launch_planned<MODE_DGRAD>(parity_plan(d, q), p, split, st);
+    }
+    const int64_t total4 = M * d->C / 4;
+    hipLaunchKernelGGL(k_parity_scatter, dim3(cdiv(total4, 256)), dim3(256), 0, st, taps ? (const float*)tmp : nullptr,
+                       dx, residual, mask_ref, epi, d->H, d->W, d->C / 4, q.Hs, q.Ws, q.py, q.px, total4);
+  }
+}
+
 }  // namespace mtlssl
 
 using namespace mtlssl;
@@ -691,6 +802,7 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
   if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : mfma_dgrad_ok(d))) return 0;
   WinoChoice wc;
   if (choose_wino(d, mode, &wc)) return wino_workspace_bytes(d, wc.variant, mode);
+  if (mode == MODE_DGRAD && parity_ok(d)) return parity_workspace_bytes(d);
   Plan pl = plan_dir(d, mode);
   if (pl.tail_rows > 0) {
     int64_t m_tail0 = (cdiv(M, CFG_BM[pl.cfg]) - pl.tail_rows) * CFG_BM[pl.cfg];
@@ -747,6 +859,8 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   WinoChoice wc;
   if (workspace && choose_wino(d, MODE_DGRAD, &wc)) {
     wino_dgrad(d, wc.variant, wc.tile, dy, w, residual, mask_ref, dx, epi, workspace, S(stream));
+  } else if (workspace && parity_ok(d)) {
+    parity_dgrad(d, dy, w, residual, mask_ref, dx, epi, workspace, S(stream));
   } else if (mfma_dgrad_ok(d)) {
     Plan pl = plan_dir(d, MODE_DGRAD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};

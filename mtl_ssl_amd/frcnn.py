@@ -292,8 +292,41 @@ class FasterRCNNMetaArch:
     def predict(self, preprocessed_inputs):
         """faster_rcnn_meta_arch.py:507-609 (training mode)."""
         x = preprocessed_inputs
-        B, H, W, _ = x.shape
         F, trunk_ctx = self._feature_extractor.extract_proposal_features(x, save=self._is_training)
+        return self._predict_from_features(x, F, trunk_ctx)
+
+    def predict_for_training(self, preprocessed_inputs):
+        """predict + predict_with_window + predict_edgemask (trainer.py:176-190) with the two auxiliary
+        forwards that need only the shared feature map and the groundtruth windows issued on the second
+        HIP stream: they overlap the RPN head -> decode -> NMS -> sampling chain, which is a string of
+        latency-bound kernels (a one-wavefront greedy scan among them) that leaves the chip idle."""
+        x, mtl = preprocessed_inputs, self._mtl
+        F, trunk_ctx = self._feature_extractor.extract_proposal_features(x, save=self._is_training)
+
+        def aux_forward():
+            t = {"rpn_features_to_crop": F}
+            if mtl.window:
+                self.predict_with_window(t)
+            if mtl.edgemask:
+                self.predict_edgemask(t)
+            del t["rpn_features_to_crop"]
+            return t
+
+        side = self._aux_stream() if (mtl.window or mtl.edgemask) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                aux = aux_forward()
+        pd = self._predict_from_features(x, F, trunk_ctx)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            aux = aux_forward()
+        pd.update(aux)
+        return pd
+
+    def _predict_from_features(self, x, F, trunk_ctx):
+        B, H, W, _ = x.shape
         Hf, Wf = F.shape[1], F.shape[2]
         anchors, keep, n_all = self._anchors_for(Hf, Wf, H, W, x.device)
         rpn_feat = self.rpn_conv.forward(F)

@@ -123,6 +123,7 @@ PROFILER = None
 # plan registry (mtlssl_conv2d_force_config) only when it beat the planner's own by > 5 %.
 AUTOTUNE = os.environ.get("MTLSSL_AUTOTUNE", "1") != "0"
 TUNE_RUNS = int(os.environ.get("MTLSSL_TUNE_RUNS", "4"))
+TUNE_MARGIN = float(os.environ.get("MTLSSL_TUNE_MARGIN", "0.05"))   # a candidate must beat the planner's choice by this much
 _PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_plans.json")
 _tuned = {}
 _plan_db = None
@@ -206,7 +207,7 @@ def _autotune(d, mode, run):
         times[cfg] = s.elapsed_time(e)
     L.conv2d_force_config(ref, mode, -1)
     best = min(times, key=times.get)
-    if not (best != default and times[best] < 0.95 * times.get(default, float("inf"))):
+    if not (best != default and times[best] < (1.0 - TUNE_MARGIN) * times.get(default, float("inf"))):
         best = default
     if best != default:
         L.conv2d_force_config(ref, mode, best)

@@ -176,12 +176,8 @@ class Trainer:
         self.reducer.compute_streams = m.compute_streams()
         self.reducer.begin_step()
         images = m.preprocess(batch["images"])
-        pd = m.predict(images)
+        pd = m.predict_for_training(images)       # predict + predict_with_window + predict_edgemask
         mtl = m._mtl
-        if mtl.window:
-            pd = m.predict_with_window(pd)
-        if mtl.edgemask:
-            pd = m.predict_edgemask(pd)
         if mtl.refine:
             pd = m.predict_with_mtl_results(pd)
         losses = m.loss(pd, loss_scale=1.0 / self.world)

@@ -50,6 +50,11 @@ CONV_CASES = [
     (4, 8, 8, 2080, 192, 1, 1, 1, "SAME"),       # block8 1x1 in
     (4, 8, 8, 448, 2080, 1, 1, 1, "SAME"),       # block8 1x1 up (ragged N = 2080)
     (3, 8, 8, 192, 224, (1, 3), 1, 1, "SAME"),   # block8 1x3
+    # stride-2 dgrad runs as four stride-1 problems on the input-parity classes: 5x5 gives 3/2-tap sub-filters,
+    # the 1x3 a class without taps in one direction, VALID an odd pad
+    (2, 13, 16, 64, 96, 5, 2, 1, "SAME"),
+    (2, 12, 17, 64, 64, (1, 3), 2, 1, "SAME"),
+    (2, 11, 11, 32, 64, 3, 2, 1, "VALID"),
     # 784 tiles of 128x128 on 768 resident slots: main launch + K-split tail launch + fold (fwd and dgrad)
     (512, 7, 7, 512, 512, 1, 1, 1, "SAME"),
 ]
