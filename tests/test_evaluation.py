@@ -82,3 +82,78 @@ def test_evaluate_detections_wrapper_on_postprocess_shaped_arrays():
     res = E.evaluate_detections(det, gt, 2)
     np.testing.assert_allclose(res["ap_per_class"], [0.0, 1.0])
     assert res["mean_ap"] == 0.5
+
+
+# ------------------------------------------------------------------------------ MS-COCO metrics
+def _coco(num_classes=1):
+    from mtl_ssl_amd.evaluation import CocoDetectionEvaluator
+    return CocoDetectionEvaluator(num_classes)
+
+
+def test_coco_perfect_detections_score_one_and_missing_categories_are_skipped():
+    ev = _coco(3)
+    gt = np.array([[10, 10, 60, 60], [100, 100, 300, 300], [5, 5, 25, 25]], float)   # medium, large, small
+    ev.add_single_ground_truth_image_info("a", gt, [0, 0, 1])
+    ev.add_single_detected_image_info("a", gt, [0.9, 0.8, 0.7], [0, 0, 1])
+    r = ev.evaluate()
+    assert r["AP"] == pytest.approx(1.0) and r["AP50"] == pytest.approx(1.0) and r["AR_100"] == pytest.approx(1.0)
+    assert r["AR_1"] == pytest.approx(0.75)          # class 0: 1 of 2 boxes with one detection, class 1: 1 of 1
+    assert r["AP_small"] == pytest.approx(1.0) and r["AP_medium"] == pytest.approx(1.0) and r["AP_large"] == pytest.approx(1.0)
+    assert r["per_class_ap"][2] == -1                # no groundtruth of class 2: not averaged
+    assert _coco(2).evaluate()["AP"] == -1           # nothing at all
+
+
+def test_coco_known_answer_tp_fp_tp():
+    """Two boxes, detections TP(.9) FP(.8) TP(.7): precision 1, .5, 2/3 at recall .5, .5, 1 -> envelope
+    1, 2/3, 2/3; 51 recall thresholds (0..0.5) read 1, the other 50 read 2/3: AP = (51 + 50*2/3)/101."""
+    ev = _coco()
+    gt = np.array([[0, 0, 100, 100], [200, 200, 300, 300]], float)
+    ev.add_single_ground_truth_image_info(0, gt, [0, 0])
+    det = np.array([[0, 0, 100, 100], [400, 400, 500, 500], [200, 200, 300, 300]], float)
+    ev.add_single_detected_image_info(0, det, [0.9, 0.8, 0.7], [0, 0, 0])
+    r = ev.evaluate()
+    expected = (51 + 50 * 2.0 / 3.0) / 101
+    assert r["AP"] == pytest.approx(expected) and r["AP50"] == pytest.approx(expected)
+    assert r["AR_1"] == pytest.approx(0.5) and r["AR_10"] == pytest.approx(1.0)
+
+
+def test_coco_iou_thresholds_and_localisation_quality():
+    """A detection with IoU 0.64 counts at thresholds .50-.60 only: AP = 3/10, AP50 = 1, AP75 = 0."""
+    ev = _coco()
+    ev.add_single_ground_truth_image_info(0, [[0, 0, 100, 100]], [0])
+    ev.add_single_detected_image_info(0, [[0, 0, 80, 80]], [0.5], [0])            # IoU = 6400/10000
+    r = ev.evaluate()
+    assert r["AP50"] == pytest.approx(1.0) and r["AP75"] == pytest.approx(0.0) and r["AP"] == pytest.approx(0.3)
+
+
+def test_coco_crowd_boxes_and_area_ranges_ignore_instead_of_penalise():
+    ev = _coco()
+    gt = np.array([[0, 0, 100, 100], [200, 200, 400, 400]], float)
+    ev.add_single_ground_truth_image_info(0, gt, [0, 0], is_crowd=[False, True])
+    # one true positive, two detections inside the crowd region (both ignored, not false positives)
+    det = np.array([[0, 0, 100, 100], [210, 210, 260, 260], [300, 300, 350, 350]], float)
+    ev.add_single_detected_image_info(0, det, [0.9, 0.95, 0.85], [0, 0, 0])
+    r = ev.evaluate()
+    assert r["AP"] == pytest.approx(1.0) and r["AR_100"] == pytest.approx(1.0)
+    # the only regular box is "large" (10 000 px^2 >= 96^2): no small / medium groundtruth at all
+    assert r["AP_large"] == pytest.approx(1.0) and r["AP_small"] == -1 and r["AP_medium"] == -1
+
+
+def test_coco_keeps_the_best_100_detections_per_image_like_the_reference_wrapper():
+    ev = _coco()
+    ev.add_single_ground_truth_image_info(0, [[0, 0, 50, 50]], [0])
+    boxes = np.tile(np.array([[500, 500, 600, 600]], float), (150, 1))
+    boxes[149] = [0, 0, 50, 50]                       # the true positive has the LOWEST score: cut off
+    ev.add_single_detected_image_info(0, boxes, np.linspace(0.99, 0.01, 150), np.zeros(150, int))
+    assert ev.evaluate()["AP"] == pytest.approx(0.0)
+    with pytest.raises(ValueError):
+        ev.add_single_detected_image_info(1, np.zeros((2, 4)), [0.5], [0])
+
+
+def test_coco_wrapper_scales_normalised_boxes_to_pixels():
+    from mtl_ssl_amd.evaluation import evaluate_detections_coco
+    det = dict(detection_boxes=np.array([[[0.1, 0.1, 0.2, 0.2], [0, 0, 0, 0]]]), detection_scores=np.array([[0.9, 0.0]]),
+               detection_classes=np.array([[1, 0]]), num_detections=np.array([1]))
+    r = evaluate_detections_coco(det, [(np.array([[0.1, 0.1, 0.2, 0.2]]), np.array([1]))], 2, (600, 1000))
+    assert r["AP"] == pytest.approx(1.0)
+    assert r["AP_medium"] == pytest.approx(1.0) and r["AP_small"] == -1      # 60 x 100 px box
