@@ -535,11 +535,50 @@ static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double
   if (t_out) *t_out = best_t;
   return best;
 }
-// Direct-path plan of a fwd / dgrad problem.
+// Direct-path plan of a fwd / dgrad problem, memoised per (problem, mode): every conv call asks two or
+// three times (workspace size, launch, profiler attribution) and the planner is a loop over tiles x splits.
+// The memo is cleared whenever the plan registry or the algorithm policy changes (plans_clear).
+struct DescKey {
+  mtlssl_conv_desc d; int mode;
+  bool operator==(const DescKey& o) const { return mode == o.mode && memcmp(&d, &o.d, sizeof(d)) == 0; }
+};
+struct DescHash {
+  size_t operator()(const DescKey& k) const {
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)k.mode;
+    const int32_t* p = reinterpret_cast<const int32_t*>(&k.d);
+    for (size_t i = 0; i < sizeof(k.d) / 4; ++i) { h ^= (uint32_t)p[i]; h *= 1099511628211ull; }
+    return (size_t)h;
+  }
+};
+static DescKey desc_key(const mtlssl_conv_desc* d, int mode) {
+  DescKey k;
+  memset(&k, 0, sizeof(k));
+  k.d = *d; k.mode = mode;
+  return k;
+}
+struct PlanMemo { Plan plan; double t; };
+static std::unordered_map<DescKey, PlanMemo, DescHash>& plan_map() {
+  static std::unordered_map<DescKey, PlanMemo, DescHash> m;
+  return m;
+}
+static std::mutex& memo_mutex() { static std::mutex m; return m; }
 static Plan plan_dir(const mtlssl_conv_desc* d, int mode, double* t_out = nullptr) {
+  const DescKey k = desc_key(d, mode);
+  {
+    std::lock_guard<std::mutex> g(memo_mutex());
+    auto it = plan_map().find(k);
+    if (it != plan_map().end()) { if (t_out) *t_out = it->second.t; return it->second.plan; }
+  }
   const int64_t M = mode == MODE_FWD ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W;
-  return plan_gemm(M, mode == MODE_FWD ? d->K : d->C, d->R * d->S, mode == MODE_FWD ? d->C : d->K,
-                   tuned_cfg(d, mode), t_out);
+  PlanMemo pm;
+  pm.plan = plan_gemm(M, mode == MODE_FWD ? d->K : d->C, d->R * d->S, mode == MODE_FWD ? d->C : d->K,
+                      tuned_cfg(d, mode), &pm.t);
+  {
+    std::lock_guard<std::mutex> g(memo_mutex());
+    plan_map()[k] = pm;
+  }
+  if (t_out) *t_out = pm.t;
+  return pm.plan;
 }
 
 constexpr int COLSUM_MAX_PARTS = 64;
@@ -608,7 +647,7 @@ static void launch_planned(const Plan& pl, ConvArgs& p, float* ws, hipStream_t s
   hipLaunchKernelGGL(k_splitk_epilogue<MODE>, dim3(cdiv((int64_t)f.M * f.NG / 4, 256)), dim3(256), 0, st, f);
 }
 
-static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pps, double* t_out = nullptr) {
+static void wgrad_plan_uncached(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pps, double* t_out) {
   int64_t P = (int64_t)d->N * d->OH * d->OW;
   int RS = d->R * d->S;
   double best_t = 1e30;
@@ -633,6 +672,29 @@ static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pp
   if (t_out) *t_out = best_t;
 }
 
+struct WgradMemo { int cfg, ns, pps; double t; };
+static std::unordered_map<DescKey, WgradMemo, DescHash>& wgrad_map() {
+  static std::unordered_map<DescKey, WgradMemo, DescHash> m;
+  return m;
+}
+static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pps, double* t_out = nullptr) {
+  const DescKey k = desc_key(d, MODE_WGRAD);
+  WgradMemo w;
+  bool hit = false;
+  {
+    std::lock_guard<std::mutex> g(memo_mutex());
+    auto it = wgrad_map().find(k);
+    if (it != wgrad_map().end()) { w = it->second; hit = true; }
+  }
+  if (!hit) {
+    wgrad_plan_uncached(d, &w.cfg, &w.ns, &w.pps, &w.t);
+    std::lock_guard<std::mutex> g(memo_mutex());
+    wgrad_map()[k] = w;
+  }
+  *cfg = w.cfg; *nsplit = w.ns; *pps = w.pps;
+  if (t_out) *t_out = w.t;
+}
+
 // Direct or Winograd? MTLSSL_WINOGRAD / mtlssl_conv2d_set_winograd: 0 never, 1 (default) by the plan
 // registry, else by the time models; 2 every eligible problem. Registry codes WINO_CFG0 + 4*variant + tile
 // select a Winograd variant (0: F(4x4,3x3), 1: whole-7-span) with that GEMM tile; codes 0..NCFG-1 pin the
@@ -653,7 +715,7 @@ static int wino_env() {
   }
   return v;
 }
-static bool choose_wino(const mtlssl_conv_desc* d, int mode, WinoChoice* wc) {
+static bool choose_wino_uncached(const mtlssl_conv_desc* d, int mode, WinoChoice* wc) {
   const int env = wino_env();
   if (env == 0 || !wino_eligible(d, WINO_F43)) return false;     // F43's domain contains M7's
   if (mode == MODE_FWD ? !mfma_fwd_ok(d) : (mode == MODE_DGRAD ? !mfma_dgrad_ok(d) : !mfma_wgrad_ok(d))) return false;
@@ -675,6 +737,37 @@ static bool choose_wino(const mtlssl_conv_desc* d, int mode, WinoChoice* wc) {
   if (mode == MODE_WGRAD) { int c, ns, pps; wgrad_plan(d, &c, &ns, &pps, &td); }
   else plan_dir(d, mode, &td);
   return tw < td;
+}
+
+// Memo of the direct-vs-Winograd decisions (same life cycle as the plan memo).
+struct Decision { bool wino; WinoChoice wc; };
+static std::unordered_map<DescKey, Decision, DescHash>& decision_map() {
+  static std::unordered_map<DescKey, Decision, DescHash> m;
+  return m;
+}
+static void plans_clear() {
+  std::lock_guard<std::mutex> g(memo_mutex());
+  decision_map().clear();
+  plan_map().clear();
+  wgrad_map().clear();
+}
+static bool choose_wino(const mtlssl_conv_desc* d, int mode, WinoChoice* wc) {
+  if (!(d->R == 3 && d->S == 3 && d->stride == 1)) return false;       // cheap reject: most layers are 1x1
+  const DescKey k = desc_key(d, mode);
+  {
+    std::lock_guard<std::mutex> g(memo_mutex());
+    auto it = decision_map().find(k);
+    if (it != decision_map().end()) { *wc = it->second.wc; return it->second.wino; }
+  }
+  Decision dec;
+  dec.wc = WinoChoice{0, 0};
+  dec.wino = choose_wino_uncached(d, mode, &dec.wc);
+  {
+    std::lock_guard<std::mutex> g(memo_mutex());
+    decision_map()[k] = dec;
+  }
+  *wc = dec.wc;
+  return dec.wino;
 }
 
 // ---- stride-2 dgrad by input parity. dX[ih][iw] only receives the taps r with (ih + pt - r) even, so
@@ -893,14 +986,17 @@ int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg) {
   MTLSSL_REQUIRE(cfg < WINO_CFG0 + 4 * WINO_VARIANTS && (cfg < 0 || cfg % 4 < NCFG),
                  "force_config: tile configuration out of range");
   TunedKey k = make_key(d, mode);
-  std::lock_guard<std::mutex> g(tuned_mutex());
-  if (cfg < 0) tuned_map().erase(k); else tuned_map()[k] = cfg;
+  {
+    std::lock_guard<std::mutex> g(tuned_mutex());
+    if (cfg < 0) tuned_map().erase(k); else tuned_map()[k] = cfg;
+  }
+  plans_clear();
   return MTLSSL_OK;
 }
 
 int mtlssl_conv2d_set_winograd(int mode) {
   const int prev = wino_env();
-  if (mode >= 0 && mode <= 2) wino_mode_ref().store(mode);
+  if (mode >= 0 && mode <= 2) { wino_mode_ref().store(mode); plans_clear(); }
   return prev;
 }
 

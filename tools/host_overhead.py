@@ -1,5 +1,5 @@
 """Host (Python + ctypes) enqueue time per training step vs the GPU time of the step: how far the
-launch thread runs ahead of the device. Usage: python tools/host_overhead.py"""
+launch thread runs ahead of the device. Usage: python tools/host_overhead.py [config [H W]]"""
 import os
 import sys
 import time
@@ -12,10 +12,13 @@ import __graft_entry__ as g  # noqa: E402
 g.build()
 from mtl_ssl_amd import config, model_builder, synthetic, trainer  # noqa: E402
 
-cfg = config.parse_pipeline_config(open(os.path.join(os.path.dirname(__file__), "..", "configs", "frcnn_resnet101_coco_mtl.config")).read())
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), "..", "configs", "frcnn_resnet101_coco_mtl.config")
+H, W = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (600, 1024)
+cfg = config.parse_pipeline_config(open(path).read())
 model = model_builder.build(cfg.model, True, "cuda", seed=0)
 tr = trainer.Trainer(model, cfg.train_config, 1)
-batch = tr.stage_batch(synthetic.make_batch(2, 600, 1024, 90, seed=1234, device="cuda"))
+batch = tr.stage_batch(synthetic.make_batch(int(cfg.train_config.batch_size), H, W, int(cfg.model.faster_rcnn.num_classes),
+                                            seed=1234, device="cuda"))
 for _ in range(3):
     tr.step(batch)
 torch.cuda.synchronize()
