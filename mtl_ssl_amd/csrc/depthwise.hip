@@ -88,58 +88,82 @@ __global__ void k_dw_dgrad(DwArgs p) {
 
 // dw[r,s,c] partials. Block = CQ channel quads x PL pixel lanes (CQ = min(C/4, 64), PL = 256/CQ, so
 // the narrow early layers — 32 channels x 150k pixels — still use every lane); grid (C/4/CQ, chunks);
-// each block reduces a contiguous range of output pixels; partials [chunk][R*S][C].
+// each block reduces a contiguous range of output pixels; partials [chunk][R*S][C]. These layers are
+// latency- before they are bandwidth-bound (a 38x64x512 map is 5 MB): the launch uses ~2048 blocks of a few
+// pixels per thread, and each thread keeps the ten loads of TWO pixels in flight.
 __global__ void __launch_bounds__(256) k_dw_wgrad_partial(DwArgs p, int pix_per_chunk, int CQ, float* part) {
   const int C4 = p.C / 4;
   const int PL = 256 / CQ;
   const int cq = threadIdx.x % CQ, sub = threadIdx.x / CQ;
   const int c4 = blockIdx.x * CQ + cq;
-  int chunk = blockIdx.y;
-  int64_t P = (int64_t)p.N * p.OH * p.OW;
-  int64_t p0 = (int64_t)chunk * pix_per_chunk, p1 = p0 + pix_per_chunk < P ? p0 + pix_per_chunk : P;
+  const int chunk = blockIdx.y;
+  const int P = p.N * p.OH * p.OW;
+  const int p0 = chunk * pix_per_chunk, p1 = min(p0 + pix_per_chunk, P);
+  const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
   floatx4 acc[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < 9; ++k) acc[k] = zero;
   if (c4 < C4) {
-    for (int64_t pix = p0 + sub; pix < p1; pix += PL) {
-      int ow = pix % p.OW;
-      int64_t t = pix / p.OW;
-      int oh = t % p.OH, n = t / p.OH;
-      floatx4 gv = *reinterpret_cast<const floatx4*>(p.g + pix * p.C + c4 * 4);
+    const float* xb = p.x + c4 * 4;
+    const float* gb = p.g + c4 * 4;
+    for (int pix = p0 + sub; pix < p1; pix += 2 * PL) {
+      floatx4 gv[2], xv[2][9];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        int ih = oh * p.stride - p.pt + r * p.dil;
-        if (ih < 0 || ih >= p.H) continue;
+      for (int u = 0; u < 2; ++u) {
+        const int q = pix + u * PL;
+        const bool live = q < p1;
+        const int qq = live ? q : p0;
+        const int ow = qq % p.OW, t = qq / p.OW;
+        const int oh = t % p.OH, n = t / p.OH;
+        gv[u] = live ? *reinterpret_cast<const floatx4*>(gb + (int64_t)qq * p.C) : zero;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          int iw = ow * p.stride - p.pl + s * p.dil;
-          if (iw < 0 || iw >= p.W) continue;
-          floatx4 xv = *reinterpret_cast<const floatx4*>(p.x + (((int64_t)n * p.H + ih) * p.W + iw) * p.C + c4 * 4);
-          acc[r * 3 + s] += xv * gv;
+        for (int r = 0; r < 3; ++r) {
+          const int ih = oh * p.stride - p.pt + r * p.dil;
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            const int iw = ow * p.stride - p.pl + s * p.dil;
+            const bool ok = live && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            xv[u][r * 3 + s] = ok ? *reinterpret_cast<const floatx4*>(xb + (((int64_t)n * p.H + ih) * p.W + iw) * p.C) : zero;
+          }
         }
       }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] += xv[u][k] * gv[u];
     }
   }
-  __shared__ floatx4 red[256];
-  for (int k = 0; k < 9; ++k) {
-    red[threadIdx.x] = acc[k];
-    __syncthreads();
-    if (sub == 0 && c4 < C4) {
-      floatx4 v = red[cq];
-      for (int l = 1; l < PL; ++l) v += red[l * CQ + cq];          // fixed order: deterministic
-      *reinterpret_cast<floatx4*>(part + ((int64_t)chunk * 9 + k) * p.C + c4 * 4) = v;
-    }
-    __syncthreads();
+  // block reduction over the pixel lanes, fixed order (deterministic): one barrier, then thread o sums
+  // output (tap k, quad cq) = o over the PL lanes
+  __shared__ floatx4 red[9][256];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 9 * CQ; o += 256) {
+    const int k = o / CQ, q = o - k * CQ;
+    const int oc4 = blockIdx.x * CQ + q;
+    if (oc4 >= C4) continue;
+    floatx4 v = red[k][q];
+    for (int l = 1; l < PL; ++l) v += red[k][l * CQ + q];
+    *reinterpret_cast<floatx4*>(part + ((int64_t)chunk * 9 + k) * p.C + oc4 * 4) = v;
   }
 }
-__global__ void k_dw_wgrad_fold(const float* part, int chunks, int total, int C, const float* scale,
-                                float* dw, float beta) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += part[(int64_t)k * total + i];
-  if (scale) s *= scale[i % C];
-  dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+// dw = beta*dw + scale[c] * sum_chunks part: one wavefront per output quad, lanes stride over the chunks,
+// butterfly reduction (a fixed pattern: deterministic).
+__global__ void __launch_bounds__(256) k_dw_wgrad_fold(const float* part, int chunks, int total4, int C,
+                                                       const float* scale, float* dw, float beta) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= total4) return;
+  floatx4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane; k < chunks; k += 64) s += *reinterpret_cast<const floatx4*>(part + ((int64_t)k * total4 + o) * 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s[e] = wave_sum(s[e]);
+  if (lane == 0) {
+    if (scale) s *= *reinterpret_cast<const floatx4*>(scale + (o * 4) % C);
+    floatx4* d = reinterpret_cast<floatx4*>(dw) + o;
+    *d = beta != 0.f ? beta * *d + s : s;
+  }
 }
 
 // Trainable gamma/beta of an inference-mode BatchNorm folded into the producing conv:
@@ -147,41 +171,79 @@ __global__ void k_dw_wgrad_fold(const float* part, int chunks, int total, int C,
 // activation clipped, so y equals the pre-activation wherever g != 0):
 //   dbeta[c] = sum_rows g,   dgamma[c] = sum_rows g*(y-beta[c]) / gamma[c].
 // Partials [chunk][2][C], rows split over blockIdx.y; deterministic fold (no float atomics).
-__global__ void __launch_bounds__(256) k_bn_partial(const float* y, const float* g, int64_t rows, int C,
-                                                    int rows_per_chunk, float* part) {
-  __shared__ float s0[4][64], s1[4][64];
-  int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  int w = threadIdx.x >> 6;
-  int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
-  int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
-  float sg = 0.f, sgy = 0.f;
-  if (c < C)
-    for (int64_t r = r0 + w; r < r1; r += 4) {
-      float gv = g[r * C + c];
-      sg += gv;
-      sgy += gv * y[r * C + c];
+// Block = CQ channel quads x PL row lanes (as in k_dw_wgrad_partial), two rows in flight per thread.
+__global__ void __launch_bounds__(256) k_bn_partial(const float* y, const float* g, int rows, int C,
+                                                    int rows_per_chunk, int CQ, float* part) {
+  const int C4 = C / 4, PL = 256 / CQ;
+  const int cq = threadIdx.x % CQ, sub = threadIdx.x / CQ;
+  const int c4 = blockIdx.x * CQ + cq;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(r0 + rows_per_chunk, rows);
+  const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+  floatx4 sg = zero, sgy = zero;
+  if (c4 < C4) {
+    const float* yb = y + c4 * 4;
+    const float* gb = g + c4 * 4;
+    for (int r = r0 + sub; r < r1; r += 2 * PL) {
+      const bool two = r + PL < r1;
+      floatx4 g0 = *reinterpret_cast<const floatx4*>(gb + (int64_t)r * C);
+      floatx4 y0 = *reinterpret_cast<const floatx4*>(yb + (int64_t)r * C);
+      floatx4 g1 = two ? *reinterpret_cast<const floatx4*>(gb + (int64_t)(r + PL) * C) : zero;
+      floatx4 y1 = two ? *reinterpret_cast<const floatx4*>(yb + (int64_t)(r + PL) * C) : zero;
+      sg += g0; sgy += g0 * y0;
+      sg += g1; sgy += g1 * y1;
     }
-  s0[w][threadIdx.x & 63] = sg;
-  s1[w][threadIdx.x & 63] = sgy;
+  }
+  __shared__ floatx4 red[2][256];
+  red[0][threadIdx.x] = sg;
+  red[1][threadIdx.x] = sgy;
   __syncthreads();
-  if (w == 0 && c < C) {
-    int t = threadIdx.x;
-    part[((int64_t)blockIdx.y * 2 + 0) * C + c] = s0[0][t] + s0[1][t] + s0[2][t] + s0[3][t];
-    part[((int64_t)blockIdx.y * 2 + 1) * C + c] = s1[0][t] + s1[1][t] + s1[2][t] + s1[3][t];
+  for (int o = threadIdx.x; o < 2 * CQ; o += 256) {
+    const int k = o / CQ, q = o - k * CQ;
+    const int oc4 = blockIdx.x * CQ + q;
+    if (oc4 >= C4) continue;
+    floatx4 v = red[k][q];
+    for (int l = 1; l < PL; ++l) v += red[k][l * CQ + q];
+    *reinterpret_cast<floatx4*>(part + ((int64_t)blockIdx.y * 2 + k) * C + oc4 * 4) = v;
   }
 }
-__global__ void k_bn_fold(const float* part, int chunks, int C, const float* gamma, const float* beta,
-                          float* dgamma, float* dbeta, float accum) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per channel: lanes stride over the chunks, butterfly reduction (deterministic)
+__global__ void __launch_bounds__(256) k_bn_fold(const float* part, int chunks, int C, const float* gamma,
+                                                 const float* beta, float* dgamma, float* dbeta, float accum) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   float sg = 0.f, sgy = 0.f;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = lane; k < chunks; k += 64) {
     sg += part[((int64_t)k * 2 + 0) * C + c];
     sgy += part[((int64_t)k * 2 + 1) * C + c];
   }
-  float dgm = gamma[c] != 0.f ? (sgy - beta[c] * sg) / gamma[c] : 0.f;
-  dgamma[c] = accum != 0.f ? accum * dgamma[c] + dgm : dgm;
-  dbeta[c] = accum != 0.f ? accum * dbeta[c] + sg : sg;
+  sg = wave_sum(sg);
+  sgy = wave_sum(sgy);
+  if (lane == 0) {
+    float dgm = gamma[c] != 0.f ? (sgy - beta[c] * sg) / gamma[c] : 0.f;
+    dgamma[c] = accum != 0.f ? accum * dgamma[c] + dgm : dgm;
+    dbeta[c] = accum != 0.f ? accum * dbeta[c] + sg : sg;
+  }
+}
+
+// Launch shape shared by the two reductions over pixels: CQ channel quads per block (a power of two
+// <= 64), ~2048 blocks in total, whole multiples of the lane count per chunk.
+constexpr int DW_MAX_CHUNKS = 2048;
+struct ReducePlan { int CQ, chunks, per_chunk; };
+static ReducePlan reduce_plan(int64_t P, int C) {
+  ReducePlan r;
+  r.CQ = 64;
+  while (r.CQ > 1 && r.CQ / 2 >= C / 4) r.CQ /= 2;
+  const int PL = 256 / r.CQ;
+  const int64_t bx = cdiv(C / 4, r.CQ);
+  int64_t chunks = 2048 / bx;
+  const int64_t most = cdiv(P, 2 * PL);                 // at least two pixels per lane
+  if (chunks > most) chunks = most;
+  if (chunks > DW_MAX_CHUNKS) chunks = DW_MAX_CHUNKS;
+  if (chunks < 1) chunks = 1;
+  r.per_chunk = (int)align_up(cdiv(P > 0 ? P : 1, chunks), PL);
+  r.chunks = (int)cdiv(P > 0 ? P : 1, r.per_chunk);
+  return r;
 }
 
 static int fill(DwArgs& a, const mtlssl_conv_desc* d) {
@@ -191,7 +253,6 @@ static int fill(DwArgs& a, const mtlssl_conv_desc* d) {
   a.stride = d->stride; a.dil = d->dilation; a.pt = d->pad_t; a.pl = d->pad_l;
   return MTLSSL_OK;
 }
-constexpr int DW_MAX_CHUNKS = 512;
 
 }  // namespace mtlssl
 
@@ -220,7 +281,8 @@ int mtlssl_depthwise_dgrad(const mtlssl_conv_desc* d, const float* dy, const flo
 }
 int64_t mtlssl_depthwise_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
   if (!d) return 0;
-  return (int64_t)DW_MAX_CHUNKS * d->R * d->S * d->C * 4;
+  ReducePlan rp = reduce_plan((int64_t)d->N * d->OH * d->OW, d->C);
+  return align_up((int64_t)rp.chunks * d->R * d->S * d->C * 4, 256);
 }
 int mtlssl_depthwise_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,
                            const float* out_scale, float* dw, float beta, void* workspace,
@@ -231,16 +293,13 @@ int mtlssl_depthwise_wgrad(const mtlssl_conv_desc* d, const float* x, const floa
   MTLSSL_REQUIRE(workspace != nullptr, "depthwise_wgrad: workspace required");
   a.x = x; a.g = dy;
   int64_t P = (int64_t)a.N * a.OH * a.OW;
-  int chunks = (int)(cdiv(P, 256) < DW_MAX_CHUNKS ? cdiv(P, 256) : DW_MAX_CHUNKS);
-  int ppc = (int)cdiv(P, chunks);
-  chunks = (int)cdiv(P, ppc);
-  int CQ = 64;                                     // channel quads per block: a power of two <= 64
-  while (CQ > 1 && CQ / 2 >= a.C / 4) CQ /= 2;
-  hipLaunchKernelGGL(k_dw_wgrad_partial, dim3(cdiv(a.C / 4, CQ), chunks), dim3(256), 0, S(stream), a, ppc, CQ,
-                     (float*)workspace);
-  int total = 9 * a.C;
-  hipLaunchKernelGGL(k_dw_wgrad_fold, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), (const float*)workspace,
-                     chunks, total, a.C, out_scale, dw, beta);
+  MTLSSL_REQUIRE(P < (1ll << 31) && (int64_t)a.N * a.H * a.W * a.C < (1ll << 40), "depthwise_wgrad: tensor too large");
+  ReducePlan rp = reduce_plan(P, a.C);
+  hipLaunchKernelGGL(k_dw_wgrad_partial, dim3(cdiv(a.C / 4, rp.CQ), rp.chunks), dim3(256), 0, S(stream), a,
+                     rp.per_chunk, rp.CQ, (float*)workspace);
+  int total4 = 9 * a.C / 4;
+  hipLaunchKernelGGL(k_dw_wgrad_fold, dim3(cdiv(total4, 4)), dim3(256), 0, S(stream), (const float*)workspace,
+                     rp.chunks, total4, a.C, out_scale, dw, beta);
   return check_launch("depthwise_wgrad");
 }
 
@@ -248,16 +307,15 @@ int64_t mtlssl_bn_param_grads_workspace_bytes(int C) { return (int64_t)DW_MAX_CH
 int mtlssl_bn_param_grads(const float* y, const float* g, const float* gamma, const float* beta,
                           float* dgamma, float* dbeta, int64_t rows, int C, float accum, void* workspace,
                           mtlssl_stream_t stream) {
-  MTLSSL_REQUIRE(C > 0 && rows >= 0, "bn_param_grads: bad sizes");
+  MTLSSL_REQUIRE(C > 0 && C % 4 == 0 && rows >= 0 && rows < (1ll << 31), "bn_param_grads: bad sizes (C must be a multiple of 4)");
   MTLSSL_REQUIRE(workspace != nullptr, "bn_param_grads: workspace required");
-  int chunks = (int)(cdiv(rows, 256) < DW_MAX_CHUNKS ? cdiv(rows, 256) : DW_MAX_CHUNKS);
-  if (chunks < 1) chunks = 1;
-  int rpc = (int)cdiv(rows > 0 ? rows : 1, chunks);
-  chunks = (int)cdiv(rows > 0 ? rows : 1, rpc);
-  hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C, 64), chunks), dim3(256), 0, S(stream), y, g, rows, C, rpc,
-                     (float*)workspace);
-  hipLaunchKernelGGL(k_bn_fold, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), (const float*)workspace, chunks, C,
-                     gamma, beta, dgamma, dbeta, accum);
+  ReducePlan rp = reduce_plan(rows, C);
+  if (rows == 0) (void)hipMemsetAsync(workspace, 0, sizeof(float) * 2 * C, S(stream));
+  else
+    hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C / 4, rp.CQ), rp.chunks), dim3(256), 0, S(stream), y, g, (int)rows, C,
+                       rp.per_chunk, rp.CQ, (float*)workspace);
+  hipLaunchKernelGGL(k_bn_fold, dim3(cdiv(C, 4)), dim3(256), 0, S(stream), (const float*)workspace,
+                     rows == 0 ? 1 : rp.chunks, C, gamma, beta, dgamma, dbeta, accum);
   return check_launch("bn_param_grads");
 }
 
