@@ -23,25 +23,27 @@
 namespace mtlssl {
 
 
-// wgrad split-K fold: dw = beta*dw + scale[k] * sum_split ws[split]; float4 over k.
-__global__ void k_wgrad_reduce(const float* ws, int nsplit, int64_t total4, int K,
-                               const float* scale, float* dw, float beta) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= total4) return;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < nsplit; ++k) {
-    float4 v = reinterpret_cast<const float4*>(ws)[(int64_t)k * total4 + i];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+// wgrad split-K fold: dw = beta*dw + scale[k] * sum_split ws[split]; float4 over k. Four lanes share one
+// output quad and stride over the splits (the sum of 8-64 partials is a latency chain, not bandwidth), then
+// combine with two shuffles: a fixed order, deterministic.
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* ws, int nsplit, int64_t total4, int K,
+                                                      const float* scale, float* dw, float beta) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t i = t >> 2;
+  const int sl = (int)(t & 3);
+  const bool live = i < total4;
+  floatx4 s = {0.f, 0.f, 0.f, 0.f};
+  if (live)
+    for (int k = sl; k < nsplit; k += 4) s += reinterpret_cast<const floatx4*>(ws)[(int64_t)k * total4 + i];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s[e] += __shfl_xor(s[e], 1, 64);
+    s[e] += __shfl_xor(s[e], 2, 64);
   }
-  if (scale) {
-    float4 sc = *reinterpret_cast<const float4*>(scale + (i * 4) % K);
-    s.x *= sc.x; s.y *= sc.y; s.z *= sc.z; s.w *= sc.w;
-  }
-  if (beta != 0.f) {
-    float4 d = reinterpret_cast<float4*>(dw)[i];
-    s.x += beta * d.x; s.y += beta * d.y; s.z += beta * d.z; s.w += beta * d.w;
-  }
-  reinterpret_cast<float4*>(dw)[i] = s;
+  if (!live || sl) return;
+  if (scale) s *= *reinterpret_cast<const floatx4*>(scale + (i * 4) % K);
+  floatx4* d = reinterpret_cast<floatx4*>(dw) + i;
+  *d = beta != 0.f ? beta * *d + s : s;
 }
 
 // dbias[k] = sum over rows of dy[row][k]; one block per 64 columns, rows strided over waves.
@@ -296,21 +298,64 @@ __global__ void k_small_reduce(const float* ws, int nsplit, int64_t total, int K
   if (scale) s *= scale[i % K];
   dw[i] = beta != 0.f ? beta * dw[i] + s : s;
 }
-// dbias: two-stage column sum, rows split over blockIdx.y; partials [gridDim.y][K] in workspace.
-__global__ void __launch_bounds__(256) k_colsum_partial(const float* dy, int64_t rows, int K,
-                                                        int rows_per_block, float* part) {
-  __shared__ float s[4][64];
-  int k = blockIdx.x * 64 + (threadIdx.x & 63);
-  int w = threadIdx.x >> 6;
-  int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
-  int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-  float acc = 0.f;
-  if (k < K)
-    for (int64_t r = r0 + w; r < r1; r += 4) acc += dy[r * K + k];
-  s[w][threadIdx.x & 63] = acc;
+// dbias: two-stage column sum; partials [chunk][K] in the workspace. Block = CQ channel groups (VT = float4
+// when K % 4 == 0, else float) x PL row lanes, two rows in flight per lane, ~2048 blocks in total: the
+// reduction is latency- before it is bandwidth-bound on the B=1/B=2 feature maps. The fold gives one
+// wavefront to each channel (lanes stride over the chunks, butterfly sum): deterministic, no atomics.
+template <typename VT>
+__global__ void __launch_bounds__(256) k_colsum_partial(const float* dy, int rows, int K, int rows_per_chunk,
+                                                        int CQ, float* part) {
+  constexpr int VW = sizeof(VT) / 4;
+  const int KG = (K + VW - 1) / VW, PL = 256 / CQ;
+  const int cq = threadIdx.x % CQ, sub = threadIdx.x / CQ;
+  const int g = blockIdx.x * CQ + cq;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(r0 + rows_per_chunk, rows);
+  VT acc{};
+  if (g < KG) {
+    const float* b = dy + g * VW;
+    for (int r = r0 + sub; r < r1; r += 2 * PL) {
+      VT v0 = *reinterpret_cast<const VT*>(b + (int64_t)r * K);
+      VT v1 = r + PL < r1 ? *reinterpret_cast<const VT*>(b + (int64_t)(r + PL) * K) : VT{};
+      acc += v0;
+      acc += v1;
+    }
+  }
+  __shared__ floatx4 red_[256];
+  VT* red = reinterpret_cast<VT*>(red_);
+  red[threadIdx.x] = acc;
   __syncthreads();
-  if (w == 0 && k < K)
-    part[(int64_t)blockIdx.y * K + k] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+  if (sub == 0 && g < KG) {
+    VT v = red[cq];
+    for (int l = 1; l < PL; ++l) v += red[l * CQ + cq];
+    *reinterpret_cast<VT*>(part + (int64_t)blockIdx.y * K + g * VW) = v;
+  }
+}
+__global__ void __launch_bounds__(256) k_colsum_fold(const float* part, int chunks, int K, float* out, float beta) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= K) return;
+  float s = 0.f;
+  for (int c = lane; c < chunks; c += 64) s += part[(int64_t)c * K + k];
+  s = wave_sum(s);
+  if (lane == 0) out[k] = beta != 0.f ? beta * out[k] + s : s;
+}
+constexpr int COLSUM_MAX_PARTS = 2048;
+struct ColsumPlan { int CQ, chunks, per_chunk; };
+static ColsumPlan colsum_plan(int64_t P, int K) {
+  const int vw = (K & 3) ? 1 : 4;
+  const int kg = (int)cdiv(K, vw);
+  ColsumPlan r;
+  r.CQ = 64;
+  while (r.CQ > 1 && r.CQ / 2 >= kg) r.CQ /= 2;
+  const int PL = 256 / r.CQ;
+  int64_t chunks = 2048 / cdiv(kg, r.CQ);
+  const int64_t most = cdiv(P, 2 * PL);
+  if (chunks > most) chunks = most;
+  if (chunks > COLSUM_MAX_PARTS) chunks = COLSUM_MAX_PARTS;
+  if (chunks < 1) chunks = 1;
+  r.per_chunk = (int)align_up(cdiv(P > 0 ? P : 1, chunks), PL);
+  r.chunks = (int)cdiv(P > 0 ? P : 1, r.per_chunk);
+  return r;
 }
 
 // Stem: 7x7/2 conv on 3 input channels -> 64 (slim/nets/resnet_v1.py:216-219). Weights and the
@@ -581,7 +626,6 @@ static Plan plan_dir(const mtlssl_conv_desc* d, int mode, double* t_out = nullpt
   return pm.plan;
 }
 
-constexpr int COLSUM_MAX_PARTS = 64;
 static bool is_pointwise(const mtlssl_conv_desc* d) {
   return d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->OH == d->H &&
          d->OW == d->W;
@@ -1047,7 +1091,7 @@ int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* 
     p.M = d->C; p.NG = d->K; p.nsplit = ns; p.pix_per_split = pps;
     launch_mfma<MODE_WGRAD>(cfg, p, dim3(1, d->R * d->S, ns), st);
     int64_t total4 = (int64_t)d->R * d->S * d->C * d->K / 4;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(total4, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(total4 * 4, 256)), dim3(256), 0, st,
                        (const float*)ws_main, ns, total4, d->K, out_scale, dw, beta);
   } else if (is_pointwise(d)) {
     int ns, kps;
@@ -1069,12 +1113,17 @@ int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* 
                        dw, beta);
   }
   if (dbias) {
-    int parts = (int)(cdiv(P, 256) < COLSUM_MAX_PARTS ? cdiv(P, 256) : COLSUM_MAX_PARTS);
-    int rpb = (int)cdiv(P, parts);
-    hipLaunchKernelGGL(k_colsum_partial, dim3(cdiv(d->K, 64), parts), dim3(256), 0, st, dy, P, d->K, rpb,
-                       (float*)workspace);
-    hipLaunchKernelGGL(k_small_reduce, dim3(cdiv(d->K, 256)), dim3(256), 0, st, (const float*)workspace,
-                       parts, (int64_t)d->K, d->K, (const float*)nullptr, dbias, beta);
+    ColsumPlan cp = colsum_plan(P, d->K);
+    const int kg = (int)cdiv(d->K, (d->K & 3) ? 1 : 4);
+    dim3 grid(cdiv(kg, cp.CQ), cp.chunks);
+    if (d->K & 3)
+      hipLaunchKernelGGL(k_colsum_partial<float>, grid, dim3(256), 0, st, dy, (int)P, d->K, cp.per_chunk, cp.CQ,
+                         (float*)workspace);
+    else
+      hipLaunchKernelGGL(k_colsum_partial<floatx4>, grid, dim3(256), 0, st, dy, (int)P, d->K, cp.per_chunk, cp.CQ,
+                         (float*)workspace);
+    hipLaunchKernelGGL(k_colsum_fold, dim3(cdiv(d->K, 4)), dim3(256), 0, st, (const float*)workspace, cp.chunks, d->K,
+                       dbias, beta);
   }
   return check_launch("conv2d_wgrad");
 }
