@@ -338,6 +338,15 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
 int mtlssl_fold_scales(const float* weights, float* eff, const int32_t* var_offsets, int num_vars,
                        int64_t total, const void* scale_ptrs, const int32_t* scale_len,
                        mtlssl_stream_t stream);
+/* Batched refresh of the folded inference-mode BatchNorm constants after an optimizer step moved gamma /
+ * beta (slim arg scopes that leave BatchNorm trainable: MobileNet-v1, Inception-ResNet-v2): for every layer l
+ * of the six device pointer tables (n_layers device pointers each; gamma[l] may be null = no scale variable)
+ *   scale_l[c] = gamma_l[c] * inv_std_l[c]   (only when gamma_l != null)
+ *   shift_l[c] = beta_l[c] - mean_l[c] * scale_l[c]
+ * for c < channels[l] (device int32 array), one launch for the whole model. */
+int mtlssl_bn_refresh(int n_layers, const void* gamma_ptrs, const void* beta_ptrs, const void* mean_ptrs,
+                      const void* inv_std_ptrs, const void* scale_ptrs, const void* shift_ptrs,
+                      const int32_t* channels, int max_channels, mtlssl_stream_t stream);
 /* Elementwise helpers used by the graph glue. */
 int mtlssl_axpby(const float* x, float* y, int64_t n, float a, float b, mtlssl_stream_t s); /* y=a*x+b*y */
 int mtlssl_scale_channels(const float* w, const float* scale, float* out, int64_t rows, int K,

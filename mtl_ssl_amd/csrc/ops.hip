@@ -458,6 +458,22 @@ __global__ void k_scale_channels(const float* w, const float* sc, float* out, in
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < total) out[i] = w[i] * sc[i % K];
 }
+// Batched refresh of the folded BatchNorm constants of every layer whose gamma / beta train
+// (blockIdx.y = layer): scale = gamma * inv_std (when the layer has a gamma), shift = beta - mean * scale.
+__global__ void __launch_bounds__(256)
+    k_bn_refresh(const float* const* gamma, const float* const* beta, const float* const* mean,
+                 const float* const* inv_std, float* const* scale, float* const* shift, const int32_t* channels) {
+  const int l = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= channels[l]) return;
+  float sc = scale[l][c];
+  if (gamma[l]) {
+    sc = gamma[l][c] * inv_std[l][c];
+    scale[l][c] = sc;
+  }
+  shift[l][c] = beta[l][c] - mean[l][c] * sc;
+}
+
 // Batched BatchNorm / residual-scale fold over the flat parameter buffer: eff[i] = w[i] *
 // scale_v[(i - off[v]) % K_v] for every variable v that has a scale vector registered.
 __global__ void __launch_bounds__(256)
@@ -663,6 +679,19 @@ int mtlssl_fold_scales(const float* weights, float* eff, const int32_t* var_offs
   hipLaunchKernelGGL(k_fold_scales, dim3(cdiv(total / 4, 256)), dim3(256), 0, S(stream), weights, eff,
                      var_offsets, num_vars, total / 4, (const float* const*)scale_ptrs, scale_len);
   return check_launch("fold_scales");
+}
+
+int mtlssl_bn_refresh(int n_layers, const void* gamma_ptrs, const void* beta_ptrs, const void* mean_ptrs,
+                      const void* inv_std_ptrs, const void* scale_ptrs, const void* shift_ptrs,
+                      const int32_t* channels, int max_channels, mtlssl_stream_t stream) {
+  if (n_layers <= 0 || max_channels <= 0) return MTLSSL_OK;
+  MTLSSL_REQUIRE(gamma_ptrs && beta_ptrs && mean_ptrs && inv_std_ptrs && scale_ptrs && shift_ptrs && channels,
+                 "bn_refresh: null table");
+  MTLSSL_REQUIRE(n_layers <= 65535, "bn_refresh: too many layers for one launch");
+  hipLaunchKernelGGL(k_bn_refresh, dim3(cdiv(max_channels, 256), n_layers), dim3(256), 0, S(stream),
+                     (const float* const*)gamma_ptrs, (const float* const*)beta_ptrs, (const float* const*)mean_ptrs,
+                     (const float* const*)inv_std_ptrs, (float* const*)scale_ptrs, (float* const*)shift_ptrs, channels);
+  return check_launch("bn_refresh");
 }
 
 int mtlssl_axpby(const float* x, float* y, int64_t n, float a, float b, mtlssl_stream_t stream) {

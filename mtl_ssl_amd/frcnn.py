@@ -194,14 +194,21 @@ class FasterRCNNMetaArch:
     def prepare(self):
         for l in self.layers:
             l.prepare()
+        self._bn_table = None          # the layers' scale / shift tensors were re-created
         ops.fold_scales(self.ps)
 
     def refold(self):
-        """After an optimizer step: per-layer normaliser refresh (only layers whose BatchNorm
-        parameters train do anything), then ONE batched fold of every scale into the shadow weights."""
-        for l in self.layers:
-            if getattr(l, "trainable", False):
-                l.refold()
+        """After an optimizer step: ONE batched refresh of the normaliser constants of the layers whose
+        BatchNorm parameters train, then ONE batched fold of every scale into the shadow weights."""
+        if self.ps.device.type == "cuda":
+            if getattr(self, "_bn_table", None) is None:
+                self._bn_table = ops.BnRefreshTable([l for l in self.layers if getattr(l, "trainable", False)],
+                                                    self.ps.device)
+            ops.bn_refresh(self._bn_table)
+        else:
+            for l in self.layers:
+                if getattr(l, "trainable", False):
+                    l.refold()
         ops.fold_scales(self.ps)
 
     @staticmethod

@@ -662,6 +662,38 @@ def fold_scales(ps):
                       ps.weights.numel(), ptr(ps.fold_ptrs), ptr(ps.fold_len), _stream())
 
 
+class BnRefreshTable:
+    """Device pointer tables for `bn_refresh`: built once from the layers whose BatchNorm parameters train
+    (the tensors they point to live as long as the model)."""
+
+    def __init__(self, layers, device):
+        self.layers = [l for l in layers if getattr(l, "bn_trainable", False)]
+        self.n = len(self.layers)
+        if not self.n:
+            return
+        ps = self.layers[0].ps
+
+        def table(fn):
+            return torch.tensor([fn(l) for l in self.layers], dtype=torch.int64, device=device)
+        self.gamma = table(lambda l: ps.value(l.gamma.name).data_ptr() if l.gamma is not None else 0)
+        self.beta = table(lambda l: ps.value(l.beta.name).data_ptr())
+        self.mean = table(lambda l: ps.value(l.mean.name).data_ptr())
+        self.inv_std = table(lambda l: l.inv_std.data_ptr())
+        self.scale = table(lambda l: _chk(l.scale).data_ptr())
+        self.shift = table(lambda l: _chk(l.shift).data_ptr())
+        ch = [int(l.scale.numel()) for l in self.layers]
+        self.channels = torch.tensor(ch, dtype=i32, device=device)
+        self.max_c = max(ch)
+        self._keep = [(l.inv_std, l.scale, l.shift) for l in self.layers]
+
+
+def bn_refresh(tab):
+    """scale = gamma * inv_std, shift = beta - mean * scale for every trainable-BatchNorm layer, one launch."""
+    if tab.n:
+        lib().bn_refresh(tab.n, ptr(tab.gamma), ptr(tab.beta), ptr(tab.mean), ptr(tab.inv_std), ptr(tab.scale),
+                         ptr(tab.shift), ptr(tab.channels), tab.max_c, _stream())
+
+
 def axpby(x, y, a, b):
     lib().axpby(ptr(_chk(x)), ptr(_chk(y)), x.numel(), float(a), float(b), _stream())
     return y
