@@ -35,6 +35,7 @@ CASES = [
     (3, 4, 4, 32, 48),              # a single tile per image, narrow channels
     (2, 5, 9, 128, 96),             # maps one past a tile edge
     (1, 75, 128, 128, 128),         # block2 unit
+    (600, 7, 7, 256, 256),          # wide planes: the four-channels-per-thread transforms with every epilogue
 ]
 
 
