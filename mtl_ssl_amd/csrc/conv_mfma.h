@@ -2,6 +2,8 @@
 // implicit-GEMM MFMA kernel body with its three gather modes, the kernel wrappers and the tile /
 // time-model tables shared by conv.hip (direct path) and winograd.hip (Winograd-domain GEMM stacks).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace mtlssl {
@@ -160,9 +162,16 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     }
   }
 
-  floatx4 ra[A_LD], rb[B_LD];
+  // Two register sets for the global->LDS staging: the loads of tile t+2 are issued while tile t is being
+  // multiplied and tile t+1 waits in the other set, i.e. a global load has two K-steps to land (one K-step
+  // of a 64x64 tile is only 512 MFMA cycles per wave — less than the HBM round trip).
+  floatx4 rA[2][A_LD], rB[2][B_LD];
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
 
-  auto load_tile = [&](int ks) {
+  auto load_tile = [&](int ks, auto SET) {
+    floatx4 (&ra)[A_LD] = rA[decltype(SET)::value];
+    floatx4 (&rb)[B_LD] = rB[decltype(SET)::value];
     if constexpr (MODE == MODE_FWD) {
       int cpk = p.C / BKT;
       int rs = ks / cpk, c0 = (ks - rs * cpk) * BKT;
@@ -243,7 +252,9 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     }
   };
 
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, auto SET) {
+    floatx4 (&ra)[A_LD] = rA[decltype(SET)::value];
+    floatx4 (&rb)[B_LD] = rB[decltype(SET)::value];
     float* a = sA + buf * (BKT * LDA);
     float* b = sB + buf * (BKT * LDB);
 #pragma unroll
@@ -278,14 +289,17 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (ksteps > ks_begin) {
-    load_tile(ks_begin);
-    store_tile(ks_begin & 1);
+  const int nk = ksteps - ks_begin;
+  if (nk > 0) {
+    load_tile(ks_begin, Set0{});
+    store_tile(0, Set0{});
   }
+  if (nk > 1) load_tile(ks_begin + 1, Set1{});
   __syncthreads();
-  for (int ks = ks_begin; ks < ksteps; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < ksteps) load_tile(ks + 1);
+  // One K-step: `next` holds tile it+1 (loaded during step it-1), `spare` is free for tile it+2.
+  auto kstep = [&](int it, auto next, auto spare) {
+    const int cur = it & 1;
+    if (it + 2 < nk) load_tile(ks_begin + it + 2, spare);
     const float* a = sA + cur * (BKT * LDA) + wr * (BM / WR) + lo;
     const float* b = sB + cur * (BKT * LDB) + wc * (BN / 2) + lo;
     // Software-pipelined fragments: the ds_reads of k-pair kk+1 are issued BEFORE the MFMAs of
@@ -314,8 +328,12 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cs][i], fb[cs][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ks + 1 < ksteps) store_tile(cur ^ 1);
+    if (it + 1 < nk) store_tile(cur ^ 1, next);
     __syncthreads();
+  };
+  for (int it = 0; it < nk; it += 2) {
+    kstep(it, Set1{}, Set0{});
+    if (it + 1 < nk) kstep(it + 1, Set0{}, Set1{});
   }
 
   // ---- epilogue. MFMA C/D map: lane l, reg e -> row (e&3) + 8*(e>>2) + 4*(l>>5), col l&31.
