@@ -46,23 +46,6 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* ws, int nspli
   *d = beta != 0.f ? beta * *d + s : s;
 }
 
-// dbias[k] = sum over rows of dy[row][k]; one block per 64 columns, rows strided over waves.
-__global__ void __launch_bounds__(256) k_colsum(const float* dy, int64_t rows, int K, float* out,
-                                                float beta) {
-  __shared__ float s[4][64];
-  int k = blockIdx.x * 64 + (threadIdx.x & 63);
-  int w = threadIdx.x >> 6;
-  float acc = 0.f;
-  if (k < K)
-    for (int64_t r = w; r < rows; r += 4) acc += dy[r * K + k];
-  s[w][threadIdx.x & 63] = acc;
-  __syncthreads();
-  if (w == 0 && k < K) {
-    float t = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
-    out[k] = beta != 0.f ? beta * out[k] + t : t;
-  }
-}
-
 // ------------------------------------------------------------------------------ generic paths
 // Direct convolution for shapes the MFMA path does not take (the 7x7x3 stem, heads with a
 // handful of output channels). One thread per output element group; VALU only. These layers are
