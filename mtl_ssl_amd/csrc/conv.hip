@@ -474,6 +474,30 @@ __global__ void k_splitk_epilogue(ConvArgs p) {
   *reinterpret_cast<floatx4*>(p.out + o) = v;
 }
 
+// The same fold for GEMM widths that are not a multiple of 4 (the K = 91 class heads: a 512 x 2048 x 91
+// GEMM is 16 tiles with a 128-step K loop unless it is split).
+template <int MODE>
+__global__ void k_splitk_epilogue_scalar(ConvArgs p) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)p.M * p.NG;
+  if (i >= total) return;
+  float v = p.splitk_ws[i];
+  for (int z = 1; z < p.nsplit; ++z) v += p.splitk_ws[(int64_t)z * total + i];
+  int col = (int)(i % p.NG);
+  if constexpr (MODE == MODE_FWD) {
+    if (p.epi & MTLSSL_EPI_BIAS) v += p.bias[col];
+    if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[i];
+    if (p.epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
+    if (p.epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+    if (p.epi & MTLSSL_EPI_TANH) v = tanhf(v);
+  } else {
+    if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[i];
+    if (p.epi & MTLSSL_EPI_ACCUM) v += p.out[i];
+    if (p.epi & MASK_ANY) v = act_mask(v, p.mask[i], p.epi);
+  }
+  p.out[i] = v;
+}
+
 // Launch plan for fwd/dgrad: tile config + K split, from a per-CU MFMA time model (a CU retires
 // one 32-deep block-step of an bm x bn tile in bm*bn*32 / 614 GFLOP/s; blocks beyond 256 queue).
 // tail_rows > 0: the last `tail_rows` tile rows are a second launch whose K loop is split
@@ -534,7 +558,7 @@ static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double
     const int64_t tiles_m = cdiv(M, CFG_BM[c]), tiles_n = cdiv(NG, CFG_BN[c]);
     int64_t tiles = tiles_m * tiles_n;
     for (int s = 1; s <= 8; ++s) {
-      if (s > 1 && (ksteps * CFG_BK[c] / s < 192 || (NG & 3))) break;   // the fold kernel is float4 over N
+      if (s > 1 && ksteps * CFG_BK[c] / s < 192) break;
       int per = (int)cdiv(ksteps, s);
       int ns = (int)cdiv(ksteps, per);
       if (ns != s) continue;
@@ -652,8 +676,12 @@ static void launch_planned(const Plan& pl, ConvArgs& p, float* ws, hipStream_t s
   if (pl.tail_rows == 0) {
     p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split;
     launch_mfma<MODE>(pl.cfg, p, dim3(1, 1, pl.nsplit), st);
-    if (pl.nsplit > 1)
-      hipLaunchKernelGGL(k_splitk_epilogue<MODE>, dim3(cdiv((int64_t)p.M * p.NG / 4, 256)), dim3(256), 0, st, p);
+    if (pl.nsplit > 1) {
+      if (p.NG & 3)
+        hipLaunchKernelGGL(k_splitk_epilogue_scalar<MODE>, dim3(cdiv((int64_t)p.M * p.NG, 256)), dim3(256), 0, st, p);
+      else
+        hipLaunchKernelGGL(k_splitk_epilogue<MODE>, dim3(cdiv((int64_t)p.M * p.NG / 4, 256)), dim3(256), 0, st, p);
+    }
     return;
   }
   const int rows_total = (int)cdiv(p.M, CFG_BM[pl.cfg]);
