@@ -146,36 +146,43 @@ def hbm_kernels(tr, iters=10):
     return res
 
 
-def cpu_baseline(cfg, model, H, W, seed):
-    """The CPU oracle (torch-CPU fp32 + numpy, oracle/model.py) of the identical training step —
-    forward + losses + backward — timed on this host. Bounded sample: ONE step on ONE image
-    (the reference's own TF-CPU path cannot run here: no TensorFlow)."""
+def cpu_baseline(cfg, model, tr, H, W, seed, steps=3, batch=1):
+    """The CPU oracle (torch-CPU fp32 + numpy: oracle/model.py + oracle/optimizer.py) of the identical
+    training step — forward + losses + backward + per-variable clip + momentum update — timed on this
+    host's cores. Bounded sample: `steps` steps on `batch` image(s) (the reference's own TF-CPU path cannot
+    run here: no TensorFlow)."""
     import torch
     from mtl_ssl_amd import synthetic
+    from oracle import optimizer as oopt
     from oracle.model import Oracle
-    cores = min(os.cpu_count() or 1, 64)       # torch-CPU stops scaling well past ~64 threads
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 64)                # torch-CPU stops scaling well past ~64 threads
     torch.set_num_threads(cores)
     K = int(cfg.model.faster_rcnn.num_classes)
-    # Bounded sample: ONE full training step (all 1 856 second-stage ROIs, fwd + losses + bwd) on
-    # ONE synthetic image = 4.93 TFLOP of algorithmic work (SURVEY.md §8d), ~20 s on 64 threads.
     hp = hyper_params_for_oracle(cfg)
-    batch = synthetic.make_batch(1, H, W, K, seed=seed, device="cpu")
-    batch["images"] = batch["images"].numpy()
-    ora = Oracle(hp, model.ps.state_dict())
+    b = synthetic.make_batch(batch, H, W, K, seed=seed, device="cpu")
+    b["images"] = b["images"].numpy()
+    values = model.ps.state_dict()
+    accum = {}
+    wd = {s.name: s.weight_decay for s in model.ps.trainable_specs if s.weight_decay}
     t0 = time.time()
-    losses, _, _ = ora.step(batch, seed=model.seed, step=0)
-    dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "CPU oracle (torch-CPU fp32 + numpy): 1 full training step (fwd+loss+bwd, no "
-                      "optimizer) on 1 synthetic %dx%d image, %.1f s on %d threads" % (W, H, dt, cores),
-            "total_loss": float(sum(losses.values()))}
+    for step in range(steps):
+        losses, grads, _ = Oracle(hp, values).step(b, seed=model.seed, step=step)
+        oopt.momentum_update(values, grads, accum, tr.lr_fn(step), tr.momentum, tr.clip, wd)
+    dt = (time.time() - t0) / steps
+    return {"value": batch / dt, "unit": "images/sec", "cores": cores, "host_cores": host_cores, "kind": "port",
+            "sample": "CPU oracle (torch-CPU fp32 + numpy): %d full training steps (fwd + losses + bwd + clip + "
+                      "momentum update) on %d synthetic %dx%d image(s), %.1f s/step on %d torch threads (host has %d "
+                      "cores)" % (steps, batch, W, H, dt, cores, host_cores),
+            "total_loss_last_step": float(sum(losses.values()))}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)      # SURVEY.md §8d: >= 50 timed steps after >= 10 warm-up
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "frcnn_resnet101_coco_mtl.config"))
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1024)
@@ -194,35 +201,37 @@ def main():
     if rank == 0:
         ge.build()
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if world > 1 else 0
+    from mtl_ssl_amd import comm as comm_mod
+    from mtl_ssl_amd import config, model_builder, ops, synthetic, trainer
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev_index)
-        # RCCL ("nccl") needs one device per rank; MTLSSL_DIST_BACKEND=gloo lets the whole multi-rank
-        # code path be exercised on a single GPU (debugging only, not a performance configuration)
-        backend = os.environ.get("MTLSSL_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
+        # torch.distributed (gloo, host side) is only the bootstrap channel and the barrier around the timed
+        # region; every byte of gradient traffic goes through the library's own RCCL wrappers (mtlssl_comm_*,
+        # include/mtlssl_hip.h). MTLSSL_DIST_BACKEND=gloo swaps in the torch.distributed stand-in, which lets the
+        # multi-rank code path run on a single GPU (debugging only, not a performance configuration).
+        dist.init_process_group("gloo")
         dist.barrier()
+        comm = comm_mod.default_comm(torch.device("cuda", dev_index))
     else:
         torch.cuda.set_device(0)
-    from mtl_ssl_amd import config, model_builder, ops, synthetic, trainer
+        if os.environ.get("MTLSSL_COMM_SELFTEST") == "1":    # 1-rank RCCL through the whole reducer (diagnostic)
+            comm = comm_mod.RcclComm(torch.device("cuda", 0), 0, 1)
     dev = torch.device("cuda", dev_index)
     cfg = config.parse_pipeline_config(open(a.config).read())
     B = int(cfg.train_config.batch_size)                     # per-GPU batch (weak scaling)
     K = int(cfg.model.faster_rcnn.num_classes)
     model = model_builder.build(cfg.model, True, dev, seed=0)
-    if world > 1:                                            # C2: identical weights on every replica
-        dist.broadcast(model.ps.weights, 0)
-        dist.broadcast(model.ps.frozen, 0)
-        model.prepare()
-    tr = trainer.Trainer(model, cfg.train_config, world)
+    tr = trainer.Trainer(model, cfg.train_config, world, comm=comm, reduce_always=comm is not None)
+    tr.broadcast_weights(0)                                  # C2: identical weights on every replica
     batch = tr.stage_batch(synthetic.make_batch(B, a.height, a.width, K, seed=1234 + rank, device=dev))
 
     for _ in range(a.warmup):
         tr.step(batch)
+    if comm is not None:
+        tr.reducer.timing = True
     if not a.no_roofline:
         # live HIP-event timing of the roofline kernel (forward, 128x128 tile) inside the timed region
         ops.PROFILER = ops.ConvProfiler(None if a.conv_breakdown else (0, 0))
@@ -239,8 +248,30 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILER = ops.PROFILER, None
+    dp = None
+    if comm is not None:
+        # what a reader needs to trust an N-GPU line: the ranks RCCL itself reports, how much of the all-reduce
+        # time was exposed, every rank's own step time, and a checksum of every rank's weights after the timed steps
+        import zlib
+        red = tr.reducer.timing_summary(a.steps)
+        mine = {"rank": rank, "ms_per_step": 1e3 * dt / a.steps, "comm": comm.info(),
+                "weights_crc32": zlib.crc32(model.ps.weights.cpu().numpy().tobytes()), **red}
+        if world > 1:
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+        else:
+            everyone = [mine]
+        dp = {"backend": comm.info()["backend"], "ranks_reported": sorted(e["comm"]["ranks"] for e in everyone),
+              "rccl_version": comm.info().get("rccl_version"),
+              "per_rank_ms_per_step": [round(e["ms_per_step"], 3) for e in everyone],
+              "allreduce_ms_per_step": [round(e["allreduce_ms_per_step"], 3) for e in everyone],
+              "allreduce_exposed_ms_per_step": [round(e["exposed_ms_per_step"], 3) for e in everyone],
+              "allreduce_hidden_ms_per_step": [round(e["hidden_ms_per_step"], 3) for e in everyone],
+              "gradient_bytes_per_step": everyone[0]["bytes_per_step"], "buckets": everyone[0]["buckets"],
+              "weights_crc32": ["%08x" % e["weights_crc32"] for e in everyone],
+              "replicas_identical": len({e["weights_crc32"] for e in everyone}) == 1}
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_loss = float(sum(v.item() for v in losses.values()))
@@ -269,6 +300,8 @@ def main():
                    "pipeline_config": os.path.relpath(a.config, ROOT)},
         "final_total_loss": total_loss,
     }
+    if dp is not None:
+        out["data_parallel"] = dp
     if default_cfg:
         # FLOPs of the DIRECT convolution algorithm per step over the step time. The 3x3 stride-1 layers
         # run as Winograd F(4x4,3x3) (3.06x-4x fewer multiplies than counted here), so this is an
@@ -306,7 +339,7 @@ def main():
     if world == 1 and not a.no_roofline:
         out["hbm_kernels"] = hbm_kernels(tr)
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, model, a.height, a.width, seed=1234)
+        out["cpu_baseline"] = cpu_baseline(cfg, model, tr, a.height, a.width, seed=1234, steps=a.cpu_steps)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

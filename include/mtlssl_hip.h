@@ -27,6 +27,7 @@ typedef void* mtlssl_stream_t; /* hipStream_t */
 #define MTLSSL_OK 0
 #define MTLSSL_EINVAL (-1)   /* bad argument / unsupported shape */
 #define MTLSSL_ELAUNCH (-2)  /* HIP launch error */
+#define MTLSSL_ECOMM (-3)    /* RCCL unavailable or an RCCL call failed */
 
 const char* mtlssl_last_error(void);
 int mtlssl_abi_version(void);
@@ -316,6 +317,9 @@ int mtlssl_reduce_sum(const float* x, int n, float scale, float* out, mtlssl_str
  * slim.learning.clip_gradient_norms (per-variable tf.clip_by_norm, slim/learning.py:282-301)
  * + tf.train.MomentumOptimizer (builders/optimizer_builder.py:48-52):
  *   g <- grad_scale*grad + var_weight_decay[v]*w  (L2 regulariser gradient, nullable table);
+ *   g <- var_grad_mult[v]*g  (nullable table: trainer.py:389-405 grad_multiplier / divide_grad_by_batch /
+ *        bias_grad_multiplier; a NEGATIVE entry freezes the variable — it is left out of the update like
+ *        utils/variables_helper.py:100-118 leaves it out of apply_gradients, trainer.py:408-410);
  *   g <- g * min(1, clip/||g||_2) per variable; acc <- momentum*acc + g; w <- w - lr*acc.
  * The parameters live in one flat buffer; var_offsets int32[num_vars+1] (device) delimits the
  * variables (offsets in floats, multiples of 4); max_var_size = largest variable (floats).
@@ -326,8 +330,8 @@ int64_t mtlssl_sgd_workspace_bytes(int num_vars, int64_t max_var_size);
 int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              const int32_t* var_offsets, int num_vars, int64_t total,
                              int64_t max_var_size, float lr, float momentum, float clip_norm,
-                             float grad_scale, const float* var_weight_decay, float* norms_ws,
-                             mtlssl_stream_t stream);
+                             float grad_scale, const float* var_weight_decay, const float* var_grad_mult,
+                             float* norms_ws, mtlssl_stream_t stream);
 
 /* Batched fold of per-output-channel scales into a shadow copy of the flat parameter buffer, one
  * launch for every convolution of the model: eff[i] = weights[i] * scale_v[(i - var_offsets[v]) %
@@ -400,6 +404,38 @@ int mtlssl_expand_windows(const float* proposals_norm, int batch, int n2, int n_
 int mtlssl_refine_concat(const float* cls, const float* win, const float* clo, int batch, int n2,
                          int k1, int n_expand, int global_closeness, float* out,
                          mtlssl_stream_t stream);
+
+/* ------------------------------------------------------------------ cross-replica communication
+ * Replaces the reference's only cross-replica step — the sum of the clones' gradients on the CPU
+ * (slim/deployment/model_deploy.py:414-444 _sum_clones_gradients, :265-307 optimize_clones; the loss of
+ * each clone is pre-scaled by 1/num_clones, :221-223) — and its shared-variable placement (one copy of
+ * every variable on the CPU read by all towers, :640-675): here one process per GPU holds a replica in
+ * HBM, rank 0 broadcasts the initial values and the gradient buckets are summed GPU-to-GPU by RCCL
+ * all-reduce over xGMI. Thin wrappers: one communicator rank per process, bound to the device that is
+ * current when mtlssl_comm_init is called; collectives are asynchronous on the given stream and in place.
+ * Bootstrap: rank 0 calls mtlssl_comm_unique_id and ships the MTLSSL_COMM_ID_BYTES to the other ranks by
+ * any host channel (the Python host uses a torch.distributed gloo store), then EVERY rank calls
+ * mtlssl_comm_init (collective). RCCL is bound with dlopen at first use; MTLSSL_ECOMM if it is missing. */
+#define MTLSSL_COMM_ID_BYTES 128
+typedef struct mtlssl_comm* mtlssl_comm_t;
+#define MTLSSL_COMM_F32 0
+#define MTLSSL_COMM_F64 1
+#define MTLSSL_COMM_I32 2
+#define MTLSSL_COMM_I64 3
+#define MTLSSL_COMM_SUM 0
+#define MTLSSL_COMM_MAX 1
+#define MTLSSL_COMM_MIN 2
+int mtlssl_comm_unique_id(void* id_out);
+int mtlssl_comm_init(mtlssl_comm_t* comm_out, const void* id, int nranks, int rank);
+/* What RCCL itself reports for the communicator (ncclCommCount / UserRank / CuDevice / ncclGetVersion);
+ * any output pointer may be null. */
+int mtlssl_comm_info(mtlssl_comm_t comm, int* nranks, int* rank, int* device, int* rccl_version);
+/* buf[i] = op over ranks of buf[i], count elements of dtype (device memory). */
+int mtlssl_comm_allreduce(mtlssl_comm_t comm, void* buf, int64_t count, int dtype, int op,
+                          mtlssl_stream_t stream);
+/* bytes of buf on every rank = rank root's. */
+int mtlssl_comm_broadcast(mtlssl_comm_t comm, void* buf, int64_t bytes, int root, mtlssl_stream_t stream);
+int mtlssl_comm_destroy(mtlssl_comm_t comm);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@ SOURCES = {
     "conv.hip": [],
     "glue.hip": ["-ffp-contract=off"],
     "depthwise.hip": [], "pool_concat.hip": [], "winograd.hip": [],
+    "comm.hip": [],                     # RCCL wrappers (host code only; RCCL itself is bound with dlopen)
 }
 
 
@@ -62,7 +63,7 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(OUT):
         objs = [os.path.join(OBJ, s + ".o") for s in SOURCES]
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -4,11 +4,14 @@ Mirrors `FasterRCNNMetaArch.restore_map` (meta_architectures/faster_rcnn_meta_ar
 `FasterRCNNFeatureExtractor.restore_from_classification_checkpoint_fn` /
 `mtl_restore_from_classification_checkpoint_fn` (:167-205, and the Inception-ResNet-v2 override
 models/faster_rcnn_inception_resnet_v2_feature_extractor.py:173-248) and the init logic of
-`trainer.train` (trainer.py:309-356). TensorFlow's checkpoint container itself cannot be read here
-(TensorFlow is absent); the container is a flat `.npz` {checkpoint variable name: array}, which is
-what a one-line `tf.train.load_checkpoint` dump on a TensorFlow machine produces. Momentum slots are
-stored as `<variable>/Momentum` like TF's MomentumOptimizer names them.
+`trainer.train` (trainer.py:309-356). Containers: this build's flat `.npz` {checkpoint variable name:
+array} and TensorFlow's own V1 / V2 checkpoint files, read without TensorFlow by
+mtl_ssl_amd/tf_checkpoint.py (`open_checkpoint` picks by what is on disk). Momentum slots are stored as
+`<variable>/Momentum` like TF's MomentumOptimizer names them, moving averages as
+`<variable>/ExponentialMovingAverage` (tf.contrib.opt.MovingAverageOptimizer).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -72,12 +75,16 @@ def mtl_init_maps(ps, mtl, from_detection_checkpoint, share_second_stage_init=Tr
     return maps
 
 
+def _ckpt_shape(ckpt, name):
+    return tuple(ckpt.shape(name)) if hasattr(ckpt, "shape") and callable(ckpt.shape) else tuple(ckpt[name].shape)
+
+
 def available(var_map, ckpt, ps):
     """utils/variables_helper.py:120-154 get_variables_available_in_checkpoint: keep entries whose
     checkpoint name exists with the variable's shape."""
     out = {}
     for ck, name in var_map.items():
-        if ck in ckpt and tuple(ckpt[ck].shape) == ps.by_name[name].shape:
+        if ck in ckpt and _ckpt_shape(ckpt, ck) == ps.by_name[name].shape:
             out[ck] = name
     return out
 
@@ -107,16 +114,35 @@ def init_from_checkpoint(model, ckpt, train_config, mtl):
     return done
 
 
-def save(path, ps, global_step=0):
-    """Full training state: every variable under its reference name, momentum slots, step."""
+def open_checkpoint(path):
+    """{name: ndarray}-like view of a checkpoint: a `.npz` of this build, or a TensorFlow V2 prefix / V1
+    file. Raises when nothing readable is there — a configured fine_tune_checkpoint that cannot be opened
+    must not silently leave the model at its random initialisation (the reference's Saver fails hard)."""
+    if os.path.isfile(path) and path.endswith(".npz"):
+        return np.load(path)
+    if os.path.isfile(path + ".npz"):
+        return np.load(path + ".npz")
+    from . import tf_checkpoint
+    try:
+        return tf_checkpoint.open_tf_checkpoint(path)
+    except FileNotFoundError as e:
+        raise FileNotFoundError("fine_tune_checkpoint %r: %s; expected <path>.npz {variable name: array}, a "
+                                "TensorFlow V2 prefix (<path>.index + .data-*) or a V1 checkpoint file" % (path, e))
+
+
+def save(path, ps, global_step=0, trainer=None):
+    """Full training state: every variable under its reference name, momentum slots, moving averages
+    (when the trainer keeps them), step."""
     out = {s.name: ps.value(s.name).detach().cpu().numpy() for s in ps.specs}
     for s in ps.trainable_specs:
         out[s.name + "/Momentum"] = ps._view(ps.accum, s).detach().cpu().numpy()
+        if trainer is not None and trainer.ema is not None:
+            out[s.name + "/ExponentialMovingAverage"] = ps._view(trainer.ema, s).detach().cpu().numpy()
     out["global_step"] = np.asarray(global_step, np.int64)
     np.savez(path, **out)
 
 
-def load(path, ps):
+def load(path, ps, trainer=None):
     """Inverse of save(); returns the stored global step. Call model.prepare() afterwards."""
     ck = np.load(path)
     for s in ps.specs:
@@ -125,4 +151,6 @@ def load(path, ps):
     for s in ps.trainable_specs:
         if s.name + "/Momentum" in ck.files:
             ps._view(ps.accum, s).copy_(torch.as_tensor(ck[s.name + "/Momentum"]).to(ps.device))
+        if trainer is not None and trainer.ema is not None and s.name + "/ExponentialMovingAverage" in ck.files:
+            ps._view(trainer.ema, s).copy_(torch.as_tensor(ck[s.name + "/ExponentialMovingAverage"]).to(ps.device))
     return int(ck["global_step"]) if "global_step" in ck.files else 0

@@ -1,0 +1,121 @@
+"""Cross-replica communicators for the data-parallel trainer.
+
+The reference sums the clones' gradients with `tf.add_n` on the CPU (slim/deployment/model_deploy.py:
+414-444) and shares one CPU copy of every variable between towers (:640-675). Here every rank holds a
+replica in HBM and the product path is RCCL behind the library's C ABI (`mtlssl_comm_*`,
+include/mtlssl_hip.h): `RcclComm`. `torch.distributed` (gloo) is only the host-side channel that
+ships the 128-byte RCCL unique id from rank 0 to the other ranks, and — as `GlooComm` — the stand-in
+transport of the CPU unit tests and of the two-replicas-on-one-GPU test (RCCL needs one device per
+rank).
+"""
+import ctypes
+import os
+
+import torch
+
+from .lib import lib, ptr
+
+_DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3}
+_OPS = {"sum": 0, "max": 1, "min": 2}
+ID_BYTES = 128
+
+
+def _stream_ptr(stream):
+    return (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+
+
+class RcclComm:
+    """One RCCL communicator rank bound to `device` (mtlssl_comm_init). `exchange(id_or_None)` must
+    return rank 0's unique id on every rank; the default uses the initialised torch.distributed
+    group (any backend) as the host channel. world == 1 needs no channel at all."""
+    backend = "rccl"
+
+    def __init__(self, device, rank=0, world=1, exchange=None):
+        self.device = torch.device(device)
+        assert self.device.type == "cuda", "RCCL communicators live on a GPU"
+        self._lib = lib()
+        uid = ctypes.create_string_buffer(ID_BYTES)
+        if rank == 0:
+            self._lib.comm_unique_id(uid)
+        if world > 1:
+            raw = (exchange or _dist_exchange)(uid.raw if rank == 0 else None)
+            uid = ctypes.create_string_buffer(raw, ID_BYTES)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._lib.comm_init(ctypes.byref(handle), uid, world, rank)
+        self._h = handle
+        n, r, d, v = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._lib.comm_info(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d), ctypes.byref(v))
+        # what RCCL reports, not what was asked for
+        self.world, self.rank, self.rccl_device, self.rccl_version = n.value, r.value, d.value, v.value
+        if (self.world, self.rank) != (world, rank):
+            raise RuntimeError("RCCL reports rank %d of %d, expected %d of %d" % (self.rank, self.world, rank, world))
+
+    def allreduce(self, t, op="sum", stream=None):
+        """In-place all-reduce of a contiguous device tensor, asynchronous on `stream`."""
+        assert t.is_cuda and t.is_contiguous()
+        self._lib.comm_allreduce(self._h, ptr(t), t.numel(), _DTYPES[t.dtype], _OPS[op], _stream_ptr(stream))
+
+    def broadcast(self, t, root=0, stream=None):
+        assert t.is_cuda and t.is_contiguous()
+        self._lib.comm_broadcast(self._h, ptr(t), t.numel() * t.element_size(), root, _stream_ptr(stream))
+
+    def info(self):
+        return {"backend": "rccl", "ranks": self.world, "rank": self.rank, "device": self.rccl_device,
+                "rccl_version": self.rccl_version}
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.comm_destroy(self._h)
+        self._h = None
+
+
+class GlooComm:
+    """torch.distributed stand-in with the same interface (tests only; not a performance path)."""
+    backend = "gloo"
+
+    def __init__(self):
+        import torch.distributed as dist
+        assert dist.is_initialized()
+        self._dist = dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def _on(self, stream, fn):
+        if stream is None:
+            return fn()
+        with torch.cuda.stream(stream):
+            return fn()
+
+    def allreduce(self, t, op="sum", stream=None):
+        ops = {"sum": self._dist.ReduceOp.SUM, "max": self._dist.ReduceOp.MAX, "min": self._dist.ReduceOp.MIN}
+        self._on(stream, lambda: self._dist.all_reduce(t, op=ops[op]))
+
+    def broadcast(self, t, root=0, stream=None):
+        self._on(stream, lambda: self._dist.broadcast(t, root))
+
+    def info(self):
+        return {"backend": self._dist.get_backend(), "ranks": self.world, "rank": self.rank}
+
+    def close(self):
+        pass
+
+
+def _dist_exchange(uid):
+    import torch.distributed as dist
+    assert dist.is_initialized(), "RcclComm(world > 1) needs a host channel: initialise torch.distributed (gloo) first"
+    box = [uid]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def default_comm(device):
+    """The communicator a trainer uses when none is given: none for a single process, RCCL for a GPU
+    replica of an initialised torch.distributed job (MTLSSL_DIST_BACKEND=gloo forces the stand-in, which
+    lets the multi-rank code path run on one GPU), gloo for CPU tensors."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    dev = torch.device(device)
+    if dev.type == "cuda" and os.environ.get("MTLSSL_DIST_BACKEND", "rccl") != "gloo":
+        return RcclComm(dev, dist.get_rank(), dist.get_world_size())
+    return GlooComm()

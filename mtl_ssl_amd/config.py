@@ -121,7 +121,8 @@ DEFAULTS = {
                     "prefetch_queue_capacity": 10, "save_interval_secs": 600, "restore_box_predictor": False,
                     "restore_mtl_refine": False, "restore_window": False, "restore_closeness": False,
                     "restore_edgemask": False, "data_augmentation_options": [],
-                    "divide_grad_by_batch": False, "optimizer": "@Optimizer"},
+                    "divide_grad_by_batch": False, "grad_multiplier": 0.0, "freeze_variables": [],
+                    "replicas_to_aggregate": 1, "log_every_n_steps": 1, "optimizer": "@Optimizer"},
     # protos/optimizer.proto
     "Optimizer": {"use_moving_average": True, "moving_average_decay": 0.9999},
     "MomentumOptimizer": {"momentum_optimizer_value": 0.9, "learning_rate": "@LearningRate"},

@@ -19,6 +19,12 @@ __device__ __forceinline__ float act_mask(float g, float y, int epi) {
 }
 constexpr int MASK_ANY = MTLSSL_EPI_MASK | MTLSSL_EPI_MASK6;
 constexpr int BK = 16;
+// Ablation switches of tools/lab/gemm_lab.hip (0 in the product build): 1 no global loads, 2 no LDS
+// stores, 4 no barrier, 8 no LDS fragment reads, 16 no epilogue stores.
+#ifndef MTLSSL_LAB_FLAGS
+#define MTLSSL_LAB_FLAGS 0
+#endif
+constexpr int LAB = MTLSSL_LAB_FLAGS;
 
 struct ConvArgs {
   const float* a;        // fwd: x     dgrad: dy    wgrad: x
@@ -49,6 +55,123 @@ __device__ __forceinline__ floatx4 bufload4(__amdgpu_buffer_rsrc_t rsrc, unsigne
   // raw buffer load: an offset beyond num_records returns zeros, which is exactly the zero
   // padding / ragged-tile semantics the gathers need — no branches around the loads.
   return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+}
+
+// Epilogue shared by the tile engines: split-K partial store, or bias / residual / activation (fwd),
+// residual / accumulate / activation mask (dgrad), or the wgrad partial-tile store. `smem` is the
+// block's LDS (free once the last K-step's barrier has been passed).
+template <int BM, int BN, int MODE, int NW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)[BM / (16 * NW)][BN / 64], float* smem,
+                                              int m0, int n0) {
+  constexpr int WR = NW / 2, TM = BM / (32 * WR), TN = BN / 64, LDT = 36;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int lo = lane & 31, hi = lane >> 5;
+  // ---- epilogue. MFMA C/D map: lane l, reg e -> row (e&3) + 8*(e>>2) + 4*(l>>5), col l&31.
+  if constexpr (LAB & 16)
+    if (p.epi != 0x7fffffff) {      // keep the accumulators alive without storing the tile
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+      if (t == 1.2345e-30f) p.out[0] = t;
+      return;
+    }
+  const int ldo = p.NG;
+  float* outp = p.out;
+  if constexpr (MODE == MODE_WGRAD)
+    outp += ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (int64_t)p.M * p.NG;
+  const bool raw = (MODE != MODE_WGRAD) && p.nsplit > 1;   // split-K partial: epilogue runs later
+  if (raw) outp = p.splitk_ws + (int64_t)blockIdx.z * (int64_t)(p.M - p.ws_m0) * p.NG;
+  if (!(p.NG & 3)) {
+    // Coalesced epilogue: each wave transposes its 32x32 accumulator tiles through a private LDS
+    // patch (the operand buffers are free after the last K-step's barrier) so that a lane holds 4
+    // consecutive columns: 4 ds_read_b128 + 4 global 16-byte stores per tile instead of 64 scalar
+    // stores, and the bias / residual / mask / accumulate operands come in as 16-byte loads too.
+    float* tile = smem + wid * (32 * LDT);                 // LDT: 16-byte aligned rows, conflict-light
+    const int r_in = lane >> 3, c4 = (lane & 7) * 4;      // this lane's row (mod 8) and first column in the tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hi) * LDT + lo] = acc[i][j][e];
+        const int col = n0 + wc * (BN / 2) + j * 32 + c4;
+        floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == MODE_FWD)
+          if ((p.epi & MTLSSL_EPI_BIAS) && col < p.NG && !raw) bv = *reinterpret_cast<const floatx4*>(p.bias + col);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int rt = r_in + 8 * k;
+          floatx4 v = *reinterpret_cast<const floatx4*>(tile + rt * LDT + c4);
+          const int row = m0 + wr * (BM / WR) + i * 32 + rt;
+          if (row >= p.M || col >= p.NG) continue;
+          if (raw) {
+            *reinterpret_cast<floatx4*>(outp + (int64_t)(row - p.ws_m0) * ldo + col) = v;
+            continue;
+          }
+          const int64_t o = (int64_t)row * ldo + col;
+          if constexpr (MODE == MODE_FWD) {
+            v += bv;
+            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (p.epi & MTLSSL_EPI_RELU) v[q] = fmaxf(v[q], 0.f);
+              if (p.epi & MTLSSL_EPI_RELU6) v[q] = fminf(fmaxf(v[q], 0.f), 6.f);
+              if (p.epi & MTLSSL_EPI_TANH) v[q] = tanhf(v[q]);
+            }
+          } else if constexpr (MODE == MODE_DGRAD) {
+            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
+            if (p.epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const floatx4*>(outp + o);
+            if (p.epi & MASK_ANY) {
+              floatx4 mk = *reinterpret_cast<const floatx4*>(p.mask + o);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = act_mask(v[q], mk[q], p.epi);
+            }
+          }
+          *reinterpret_cast<floatx4*>(outp + o) = v;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wc * (BN / 2) + j * 32 + lo;
+      const bool col_ok = col < p.NG;
+      float bv = 0.f;
+      if constexpr (MODE == MODE_FWD)
+        if ((p.epi & MTLSSL_EPI_BIAS) && col_ok) bv = p.bias[col];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wr * (BM / WR) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        if (row >= p.M || !col_ok) continue;
+        const int64_t o = (int64_t)row * ldo + col;
+        float v = acc[i][j][e];
+        if (raw) {
+          outp[(int64_t)(row - p.ws_m0) * ldo + col] = v;
+          continue;
+        }
+        if constexpr (MODE == MODE_FWD) {
+          v += bv;
+          if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
+          if (p.epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
+          if (p.epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+          if (p.epi & MTLSSL_EPI_TANH) v = tanhf(v);
+        } else if constexpr (MODE == MODE_DGRAD) {
+          if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
+          if (p.epi & MTLSSL_EPI_ACCUM) v += outp[o];
+          if (p.epi & MASK_ANY) v = act_mask(v, p.mask[o], p.epi);
+        }
+        outp[o] = v;
+      }
+    }
+  }
 }
 
 // BATCH: the launch is a stack of gridDim.y independent GEMMs (the Winograd-domain products);
@@ -299,7 +422,8 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
   // One K-step: `next` holds tile it+1 (loaded during step it-1), `spare` is free for tile it+2.
   auto kstep = [&](int it, auto next, auto spare) {
     const int cur = it & 1;
-    if (it + 2 < nk) load_tile(ks_begin + it + 2, spare);
+    if constexpr (!(LAB & 1))
+      if (it + 2 < nk) load_tile(ks_begin + it + 2, spare);
     const float* a = sA + cur * (BKT * LDA) + wr * (BM / WR) + lo;
     const float* b = sB + cur * (BKT * LDB) + wc * (BN / 2) + lo;
     // Software-pipelined fragments: the ds_reads of k-pair kk+1 are issued BEFORE the MFMAs of
@@ -315,10 +439,17 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
       const int cs = kk & 1, ns = cs ^ 1;
       if (kk + 1 < BKT / 2) {
         const int kr = 2 * (kk + 1) + hi;
+        if constexpr (LAB & 8) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[ns][i] = a[kr * LDA + i * 32];
+          for (int i = 0; i < TM; ++i) fa[ns][i] = fa[cs][i] * 1.0001f;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[ns][j] = b[kr * LDB + j * 32];
+          for (int j = 0; j < TN; ++j) fb[ns][j] = fb[cs][j] * 0.9999f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[ns][i] = a[kr * LDA + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[ns][j] = b[kr * LDB + j * 32];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -328,107 +459,363 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cs][i], fb[cs][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (it + 1 < nk) store_tile(cur ^ 1, next);
-    __syncthreads();
+    if constexpr (!(LAB & 2))
+      if (it + 1 < nk) store_tile(cur ^ 1, next);
+    if constexpr (!(LAB & 4)) __syncthreads();
   };
   for (int it = 0; it < nk; it += 2) {
     kstep(it, Set1{}, Set0{});
     if (it + 1 < nk) kstep(it + 1, Set0{}, Set1{});
   }
 
-  // ---- epilogue. MFMA C/D map: lane l, reg e -> row (e&3) + 8*(e>>2) + 4*(l>>5), col l&31.
-  const int ldo = p.NG;
-  float* outp = p.out;
-  if constexpr (MODE == MODE_WGRAD)
-    outp += ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (int64_t)p.M * p.NG;
-  const bool raw = (MODE != MODE_WGRAD) && p.nsplit > 1;   // split-K partial: epilogue runs later
-  if (raw) outp = p.splitk_ws + (int64_t)blockIdx.z * (int64_t)(p.M - p.ws_m0) * p.NG;
-  if (!(p.NG & 3)) {
-    // Coalesced epilogue: each wave transposes its 32x32 accumulator tiles through a private LDS
-    // patch (the operand buffers are free after the last K-step's barrier) so that a lane holds 4
-    // consecutive columns: 4 ds_read_b128 + 4 global 16-byte stores per tile instead of 64 scalar
-    // stores, and the bias / residual / mask / accumulate operands come in as 16-byte loads too.
-    float* tile = smem + wid * (32 * LDT);                 // LDT: 16-byte aligned rows, conflict-light
-    const int r_in = lane >> 3, c4 = (lane & 7) * 4;      // this lane's row (mod 8) and first column in the tile
+  conv_epilogue<BM, BN, MODE, NW>(p, acc, smem, m0, n0);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// The same tile engine with its operands staged by LDS-DMA (`buffer_load_dwordx4 ... lds`): global
+// memory -> LDS directly, no VGPR round trip, no ds_write pass, no wait on a load before an LDS store.
+// An LDS-DMA writes wave-uniform base + lane*16 B, so the LDS image of a tile is lane-linear in 1-KiB
+// pieces and any swizzle is applied to the per-lane SOURCE address:
+//   * K-contiguous operands (x / dy rows of 16 channels = 64 B; the [c][k] filter view of dgrad) land as
+//     [row][4 quads] with quad q of row r in slot q ^ ((r >> 2) & 3), which makes the fragment read — one
+//     ds_read_b128 per lane: row = lane % 32, 4 consecutive k — conflict-free in every 16-lane group;
+//   * M/N-contiguous operands (filter rows [k][n]; x / dy pixel rows of wgrad) land as [k][BM or BN] and are
+//     read with ds_read_b32 like before.
+// The MFMA k index is permuted inside a 16-deep K-step: step t (0..7) multiplies k = t (lanes 0-31) and
+// k = 8 + t (lanes 32-63), so a lane's 8 A values are the two quads {2*hi, 2*hi+1} of its row. A sum over
+// k in a different order — same fp32 products, not bit-identical to the register-staged engine.
+// NSTAGE LDS stages of BKT x (BM + BN) floats; tile it+NSTAGE-1 is in flight while tile it is multiplied;
+// one raw s_barrier per K-step behind a counted s_waitcnt vmcnt (never a drain while a tile is in flight).
+template <int BM, int BN, int MODE, int BKT, int NSTAGE, bool BATCH>
+__device__ __forceinline__ void conv_glds_body(ConvArgs p) {
+  constexpr int NW = BM > 128 ? 8 : 4, WR = NW / 2;
+  constexpr int TM = BM / (32 * WR), TN = BN / 64;   // 32x32 MFMA tiles per wave in m / n
+  constexpr bool A_KC = (MODE != MODE_WGRAD);     // A rows are K-contiguous (else M-contiguous)
+  constexpr bool B_KC = (MODE == MODE_DGRAD);     // B rows are K-contiguous (else N-contiguous)
+  constexpr int QPR = BKT / 4;                    // 16-byte quads per row of a K-contiguous image
+  constexpr int RPP = 64 / QPR;                   // rows one 1-KiB piece covers
+  constexpr int RSH = QPR == 4 ? 2 : 1;           // swizzle: quad q of row r sits in slot q ^ ((r >> RSH) & (QPR-1))
+  constexpr int A_FL = BM * BKT, B_FL = BN * BKT; // floats per stage
+  constexpr int STAGE = A_FL + B_FL;
+  constexpr int PA = BM * BKT / 256 / NW, PB = BN * BKT / 256 / NW;   // 1-KiB pieces per wave per K-step
+  constexpr int G = BKT / 8;                      // fragment groups of 4 MFMA k-steps
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  constexpr int LDT = 36;
+  constexpr int SMEM_OPS = NSTAGE * STAGE, SMEM_EPI = NW * 32 * LDT;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_OPS > SMEM_EPI ? SMEM_OPS : SMEM_EPI];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tile_m = bid / p.tiles_n + p.tile_m0, tile_n = bid % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int lo = lane & 31, hi = lane >> 5;
+  // K-contiguous piece j: this lane fills slot lane % QPR of row j*RPP + lane / QPR with the quad the swizzle puts there
+  auto kc_row = [&](int piece) { return piece * RPP + lane / QPR; };
+  auto kc_quad4 = [&](int row) { return (((lane % QPR) ^ ((row >> RSH) & (QPR - 1)))) * 4; };
+
+  if constexpr (BATCH) {
+    p.a += (int64_t)blockIdx.y * p.a_bs;
+    p.b += (int64_t)blockIdx.y * p.b_bs;
+    if constexpr (MODE != MODE_WGRAD) p.out += (int64_t)blockIdx.y * p.o_bs;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
+
+  int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps, ks_begin = 0;
+  if constexpr (MODE == MODE_FWD) {
+    ksteps = p.R * p.S * (p.C / BKT);
+  } else if constexpr (MODE == MODE_DGRAD) {
+    ksteps = p.R * p.S * (p.K / BKT);
+  } else {
+    rs_fixed = BATCH ? 0 : blockIdx.y;
+    int split = blockIdx.z;
+    int P = p.N * p.OH * p.OW;
+    pix0 = split * p.pix_per_split;
+    pix1 = min(P, pix0 + p.pix_per_split);
+    ksteps = (max(pix1 - pix0, 0) + BKT - 1) / BKT;
+  }
+  if constexpr (MODE != MODE_WGRAD) {
+    if (p.nsplit > 1) {
+      ks_begin = blockIdx.z * p.ks_per_split;
+      ksteps = min(ksteps, ks_begin + p.ks_per_split);
+    }
+  }
+
+  // ---- per-lane gather state. Piece i of wave w is piece w*P? + i of the operand's stage image.
+  int a_base[PA], a_y[PA], a_x[PA], a_n[PA], a_q4[PA];
+  bool a_ok[PA];
+  unsigned b_base[PB];
+  if constexpr (A_KC) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hi) * LDT + lo] = acc[i][j][e];
-        const int col = n0 + wc * (BN / 2) + j * 32 + c4;
-        floatx4 bv = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == MODE_FWD)
-          if ((p.epi & MTLSSL_EPI_BIAS) && col < p.NG && !raw) bv = *reinterpret_cast<const floatx4*>(p.bias + col);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int rt = r_in + 8 * k;
-          floatx4 v = *reinterpret_cast<const floatx4*>(tile + rt * LDT + c4);
-          const int row = m0 + wr * (BM / WR) + i * 32 + rt;
-          if (row >= p.M || col >= p.NG) continue;
-          if (raw) {
-            *reinterpret_cast<floatx4*>(outp + (int64_t)(row - p.ws_m0) * ldo + col) = v;
-            continue;
-          }
-          const int64_t o = (int64_t)row * ldo + col;
-          if constexpr (MODE == MODE_FWD) {
-            v += bv;
-            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              if (p.epi & MTLSSL_EPI_RELU) v[q] = fmaxf(v[q], 0.f);
-              if (p.epi & MTLSSL_EPI_RELU6) v[q] = fminf(fmaxf(v[q], 0.f), 6.f);
-              if (p.epi & MTLSSL_EPI_TANH) v[q] = tanhf(v[q]);
-            }
-          } else if constexpr (MODE == MODE_DGRAD) {
-            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
-            if (p.epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const floatx4*>(outp + o);
-            if (p.epi & MASK_ANY) {
-              floatx4 mk = *reinterpret_cast<const floatx4*>(p.mask + o);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = act_mask(v[q], mk[q], p.epi);
-            }
-          }
-          *reinterpret_cast<floatx4*>(outp + o) = v;
-        }
+    for (int i = 0; i < PA; ++i) {
+      const int row = kc_row(wid * PA + i);
+      a_q4[i] = kc_quad4(row);
+      int m = m0 + row;
+      a_ok[i] = m < p.M;
+      int mm = a_ok[i] ? m : 0;
+      if constexpr (MODE == MODE_FWD) {
+        int ow = mm % p.OW, t = mm / p.OW;
+        a_x[i] = ow * p.stride - p.pl;
+        a_y[i] = (t % p.OH) * p.stride - p.pt;
+        a_n[i] = t / p.OH;
+        a_base[i] = ((a_n[i] * p.H + a_y[i]) * p.W + a_x[i]) * p.C + a_q4[i];
+      } else {
+        int iw = mm % p.W, t = mm / p.W;
+        a_x[i] = iw + p.pl;
+        a_y[i] = (t % p.H) + p.pt;
+        a_n[i] = t / p.H;
+        a_base[i] = ((a_n[i] * p.OH + a_y[i]) * p.OW + a_x[i]) * p.K + a_q4[i];   // stride-1 form
       }
     }
-    return;
   }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int pos = (wid * PB + i) * 64 + lane;             // 16-byte slot of the B stage image
+    if constexpr (MODE == MODE_FWD) {
+      int col = n0 + (pos % (BN / 4)) * 4;
+      b_base[i] = col < p.NG ? (unsigned)((pos / (BN / 4)) * p.K + col) * 4u : OOB;
+    } else if constexpr (MODE == MODE_DGRAD) {
+      const int row = kc_row(wid * PB + i);
+      b_base[i] = n0 + row < p.NG ? (unsigned)((n0 + row) * p.K + kc_quad4(row)) * 4u : OOB;
+    } else {
+      int col = n0 + (pos % (BN / 4)) * 4;
+      b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
+    }
+  }
+
+  // Issue the LDS-DMA of K-step ks into stage `st` (this wave's PA + PB pieces).
+  auto issue_tile = [&](int ks, int st) {
+    if constexpr (LAB & 32) ks = ks_begin;          // lab: every K-step re-reads the first tile (cache-resident)
+    float* sa = smem + st * STAGE + wid * (PA * 256);
+    float* sb = smem + st * STAGE + A_FL + wid * (PB * 256);
+    if constexpr (MODE == MODE_FWD) {
+      int cpk = p.C / BKT;
+      int rs = ks / cpk, c0 = (ks - rs * cpk) * BKT;
+      int r = rs / p.S, s = rs - r * p.S;
+      int dy = r * p.dil, dx = s * p.dil;
+      int tapoff = (dy * p.W + dx) * p.C + c0;
+      if constexpr (!(LAB & 64)) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          int ih = a_y[i] + dy, iw = a_x[i] + dx;
+          bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + i * 256), 16,
+                                                   ok ? (unsigned)(a_base[i] + tapoff) * 4u : OOB, 0, 0, 0);
+        }
+      }
+      unsigned so = (unsigned)(ks * BKT * p.K) * 4u;
+      if constexpr (!(LAB & 128)) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(sb + i * 256), 16, b_base[i], so, 0, 0);
+      }
+    } else if constexpr (MODE == MODE_DGRAD) {
+      int kpk = p.K / BKT;
+      int rs = ks / kpk, k0 = (ks - rs * kpk) * BKT;
+      int r = rs / p.S, s = rs - r * p.S;
+      int dy = r * p.dil, dx = s * p.dil;
+      if (p.stride == 1) {
+        int tapoff = k0 - (dy * p.OW + dx) * p.K;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          int oh = a_y[i] - dy, ow = a_x[i] - dx;
+          bool ok = a_ok[i] && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + i * 256), 16,
+                                                   ok ? (unsigned)(a_base[i] + tapoff) * 4u : OOB, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          int ny = a_y[i] - dy, nx = a_x[i] - dx;
+          bool ok = a_ok[i] && ny >= 0 && nx >= 0 && (ny % p.stride == 0) && (nx % p.stride == 0);
+          int oh = ny / p.stride, ow = nx / p.stride;
+          ok = ok && oh < p.OH && ow < p.OW;
+          int off = ((a_n[i] * p.OH + oh) * p.OW + ow) * p.K + k0 + a_q4[i];
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + i * 256), 16,
+                                                   ok ? (unsigned)off * 4u : OOB, 0, 0, 0);
+        }
+      }
+      unsigned so = (unsigned)(rs * p.C * p.K + k0) * 4u;
+#pragma unroll
+      for (int i = 0; i < PB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(sb + i * 256), 16, b_base[i], so, 0, 0);
+    } else {
+      int r = rs_fixed / p.S, s = rs_fixed - r * p.S;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int pos = (wid * PA + i) * 64 + lane;
+        int kr = pos / (BM / 4), m4 = pos % (BM / 4);
+        int pix = pix0 + ks * BKT + kr;
+        bool ok = pix < pix1;
+        int off = 0;
+        if (p.R == 1 && p.S == 1 && p.stride == 1) {
+          off = pix * p.C;
+        } else {
+          int ow = pix % p.OW, t = pix / p.OW;
+          int oh = t % p.OH, n = t / p.OH;
+          int ih = oh * p.stride - p.pt + r * p.dil, iw = ow * p.stride - p.pl + s * p.dil;
+          ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          off = ((n * p.H + ih) * p.W + iw) * p.C;
+        }
+        ok = ok && (m0 + m4 * 4) < p.M;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + i * 256), 16,
+                                                 ok ? (unsigned)(off + m0 + m4 * 4) * 4u : OOB, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int pos = (wid * PB + i) * 64 + lane;
+        int pix = pix0 + ks * BKT + pos / (BN / 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc_b, (lds_ptr_t)(sb + i * 256), 16,
+            (pix < pix1 && b_base[i] != OOB) ? b_base[i] + (unsigned)(pix * p.K) * 4u : OOB, 0, 0, 0);
+      }
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses of group 0 (floats, relative to the operand's stage image): lanes 0-31 multiply
+  // k = 0 .. BKT/2-1, lanes 32-63 k = BKT/2 .. BKT-1; group g of a K-contiguous row is the quad at XOR g*4
+  int fa_off[TM], fb_off[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    const int row = wr * (BM / WR) + i * 32 + lo;
+    fa_off[i] = A_KC ? row * BKT + (((hi * (QPR / 2)) ^ ((row >> RSH) & (QPR - 1))) * 4) : hi * (BKT / 2) * BM + row;
+  }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wc * (BN / 2) + j * 32 + lo;
-      const bool col_ok = col < p.NG;
-      float bv = 0.f;
-      if constexpr (MODE == MODE_FWD)
-        if ((p.epi & MTLSSL_EPI_BIAS) && col_ok) bv = p.bias[col];
+  for (int j = 0; j < TN; ++j) {
+    const int col = wc * (BN / 2) + j * 32 + lo;
+    fb_off[j] = B_KC ? col * BKT + (((hi * (QPR / 2)) ^ ((col >> RSH) & (QPR - 1))) * 4) : hi * (BKT / 2) * BN + col;
+  }
+
+  const int nk = ksteps - ks_begin;
+  constexpr int PW = ((LAB & 64) ? 0 : PA) + ((LAB & 128) ? 0 : PB);   // LDS-DMA instructions per wave per tile
+  // ---- prologue: NSTAGE-1 tiles in flight, the first one landed
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wr * (BM / WR) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        if (row >= p.M || !col_ok) continue;
-        const int64_t o = (int64_t)row * ldo + col;
-        float v = acc[i][j][e];
-        if (raw) {
-          outp[(int64_t)(row - p.ws_m0) * ldo + col] = v;
-          continue;
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue_tile(ks_begin + s, s);
+  if (NSTAGE == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  int cur = 0, nxt = NSTAGE - 1;                 // stage being multiplied / stage the next DMA targets
+  for (int it = 0; it < nk; ++it) {
+    const bool more = it + NSTAGE - 1 < nk;
+    if constexpr (!(LAB & 1))
+      if (more) issue_tile(ks_begin + it + NSTAGE - 1, nxt);
+    const float* a = smem + cur * STAGE;
+    const float* b = a + A_FL;
+    // fragments in groups of 4 MFMA k-steps; group g+1 is requested behind the first MFMAs of group g, so
+    // only the first group's LDS latency is exposed (once per K-step)
+    float fa[TM][BKT / 2], fb[TN][BKT / 2];
+    auto read_group = [&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (A_KC) {
+          floatx4 v = *reinterpret_cast<const floatx4*>(a + (fa_off[i] ^ (g * 4)));
+          fa[i][4 * g + 0] = v.x; fa[i][4 * g + 1] = v.y; fa[i][4 * g + 2] = v.z; fa[i][4 * g + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fa[i][4 * g + t] = a[fa_off[i] + (4 * g + t) * BM];
         }
-        if constexpr (MODE == MODE_FWD) {
-          v += bv;
-          if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
-          if (p.epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
-          if (p.epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
-          if (p.epi & MTLSSL_EPI_TANH) v = tanhf(v);
-        } else if constexpr (MODE == MODE_DGRAD) {
-          if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[o];
-          if (p.epi & MTLSSL_EPI_ACCUM) v += outp[o];
-          if (p.epi & MASK_ANY) v = act_mask(v, p.mask[o], p.epi);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (B_KC) {
+          floatx4 v = *reinterpret_cast<const floatx4*>(b + (fb_off[j] ^ (g * 4)));
+          fb[j][4 * g + 0] = v.x; fb[j][4 * g + 1] = v.y; fb[j][4 * g + 2] = v.z; fb[j][4 * g + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fb[j][4 * g + t] = b[fb_off[j] + (4 * g + t) * BN];
         }
-        outp[o] = v;
+      }
+    };
+    auto mma = [&](int t) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    };
+    if constexpr (LAB & 8) {
+#pragma unroll
+      for (int t = 0; t < BKT / 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i][t] = (float)(lane + it + t) * 1e-3f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j][t] = (float)(lane - it - t) * 1e-3f;
+      }
+#pragma unroll
+      for (int t = 0; t < BKT / 2; ++t) mma(t);
+    } else {
+      read_group(std::integral_constant<int, 0>{});
+      auto group = [&](auto GI) {
+        constexpr int g = decltype(GI)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        mma(4 * g);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g + 1 < G) read_group(std::integral_constant<int, g + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(4 * g + 1); mma(4 * g + 2); mma(4 * g + 3);
+      };
+      group(std::integral_constant<int, 0>{});
+      group(std::integral_constant<int, 1>{});
+      if constexpr (G > 2) {
+        group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{});
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile (issued NSTAGE-1 K-steps ago by this wave) must have landed before anyone reads it;
+    // the tile issued this K-step (NSTAGE == 3) stays in flight across the barrier
+    if constexpr (!(LAB & 4)) {
+      if (NSTAGE == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("" ::: "memory");
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
+  conv_epilogue<BM, BN, MODE, NW>(p, acc, smem, m0, n0);
+}
+
+// waves per SIMD the grid needs: what the LDS footprint admits (160 KiB per CU), at most 4
+template <int BM, int BN, int BKT, int NSTAGE>
+constexpr int glds_waves() {
+  constexpr int lds = NSTAGE * (BM + BN) * BKT * 4;
+  constexpr int nw = BM > 128 ? 8 : 4;
+  constexpr int blocks = 163840 / lds;
+  constexpr int w = blocks * nw / 4;
+  return w > 4 ? 4 : (w < 1 ? 1 : w);
+}
+template <int BM, int BN, int MODE, int BKT, int NSTAGE>
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (glds_waves<BM, BN, BKT, NSTAGE>()))
+k_conv_glds(ConvArgs p) {
+  conv_glds_body<BM, BN, MODE, BKT, NSTAGE, false>(p);
+}
+template <int BM, int BN, int MODE, int BKT, int NSTAGE>
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (glds_waves<BM, BN, BKT, NSTAGE>()))
+k_wino_glds(ConvArgs p) {
+  conv_glds_body<BM, BN, MODE, BKT, NSTAGE, true>(p);
 }
 
 template <int BM, int BN, int MODE, int BKT>

@@ -388,10 +388,11 @@ constexpr int NORM_CHUNK = 1 << 16;
 // fold below adds them in chunk order, so the norm — and with it the clip factor and the updated
 // weights — is bit-reproducible (data-parallel replicas must stay bit-identical after the update).
 __global__ void __launch_bounds__(256)
-    k_var_sumsq(const float* g, const float* w, const float* var_wd, const int32_t* off,
+    k_var_sumsq(const float* g, const float* w, const float* var_wd, const float* var_mult, const int32_t* off,
                 float gscale, int chunks, float* part) {
   int v = blockIdx.y;
   const float wd = var_wd ? var_wd[v] : 0.f;
+  const float mult = var_mult ? var_mult[v] : 1.f;   // trainer.py:389-405 multipliers act on the whole gradient
   int64_t lo = off[v], hi = off[v + 1];
   int64_t s = lo + (int64_t)blockIdx.x * NORM_CHUNK;
   if (s >= hi) return;                      // part[] was zeroed
@@ -404,6 +405,7 @@ __global__ void __launch_bounds__(256)
       float4 ww = *reinterpret_cast<const float4*>(w + i);
       q.x += wd * ww.x; q.y += wd * ww.y; q.z += wd * ww.z; q.w += wd * ww.w;
     }
+    q.x *= mult; q.y *= mult; q.z *= mult; q.w *= mult;
     acc += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
   }
   acc = wave_sum(acc);
@@ -422,7 +424,7 @@ __global__ void k_var_norm_fold(const float* part, int chunks, int num_vars, flo
 __global__ void __launch_bounds__(256)
     k_momentum_update(float* w, const float* g, float* acc, const int32_t* off, int num_vars,
                       int64_t total4, float lr, float mom, float clip, float gscale,
-                      const float* norms, const float* var_wd) {
+                      const float* norms, const float* var_wd, const float* var_mult) {
   int64_t i4 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i4 >= total4) return;
   int64_t i = i4 * 4;
@@ -431,6 +433,8 @@ __global__ void __launch_bounds__(256)
     int mid = (lo + hi) >> 1;
     if ((int64_t)off[mid] <= i) lo = mid; else hi = mid;
   }
+  const float mult = var_mult ? var_mult[lo] : 1.f;
+  if (mult < 0.f) return;                  // frozen variable: left out of apply_gradients (trainer.py:408-410)
   float f = 1.f;
   if (clip > 0.f) {
     float nrm = sqrtf(norms[lo]);
@@ -440,8 +444,8 @@ __global__ void __launch_bounds__(256)
   float4 gv = *reinterpret_cast<const float4*>(g + i);
   float4 av = *reinterpret_cast<float4*>(acc + i);
   float4 wv = *reinterpret_cast<float4*>(w + i);
-  gv.x = gv.x * gscale + wd * wv.x; gv.y = gv.y * gscale + wd * wv.y;
-  gv.z = gv.z * gscale + wd * wv.z; gv.w = gv.w * gscale + wd * wv.w;
+  gv.x = (gv.x * gscale + wd * wv.x) * mult; gv.y = (gv.y * gscale + wd * wv.y) * mult;
+  gv.z = (gv.z * gscale + wd * wv.z) * mult; gv.w = (gv.w * gscale + wd * wv.w) * mult;
   av.x = mom * av.x + gv.x * f; av.y = mom * av.y + gv.y * f;
   av.z = mom * av.z + gv.z * f; av.w = mom * av.w + gv.w * f;
   wv.x -= lr * av.x; wv.y -= lr * av.y; wv.z -= lr * av.z; wv.w -= lr * av.w;
@@ -647,8 +651,8 @@ int64_t mtlssl_sgd_workspace_bytes(int num_vars, int64_t max_var_size) {
 int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              const int32_t* var_offsets, int num_vars, int64_t total,
                              int64_t max_var_size, float lr, float momentum, float clip_norm,
-                             float grad_scale, const float* var_weight_decay, float* norms_ws,
-                             mtlssl_stream_t stream) {
+                             float grad_scale, const float* var_weight_decay, const float* var_grad_mult,
+                             float* norms_ws, mtlssl_stream_t stream) {
   MTLSSL_REQUIRE(total % 4 == 0, "sgd: total must be a multiple of 4");
   MTLSSL_REQUIRE(total < (1ll << 31), "sgd: flat parameter buffer must be < 2^31 floats");
   if (!total) return MTLSSL_OK;
@@ -661,13 +665,13 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
     if (hipMemsetAsync(part, 0, sizeof(float) * (size_t)num_vars * chunks, st) != hipSuccess)
       return check_launch("sgd memset");
     hipLaunchKernelGGL(k_var_sumsq, dim3(chunks, num_vars), dim3(256), 0, st, grads, weights,
-                       var_weight_decay, var_offsets, grad_scale, chunks, part);
+                       var_weight_decay, var_grad_mult, var_offsets, grad_scale, chunks, part);
     hipLaunchKernelGGL(k_var_norm_fold, dim3(cdiv(num_vars, 256)), dim3(256), 0, st, (const float*)part, chunks,
                        num_vars, norms_ws);
   }
   hipLaunchKernelGGL(k_momentum_update, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads,
                      accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
-                     norms_ws, var_weight_decay);
+                     norms_ws, var_weight_decay, var_grad_mult);
   return check_launch("sgd_momentum_clip");
 }
 

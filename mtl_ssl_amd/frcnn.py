@@ -41,6 +41,9 @@ class MaskRCNNBoxPredictor:
         if not cfg.spatial_average:
             raise ValueError("mask_rcnn_box_predictor without spatial_average is not supported "
                              "(every paper config sets spatial_average: true)")
+        if cfg.use_dropout and is_training:
+            # core/box_predictor.py:484-488 (slim.dropout on the pooled features while training)
+            raise ValueError("mask_rcnn_box_predictor.use_dropout is not supported (no paper config enables it)")
         init, wd = _init_from_hyperparams(cfg.fc_hyperparams), _l2_from_hyperparams(cfg.fc_hyperparams)
         self.num_classes, self.class_only = num_classes, class_only
         self.box = None

@@ -23,7 +23,7 @@ class ConvDesc(ctypes.Structure):
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
     "uint32_t": ctypes.c_uint32, "float": ctypes.c_float,
-    "mtlssl_stream_t": ctypes.c_void_p,
+    "mtlssl_stream_t": ctypes.c_void_p, "mtlssl_comm_t": ctypes.c_void_p,
 }
 
 

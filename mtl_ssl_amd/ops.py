@@ -645,13 +645,13 @@ def reduce_sum(x, scale=1.0, out=None):
 
 
 def sgd_momentum_clip(weights, grads, accum, var_offsets, max_var_size, lr, momentum, clip_norm,
-                      grad_scale=1.0, var_weight_decay=None):
+                      grad_scale=1.0, var_weight_decay=None, var_grad_mult=None):
     nv = var_offsets.numel() - 1
     norms = workspace(lib().sgd_workspace_bytes(max(nv, 1), int(max_var_size)), "norms", weights.device)
     lib().sgd_momentum_clip(ptr(_chk(weights)), ptr(_chk(grads)), ptr(_chk(accum)),
                             ptr(_chk(var_offsets, i32)), nv, weights.numel(), int(max_var_size),
                             float(lr), float(momentum), float(clip_norm), float(grad_scale),
-                            ptr(var_weight_decay), ptr(norms), _stream())
+                            ptr(var_weight_decay), ptr(var_grad_mult), ptr(norms), _stream())
 
 
 def fold_scales(ps):

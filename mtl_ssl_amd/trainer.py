@@ -46,13 +46,17 @@ class GradientReducer:
     finalise a variable's gradient, and a bucket's all-reduce (sum) is issued on a side stream as
     soon as its last variable has reported — behind an event on the compute stream(s), so it runs
     while the rest of backward is still executing. xGMI is point-to-point, so buckets are large
-    (default 32 MiB) to stay per-link bandwidth-bound rather than latency-bound."""
+    (default 32 MiB) to stay per-link bandwidth-bound rather than latency-bound.
 
-    def __init__(self, ps, bucket_bytes=32 << 20):
-        import torch.distributed as dist
-        self.dist = dist
-        self.ps = ps
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
+    `comm` is a communicator of mtl_ssl_amd.comm (RcclComm = mtlssl_comm_* = RCCL, the product path;
+    GlooComm for CPU tests); None or a single rank disables the reducer unless `always` is set, which
+    runs the full machinery — side stream, events, buckets, RCCL calls — on one rank (the 1-GPU test of
+    the RCCL path)."""
+
+    def __init__(self, ps, comm=None, bucket_bytes=32 << 20, always=False):
+        self.ps, self.comm = ps, comm
+        self.world = comm.world if comm is not None else 1
+        self.active = comm is not None and (self.world > 1 or always)
         per = max(bucket_bytes // 4, 1)
         self.buckets, self.var_bucket, self.nvars = [], {}, []
         start, count = 0, 0
@@ -67,12 +71,14 @@ class GradientReducer:
             self.buckets.append((start, ps.n_train)); self.nvars.append(count)
         if self.buckets:
             self.buckets[-1] = (self.buckets[-1][0], ps.n_train)
-        self.stream = torch.cuda.Stream() if (self.world > 1 and ps.device.type == "cuda") else None
+        self.stream = torch.cuda.Stream() if (self.active and ps.device.type == "cuda") else None
         self.compute_streams = []          # extra compute streams whose work a bucket may depend on
         self.main_stream = None
         self.pending, self.done, self.seen = [], [], set()
         self.launch_order = []             # bucket ids in the order they were issued (diagnostics/tests)
-        if self.world > 1:
+        self.timing = False                # bench: HIP events around every bucket and around the final wait
+        self._ev_buckets, self._ev_wait = [], []
+        if self.active:
             ps.grad_ready_hook = self.mark_ready
 
     def begin_step(self):
@@ -83,7 +89,7 @@ class GradientReducer:
         self.launch_order = []
 
     def mark_ready(self, spec):
-        if self.world == 1 or not self.pending or spec.name in self.seen:
+        if not self.active or not self.pending or spec.name in self.seen:
             return
         self.seen.add(spec.name)
         b = self.var_bucket[spec.name]
@@ -96,8 +102,8 @@ class GradientReducer:
         g = self.ps.grads
         self.done[b] = True
         self.launch_order.append(b)
-        if self.stream is None:                      # gloo / CPU path used by the unit tests
-            self.dist.all_reduce(g[s:e])
+        if self.stream is None:                      # CPU tensors (gloo unit tests)
+            self.comm.allreduce(g[s:e])
             return
         # the bucket's variables may have been produced on any compute stream (main or auxiliary)
         streams = {id(cs): cs for cs in [self.main_stream, torch.cuda.current_stream()] + self.compute_streams
@@ -106,12 +112,17 @@ class GradientReducer:
             ev = torch.cuda.Event()
             ev.record(cs)
             self.stream.wait_event(ev)
-        with torch.cuda.stream(self.stream):
-            self.dist.all_reduce(g[s:e])
+        if self.timing:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+        self.comm.allreduce(g[s:e], stream=self.stream)
+        if self.timing:
+            e1.record(self.stream)
+            self._ev_buckets.append((e0, e1, (e - s) * 4))
 
     def finish(self):
         """Issue whatever has not been reduced yet and make the compute stream wait for all of it."""
-        if self.world == 1:
+        if not self.active:
             return
         if not self.done:
             self.begin_step()
@@ -119,7 +130,14 @@ class GradientReducer:
             if not self.done[b]:
                 self._launch(b)
         if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur = torch.cuda.current_stream()
+            if self.timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+            cur.wait_stream(self.stream)
+            if self.timing:
+                e1.record(cur)
+                self._ev_wait.append((e0, e1))
         self.pending = []
 
     def all_reduce(self):
@@ -127,24 +145,80 @@ class GradientReducer:
         self.begin_step()
         self.finish()
 
+    def timing_summary(self, steps):
+        """After a synchronize: per-step milliseconds the side stream spent in all-reduce calls, and how
+        much of that the compute stream had to wait for (exposed) vs ran under backward (hidden)."""
+        busy = sum(a.elapsed_time(b) for a, b, _ in self._ev_buckets)
+        nbytes = sum(n for _, _, n in self._ev_buckets)
+        exposed = sum(a.elapsed_time(b) for a, b in self._ev_wait)
+        steps = max(steps, 1)
+        return {"allreduce_ms_per_step": busy / steps, "exposed_ms_per_step": exposed / steps,
+                "hidden_ms_per_step": max(busy - exposed, 0.0) / steps, "bytes_per_step": nbytes // steps,
+                "buckets": len(self.buckets)}
+
+
+def gradient_multipliers(ps, train_config):
+    """Per-variable table for the fused optimizer launch, object_detection/trainer.py:389-410:
+    grad_multiplier / divide_grad_by_batch on every gradient, bias_grad_multiplier on '.*/biases'
+    (utils/variables_helper.py:58-78), freeze_variables (regex list, `re.match`, :29-55,100-118) as a
+    negative entry = the variable is left out of the update. None when every entry is 1."""
+    import re
+    base = float(train_config.grad_multiplier) if train_config.grad_multiplier else 1.0
+    if train_config.divide_grad_by_batch:
+        base /= float(train_config.batch_size)
+    bias = float(train_config.bias_grad_multiplier) if train_config.bias_grad_multiplier else None
+    freeze = [str(r) for r in (train_config.freeze_variables or [])]
+    mult = []
+    for sp in ps.trainable_specs:
+        m = base
+        if bias is not None and re.match(".*/biases", sp.name):
+            m *= bias
+        if any(re.match(r, sp.name) for r in freeze):
+            m = -1.0
+        mult.append(m)
+    if all(m == 1.0 for m in mult):
+        return None
+    return torch.tensor(mult, dtype=torch.float32, device=ps.device)
+
 
 class Trainer:
     """One training replica. step(batch) = forward + loss + backward + all-reduce + update."""
 
-    def __init__(self, model, train_config, world_size=1):
+    def __init__(self, model, train_config, world_size=1, comm=None, reduce_always=False):
         self.model, self.ps, self.cfg = model, model.ps, train_config
         self.lr_fn, self.momentum = learning_rate_fn(train_config.optimizer)
         self.clip = float(train_config.gradient_clipping_by_norm)
         self.world = world_size
         self.global_step = 0
-        self.reducer = GradientReducer(self.ps)
+        if comm is None and world_size > 1:
+            from . import comm as comm_mod
+            comm = comm_mod.default_comm(self.ps.device)
+        if comm is not None and comm.world != world_size:
+            raise ValueError("communicator has %d ranks, trainer was given world_size %d" % (comm.world, world_size))
+        self.comm = comm
+        self.reducer = GradientReducer(self.ps, comm, always=reduce_always)
         wd = [s.weight_decay for s in self.ps.trainable_specs]
         self.var_wd = (torch.tensor(wd, dtype=torch.float32, device=self.ps.device)
                        if any(w != 0.0 for w in wd) else None)
+        self.var_mult = gradient_multipliers(self.ps, train_config)
+        # builders/optimizer_builder.py:105-111: tf.contrib.opt.MovingAverageOptimizer keeps an exponential
+        # moving average of every variable beside it (the trainer's plain Saver stores both); decay as given.
+        self.ema = None
         if train_config.optimizer.use_moving_average:
-            # the reference wraps the optimizer in an EMA of the weights for evaluation only
-            # (builders/optimizer_builder.py:105-111); every paper config disables it.
-            pass
+            self.ema_decay = float(train_config.optimizer.moving_average_decay)
+            self.ema = self.ps.weights.clone()
+
+    def broadcast_weights(self, root=0):
+        """C2: identical initial values on every replica — the reference gets this from its
+        single CPU copy of each variable (model_deploy.py:640-675)."""
+        if self.comm is None or self.comm.world == 1:
+            return
+        self.comm.broadcast(self.ps.weights, root)
+        self.comm.broadcast(self.ps.frozen, root)
+        self.comm.broadcast(self.ps.accum, root)
+        if self.ps.device.type == "cuda":
+            torch.cuda.current_stream().synchronize()
+        self.model.prepare()
 
     def stage_batch(self, batch):
         """Move a batch's groundtruth to HBM once (padded device tensors); later provide() calls
@@ -186,13 +260,16 @@ class Trainer:
         return losses
 
     def apply_gradients(self):
-        """trainer.py:379-427: cross-replica sum, per-variable clip_by_norm, momentum update."""
+        """trainer.py:379-427: cross-replica sum, gradient multipliers / frozen variables, per-variable
+        clip_by_norm, momentum update."""
         self.reducer.compute_streams = self.model.compute_streams()
         self.reducer.finish()
         lr = self.lr_fn(self.global_step)
         ps = self.ps
         ops.sgd_momentum_clip(ps.weights, ps.grads, ps.accum, ps.var_offsets, ps.max_var_size, lr,
-                              self.momentum, self.clip, 1.0, self.var_wd)
+                              self.momentum, self.clip, 1.0, self.var_wd, self.var_mult)
+        if self.ema is not None:
+            ops.axpby(ps.weights, self.ema, 1.0 - self.ema_decay, self.ema_decay)
         self.model.refold()
         self.global_step += 1
 
@@ -205,36 +282,56 @@ class Trainer:
 def train(create_tensor_dict_fn, create_model_fn, train_config, master="", task=0, num_clones=1,
           worker_replicas=1, clone_on_cpu=False, ps_tasks=0, worker_job_name="lonely_worker",
           is_chief=True, train_dir=None, num_examples=0, total_configs=None, model_config=None,
-          is_first_training=True, num_steps=None, log_every=10):
+          is_first_training=True, num_steps=None, log_every=10, save_interval_secs=600):
     """object_detection/trainer.py:217-219 signature. `create_tensor_dict_fn()` yields one batch
     dict per call (see mtl_ssl_amd.synthetic.make_batch for the field contract);
     `create_model_fn()` returns a built FasterRCNNMetaArch. Parameter-server arguments
     (master, ps_tasks, worker_job_name, clone_on_cpu) are accepted and ignored: data parallelism
     here is one process per GPU over RCCL."""
-    import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_initialized() else 1
     import os
+    import torch.distributed as dist
     from . import checkpoint
+    world = dist.get_world_size() if dist.is_initialized() else 1
     model = create_model_fn()
     trainer = Trainer(model, train_config, world)
-    # Resume from train_dir if a state file is there, else initialise from fine_tune_checkpoint
-    # (trainer.py:309-356; slim.learning.train restores the latest checkpoint of logdir). The
-    # container is .npz keyed by the reference's variable names (mtl_ssl_amd/checkpoint.py).
+    # Resume from train_dir if a state file is there (slim.learning.train restores the latest checkpoint of
+    # logdir), else initialise from fine_tune_checkpoint (trainer.py:309-356: a Saver over restore_map() that
+    # FAILS when the checkpoint cannot be read). Containers: this build's .npz keyed by the reference's variable
+    # names, or TensorFlow's own checkpoint files (mtl_ssl_amd/tf_checkpoint.py).
     state = os.path.join(train_dir, "model.ckpt.npz") if train_dir else None
     if state and os.path.exists(state):
-        trainer.global_step = checkpoint.load(state, model.ps)
+        trainer.global_step = checkpoint.load(state, model.ps, trainer)
         model.prepare()
-    elif train_config.fine_tune_checkpoint and os.path.exists(str(train_config.fine_tune_checkpoint)):
-        import numpy as np
+    elif train_config.fine_tune_checkpoint:
         mtl = model_config.mtl if model_config is not None else model._mtl
-        checkpoint.init_from_checkpoint(model, np.load(str(train_config.fine_tune_checkpoint)), train_config, mtl)
-    steps = num_steps if num_steps is not None else (int(train_config.num_steps) or 10)
+        ckpt = checkpoint.open_checkpoint(str(train_config.fine_tune_checkpoint))
+        done = checkpoint.init_from_checkpoint(model, ckpt, train_config, mtl)
+        if not done:
+            raise ValueError("fine_tune_checkpoint %s holds none of the %d variables the restore map asks for"
+                             % (train_config.fine_tune_checkpoint, len(model.ps.specs)))
+        if is_chief:
+            print("restored %d of %d variables from %s" % (len(done), len(model.ps.specs),
+                                                            train_config.fine_tune_checkpoint))
+    trainer.broadcast_weights(0)
+    # num_steps == 0 trains indefinitely (train.proto:42-44; slim.learning.train number_of_steps=None)
+    steps = num_steps if num_steps is not None else (int(train_config.num_steps) or None)
+    save_secs = float(save_interval_secs) if save_interval_secs else 0.0
+    last_save = time.time()
+
+    def save_state():
+        if state and is_chief:
+            os.makedirs(train_dir, exist_ok=True)
+            tmp = state + ".tmp.npz"
+            checkpoint.save(tmp, model.ps, trainer.global_step, trainer)
+            os.replace(tmp, state)             # a crash mid-write never clobbers the previous state
+
     log = []
-    for _ in range(max(steps - trainer.global_step, 0)):
+    while steps is None or trainer.global_step < steps:
         t0 = time.time()
         losses = trainer.step(create_tensor_dict_fn())
         if trainer.global_step % log_every == 0 or trainer.global_step == steps:
-            torch.cuda.synchronize()
+            if model.ps.device.type == "cuda":
+                torch.cuda.synchronize()
             total = float(sum(v.item() for v in losses.values()))
             if not (total == total and abs(total) != float("inf")):
                 raise FloatingPointError("LossTensor is inf or nan")     # tf.check_numerics, :207-209
@@ -242,7 +339,8 @@ def train(create_tensor_dict_fn, create_model_fn, train_config, master="", task=
             log.append({"step": trainer.global_step, "loss": total, "sec_per_step": dt})
             if is_chief:
                 print("global step %d: loss = %.4f (%.3f sec/step)" % (trainer.global_step, total, dt))
-    if state and is_chief:
-        os.makedirs(train_dir, exist_ok=True)
-        checkpoint.save(state, model.ps, trainer.global_step)
+        if save_secs and time.time() - last_save >= save_secs:          # trainer.py:464-466 save_interval_secs
+            save_state()
+            last_save = time.time()
+    save_state()
     return trainer, log

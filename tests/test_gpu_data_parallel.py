@@ -1,7 +1,8 @@
 """Two data-parallel replicas on ONE GPU (gloo backend over device tensors): exercises the real
 overlapped reducer — side stream, events on the main and auxiliary compute streams, buckets issued
 from `grad_ready` reports in the middle of backward — which the CPU gloo test cannot. RCCL itself
-needs one device per rank, so the 8-GPU path is only run by the round driver."""
+needs one device per rank: its single-rank run through the same reducer is tests/test_gpu_comm.py, the
+8-GPU path is only run by the round driver."""
 import os
 
 import numpy as np
@@ -21,9 +22,10 @@ def _worker(rank, world, port, out):
     import sys
     sys.path.insert(0, ROOT)
     from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    from mtl_ssl_amd.comm import GlooComm
     cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", "smoke_resnet50_mtl.config")).read())
     model = model_builder.build(cfg.model, True, "cuda", seed=3)          # same seed -> same weights
-    tr = trainer.Trainer(model, cfg.train_config, world)
+    tr = trainer.Trainer(model, cfg.train_config, world, comm=GlooComm())
     assert tr.reducer.stream is not None and model.ps.grad_ready_hook is not None
     batch = synthetic.make_batch(2, 160, 224, 5, seed=100 + rank, device="cuda", max_gt=4, num_windows=6)
     # local (unreduced) gradients of this replica's shard, loss already scaled by 1/world

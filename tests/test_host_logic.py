@@ -272,7 +272,8 @@ def _dp_worker(rank, world, port, out):
         ps.add(n, shape, ("truncated_normal", 0.1))
     ps.add("c/frozen", (5,), ("zeros",), trainable=False)
     ps.finalize("cpu", seed=0)
-    red = trainer.GradientReducer(ps, bucket_bytes=4096)       # several variable-aligned buckets
+    from mtl_ssl_amd.comm import GlooComm
+    red = trainer.GradientReducer(ps, GlooComm(), bucket_bytes=4096)       # several variable-aligned buckets
     assert len(red.buckets) > 2 and red.buckets[0][0] == 0 and red.buckets[-1][1] == ps.n_train
     assert all(red.buckets[i][1] == red.buckets[i + 1][0] for i in range(len(red.buckets) - 1))
     g = torch.arange(ps.n_train, dtype=torch.float32) * (rank + 1) / world   # clone loss is scaled 1/N
