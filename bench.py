@@ -340,6 +340,9 @@ def main():
         out["hbm_kernels"] = hbm_kernels(tr)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, model, tr, a.height, a.width, seed=1234, steps=a.cpu_steps)
+    if comm is not None:
+        with comm_mod._stdout_to_stderr():      # anything RCCL left in C stdio's stdout buffer goes to stderr,
+            pass                                # so that stdout carries exactly the one JSON line
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

