@@ -398,6 +398,17 @@ int mtlssl_edgemask_targets(const float* gt, int batch, int H, int W, float coef
  * out [B,n_expand,n2,4], window i = proposal pushed i/(n_expand-1) of the way to the image. */
 int mtlssl_expand_windows(const float* proposals_norm, int batch, int n2, int n_expand, float* out,
                           mtlssl_stream_t stream);
+/* Exact de-duplication of the refiner's expanded windows [B,n_expand,n2,4] (faster_rcnn_meta_arch.py:774-803):
+ * window n_expand-1 of every proposal is the proposal pushed all the way to the full image — [0,0,1,1] up to
+ * the last bit of the fp32 sum z + (1 - z) — so that group holds only a handful of DISTINCT boxes per image,
+ * which the reference nevertheless crops and runs through the window tower once per proposal. rois_out
+ * [B,(n_expand-1)*n2+capacity,4] = windows 0..n_expand-2 unchanged, then the distinct boxes of the last group
+ * (bitwise comparison, first-occurrence order, unused slots repeat the first); src_row int32 [B,n_expand,n2] =
+ * the row of rois_out (flattened over B) that holds each window, i.e. the gather that expands the tower's
+ * outputs back to [B,n_expand,n2]. *overflow (device int32, zeroed by the caller) is set to 1 if an image has
+ * more than `capacity` distinct last windows (then results are wrong and the caller must fail). */
+int mtlssl_dedup_windows(const float* windows, int batch, int n_expand, int n2, int capacity, float* rois_out,
+                         int32_t* src_row, int32_t* overflow, mtlssl_stream_t stream);
 /* Refiner input (faster_rcnn_meta_arch.py:817-831), per image: [cls (k1) | window predictions
  * win[B,n_expand,n2,k1] laid out proposal-major (nullable) | closeness (nullable; per-image mean
  * tiled when global_closeness)] -> out [B*n2, ld]. */

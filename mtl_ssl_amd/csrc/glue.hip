@@ -113,6 +113,60 @@ __global__ void k_expand_windows(const float* prop, int n2, int n_expand, float*
       make_float4(v.x - dyn * fi, v.y - dxn * fi, v.z + dyp * fi, v.w + dxp * fi);
 }
 
+// The refiner's last expanded window is the proposal pushed ALL the way to the full image
+// (faster_rcnn_meta_arch.py:774-803 with i = n_expand-1): [0, 0, z + (1 - z), ...] = [0, 0, 1, 1] up to the
+// last bit of the fp32 sum, i.e. a handful of distinct boxes per image, each of which the reference crops
+// and runs through the window tower once per proposal. This kernel keeps windows 0..n_expand-2 as they are,
+// replaces the last group by its DISTINCT boxes (bitwise comparison, first-occurrence order, `capacity`
+// slots per image, unused slots repeat slot 0) and emits the row map that expands the tower's outputs back
+// to [B, n_expand, n2]: identical results, (n_expand-1)*n2 + capacity ROIs instead of n_expand*n2.
+__global__ void __launch_bounds__(256)
+    k_dedup_windows(const float* win, int n_expand, int n2, int capacity, float* rois, int32_t* src_row,
+                    int32_t* overflow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dd_smem[];
+  uint4* box = reinterpret_cast<uint4*>(dd_smem);                 // [n2] last-window boxes, as bit patterns
+  int* rep = reinterpret_cast<int*>(box + n2);                      // [n2] first index holding the same box
+  int* slot = rep + n2;                                             // [n2] rank of a representative among the distinct
+  const int b = blockIdx.x, keep = (n_expand - 1) * n2, R = keep + capacity;
+  const float* wb = win + (int64_t)b * n_expand * n2 * 4;
+  float* rb = rois + (int64_t)b * R * 4;
+  int32_t* sr = src_row + (int64_t)b * n_expand * n2;
+  for (int t = threadIdx.x; t < keep; t += blockDim.x) {
+    *reinterpret_cast<float4*>(rb + (int64_t)t * 4) = *reinterpret_cast<const float4*>(wb + (int64_t)t * 4);
+    sr[t] = b * R + t;
+  }
+  for (int p = threadIdx.x; p < n2; p += blockDim.x)
+    box[p] = *reinterpret_cast<const uint4*>(wb + (int64_t)(keep + p) * 4);
+  __syncthreads();
+  for (int p = threadIdx.x; p < n2; p += blockDim.x) {
+    const uint4 me = box[p];
+    int r = p;
+    for (int q = 0; q < p; ++q) {
+      const uint4 o = box[q];
+      if (o.x == me.x && o.y == me.y && o.z == me.z && o.w == me.w) { r = q; break; }
+    }
+    rep[p] = r;
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < n2; p += blockDim.x) {
+    int s = 0;
+    for (int q = 0; q < p; ++q) s += rep[q] == q;
+    slot[p] = s;
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < n2; p += blockDim.x) {
+    int s = slot[rep[p]];
+    if (s >= capacity) { s = 0; *overflow = 1; }
+    sr[keep + p] = b * R + keep + s;
+    if (rep[p] == p && slot[p] < capacity)
+      *reinterpret_cast<uint4*>(rb + (int64_t)(keep + slot[p]) * 4) = box[p];
+  }
+  // slots beyond the number of distinct boxes repeat slot 0 (= box[0], always a representative)
+  int distinct = slot[n2 - 1] + (rep[n2 - 1] == n2 - 1);
+  for (int s = distinct + threadIdx.x; s < capacity; s += blockDim.x)
+    *reinterpret_cast<uint4*>(rb + (int64_t)(keep + s) * 4) = box[0];
+}
+
 // faster_rcnn_meta_arch.py:817-831 per image: [cls | window preds (proposal-major over the
 // n_expand windows) | closeness (batch-mean tiled when global)].
 constexpr int RC_ROWS = 8;   // proposals per block
@@ -228,6 +282,18 @@ int mtlssl_expand_windows(const float* proposals_norm, int batch, int n2, int n_
   hipLaunchKernelGGL(k_expand_windows, dim3(cdiv(n_expand * n2, 256), batch), dim3(256), 0, S(stream),
                      proposals_norm, n2, n_expand, out);
   return check_launch("expand_windows");
+}
+
+int mtlssl_dedup_windows(const float* windows, int batch, int n_expand, int n2, int capacity, float* rois_out,
+                         int32_t* src_row, int32_t* overflow, mtlssl_stream_t stream) {
+  if (!batch || !n2) return MTLSSL_OK;
+  MTLSSL_REQUIRE(n_expand >= 2 && capacity >= 1, "dedup_windows: n_expand %d, capacity %d", n_expand, capacity);
+  MTLSSL_REQUIRE(windows && rois_out && src_row && overflow, "dedup_windows: null pointer");
+  size_t smem = (size_t)n2 * (sizeof(uint4) + 2 * sizeof(int));
+  MTLSSL_REQUIRE(smem <= 64 * 1024, "dedup_windows: n2 = %d is too large", n2);
+  hipLaunchKernelGGL(k_dedup_windows, dim3(batch), dim3(256), smem, S(stream), windows, n_expand, n2, capacity,
+                     rois_out, src_row, overflow);
+  return check_launch("dedup_windows");
 }
 
 int mtlssl_refine_concat(const float* cls, const float* win, const float* clo, int batch, int n2,

@@ -190,9 +190,25 @@ class FasterRCNNMetaArch:
             self._aux_stream_obj = torch.cuda.Stream(device=self.ps.device)
         return self._aux_stream_obj
 
+    def _wgrad_exec(self):
+        """Side stream for the filter gradients of the trunk / RPN backward (nn.WgradStream); inline when
+        MTLSSL_WGRAD_STREAM=0 or on CPU."""
+        import os
+        if self.ps.device.type != "cuda" or os.environ.get("MTLSSL_WGRAD_STREAM", "1") == "0":
+            return nn.INLINE_WGRAD
+        if getattr(self, "_wgrad_stream_obj", None) is None:
+            self._wgrad_stream_obj = nn.WgradStream(torch.cuda.Stream(device=self.ps.device))
+        return self._wgrad_stream_obj
+
     def compute_streams(self):
+        out = []
         s = getattr(self, "_aux_stream_obj", None)
-        return [s] if s is not None else []
+        if s is not None:
+            out.append(s)
+        w = getattr(self, "_wgrad_stream_obj", None)
+        if w is not None:
+            out.append(w.stream)
+        return out
 
     def prepare(self):
         for l in self.layers:
@@ -370,7 +386,11 @@ class FasterRCNNMetaArch:
                                      int(c.maxpool_kernel_size), int(c.maxpool_stride), want_argmax)
 
     def _box_ind(self, B, n, device):
-        return (torch.arange(B * n, device=device, dtype=i32) // n).contiguous()
+        """box_ind of tf.image.crop_and_resize for n boxes per image: a constant, built once per shape."""
+        key = ("box_ind", B, n)
+        if key not in self._consts:
+            self._consts[key] = (torch.arange(B * n, device=device, dtype=i32) // n).contiguous()
+        return self._consts[key]
 
     def _second_stage_proposals(self, props, nprop, gt, H, W):
         """Tail of _postprocess_rpn (:1117-1132): training samples a balanced minibatch of the
@@ -441,6 +461,16 @@ class FasterRCNNMetaArch:
         pd["edgemask_predictions"] = self.edgemask_conv.forward(pd["rpn_features_to_crop"])
         return pd
 
+    DEDUP_SLOTS = 8        # distinct last-window boxes kept per image (at most 4 can occur, see mtlssl_dedup_windows)
+
+    def check_device_flags(self):
+        """Raise if a device-side invariant was violated since the last check (reads one int: call it where the
+        host synchronises anyway, e.g. with the loss NaN check)."""
+        f = getattr(self, "_dedup_overflow", None)
+        if f is not None and int(f.item()) != 0:
+            raise RuntimeError("refiner window de-duplication overflowed its %d slots per image (non-finite or "
+                               "out-of-range proposal boxes?)" % self.DEDUP_SLOTS)
+
     def predict_with_mtl_results(self, pd):
         """faster_rcnn_meta_arch.py:764-846, executed per image."""
         mtl = self._mtl
@@ -452,11 +482,23 @@ class FasterRCNNMetaArch:
         win = None
         if mtl.window:
             ew = ops.expand_windows(pd["proposal_boxes_normalized"], self.N_EXPAND)    # [B,5,N2,4]
-            flat = ew.view(B * self.N_EXPAND * N2, 4)
-            box_ind = self._box_ind(B, self.N_EXPAND * N2, F.device)
-            crops, _ = self._crop(F, flat, box_ind, False)
-            feat, _ = self.window_tower.forward(crops, False)               # forward only (:834)
-            win = self.window_predictor.predict(feat)["class"]             # [B*5*N2, K1]
+            if self.DEDUP_SLOTS > 0:
+                # The last window of every proposal is the whole image (up to the last bit of z + (1 - z)): crop
+                # and run the tower once per DISTINCT box instead of once per proposal, then expand the predictions
+                # back — bit-identical outputs, 4*N2 + 8 ROIs per image through the tower instead of 5*N2.
+                if getattr(self, "_dedup_overflow", None) is None:
+                    self._dedup_overflow = torch.zeros((1,), dtype=torch.int32, device=F.device)
+                rois, src_row = ops.dedup_windows(ew, self.DEDUP_SLOTS, self._dedup_overflow)
+                R = rois.shape[1]
+                crops, _ = self._crop(F, rois.view(B * R, 4), self._box_ind(B, R, F.device), False)
+                feat, _ = self.window_tower.forward(crops, False)               # forward only (:834)
+                compact = self.window_predictor.predict(feat)["class"]         # [B*R, K1]
+                win = ops.gather_rows(compact.view(1, B * R, K1), src_row)      # [1, B*5*N2, K1]
+            else:
+                flat = ew.view(B * self.N_EXPAND * N2, 4)
+                crops, _ = self._crop(F, flat, self._box_ind(B, self.N_EXPAND * N2, F.device), False)
+                feat, _ = self.window_tower.forward(crops, False)
+                win = self.window_predictor.predict(feat)["class"]             # [B*5*N2, K1]
             pd["expand_window_class_predictions"] = win.view(B, self.N_EXPAND, N2, K1)
         clo = pd["closeness_predictions"] if mtl.closeness else None
         net = ops.refine_concat(cls, win, clo, B, N2, self.N_EXPAND, bool(mtl.global_closeness))
@@ -659,11 +701,17 @@ class FasterRCNNMetaArch:
         g_rf = self.rpn_box.dgrad(rpn_feat.shape, g_enc)
         relu = self.rpn_conv.activation == "relu"
         self.rpn_cls.dgrad(rpn_feat.shape, g_obj, out=g_rf, accum=True, mask_ref=rpn_feat if relu else None)
-        self.rpn_conv.wgrad(F, g_rf)
+        wg = self._wgrad_exec()
+        wg.run(self.rpn_conv, F, g_rf)
         # last consumer of F: accumulate and apply the ReLU mask of the trunk output
         gpF = self.rpn_conv.dgrad(F.shape, g_rf, out=dF, accum=True, mask_ref=F,
                                   mask6=getattr(self._feature_extractor, "output_relu6", False))
         pd["_gpF"] = gpF
-        self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"])
+        if isinstance(self._feature_extractor, FasterRCNNResnetV1FeatureExtractor):
+            self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"], wgrad=wg)
+        else:
+            self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"])
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+        if wg.stream is not None:
+            torch.cuda.current_stream().wait_stream(wg.stream)

@@ -26,6 +26,39 @@ def _refresh_bn(layer):
                       out=layer.shift)
 
 
+class WgradStream:
+    """Filter gradients off the critical path: `run(layer, x, g)` enqueues layer.wgrad(x, g) on a side HIP
+    stream behind an event on the issuing stream. The backward chain of the B=2 trunk is a string of small
+    GEMMs (4 864 pixels) in which each dgrad waits for the previous one while the wgrads feed nothing but the
+    optimizer; taken out of that chain they fill the CUs the chain leaves idle. The caller joins the stream
+    before the optimizer (FasterRCNNMetaArch.backward) and lists it in compute_streams() for the reducer."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def run(self, layer, x, g):
+        if not layer.trainable:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        x.record_stream(self.stream)          # keep the caching allocator from recycling them under the side stream
+        g.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            layer.wgrad(x, g)
+
+
+class _InlineWgrad:
+    stream = None
+
+    @staticmethod
+    def run(layer, x, g):
+        layer.wgrad(x, g)
+
+
+INLINE_WGRAD = _InlineWgrad()
+
+
 class ConvBN:
     """slim.conv2d + frozen slim.batch_norm (+ReLU) — slim/nets/resnet_v1.py:102-119."""
 
@@ -254,17 +287,17 @@ class Bottleneck:
         ctx = (x, a1, a2, sc if (self.shortcut is None and self.stride > 1) else None) if save else None
         return out, ctx
 
-    def backward(self, gp, ctx, need_input_grad=True, mask_input=True):
+    def backward(self, gp, ctx, need_input_grad=True, mask_input=True, wgrad=INLINE_WGRAD):
         """gp: dL/d(pre-activation of out). Returns dL/d(pre-activation of x) (masked by x>0 when
-        mask_input), or None."""
+        mask_input), or None. `wgrad`: where the filter gradients run (inline, or a WgradStream)."""
         x, a1, a2, sc_sub = ctx
-        self.conv3.wgrad(a2, gp)
+        wgrad.run(self.conv3, a2, gp)
         gp2 = self.conv3.dgrad(a2.shape, gp, mask_ref=a2)
-        self.conv2.wgrad(a1, gp2)
+        wgrad.run(self.conv2, a1, gp2)
         gp1 = self.conv2.dgrad(a1.shape, gp2, mask_ref=a1)
-        self.conv1.wgrad(x, gp1)
+        wgrad.run(self.conv1, x, gp1)
         if self.shortcut is not None:
-            self.shortcut.wgrad(x, gp)
+            wgrad.run(self.shortcut, x, gp)
         if not need_input_grad:
             return None
         if self.shortcut is not None:

@@ -781,6 +781,16 @@ def expand_windows(proposals_norm, n_expand=5):
     return out
 
 
+def dedup_windows(windows, capacity, overflow):
+    """windows [B,E,n2,4] -> (rois [B,(E-1)*n2+capacity,4], src_row int32 [B*E*n2]); see mtlssl_dedup_windows."""
+    B, E, n2, _ = windows.shape
+    rois = torch.empty((B, (E - 1) * n2 + capacity, 4), dtype=f32, device=windows.device)
+    src = torch.empty((B * E * n2,), dtype=i32, device=windows.device)
+    lib().dedup_windows(ptr(_chk(windows)), B, E, n2, int(capacity), ptr(rois), ptr(src), ptr(_chk(overflow, i32)),
+                        _stream())
+    return rois, src
+
+
 def refine_concat(cls, win, clo, B, n2, n_expand, global_closeness):
     k1 = cls.shape[-1]
     ld = k1 + (n_expand * k1 if win is not None else 0) + (k1 if clo is not None else 0)

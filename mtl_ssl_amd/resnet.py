@@ -99,11 +99,11 @@ class FasterRCNNResnetV1FeatureExtractor:
             ctxs.append(c)
         return x, ctxs
 
-    def backward_proposal_features(self, gp, ctxs):
+    def backward_proposal_features(self, gp, ctxs, wgrad=nn.INLINE_WGRAD):
         """gp: dL/d(pre-activation of the rpn feature map) (already ReLU-masked)."""
         units = self.trunk.units
         for i in range(len(units) - 1, self.first_trainable - 1, -1):
-            gp = units[i].backward(gp, ctxs[i], need_input_grad=(i > self.first_trainable))
+            gp = units[i].backward(gp, ctxs[i], need_input_grad=(i > self.first_trainable), wgrad=wgrad)
 
     def box_classifier_tower(self, scope, trainable):
         return BoxClassifierTower(self.ps, scope, self.arch, self.cout, trainable and self.is_training,

@@ -335,6 +335,8 @@ def train(create_tensor_dict_fn, create_model_fn, train_config, master="", task=
             total = float(sum(v.item() for v in losses.values()))
             if not (total == total and abs(total) != float("inf")):
                 raise FloatingPointError("LossTensor is inf or nan")     # tf.check_numerics, :207-209
+            if hasattr(model, "check_device_flags"):
+                model.check_device_flags()
             dt = time.time() - t0
             log.append({"step": trainer.global_step, "loss": total, "sec_per_step": dt})
             if is_chief:

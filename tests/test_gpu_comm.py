@@ -98,7 +98,7 @@ def test_trainer_reduces_through_rccl_with_overlap(comm):
     for _ in range(2):
         t1.step(b1)
     torch.cuda.synchronize()
-    assert float((m1.ps.weights - m0.ps.weights).abs().max()) <= 1e-5 * float(m0.ps.weights.abs().max())
+    assert float((m1.ps.weights - m0.ps.weights).abs().max()) <= 1e-4 * float(m0.ps.weights.abs().max())
     s = red.timing_summary(3)
     assert s["bytes_per_step"] == m1.ps.n_train * 4 and s["allreduce_ms_per_step"] > 0
     assert s["exposed_ms_per_step"] >= 0 and s["hidden_ms_per_step"] >= 0

@@ -293,3 +293,36 @@ def test_sample_proposals_vs_oracle(ops):
     np.testing.assert_array_equal(ob.cpu().numpy(), rb)
     np.testing.assert_allclose(on.cpu().numpy(), rb / np.array([600, 1024, 600, 1024], np.float32),
                                rtol=1e-6)
+
+
+def test_dedup_windows_is_an_exact_regrouping():
+    """mtlssl_dedup_windows: windows 0..E-2 pass through, the last group collapses to its distinct boxes
+    (bitwise), src_row expands them back; overflow is flagged."""
+    from mtl_ssl_amd import ops
+    rng = np.random.RandomState(3)
+    B, E, n2, U = 3, 5, 256, 8
+    props = rng.uniform(0, 1, (B, n2, 4)).astype(np.float32)
+    props = np.stack([np.minimum(props[..., 0], props[..., 2]), np.minimum(props[..., 1], props[..., 3]),
+                      np.maximum(props[..., 0], props[..., 2]), np.maximum(props[..., 1], props[..., 3])], -1)
+    props[1, 200:] = 0.0                                                   # padded proposals
+    ew = ops.expand_windows(torch.from_numpy(props).cuda(), E)
+    last = ew[:, E - 1].cpu().numpy()
+    assert np.all(last[..., :2] == 0) and np.all((last[..., 2:] == 1) | (last[..., 2:] == np.nextafter(np.float32(1), np.float32(0))))
+    ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rois, src = ops.dedup_windows(ew, U, ovf)
+    assert rois.shape == (B, (E - 1) * n2 + U, 4) and int(ovf.item()) == 0
+    back = rois.view(-1, 4)[src.long()].view(B, E, n2, 4)
+    assert torch.equal(back, ew)                                           # every window maps to an identical box
+    np.testing.assert_array_equal(rois[:, :(E - 1) * n2].cpu().numpy(), ew[:, :E - 1].reshape(B, -1, 4).cpu().numpy())
+    for b in range(B):                                                     # distinct boxes in first-occurrence order
+        seen = []
+        for bx in last[b]:
+            if not any(np.array_equal(bx.view(np.uint32), s.view(np.uint32)) for s in seen):
+                seen.append(bx)
+        assert 1 <= len(seen) <= 4
+        np.testing.assert_array_equal(rois[b, (E - 1) * n2:(E - 1) * n2 + len(seen)].cpu().numpy(), np.stack(seen))
+    # more distinct boxes than slots -> flagged
+    junk = ew.clone()
+    junk[0, E - 1] = torch.rand(n2, 4, device="cuda")
+    ops.dedup_windows(junk, U, ovf)
+    assert int(ovf.item()) == 1

@@ -266,3 +266,28 @@ def test_step_with_an_image_without_groundtruth_matches_oracle():
             continue
         l2.append(np.linalg.norm((gv - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-12))
     assert max(l2) < 5e-3 and np.median(l2) < 1e-3
+
+
+def test_refiner_window_dedup_matches_the_plain_path():
+    """predict_with_mtl_results with the last expanded window computed once per distinct box
+    (mtlssl_dedup_windows) against the plain one-ROI-per-window path (faster_rcnn_meta_arch.py:764-846)."""
+    model, tr, batch, _ = _setup(True, True, 7, 1)
+    tr.provide(batch)
+    model.step = 0
+    images = model.preprocess(batch["images"])
+    pd = model.predict_for_training(images)
+    slots = model.DEDUP_SLOTS
+    assert slots > 0
+    try:
+        a = model.predict_with_mtl_results(dict(pd))
+        wa, ra = a["expand_window_class_predictions"].clone(), a["mtl_refined_class_predictions_with_background"].clone()
+        type(model).DEDUP_SLOTS = 0
+        b = model.predict_with_mtl_results(dict(pd))
+    finally:
+        type(model).DEDUP_SLOTS = slots
+    torch.cuda.synchronize()
+    model.check_device_flags()
+    # the same arithmetic per ROI; only the launch plan of the tower GEMMs may differ with the ROI count (a split
+    # K loop changes the summation order), hence a rounding-level tolerance instead of torch.equal
+    for x, y in ((wa, b["expand_window_class_predictions"]), (ra, b["mtl_refined_class_predictions_with_background"])):
+        assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max()) + 1e-7
