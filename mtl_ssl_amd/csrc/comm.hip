@@ -174,6 +174,33 @@ int mtlssl_comm_broadcast(mtlssl_comm_t comm, void* buf, int64_t bytes, int root
   return MTLSSL_OK;
 }
 
+// CRC-32C (Castagnoli, reflected 0x82F63B78), slicing-by-8 on the host.
+int64_t mtlssl_crc32c_host(const void* data, int64_t nbytes, int64_t crc_in) {
+  static uint32_t T[8][256];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
+      T[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+  });
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  uint32_t crc = ~(uint32_t)crc_in;
+  while (nbytes >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+    lo ^= crc;
+    crc = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^
+          T[3][hi & 0xFF] ^ T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+    p += 8; nbytes -= 8;
+  }
+  while (nbytes-- > 0) crc = T[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+  return (int64_t)(uint32_t)~crc;
+}
+
 int mtlssl_comm_destroy(mtlssl_comm_t comm) {
   if (!comm) return MTLSSL_OK;
   const Rccl* r = rccl();

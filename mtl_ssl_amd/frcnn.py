@@ -707,7 +707,7 @@ class FasterRCNNMetaArch:
         gpF = self.rpn_conv.dgrad(F.shape, g_rf, out=dF, accum=True, mask_ref=F,
                                   mask6=getattr(self._feature_extractor, "output_relu6", False))
         pd["_gpF"] = gpF
-        if isinstance(self._feature_extractor, FasterRCNNResnetV1FeatureExtractor):
+        if getattr(self._feature_extractor, "supports_wgrad_stream", False):
             self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"], wgrad=wg)
         else:
             self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"])

@@ -28,10 +28,30 @@ for _i in range(256):
 _TABLE = np.array(_TABLE, np.uint32)
 
 
-def crc32c(data):
+_native = None
+
+
+def _native_crc():
+    """mtlssl_crc32c_host of the built library (slicing-by-8 in C); False when the library cannot be loaded —
+    the containers stay readable everywhere, just slowly."""
+    global _native
+    if _native is None:
+        try:
+            from .lib import lib
+            _native = lib().crc32c_host
+        except Exception:
+            _native = False
+    return _native
+
+
+def crc32c(data, pure_python=False):
+    data = bytes(data)
+    fn = None if pure_python else _native_crc()
+    if fn:
+        return int(fn(data, len(data), 0))
     crc = 0xFFFFFFFF
     t = _TABLE
-    for b in bytes(data):
+    for b in data:
         crc = int(t[(crc ^ b) & 0xFF]) ^ (crc >> 8)
     return crc ^ 0xFFFFFFFF
 
@@ -242,22 +262,69 @@ def decode_example(serialized, num_classes):
     return out
 
 
-def batches(paths, num_classes, batch_size, augmentation_options=(), rng=None, loop=False):
-    """core/batcher.py + builders/input_reader_builder.py for a list of TFRecord files: decode,
-    augment (mtl_ssl_amd.preprocessor), group `batch_size` images. Images of one batch must share a
-    size (the model's preprocess resizes a batch as one tensor)."""
+def examples(paths, num_classes, augmentation_options=(), rng=None, loop=False, rank=0, world=1,
+             shuffle_buffer=0):
+    """Decoded + augmented examples of a list of TFRecord files (builders/input_reader_builder.py:34-65:
+    parallel_reader with a shuffling RandomShuffleQueue, then core/preprocessor.preprocess). Data-parallel
+    ranks read disjoint records (record i of the stream goes to rank i % world — the reference's clones each
+    dequeue their own images from one shuffled queue, trainer.py:269-279); `shuffle_buffer` > 0 draws from a
+    buffer of that many pending examples like the reference's min_after_dequeue queue."""
     from . import preprocessor
-    cur = []
+    rng = rng if rng is not None else np.random.RandomState(0)
+    buf, i = [], 0
     while True:
         for p in paths:
             for rec in read_tfrecord(p):
+                mine = (i % world) == rank
+                i += 1
+                if not mine:
+                    continue
                 ex = preprocessor.preprocess(decode_example(rec, num_classes), augmentation_options, rng)
-                cur.append(ex)
-                if len(cur) == batch_size:
-                    yield collate(cur)
-                    cur = []
+                if shuffle_buffer <= 0:
+                    yield ex
+                    continue
+                buf.append(ex)
+                if len(buf) > shuffle_buffer:
+                    j = int(rng.randint(len(buf)))
+                    buf[j], buf[-1] = buf[-1], buf[j]
+                    yield buf.pop()
         if not loop:
-            return
+            break
+    while buf:
+        j = int(rng.randint(len(buf)))
+        buf[j], buf[-1] = buf[-1], buf[j]
+        yield buf.pop()
+
+
+def batches(paths, num_classes, batch_size, augmentation_options=(), rng=None, loop=False, rank=0, world=1,
+            shuffle_buffer=0, resized_shape=None, max_pending=64, drop_remainder=False):
+    """core/batcher.py for a per-GPU batch > 1. The reference gives every clone ONE image at its own shape
+    (batch_size // num_clones, trainer.py:270) and never stacks images; a GPU here takes `batch_size` images
+    per step as one NHWC tensor, so images are grouped by shape: with `resized_shape(h, w) -> (nh, nw)` (the
+    model's image resizer, FasterRCNNMetaArch.resized_shape) every image is resized on the host exactly like
+    the device would (preprocessor.resize_bilinear_legacy) and bucketed by its resized shape; a bucket is
+    emitted when it holds `batch_size` images. Nothing is padded, so every image is computed exactly as the
+    reference computes it. More than `max_pending` waiting images flush the fullest bucket as a smaller
+    batch; what is left at the end of a non-looping stream is emitted too unless `drop_remainder`."""
+    from . import preprocessor
+    buckets, pending = {}, 0
+    for ex in examples(paths, num_classes, augmentation_options, rng, loop, rank, world, shuffle_buffer):
+        if resized_shape is not None:
+            nh, nw = resized_shape(ex["image"].shape[0], ex["image"].shape[1])
+            ex = dict(ex, image=preprocessor.resize_bilinear_legacy(ex["image"], nh, nw))
+        key = ex["image"].shape
+        buckets.setdefault(key, []).append(ex)
+        pending += 1
+        if len(buckets[key]) == batch_size:
+            pending -= batch_size
+            yield collate(buckets.pop(key))
+        elif pending > max_pending:
+            key = max(buckets, key=lambda k: len(buckets[k]))
+            pending -= len(buckets[key])
+            yield collate(buckets.pop(key))
+    if not drop_remainder:
+        for key in sorted(buckets):
+            yield collate(buckets[key])
 
 
 def collate(examples):

@@ -64,3 +64,23 @@ def preprocess(example, data_augmentation_options, rng=None):
             if ex.get("groundtruth_edgemask") is not None:
                 ex["groundtruth_edgemask"] = res[i]
     return ex
+
+
+def resize_bilinear_legacy(image, out_h, out_w):
+    """tf.image.resize_images(image, [out_h, out_w]) as the reference's resizer calls it (bilinear,
+    align_corners=False, TF 1.7: src = dst * in/out without a half-pixel offset, upper neighbour clamped to
+    the edge; core/preprocessor.py:1408-1411) on a host [H,W,C] float32 array — the same arithmetic as the
+    device kernel mtlssl_resize_bilinear_fwd, so a batch can be resized per image on the host and stacked."""
+    x = np.asarray(image, np.float32)
+    H, W = x.shape[0], x.shape[1]
+    if (H, W) == (out_h, out_w):
+        return x
+    ys = np.arange(out_h, dtype=np.float32) * np.float32(H / out_h)
+    xs = np.arange(out_w, dtype=np.float32) * np.float32(W / out_w)
+    y0 = np.floor(ys).astype(np.int64); y1 = np.minimum(y0 + 1, H - 1)
+    x0 = np.floor(xs).astype(np.int64); x1 = np.minimum(x0 + 1, W - 1)
+    yl = (ys - y0.astype(np.float32))[:, None, None]
+    xl = (xs - x0.astype(np.float32))[None, :, None]
+    top = x[y0][:, x0] + (x[y0][:, x1] - x[y0][:, x0]) * xl
+    bot = x[y1][:, x0] + (x[y1][:, x1] - x[y1][:, x0]) * xl
+    return (top + (bot - top) * yl).astype(np.float32)

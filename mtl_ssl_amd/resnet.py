@@ -47,6 +47,7 @@ class BoxClassifierTower:
 
 class FasterRCNNResnetV1FeatureExtractor:
     channel_means = (123.68, 116.779, 103.939)
+    supports_wgrad_stream = True       # backward_proposal_features(..., wgrad=) can run filter gradients on a side stream
 
     def __init__(self, ps, architecture, is_training, first_stage_features_stride=16,
                  weight_decay=0.0, freeze_layer="block1", batch_norm_trainable=False,

@@ -15,3 +15,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_terminal_summary(terminalreporter):
+    from tests import parity_report
+    if parity_report.LINES:
+        terminalreporter.section("observed parity (GPU path vs CPU oracle)")
+        for line in parity_report.LINES:
+            terminalreporter.write_line(line)

@@ -87,3 +87,64 @@ def test_records_to_training_to_detections_to_map(tmp_path):
     res = ev.evaluate()
     assert n_img == 4 and (np.isnan(res["mean_ap"]) or 0.0 <= res["mean_ap"] <= 1.0)
     assert res["ap_per_class"].shape == (K,)
+
+
+def test_mixed_aspect_ratio_records_train_from_a_tensorflow_checkpoint(tmp_path):
+    """Real-data shape of the problem: keep_aspect_ratio_resizer + images of two aspect ratios (and a third raw
+    size that resizes onto one of them), per-GPU batch 2 -> shape-bucketed batches, every image computed at its
+    own size like a clone of the reference would (trainer.py:270); initialisation from a slim classification
+    checkpoint in TensorFlow's V2 container (trainer.py:309-356) incl. the aux towers' copies."""
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import config, input_reader, model_builder, ops, preprocessor, tf_checkpoint, trainer
+    K = 5
+    rng = np.random.RandomState(9)
+    paths = []
+    for j, (n, H, W) in enumerate([(3, 160, 224), (3, 224, 160), (2, 120, 168)]):
+        p = str(tmp_path / ("part%d.record" % j))
+        _write_records(p, n, K, H, W, rng)
+        paths.append(p)
+    cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", "smoke_resnet50_mtl.config")).read())
+    rz = cfg.model.faster_rcnn.image_resizer
+    probe = model_builder.build(cfg.model, True, "cuda", seed=11)
+    fn = lambda h, w: probe.resized_shape(h, w, rz)
+    assert fn(160, 224) == (160, 224) and fn(224, 160) == (224, 160) and fn(120, 168) == (160, 224)
+    # the host-side resize is the device resize: same pixels
+    img = rng.rand(120, 168, 3).astype(np.float32) * 255
+    dev = ops.resize_bilinear_fwd(torch.from_numpy(img)[None].cuda(), 160, 224)[0].cpu().numpy()
+    np.testing.assert_allclose(preprocessor.resize_bilinear_legacy(img, 160, 224), dev, rtol=0, atol=2e-4)
+    # a "classification checkpoint": the probe's trunk + main-tower values under slim's names, V2 container
+    src = {}
+    for sp in probe.ps.specs:
+        for scope in ("FirstStageFeatureExtractor/", "SecondStageFeatureExtractor/"):
+            if sp.name.startswith(scope):
+                src[sp.name[len(scope):]] = probe.ps.value(sp.name).cpu().numpy()
+    ck = str(tmp_path / "resnet_v1_50.ckpt")
+    tf_checkpoint.write_bundle(ck, src)
+    cfg.train_config["fine_tune_checkpoint"] = ck
+    cfg.train_config["from_detection_checkpoint"] = False
+    seen = []
+    stream = input_reader.batches(paths, K, 2, rng=np.random.RandomState(2), loop=True, shuffle_buffer=4, resized_shape=fn)
+
+    def next_batch():
+        b = next(stream)
+        seen.append(tuple(b["images"].shape))
+        b["images"] = b["images"].cuda()
+        return b
+    tr, log = trainer.train(next_batch, lambda: model_builder.build(cfg.model, True, "cuda", seed=1), cfg.train_config,
+                            train_dir=str(tmp_path / "run"), num_steps=8, model_config=cfg.model, log_every=1)
+    assert tr.global_step == 8 and all(np.isfinite(e["loss"]) for e in log)
+    assert {s[1:3] for s in seen} == {(160, 224), (224, 160)}, seen        # both aspect ratios were trained on
+    tr.model.check_device_flags()
+    # the three tower copies all started from the checkpoint's block4 (trainer.py:327-348)
+    fresh = model_builder.build(cfg.model, True, "cuda", seed=1)
+    from mtl_ssl_amd import checkpoint
+    done = checkpoint.init_from_checkpoint(fresh, checkpoint.open_checkpoint(ck), cfg.train_config, cfg.model.mtl)
+    name = "resnet_v1_50/block4/unit_1/bottleneck_v1/conv2/weights"
+    for scope in ("SecondStageFeatureExtractor", "WindowBoxPredictor", "ClosenessBoxPredictor"):
+        assert scope + "/" + name in done
+        np.testing.assert_array_equal(fresh.ps.value(scope + "/" + name).cpu().numpy(), src[name])
+    with pytest.raises(FileNotFoundError):
+        cfg.train_config["fine_tune_checkpoint"] = str(tmp_path / "missing.ckpt")
+        trainer.train(next_batch, lambda: model_builder.build(cfg.model, True, "cuda", seed=1), cfg.train_config,
+                      train_dir=str(tmp_path / "run2"), num_steps=1, model_config=cfg.model)

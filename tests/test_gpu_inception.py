@@ -117,6 +117,8 @@ def test_inception_resnet_v2_step_matches_oracle(stride):
         assert l2 < 5e-3, (name, l2)
         l2errs.append(l2)
     assert len(l2errs) > 700 and np.median(l2errs) < 1e-3
+    from tests import parity_report
+    parity_report.gradients("Faster R-CNN Inception-ResNet-v2 160x224 stride %d" % stride, grads, rgrads, got, ref)
     for _ in range(3):
         tr.step(batch)
     assert np.isfinite(model.ps.weights.sum().item())

@@ -148,6 +148,8 @@ def test_mobilenet_step_matches_oracle():
         assert l2 < 5e-3, (name, l2)
         l2errs.append(l2)
     assert len(l2errs) > 100 and np.median(l2errs) < 1e-3
+    from tests import parity_report
+    parity_report.gradients("Faster R-CNN MobileNet-v1 160x224", grads, rgrads, got, ref)
     assert any("BatchNorm/gamma" in n for n in grads)
     # a few optimizer steps: finite and the refolded normalisers track gamma/beta
     first = tr.step(batch)

@@ -146,6 +146,9 @@ def test_step_losses_and_gradients_match_oracle(refine, aux, crop, pk, conv_algo
         assert l2 < 5e-3, (name, l2)
         l2errs.append(l2)
     assert len(l2errs) > 50 and np.median(l2errs) < 1e-3, np.median(l2errs)
+    from tests import parity_report
+    parity_report.gradients("Faster R-CNN ResNet-50 160x224 refine=%s aux=%s crop=%d conv=%s" % (
+        refine, aux, crop, "winograd" if conv_algorithm == 2 else "direct"), grads, rgrads, got, ref)
     # frozen variables get no gradient slot: conv1 + block1 + every BatchNorm
     assert "FirstStageFeatureExtractor/resnet_v1_50/conv1/weights" not in grads
     assert not any("block1" in n for n in grads)

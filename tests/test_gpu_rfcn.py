@@ -65,11 +65,16 @@ def test_psroi_fwd_bwd_vs_oracle(ops, K):
     assert float((df.cpu() - fr.grad).abs().max() / fr.grad.abs().max()) < 1e-4
 
 
-def test_rfcn_step_matches_oracle():
+@pytest.mark.parametrize("arch", ["faster_rcnn_resnet50", "faster_rcnn_resnet101"])
+def test_rfcn_step_matches_oracle(arch):
+    """configs[2]'s architecture (R-FCN on a ResNet-101 trunk, atrous block4 on the whole map) and its
+    ResNet-50 sibling at an oracle-sized input."""
     import bench
     from mtl_ssl_amd import config, model_builder, rfcn, synthetic, trainer
     from oracle.model import Oracle
-    cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", "smoke_rfcn_resnet50_mtl.config")).read())
+    text = open(os.path.join(ROOT, "configs", "smoke_rfcn_resnet50_mtl.config")).read()
+    assert "faster_rcnn_resnet50" in text
+    cfg = config.parse_pipeline_config(text.replace("faster_rcnn_resnet50", arch))
     model = model_builder.build(cfg.model, True, "cuda", seed=3)
     assert isinstance(model, rfcn.RFCNMetaArch)
     tr = trainer.Trainer(model, cfg.train_config, 1)
@@ -106,6 +111,8 @@ def test_rfcn_step_matches_oracle():
         assert l2 < 5e-3, (name, l2)
         l2errs.append(l2)
     assert len(l2errs) > 60 and np.median(l2errs) < 1e-3
+    from tests import parity_report
+    parity_report.gradients("R-FCN %s 160x224" % arch, grads, rgrads, got, ref)
     # aux gradients are NOT stopped in the R-FCN configs: the trunk sees them
     tr.apply_gradients()
     assert np.isfinite(model.ps.weights.sum().item())

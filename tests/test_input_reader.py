@@ -17,6 +17,8 @@ def test_crc32c_known_answers():
     assert R.crc32c(b"\xff" * 32) == 0x62A8AB43
     assert R.crc32c(bytes(range(32))) == 0x46DD794E
     assert R.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    blob = os.urandom(100003)
+    assert R.crc32c(blob) == R.crc32c(blob, pure_python=True)          # C slicing-by-8 == byte-at-a-time
     c = R.crc32c(b"abc")
     assert R.masked_crc(b"abc") == ((((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF)
 
@@ -106,3 +108,69 @@ def test_decoder_contract_and_batches(tmp_path):
                           "window_classes", "groundtruth_edgemask"}
         for g in b["groundtruth_boxes"]:             # flipped or not, boxes stay normalised and ordered
             assert (g[:, 1] <= g[:, 3]).all() and g.min() >= 0 and g.max() <= 1
+
+
+def _record_with_images(tmp_path, shapes, K=3):
+    recs = []
+    rng = np.random.RandomState(5)
+    for i, (h, w) in enumerate(shapes):
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        recs.append(R.serialize_example({
+            "image/encoded": _png(img), "image/format": b"png", "image/filename": "im%d.png" % i,
+            "image/source_id": str(i),
+            "image/object/bbox/ymin": np.array([0.1], np.float32), "image/object/bbox/xmin": np.array([0.2], np.float32),
+            "image/object/bbox/ymax": np.array([0.6], np.float32), "image/object/bbox/xmax": np.array([0.7], np.float32),
+            "image/object/class/label": np.array([1 + i % K], np.int64)}))
+    p = str(tmp_path / "mixed.record")
+    R.write_tfrecord(p, recs)
+    return p
+
+
+def test_mixed_shape_records_are_bucketed_not_padded(tmp_path):
+    """keep_aspect_ratio_resizer gives images of different aspect ratios different shapes (core/preprocessor.py:
+    1286-1325); a per-GPU batch of 2 therefore groups images by their RESIZED shape — nothing is padded and no
+    image is dropped (the reference gives every clone one image, trainer.py:270)."""
+    from mtl_ssl_amd import config
+    from mtl_ssl_amd.frcnn import FasterRCNNMetaArch
+    shapes = [(30, 40), (40, 30), (60, 80), (30, 40), (45, 60), (40, 30), (33, 47)]      # 4:3, 3:4, one odd ratio
+    p = _record_with_images(tmp_path, shapes)
+    rz = config.parse_pipeline_config(
+        "model { faster_rcnn { image_resizer { keep_aspect_ratio_resizer { min_dimension: 60 max_dimension: 100 } } } }"
+    ).model.faster_rcnn.image_resizer
+    fn = lambda h, w: FasterRCNNMetaArch.resized_shape(h, w, rz)
+    assert fn(30, 40) == (60, 80) and fn(40, 30) == (80, 60) and fn(60, 80) == (60, 80) and fn(45, 60) == (60, 80)
+    bs = list(R.batches([p], 3, 2, resized_shape=fn))
+    got = sorted(tuple(b["images"].shape) for b in bs)
+    assert got == [(1, 60, 85, 3), (2, 60, 80, 3), (2, 60, 80, 3), (2, 80, 60, 3)], got
+    assert sum(b["images"].shape[0] for b in bs) == len(shapes)
+    assert len(list(R.batches([p], 3, 2, resized_shape=fn, drop_remainder=True))) == 3
+    # without a resizer images can only be grouped by their raw shape
+    raw = sorted(tuple(b["images"].shape) for b in R.batches([p], 3, 2))
+    assert raw == [(1, 33, 47, 3), (1, 45, 60, 3), (1, 60, 80, 3), (2, 30, 40, 3), (2, 40, 30, 3)]
+    # a bound on waiting images flushes the fullest bucket early instead of growing without limit
+    many = list(R.batches([p], 3, 4, resized_shape=fn, max_pending=2))
+    assert sum(b["images"].shape[0] for b in many) == len(shapes) and max(b["images"].shape[0] for b in many) <= 3
+
+
+def test_record_sharding_and_shuffle(tmp_path):
+    p = _record_with_images(tmp_path, [(8, 8)] * 10)
+    ids = lambda it: [int(e["source_id"]) for e in it]
+    r0 = ids(R.examples([p], 3, rank=0, world=2))
+    r1 = ids(R.examples([p], 3, rank=1, world=2))
+    assert r0 == [0, 2, 4, 6, 8] and r1 == [1, 3, 5, 7, 9]                    # disjoint, together everything
+    sh = ids(R.examples([p], 3, rng=np.random.RandomState(3), shuffle_buffer=4))
+    assert sorted(sh) == list(range(10)) and sh != list(range(10))
+    assert ids(R.examples([p], 3, rng=np.random.RandomState(3), shuffle_buffer=4)) == sh      # seeded
+
+
+def test_host_resize_matches_the_oracle_restatement():
+    import torch
+    from mtl_ssl_amd import preprocessor
+    from oracle import ops_torch as T
+    rng = np.random.RandomState(0)
+    for (h, w), (oh, ow) in (((12, 16), (60, 80)), ((37, 23), (60, 37)), ((50, 50), (20, 31))):
+        x = rng.rand(h, w, 3).astype(np.float32) * 255
+        got = preprocessor.resize_bilinear_legacy(x, oh, ow)
+        ref = T.resize_bilinear_legacy(torch.from_numpy(x)[None], oh, ow)[0].numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4)
+    assert preprocessor.resize_bilinear_legacy(x, 50, 50) is not None
