@@ -194,48 +194,68 @@ __global__ void k_rpn_decode_score(const float* enc, const float* logits, const 
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(nvalid + b, __popcll(m));
 }
 
-// Stage 2: rank sort by (score desc, index asc) via counting, chunked through LDS.
+// Stage 2: rank sort by (score desc, index asc) via counting, one score chunk per block through LDS.
 // Entries with score == -inf are not candidates. Writes sorted boxes/scores/orig index.
 constexpr int RANK_CHUNK = 4096;
-__global__ void __launch_bounds__(256) k_rank_sort(const float* boxes, const float* scores, int n,
-                                                   float* sboxes, float* sscores, int32_t* sidx) {
-  __shared__ float s_sc[RANK_CHUNK];
-  int b = blockIdx.y;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ int count_ge4(const float4 v, float s) { return (v.x >= s) + (v.y >= s) + (v.z >= s) + (v.w >= s); }
+__device__ __forceinline__ int count_gt4(const float4 v, float s) { return (v.x > s) + (v.y > s) + (v.z > s) + (v.w > s); }
+// 2a: partial ranks. Block (x, y, b) counts, for its 256 candidates, the entries of score chunk y that sort before
+// them and adds the count to rank[] (integer atomics: the sum does not depend on the order). The grid is
+// (n/256) x (n/4096) x batch blocks — the single-pass form (one block per 256 candidates looping over all chunks)
+// left three quarters of the CUs idle on a 14 453-candidate image and was the slowest kernel of the proposal chain.
+__global__ void __launch_bounds__(256) k_rank_partial(const float* scores, int n, int32_t* rank) {
+  __shared__ __attribute__((aligned(16))) float s_sc[RANK_CHUNK];
+  const int b = blockIdx.z, c0 = blockIdx.y * RANK_CHUNK;
   const float* sc = scores + (int64_t)b * n;
-  float si = i < n ? sc[i] : -INFINITY;
-  bool cand = si > -INFINITY;
-  int rank = 0;
-  for (int c0 = 0; c0 < n; c0 += RANK_CHUNK) {
-    int cn = min(RANK_CHUNK, n - c0);
-    __syncthreads();
-    for (int j = threadIdx.x; j < cn; j += blockDim.x) s_sc[j] = sc[c0 + j];
-    __syncthreads();
-    if (cand) {
-      // entries before i win ties, entries after lose them
-      int jsplit = min(max(i - c0, 0), cn);
-      int r = 0;
-      for (int j = 0; j < jsplit; ++j) r += (s_sc[j] >= si);
-      for (int j = jsplit; j < cn; ++j) r += (s_sc[j] > si);
-      rank += r;
-    }
-  }
-  if (cand) {
-    int64_t o = (int64_t)b * n + rank;
-    store_box(sboxes + o * 4, load_box(boxes + ((int64_t)b * n + i) * 4));
-    sscores[o] = si;
-    sidx[o] = i;
-  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float si = i < n ? sc[i] : -INFINITY;
+  const int cn = min(RANK_CHUNK, n - c0);
+  for (int j = threadIdx.x; j < RANK_CHUNK; j += blockDim.x) s_sc[j] = j < cn ? sc[c0 + j] : -INFINITY;
+  __syncthreads();
+  if (!(si > -INFINITY)) return;
+  // entries before i win ties (>=), entries after lose them (>); the quad holding i is done per element.
+  // Slots past cn hold -inf and never count against a candidate (its score is > -inf).
+  const float4* s4 = reinterpret_cast<const float4*>(s_sc);
+  const int js = min(max(i - c0, 0), RANK_CHUNK);
+  const int q_lo = js >> 2, q_hi = (js + 3) >> 2;
+  int r = 0;
+  for (int q = 0; q < q_lo; ++q) r += count_ge4(s4[q], si);
+  for (int j = q_lo * 4; j < min(q_hi * 4, RANK_CHUNK); ++j) r += (j < js) ? (s_sc[j] >= si) : (s_sc[j] > si);
+  for (int q = q_hi; q < RANK_CHUNK / 4; ++q) r += count_gt4(s4[q], si);
+  if (r) atomicAdd(rank + (int64_t)b * n + i, r);
+}
+// 2b: scatter to the sorted position.
+__global__ void __launch_bounds__(256) k_rank_scatter(const float* boxes, const float* scores, const int32_t* rank, int n,
+                                                      float* sboxes, float* sscores, int32_t* sidx) {
+  const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float si = scores[(int64_t)b * n + i];
+  if (!(si > -INFINITY)) return;
+  const int64_t o = (int64_t)b * n + rank[(int64_t)b * n + i];
+  store_box(sboxes + o * 4, load_box(boxes + ((int64_t)b * n + i) * 4));
+  sscores[o] = si;
+  sidx[o] = i;
+}
+// `rank_tmp`: batch*n int32 of scratch (the suppression bit matrix, not yet in use when the sort runs).
+static void rank_sort(const float* boxes, const float* scores, int batch, int n, float* sboxes, float* sscores,
+                      int32_t* sidx, int32_t* rank_tmp, hipStream_t st) {
+  (void)hipMemsetAsync(rank_tmp, 0, sizeof(int32_t) * (size_t)batch * n, st);
+  hipLaunchKernelGGL(k_rank_partial, dim3(cdiv(n, 256), cdiv(n, RANK_CHUNK), batch), dim3(256), 0, st, scores, n, rank_tmp);
+  hipLaunchKernelGGL(k_rank_scatter, dim3(cdiv(n, 256), batch), dim3(256), 0, st, boxes, scores, rank_tmp, n, sboxes,
+                     sscores, sidx);
 }
 
 // Stage 3: suppression bit matrix over the sorted candidates. mask[b][row][colchunk] bit j set
 // iff IoU(row, colchunk*64+j) > thr and col > row.
+// Rows are computed in rounds (row chunks [rc0, rc0 + gridDim.y)): the greedy scan usually has its max_out
+// survivors after the first few thousand candidates, and an image that is done skips the later rounds.
 __global__ void __launch_bounds__(64) k_nms_mask(const float* sboxes, const int32_t* nvalid, int n,
-                                                 int nchunks, float thr,
+                                                 int nchunks, float thr, int rc0, const int32_t* state,
                                                  unsigned long long* mask) {
   int b = blockIdx.z;
+  if (state[b * 2 + 1]) return;                      // image finished in an earlier round
   int nv = nvalid ? min(nvalid[b], n) : n;
-  int rc = blockIdx.y, cc = blockIdx.x;
+  int rc = rc0 + blockIdx.y, cc = blockIdx.x;
   if (cc < rc || rc * 64 >= nv || cc * 64 >= nv) return;
   __shared__ float4 s_col[64];
   const float* bx = sboxes + (int64_t)b * n * 4;
@@ -255,47 +275,62 @@ __global__ void __launch_bounds__(64) k_nms_mask(const float* sboxes, const int3
   mask[((int64_t)b * n + row) * nchunks + cc] = bits;
 }
 
-// Stage 4: greedy scan, one wave per image. Chunk-wise: resolve the 64 candidates of a chunk in
-// registers against the chunk's diagonal block, then OR the selected rows into the running
-// removed-set held in LDS.
-__global__ void __launch_bounds__(64) k_nms_scan(const unsigned long long* mask,
-                                                 const int32_t* nvalid, int n, int nchunks,
-                                                 int max_out, int32_t* sel_rank, int32_t* num_out) {
+// Stage 4: greedy scan, one block per image. Chunk-wise: wave 0 resolves the 64 candidates of a chunk in
+// registers against the chunk's diagonal block (inherently serial), then ALL four waves OR the selected rows
+// into the running removed-set held in LDS (one word per thread: that fold is the bulk of the memory traffic —
+// 300 selected rows x n/64 words).
+constexpr int SCAN_THREADS = 256;
+// One round: chunks [c0, c1). state[b] = {nsel, done}; the removed-set lives in `remv` between rounds.
+__global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(const unsigned long long* mask,
+                                                           const int32_t* nvalid, int n, int nchunks,
+                                                           int max_out, int c0, int c1, int32_t* state,
+                                                           unsigned long long* remv, int32_t* sel_rank,
+                                                           int32_t* num_out) {
   extern __shared__ unsigned long long s_remv[];
-  int b = blockIdx.x;
-  int lane = threadIdx.x;
-  int nv = nvalid ? min(nvalid[b], n) : n;
+  __shared__ unsigned long long s_sel;
+  __shared__ int s_nsel;
+  const int b = blockIdx.x;
+  if (state[b * 2 + 1]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nv = nvalid ? min(nvalid[b], n) : n;
   const unsigned long long* mk = mask + (int64_t)b * n * nchunks;
-  int nch = (nv + 63) / 64;
-  for (int w = lane; w < nch; w += 64) s_remv[w] = 0;
+  unsigned long long* rv = remv + (int64_t)b * nchunks;
+  const int nch = (nv + 63) / 64;
+  int nsel = c0 ? state[b * 2] : 0;
+  for (int w = tid; w < nch; w += SCAN_THREADS) s_remv[w] = c0 ? rv[w] : 0ull;
+  if (tid == 0) s_nsel = nsel;
   __syncthreads();
-  int nsel = 0;
-  for (int c = 0; c < nch && nsel < max_out; ++c) {
-    int row = c * 64 + lane;
-    unsigned long long diag = row < nv ? mk[(int64_t)row * nchunks + c] : 0ull;
-    unsigned long long word = s_remv[c];
-    int ncand = min(64, nv - c * 64);
-    unsigned long long sel = 0;
-    for (int j = 0; j < ncand && nsel < max_out; ++j) {
-      unsigned long long dj = __shfl(diag, j, 64);
-      if (!((word >> j) & 1ull)) {
-        sel |= 1ull << j;
-        word |= dj;
-        ++nsel;
+  const int cend = min(c1, nch);
+  for (int c = c0; c < cend && nsel < max_out; ++c) {
+    if (wave == 0) {
+      int row = c * 64 + lane;
+      unsigned long long diag = row < nv ? mk[(int64_t)row * nchunks + c] : 0ull;
+      unsigned long long word = s_remv[c];
+      int ncand = min(64, nv - c * 64);
+      unsigned long long sel = 0;
+      for (int j = 0; j < ncand && nsel < max_out; ++j) {
+        unsigned long long dj = __shfl(diag, j, 64);
+        if (!((word >> j) & 1ull)) {
+          sel |= 1ull << j;
+          word |= dj;
+          ++nsel;
+        }
       }
+      // record selections (in order)
+      int base = nsel - __popcll(sel);
+      if ((sel >> lane) & 1ull) sel_rank[(int64_t)b * max_out + base + __popcll(sel & ((1ull << lane) - 1))] = row;
+      if (lane == 0) { s_sel = sel; s_nsel = nsel; }
     }
-    // record selections (in order) and fold their rows into the removed set
-    int base = nsel - __popcll(sel);
-    if ((sel >> lane) & 1ull) sel_rank[(int64_t)b * max_out + base + __popcll(sel & ((1ull << lane) - 1))] = row;
+    __syncthreads();
+    const unsigned long long sel = s_sel;
+    nsel = s_nsel;
     if (nsel < max_out) {
-      // fold the selected rows into the removed set: per word, the loads of up to 8 selected rows
-      // are issued together (independent addresses) and OR-ed in registers before the LDS update,
-      // instead of one dependent global load + LDS read-modify-write per row
-      for (int w = c + 1 + lane; w < nch; w += 64) {
+      // fold the selected rows into the removed set: per word, the loads of up to 8 selected rows are issued
+      // together (independent addresses) and OR-ed in registers before the LDS update
+      for (int w = c + 1 + tid; w < nch; w += SCAN_THREADS) {
         unsigned long long rem = sel, accw = 0;
         while (rem) {
           unsigned long long v[8];
-          int cnt = 0;
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             v[u] = 0;
@@ -303,7 +338,6 @@ __global__ void __launch_bounds__(64) k_nms_scan(const unsigned long long* mask,
               int j = __ffsll((long long)rem) - 1;
               rem &= rem - 1;
               v[u] = mk[(int64_t)(c * 64 + j) * nchunks + w];
-              ++cnt;
             }
           }
 #pragma unroll
@@ -314,7 +348,14 @@ __global__ void __launch_bounds__(64) k_nms_scan(const unsigned long long* mask,
     }
     __syncthreads();
   }
-  if (lane == 0) num_out[b] = nsel;
+  const bool done = nsel >= max_out || cend >= nch;
+  if (!done)
+    for (int w = tid; w < nch; w += SCAN_THREADS) rv[w] = s_remv[w];
+  if (tid == 0) {
+    state[b * 2] = nsel;
+    state[b * 2 + 1] = done;
+    if (done) num_out[b] = nsel;
+  }
 }
 
 // Stage 5: emit padded proposals.
@@ -350,6 +391,8 @@ struct NmsWs {
   int32_t* nvalid;
   int32_t* sel_rank;
   unsigned long long* mask;
+  unsigned long long* remv;    // [batch][nchunks] removed-set of the greedy scan between rounds
+  int32_t* state;              // [batch][2] {selected so far, done}
   int nchunks;
 };
 static int64_t nms_ws_layout(int batch, int n, int max_out, char* base, NmsWs* ws) {
@@ -370,17 +413,27 @@ static int64_t nms_ws_layout(int batch, int n, int max_out, char* base, NmsWs* w
   w.nvalid = (int32_t*)take((int64_t)batch * 4);
   w.sel_rank = (int32_t*)take((int64_t)batch * max_out * 4);
   w.mask = (unsigned long long*)take((int64_t)batch * n * nchunks * 8);
+  w.remv = (unsigned long long*)take((int64_t)batch * nchunks * 8);
+  w.state = (int32_t*)take((int64_t)batch * 2 * 4);
   if (ws) *ws = w;
   return off;
 }
 
 static int run_nms_sorted(const NmsWs& w, const int32_t* nvalid, int batch, int n, float thr,
                           int max_out, int32_t* num_out, hipStream_t st) {
-  dim3 g(w.nchunks, w.nchunks, batch);
-  hipLaunchKernelGGL(k_nms_mask, g, dim3(64), 0, st, w.sboxes, nvalid, n, w.nchunks, thr, w.mask);
+  // Rounds of row chunks: 2 048 rows, then 4 096, then the rest. Every round is launched; an image whose scan
+  // has its max_out survivors (or ran out of candidates) makes the later rounds' blocks return at once.
+  (void)hipMemsetAsync(w.state, 0, sizeof(int32_t) * 2 * batch, st);
   size_t lds = (size_t)w.nchunks * 8;
-  hipLaunchKernelGGL(k_nms_scan, dim3(batch), dim3(64), lds, st, w.mask, nvalid, n, w.nchunks,
-                     max_out, w.sel_rank, num_out);
+  const int bounds[] = {0, 32, 96, w.nchunks};
+  for (int r = 0; r < 3; ++r) {
+    const int c0 = bounds[r], c1 = r == 2 ? w.nchunks : (bounds[r + 1] < w.nchunks ? bounds[r + 1] : w.nchunks);
+    if (c0 >= w.nchunks) break;
+    hipLaunchKernelGGL(k_nms_mask, dim3(w.nchunks, c1 - c0, batch), dim3(64), 0, st, w.sboxes, nvalid, n, w.nchunks, thr,
+                       c0, w.state, w.mask);
+    hipLaunchKernelGGL(k_nms_scan, dim3(batch), dim3(SCAN_THREADS), lds, st, w.mask, nvalid, n, w.nchunks, max_out, c0,
+                       c1, w.state, w.remv, w.sel_rank, num_out);
+  }
   return check_launch("nms");
 }
 
@@ -969,8 +1022,7 @@ int mtlssl_rpn_proposals(const float* enc, const float* logits, const float* anc
   dim3 g(cdiv(n, 256), batch);
   hipLaunchKernelGGL(k_rpn_decode_score, g, dim3(256), 0, st, enc, logits, anchors, n, img_h, img_w,
                      score_thresh, w.boxes, w.scores, w.nvalid);
-  hipLaunchKernelGGL(k_rank_sort, g, dim3(256), 0, st, w.boxes, w.scores, n, w.sboxes, w.sscores,
-                     w.sidx);
+  rank_sort(w.boxes, w.scores, batch, n, w.sboxes, w.sscores, w.sidx, reinterpret_cast<int32_t*>(w.mask), st);
   int rc = run_nms_sorted(w, w.nvalid, batch, n, iou_thresh, max_proposals, num_out, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_emit_proposals, dim3(cdiv(max_proposals, 256), batch), dim3(256), 0, st,
@@ -991,8 +1043,7 @@ int mtlssl_nms(const float* boxes, const float* scores, int n, float iou_thresh,
   }
   NmsWs w;
   nms_ws_layout(1, n, 4096, (char*)workspace, &w);
-  hipLaunchKernelGGL(k_rank_sort, dim3(cdiv(n, 256), 1), dim3(256), 0, st, boxes, scores, n,
-                     w.sboxes, w.sscores, w.sidx);
+  rank_sort(boxes, scores, 1, n, w.sboxes, w.sscores, w.sidx, reinterpret_cast<int32_t*>(w.mask), st);
   int rc = run_nms_sorted(w, nullptr, 1, n, iou_thresh, max_out, num_out, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_emit_selected, dim3(cdiv(max_out, 256)), dim3(256), 0, st, w.sidx,
@@ -1056,8 +1107,7 @@ int mtlssl_batch_multiclass_nms(const float* boxes, const float* scores, int sco
   hipLaunchKernelGGL(k_mc_prepare, dim3(cdiv(n, 256), BC), dim3(256), 0, st, boxes, scores, scores_ld, num_valid,
                      n, q, num_classes, score_thresh, clip_window != nullptr, win[0], win[1], win[2], win[3],
                      change_coordinate_frame, w.boxes, w.scores, w.nvalid);
-  hipLaunchKernelGGL(k_rank_sort, dim3(cdiv(n, 256), BC), dim3(256), 0, st, w.boxes, w.scores, n, w.sboxes,
-                     w.sscores, w.sidx);
+  rank_sort(w.boxes, w.scores, BC, n, w.sboxes, w.sscores, w.sidx, reinterpret_cast<int32_t*>(w.mask), st);
   if (int rc = run_nms_sorted(w, w.nvalid, BC, n, iou_thresh, mpc, nsel, st)) return rc;
   hipLaunchKernelGGL(k_mc_merge, dim3(batch), dim3(256), 0, st, w.sboxes, w.sscores, w.sel_rank, nsel, n,
                      num_classes, mpc, max_total, cand_score, cand_src, boxes_out, scores_out, classes_out,
