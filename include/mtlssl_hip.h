@@ -69,6 +69,29 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
 int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float* w,
                         const float* residual, const float* mask_ref, float* dx, int epilogue,
                         void* workspace, mtlssl_stream_t stream);
+/* Transformed-filter cache of the Winograd layers (3x3 / stride 1, see mtlssl_conv2d_tile_config): the filter
+ * transform U = G g G^T depends on the weights only, which change once per optimizer step, while a layer is
+ * convolved several times per step (forward, the refiner's second forward, dgrad). A caller may keep U:
+ *   bytes   = mtlssl_conv2d_filter_xf_bytes(d, mode)      0 when the planned algorithm of (d, mode) is direct
+ *   variant = mtlssl_conv2d_filter_xf_variant(d, mode)    the Winograd variant planned (0 F(4x4,3x3), 1 whole-7-span), -1 direct
+ *   mtlssl_conv2d_transform_filter(d, mode, variant, w, filter_xf, stream)   mode 0 forward form, 1 dgrad (flipped) form
+ * and hand it to the _xf entry points below together with the variant it was made for; a cache made for another
+ * variant than the call's plan (or a null one) is ignored and the call transforms the filter itself.
+ * mtlssl_conv2d_fwd / _dgrad are the _xf forms without a cache. */
+int64_t mtlssl_conv2d_filter_xf_bytes(const mtlssl_conv_desc* d, int mode);
+int mtlssl_conv2d_filter_xf_variant(const mtlssl_conv_desc* d, int mode);
+int mtlssl_conv2d_transform_filter(const mtlssl_conv_desc* d, int mode, int variant, const float* w, float* filter_xf,
+                                   mtlssl_stream_t stream);
+/* The same for n filters of one variant in ONE launch, from device tables: w_ptrs / xf_ptrs (n device pointers
+ * each), ck (n x int64: C*K of each filter), flip (n x int32: 1 = dgrad form); max_ck = largest C*K. */
+int mtlssl_conv2d_transform_filters(int variant, int n, const void* w_ptrs, const void* xf_ptrs, const int64_t* ck,
+                                    const int32_t* flip, int64_t max_ck, mtlssl_stream_t stream);
+int mtlssl_conv2d_fwd_xf(const mtlssl_conv_desc* d, const float* x, const float* w, const float* bias,
+                         const float* residual, float* y, int epilogue, void* workspace, const float* filter_xf,
+                         int xf_variant, mtlssl_stream_t stream);
+int mtlssl_conv2d_dgrad_xf(const mtlssl_conv_desc* d, const float* dy, const float* w, const float* residual,
+                           const float* mask_ref, float* dx, int epilogue, void* workspace, const float* filter_xf,
+                           int xf_variant, mtlssl_stream_t stream);
 /* dw[r,s,c,k] (beta=0: overwrite, beta=1: accumulate) = sum_pixels x*dy, optionally scaled
  * per output channel by out_scale[k] (frozen-BN fold) and dbias[k] = sum dy (nullable).
  * workspace: mtlssl_conv2d_wgrad_workspace_bytes(d) bytes. */

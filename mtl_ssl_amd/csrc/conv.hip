@@ -959,9 +959,45 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
   return pl.nsplit > 1 ? align_up(M * NG * 4 * pl.nsplit, 256) : 0;
 }
 
+int64_t mtlssl_conv2d_filter_xf_bytes(const mtlssl_conv_desc* d, int mode) {
+  if (!d || (mode != MODE_FWD && mode != MODE_DGRAD) || check_desc(d)) return 0;
+  WinoChoice wc;
+  return choose_wino(d, mode, &wc) ? wino_filter_bytes(d, wc.variant) : 0;
+}
+int mtlssl_conv2d_filter_xf_variant(const mtlssl_conv_desc* d, int mode) {
+  WinoChoice wc;
+  if (!d || (mode != MODE_FWD && mode != MODE_DGRAD) || check_desc(d) || !choose_wino(d, mode, &wc)) return -1;
+  return wc.variant;
+}
+int mtlssl_conv2d_transform_filter(const mtlssl_conv_desc* d, int mode, int variant, const float* w, float* filter_xf,
+                                   mtlssl_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  MTLSSL_REQUIRE(mode == MODE_FWD || mode == MODE_DGRAD, "transform_filter: mode %d", mode);
+  MTLSSL_REQUIRE(variant >= 0 && variant < WINO_VARIANTS && wino_eligible(d, variant),
+                 "transform_filter: variant %d is not applicable to this problem", variant);
+  MTLSSL_REQUIRE(w && filter_xf, "transform_filter: null pointer");
+  wino_filter(d, variant, mode == MODE_DGRAD, w, filter_xf, S(stream));
+  return check_launch("conv2d_transform_filter");
+}
+
+int mtlssl_conv2d_transform_filters(int variant, int n, const void* w_ptrs, const void* xf_ptrs, const int64_t* ck,
+                                    const int32_t* flip, int64_t max_ck, mtlssl_stream_t stream) {
+  if (n <= 0) return MTLSSL_OK;
+  MTLSSL_REQUIRE(variant >= 0 && variant < WINO_VARIANTS, "transform_filters: variant %d", variant);
+  MTLSSL_REQUIRE(w_ptrs && xf_ptrs && ck && flip && max_ck > 0 && n <= 65535, "transform_filters: bad table");
+  wino_filters_batched(variant, n, w_ptrs, xf_ptrs, ck, flip, max_ck, S(stream));
+  return check_launch("conv2d_transform_filters");
+}
+
 int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w, const float* bias,
                       const float* residual, float* y, int epi, void* workspace,
                       mtlssl_stream_t stream) {
+  return mtlssl_conv2d_fwd_xf(d, x, w, bias, residual, y, epi, workspace, nullptr, -1, stream);
+}
+
+int mtlssl_conv2d_fwd_xf(const mtlssl_conv_desc* d, const float* x, const float* w, const float* bias,
+                         const float* residual, float* y, int epi, void* workspace, const float* filter_xf,
+                         int xf_variant, mtlssl_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_BIAS) || bias, "conv_fwd: bias pointer required");
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_fwd: residual pointer required");
@@ -973,7 +1009,8 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
   p.NG = d->K;
   WinoChoice wc;
   if (workspace && choose_wino(d, MODE_FWD, &wc)) {
-    wino_fwd(d, wc.variant, wc.tile, x, w, bias, residual, y, epi, workspace, S(stream));
+    wino_fwd(d, wc.variant, wc.tile, x, w, bias, residual, y, epi, workspace, S(stream),
+             (filter_xf && xf_variant == wc.variant) ? filter_xf : nullptr);
   } else if (mfma_fwd_ok(d)) {
     Plan pl = plan_dir(d, MODE_FWD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
@@ -995,6 +1032,12 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
 int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float* w,
                         const float* residual, const float* mask_ref, float* dx, int epi,
                         void* workspace, mtlssl_stream_t stream) {
+  return mtlssl_conv2d_dgrad_xf(d, dy, w, residual, mask_ref, dx, epi, workspace, nullptr, -1, stream);
+}
+
+int mtlssl_conv2d_dgrad_xf(const mtlssl_conv_desc* d, const float* dy, const float* w,
+                           const float* residual, const float* mask_ref, float* dx, int epi,
+                           void* workspace, const float* filter_xf, int xf_variant, mtlssl_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   MTLSSL_REQUIRE(!(epi & MASK_ANY) || mask_ref, "conv_dgrad: mask_ref pointer required");
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_dgrad: residual pointer required");
@@ -1006,7 +1049,8 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
   p.NG = d->C;
   WinoChoice wc;
   if (workspace && choose_wino(d, MODE_DGRAD, &wc)) {
-    wino_dgrad(d, wc.variant, wc.tile, dy, w, residual, mask_ref, dx, epi, workspace, S(stream));
+    wino_dgrad(d, wc.variant, wc.tile, dy, w, residual, mask_ref, dx, epi, workspace, S(stream),
+               (filter_xf && xf_variant == wc.variant) ? filter_xf : nullptr);
   } else if (workspace && parity_ok(d)) {
     parity_dgrad(d, dy, w, residual, mask_ref, dx, epi, workspace, S(stream));
   } else if (mfma_dgrad_ok(d)) {

@@ -869,10 +869,16 @@ enum { WINO_F43 = 0, WINO_M7 = 1, WINO_VARIANTS = 2 };
 bool wino_eligible(const mtlssl_conv_desc* d, int variant);
 double wino_time_us(const mtlssl_conv_desc* d, int variant, int mode, int* tile);
 int64_t wino_workspace_bytes(const mtlssl_conv_desc* d, int variant, int mode);
+// filter_xf: the layer's transformed filter if the caller keeps it (wino_filter), else nullptr
 void wino_fwd(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* w, const float* bias,
-              const float* residual, float* y, int epi, void* workspace, hipStream_t st);
+              const float* residual, float* y, int epi, void* workspace, hipStream_t st, const float* filter_xf = nullptr);
 void wino_dgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* dy, const float* w,
-                const float* residual, const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st);
+                const float* residual, const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st,
+                const float* filter_xf = nullptr);
+int64_t wino_filter_bytes(const mtlssl_conv_desc* d, int variant);
+void wino_filter(const mtlssl_conv_desc* d, int variant, int flip, const float* w, float* U, hipStream_t st);
+void wino_filters_batched(int variant, int n, const void* w_ptrs, const void* u_ptrs, const int64_t* ck,
+                          const int32_t* flip, int64_t max_ck, hipStream_t st);
 void wino_wgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* dy,
                 const float* out_scale, float* dw, float beta, void* workspace, hipStream_t st);
 

@@ -145,10 +145,8 @@ __device__ __forceinline__ floatx4 mask_bwd(floatx4 g, floatx4 y, int epi) {
 // Filter transform U[xi][c][k] = (G g G^T)[xi] of w[r][s][c][k]; flip = 1 takes g[2-r][2-s] (the
 // dgrad filter; its [C][K] layout is what the tile engine's dgrad mode reads as B[n][k]).
 template <typename S, typename VT>
-__global__ void __launch_bounds__(256) k_wino_filter(const float* w, float* U, int64_t CK, int flip) {
+__device__ __forceinline__ void wino_filter_one(const float* w, float* U, int64_t CK, int flip, int64_t i) {
   constexpr int P = S::P;
-  int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * (sizeof(VT) / 4);
-  if (i >= CK) return;
   VT t[P][3];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {           // columns: t = G g
@@ -169,6 +167,23 @@ __global__ void __launch_bounds__(256) k_wino_filter(const float* w, float* U, i
 #pragma unroll
     for (int b = 0; b < P; ++b) *reinterpret_cast<VT*>(U + (int64_t)(a * P + b) * CK + i) = o[b];
   }
+}
+template <typename S, typename VT>
+__global__ void __launch_bounds__(256) k_wino_filter(const float* w, float* U, int64_t CK, int flip) {
+  int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * (sizeof(VT) / 4);
+  if (i >= CK) return;
+  wino_filter_one<S, VT>(w, U, CK, flip, i);
+}
+// All the filters of a model in one launch (blockIdx.y = layer): the weights change once per optimizer step, so
+// every transformed filter of the coming step is made here, from device tables of pointers (cf. k_fold_scales).
+template <typename S>
+__global__ void __launch_bounds__(256) k_wino_filter_batched(const float* const* w, float* const* U, const int64_t* CK,
+                                                             const int32_t* flip) {
+  const int l = blockIdx.y;
+  const int64_t ck = CK[l];
+  int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i >= ck) return;
+  wino_filter_one<S, float>(w[l], U[l], ck, flip[l], i);
 }
 
 // Input transform V[xi][t][c] = (B^T d B)[xi] of the I x I patch of tile t (origin O*ty-1, O*tx-1,
@@ -514,14 +529,15 @@ int64_t workspace_bytes(const mtlssl_conv_desc* d, int mode) {
 
 template <typename S>
 void fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* w, const float* bias,
-         const float* residual, float* y, int epi, void* workspace, hipStream_t st) {
+         const float* residual, float* y, int epi, void* workspace, hipStream_t st, const float* U_pre = nullptr) {
   constexpr int PL = S::P * S::P;
   WinoGeom g = geom<S>(d);
   const int64_t CK = (int64_t)d->C * d->K;
   float* U = (float*)workspace;
   float* V = (float*)((char*)U + align_up(PL * CK * 4, 256));
   float* Mb = (float*)((char*)V + align_up((int64_t)PL * g.T * d->C * 4, 256));
-  run_filter<S>(w, U, CK, 0, st);
+  if (U_pre) U = const_cast<float*>(U_pre);       // transformed once per optimizer step by the caller
+  else run_filter<S>(w, U, CK, 0, st);
   run_input<S>(x, V, g, d->C, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = U; p.out = Mb;
@@ -534,14 +550,15 @@ void fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* w, co
 
 template <typename S>
 void dgrad(const mtlssl_conv_desc* d, int tile, const float* dy, const float* w, const float* residual,
-           const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st) {
+           const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st, const float* U_pre = nullptr) {
   constexpr int PL = S::P * S::P;
   WinoGeom g = geom<S>(d);
   const int64_t CK = (int64_t)d->C * d->K;
   float* U = (float*)workspace;
   float* V = (float*)((char*)U + align_up(PL * CK * 4, 256));                     // transformed dy [P^2][T][K]
   float* Mb = (float*)((char*)V + align_up((int64_t)PL * g.T * d->K * 4, 256));   // [P^2][T][C]
-  run_filter<S>(w, U, CK, 1, st);
+  if (U_pre) U = const_cast<float*>(U_pre);
+  else run_filter<S>(w, U, CK, 1, st);
   run_input<S>(dy, V, g, d->K, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = U; p.out = Mb;
@@ -587,14 +604,36 @@ int64_t wino_workspace_bytes(const mtlssl_conv_desc* d, int variant, int mode) {
   return variant == WINO_M7 ? workspace_bytes<M7>(d, mode) : workspace_bytes<F43>(d, mode);
 }
 void wino_fwd(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* w, const float* bias,
-              const float* residual, float* y, int epi, void* workspace, hipStream_t st) {
-  if (variant == WINO_M7) fwd<M7>(d, tile, x, w, bias, residual, y, epi, workspace, st);
-  else fwd<F43>(d, tile, x, w, bias, residual, y, epi, workspace, st);
+              const float* residual, float* y, int epi, void* workspace, hipStream_t st, const float* filter_xf) {
+  if (variant == WINO_M7) fwd<M7>(d, tile, x, w, bias, residual, y, epi, workspace, st, filter_xf);
+  else fwd<F43>(d, tile, x, w, bias, residual, y, epi, workspace, st, filter_xf);
 }
 void wino_dgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* dy, const float* w,
-                const float* residual, const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st) {
-  if (variant == WINO_M7) dgrad<M7>(d, tile, dy, w, residual, mask_ref, dx, epi, workspace, st);
-  else dgrad<F43>(d, tile, dy, w, residual, mask_ref, dx, epi, workspace, st);
+                const float* residual, const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st,
+                const float* filter_xf) {
+  if (variant == WINO_M7) dgrad<M7>(d, tile, dy, w, residual, mask_ref, dx, epi, workspace, st, filter_xf);
+  else dgrad<F43>(d, tile, dy, w, residual, mask_ref, dx, epi, workspace, st, filter_xf);
+}
+// The transformed filter U = G g G^T of one layer ([P^2][C][K]; `flip`: the dgrad form) on its own, so that a
+// caller can compute it once per optimizer step instead of once per convolution call.
+int64_t wino_filter_bytes(const mtlssl_conv_desc* d, int variant) {
+  const int64_t pl = variant == WINO_M7 ? M7::P * M7::P : F43::P * F43::P;
+  return align_up(pl * (int64_t)d->C * d->K * 4, 256);
+}
+void wino_filters_batched(int variant, int n, const void* w_ptrs, const void* u_ptrs, const int64_t* ck,
+                          const int32_t* flip, int64_t max_ck, hipStream_t st) {
+  dim3 grid((unsigned)cdiv(max_ck, 256), n);
+  if (variant == WINO_M7)
+    hipLaunchKernelGGL((k_wino_filter_batched<M7>), grid, dim3(256), 0, st, (const float* const*)w_ptrs,
+                       (float* const*)u_ptrs, ck, flip);
+  else
+    hipLaunchKernelGGL((k_wino_filter_batched<F43>), grid, dim3(256), 0, st, (const float* const*)w_ptrs,
+                       (float* const*)u_ptrs, ck, flip);
+}
+void wino_filter(const mtlssl_conv_desc* d, int variant, int flip, const float* w, float* U, hipStream_t st) {
+  const int64_t CK = (int64_t)d->C * d->K;
+  if (variant == WINO_M7) run_filter<M7>(w, U, CK, flip, st);
+  else run_filter<F43>(w, U, CK, flip, st);
 }
 void wino_wgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* dy,
                 const float* out_scale, float* dw, float beta, void* workspace, hipStream_t st) {

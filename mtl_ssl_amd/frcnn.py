@@ -215,6 +215,11 @@ class FasterRCNNMetaArch:
             l.prepare()
         self._bn_table = None          # the layers' scale / shift tensors were re-created
         ops.fold_scales(self.ps)
+        # transformed filters of the Winograd layers are kept per optimizer step (ops.FilterXfCache); the frozen
+        # layers' shadow filters were just re-created, so start from an empty cache
+        import os
+        on = self.ps.device.type == "cuda" and os.environ.get("MTLSSL_FILTER_CACHE", "1") != "0"
+        self.ps.filter_cache = ops.FilterXfCache() if on else None
 
     def refold(self):
         """After an optimizer step: ONE batched refresh of the normaliser constants of the layers whose
@@ -229,6 +234,10 @@ class FasterRCNNMetaArch:
                 if getattr(l, "trainable", False):
                     l.refold()
         ops.fold_scales(self.ps)
+        if self.ps.filter_cache is not None:
+            # all filter transforms of the coming step, off the critical path: on the auxiliary stream (idle between
+            # steps), behind the fold; the first consumer on each stream waits for the event
+            self.ps.filter_cache.refresh(self._aux_stream())
 
     @staticmethod
     def resized_shape(height, width, resizer):
@@ -538,17 +547,35 @@ class FasterRCNNMetaArch:
         return {"detection_boxes": ob, "detection_scores": os_, "detection_classes": oc, "num_detections": on}
 
     # ------------------------------------------------------------------ loss (+ d/d predictions)
-    def loss(self, pd, loss_scale=1.0):
+    def loss(self, pd, loss_scale=1.0, part="all"):
         """faster_rcnn_meta_arch.py:1514-1589. Returns {name: 1-element device tensor}; the
         gradients w.r.t. the prediction tensors are stored in pd['_d'] for backward().
         loss_scale multiplies every gradient (1/world_size for data parallelism,
-        slim/deployment/model_deploy.py:221-223) but not the reported loss values."""
+        slim/deployment/model_deploy.py:221-223) but not the reported loss values.
+        part: "all", or the two halves a trainer may schedule apart — "early" = every term that does not need the
+        refiner's output (a chain of small latency-bound kernels that can run on a side stream under the refiner's
+        tower forward), then "late" = the refined-classification term (after predict_with_mtl_results)."""
         c, mtl = self.cfg, self._mtl
         B, H, W, _ = pd["image_shape"]
         gt = self._format_groundtruth_data(H, W)
         dev = self.ps.device
-        losses, d = {}, {}
         g = float(loss_scale)
+        if part == "late":
+            losses, d = pd["_losses_early"], pd["_d"]
+            dt, cls_s = pd["_det_targets"], pd["_cls_s"]
+            cls_targets = dt["cls_targets"].view(B * self.max_num_proposals, self.num_classes + 1)
+            if mtl.refine:
+                rs = cls_s if c.second_stage_classification_loss_weight == mtl.refined_classification_loss_weight \
+                    else ops.detector_loss_scales(dt["cls_weights"], dt["reg_weights"], pd["num_proposals"], None,
+                                                  mtl.refined_classification_loss_weight, 0.0, 0.0)[0]
+                rl, d_ref = ops.softmax_ce(pd["mtl_refined_class_predictions_with_background"], cls_targets,
+                                           rs.view(-1))
+                losses["refined_classification_loss"] = ops.reduce_sum(rl)
+                if g != 1.0:
+                    ops.axpby(d_ref, d_ref, g, 0.0)
+                d["refined_class_predictions"] = d_ref
+            return losses
+        losses, d = {}, {}
         # ---- _loss_rpn :1591-1668
         anchors = pd["anchors"]
         n = anchors.shape[0]
@@ -610,6 +637,12 @@ class FasterRCNNMetaArch:
             rl, d_pr = ops.softmax_ce(pr, tgt, sc.view(-1))
             losses["edgemask_loss"] = ops.reduce_sum(rl)
             d["edgemask_resized"] = d_pr
+        if part == "early":
+            if g != 1.0:
+                for k in d:
+                    ops.axpby(d[k], d[k], g, 0.0)
+            pd["_d"], pd["_losses_early"], pd["_cls_s"] = d, losses, cls_s
+            return losses
         # ---- _loss_refined_classifier :1795-1837
         if mtl.refine:
             rs = cls_s if c.second_stage_classification_loss_weight == mtl.refined_classification_loss_weight \

@@ -122,7 +122,8 @@ class ConvBN:
         act = self.act if relu is None else ("relu" if relu else None)
         epi = ops.EPI_BIAS | {None: 0, "relu": ops.EPI_RELU, "relu6": ops.EPI_RELU6}[act] \
             | (ops.EPI_RESIDUAL if residual is not None else 0)
-        return ops.conv2d_fwd(self.desc(x.shape), x, self.w_eff, self.shift, residual, epi)
+        return ops.conv2d_fwd(self.desc(x.shape), x, self.w_eff, self.shift, residual, epi,
+                              xf_cache=self.ps.filter_cache)
 
     def wgrad(self, x, g):
         if self.trainable:
@@ -135,7 +136,8 @@ class ConvBN:
     def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False, mask6=False):
         epi = ((ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_ACCUM if accum else 0)
                | ((ops.EPI_MASK6 if mask6 else ops.EPI_MASK) if mask_ref is not None else 0))
-        return ops.conv2d_dgrad(self.desc(x_shape), g, self.w_eff, residual, mask_ref, epi, out=out)
+        return ops.conv2d_dgrad(self.desc(x_shape), g, self.w_eff, residual, mask_ref, epi, out=out,
+                                xf_cache=self.ps.filter_cache)
 
 
 class DepthwiseBN:
@@ -231,7 +233,8 @@ class Conv:
         """x: NHWC, or [rows, cin] for fc=True (treated as rows x 1 x 1 x cin)."""
         x4 = x.view(x.shape[0], 1, 1, self.cin) if self.fc else x
         epi = ops.EPI_BIAS | {None: 0, "relu": ops.EPI_RELU, "tanh": ops.EPI_TANH}[self.activation]
-        y = ops.conv2d_fwd(self.desc(x4.shape), x4, self._w4(), self.ps.value(self.b.name), None, epi)
+        y = ops.conv2d_fwd(self.desc(x4.shape), x4, self._w4(), self.ps.value(self.b.name), None, epi,
+                           xf_cache=self.ps.filter_cache)
         return y.view(x.shape[0], self.cout) if self.fc else y
 
     def wgrad(self, x, g):
@@ -249,7 +252,8 @@ class Conv:
         g4 = g.view(g.shape[0], 1, 1, self.cout) if self.fc else g
         epi = ((ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_ACCUM if accum else 0)
                | ((ops.EPI_MASK6 if mask6 else ops.EPI_MASK) if mask_ref is not None else 0))
-        dx = ops.conv2d_dgrad(self.desc(x4s), g4, self._w4(), residual, mask_ref, epi, out=out)
+        dx = ops.conv2d_dgrad(self.desc(x4s), g4, self._w4(), residual, mask_ref, epi, out=out,
+                              xf_cache=self.ps.filter_cache)
         return dx.view(x_shape) if self.fc else dx
 
 

@@ -214,7 +214,73 @@ def _autotune(d, mode, run):
     _tuned[key] = (default, best, times)
 
 
-def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None):
+class FilterXfCache:
+    """Transformed filters (U = G g G^T) of a model's Winograd layers, kept across the convolution calls of a step
+    and refreshed once per optimizer step (`refresh`, from the model's refold) instead of being recomputed by
+    every forward / dgrad call — the weights only change in the optimizer. Only layers whose weight tensors
+    persist and change nowhere else may use it (nn.ConvBN / nn.Conv pass it; ad-hoc tensors never do).
+    Entries are keyed by (weight storage, filter shape, mode, Winograd variant). A refresh may run on a side
+    stream: consumers wait for its event the first time they touch an entry on a given stream."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, d, mode, w):
+        """-> (U tensor or None, variant) for a forward (mode 0) / dgrad (mode 1) call of `d` with filter `w`."""
+        variant = lib().conv2d_filter_xf_variant(ctypes.byref(d), mode)
+        if variant < 0:
+            return None, -1
+        key = (w.data_ptr(), d.C, d.K, mode, variant)
+        cur = torch.cuda.current_stream()
+        e = self.entries.get(key)
+        if e is None:
+            nbytes = lib().conv2d_filter_xf_bytes(ctypes.byref(d), mode)
+            e = {"U": torch.empty(int(nbytes) // 4, dtype=f32, device=w.device), "d": d, "mode": mode, "variant": variant,
+                 "w": w, "event": torch.cuda.Event(), "waited": {cur.cuda_stream}}
+            lib().conv2d_transform_filter(ctypes.byref(d), mode, variant, ptr(_chk(w)), ptr(e["U"]), cur.cuda_stream)
+            e["event"].record(cur)
+            self.entries[key] = e
+        elif cur.cuda_stream not in e["waited"]:
+            cur.wait_event(e["event"])
+            e["waited"].add(cur.cuda_stream)
+        return e["U"], variant
+
+    def _tables(self):
+        """Device pointer tables per Winograd variant, rebuilt only when the set of entries changed."""
+        if getattr(self, "_tab_n", -1) != len(self.entries):
+            self._tab = {}
+            for variant in sorted({e["variant"] for e in self.entries.values()}):
+                es = [e for e in self.entries.values() if e["variant"] == variant]
+                dev = es[0]["U"].device
+                self._tab[variant] = dict(
+                    n=len(es), max_ck=max(e["d"].C * e["d"].K for e in es),
+                    w=torch.tensor([e["w"].data_ptr() for e in es], dtype=torch.int64, device=dev),
+                    u=torch.tensor([e["U"].data_ptr() for e in es], dtype=torch.int64, device=dev),
+                    ck=torch.tensor([e["d"].C * e["d"].K for e in es], dtype=torch.int64, device=dev),
+                    flip=torch.tensor([int(e["mode"] == 1) for e in es], dtype=i32, device=dev))
+            self._tab_n = len(self.entries)
+        return self._tab
+
+    def refresh(self, stream=None):
+        """Recompute every entry from the current weights in one launch per Winograd variant — on `stream` (behind
+        everything enqueued on the current stream so far) or on the current stream."""
+        if not self.entries:
+            return
+        cur = torch.cuda.current_stream()
+        run_on = stream if stream is not None else cur
+        tabs = self._tables()          # (host->device copies of a rebuild happen before the fork below)
+        if stream is not None:
+            stream.wait_stream(cur)
+        for variant, t in tabs.items():
+            lib().conv2d_transform_filters(variant, t["n"], ptr(t["w"]), ptr(t["u"]), ptr(t["ck"]), ptr(t["flip"]),
+                                           t["max_ck"], run_on.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(run_on)
+        for e in self.entries.values():
+            e["event"], e["waited"] = ev, {run_on.cuda_stream}
+
+
+def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None, xf_cache=None):
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
     if PROFILER is None:
         def run():
@@ -226,14 +292,15 @@ def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None):
     t0 = PROFILER.begin(d, 0) if PROFILER is not None else None
     nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 0)
     ws = workspace(nb, "splitk", x.device) if nb else None
-    lib().conv2d_fwd(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(residual),
-                     ptr(y), epilogue, ptr(ws), _stream())
+    U, variant = xf_cache.get(d, 0, w) if (xf_cache is not None and d.R == 3 and d.S == 3) else (None, -1)
+    lib().conv2d_fwd_xf(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(residual),
+                        ptr(y), epilogue, ptr(ws), ptr(U), variant, _stream())
     if t0 is not None:
         PROFILER.end(d, 0, t0)
     return y
 
 
-def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None):
+def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None, xf_cache=None):
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=f32, device=dy.device)
     if PROFILER is None:
         def run():                                    # scratch output; no accumulate into it
@@ -246,8 +313,9 @@ def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None):
     t0 = PROFILER.begin(d, 1) if PROFILER is not None else None
     nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 1)
     ws = workspace(nb, "splitk", dy.device) if nb else None
-    lib().conv2d_dgrad(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref),
-                       ptr(dx), epilogue, ptr(ws), _stream())
+    U, variant = xf_cache.get(d, 1, w) if (xf_cache is not None and d.R == 3 and d.S == 3) else (None, -1)
+    lib().conv2d_dgrad_xf(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref),
+                          ptr(dx), epilogue, ptr(ws), ptr(U), variant, _stream())
     if t0 is not None:
         PROFILER.end(d, 1, t0)
     return dx

@@ -118,6 +118,7 @@ class ParamStore:
         # residual scales), refreshed by ONE launch after each optimizer step (ops.fold_scales)
         self.eff = None
         self._fold_refs = {}
+        self.filter_cache = None         # ops.FilterXfCache of the model that owns the store (set by the model)
         self.grad_ready_hook = None      # set by trainer.GradientReducer: called once per variable per step
         self.finalized = True
         return self

@@ -201,6 +201,8 @@ class Trainer:
         self.var_wd = (torch.tensor(wd, dtype=torch.float32, device=self.ps.device)
                        if any(w != 0.0 for w in wd) else None)
         self.var_mult = gradient_multipliers(self.ps, train_config)
+        import os
+        self.split_loss = os.environ.get("MTLSSL_SPLIT_LOSS", "1") != "0" and self.ps.device.type == "cuda"
         # builders/optimizer_builder.py:105-111: tf.contrib.opt.MovingAverageOptimizer keeps an exponential
         # moving average of every variable beside it (the trainer's plain Saver stores both); decay as given.
         self.ema = None
@@ -252,9 +254,21 @@ class Trainer:
         images = m.preprocess(batch["images"])
         pd = m.predict_for_training(images)       # predict + predict_with_window + predict_edgemask
         mtl = m._mtl
-        if mtl.refine:
+        side = m._aux_stream() if (mtl.refine and self.split_loss) else None
+        if side is not None:
+            # every loss term but the refiner's is a chain of small latency-bound kernels (target assignment over
+            # 14 453 anchors, samplers, reductions): on the side stream they run under the refiner's tower forward
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                m.loss(pd, loss_scale=1.0 / self.world, part="early")
             pd = m.predict_with_mtl_results(pd)
-        losses = m.loss(pd, loss_scale=1.0 / self.world)
+            cur.wait_stream(side)
+            losses = m.loss(pd, loss_scale=1.0 / self.world, part="late")
+        else:
+            if mtl.refine:
+                pd = m.predict_with_mtl_results(pd)
+            losses = m.loss(pd, loss_scale=1.0 / self.world)
         m.backward(pd)
         self._pd = pd
         return losses
