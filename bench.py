@@ -67,8 +67,8 @@ def pmc_traffic(default_cfg):
     """HBM bytes per launch of the roofline kernel. PMC counters cannot be read from inside the
     process being timed, so this is the committed result of the separate `rocprofv3 --pmc FETCH_SIZE`
     / `--pmc WRITE_SIZE` passes over this same command (tools/pmc_bench.sh -> tools/pmc_summary.py ->
-    profiles/r01_pmc_traffic.json); null when that file is absent or the config is not the default."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    profiles/r02_pmc_traffic.json); null when that file is absent or the config is not the default."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if not default_cfg or not os.path.exists(path):
         return None
     d = json.load(open(path))

@@ -172,7 +172,9 @@ __global__ void __launch_bounds__(256) k_dw_wgrad_fold(const float* part, int ch
 //   dbeta[c] = sum_rows g,   dgamma[c] = sum_rows g*(y-beta[c]) / gamma[c].
 // Partials [chunk][2][C], rows split over blockIdx.y; deterministic fold (no float atomics).
 // Block = CQ channel quads x PL row lanes (as in k_dw_wgrad_partial), two rows in flight per thread.
-__global__ void __launch_bounds__(256) k_bn_partial(const float* y, const float* g, int rows, int C,
+// The product is taken with (y - beta) element by element: summing g*y and beta*g apart and subtracting the two
+// large sums afterwards cancels catastrophically for channels with a small gamma (then amplified by 1/gamma).
+__global__ void __launch_bounds__(256) k_bn_partial(const float* y, const float* g, const float* beta, int rows, int C,
                                                     int rows_per_chunk, int CQ, float* part) {
   const int C4 = C / 4, PL = 256 / CQ;
   const int cq = threadIdx.x % CQ, sub = threadIdx.x / CQ;
@@ -183,14 +185,15 @@ __global__ void __launch_bounds__(256) k_bn_partial(const float* y, const float*
   if (c4 < C4) {
     const float* yb = y + c4 * 4;
     const float* gb = g + c4 * 4;
+    const floatx4 b4 = *reinterpret_cast<const floatx4*>(beta + c4 * 4);
     for (int r = r0 + sub; r < r1; r += 2 * PL) {
       const bool two = r + PL < r1;
       floatx4 g0 = *reinterpret_cast<const floatx4*>(gb + (int64_t)r * C);
       floatx4 y0 = *reinterpret_cast<const floatx4*>(yb + (int64_t)r * C);
       floatx4 g1 = two ? *reinterpret_cast<const floatx4*>(gb + (int64_t)(r + PL) * C) : zero;
       floatx4 y1 = two ? *reinterpret_cast<const floatx4*>(yb + (int64_t)(r + PL) * C) : zero;
-      sg += g0; sgy += g0 * y0;
-      sg += g1; sgy += g1 * y1;
+      sg += g0; sgy += g0 * (y0 - b4);
+      sg += g1; sgy += g1 * (y1 - b4);     // (an absent second row has g1 = 0)
     }
   }
   __shared__ floatx4 red[2][256];
@@ -220,7 +223,9 @@ __global__ void __launch_bounds__(256) k_bn_fold(const float* part, int chunks, 
   sg = wave_sum(sg);
   sgy = wave_sum(sgy);
   if (lane == 0) {
-    float dgm = gamma[c] != 0.f ? (sgy - beta[c] * sg) / gamma[c] : 0.f;
+    // sgy = sum g*(y - beta) = gamma * sum g*xhat. A gamma of exactly 0 gives y == beta everywhere: xhat cannot be
+    // recovered from the folded layer's output, and the gradient is reported as 0 (documented limitation).
+    float dgm = gamma[c] != 0.f ? sgy / gamma[c] : 0.f;
     dgamma[c] = accum != 0.f ? accum * dgamma[c] + dgm : dgm;
     dbeta[c] = accum != 0.f ? accum * dbeta[c] + sg : sg;
   }
@@ -312,7 +317,7 @@ int mtlssl_bn_param_grads(const float* y, const float* g, const float* gamma, co
   ReducePlan rp = reduce_plan(rows, C);
   if (rows == 0) (void)hipMemsetAsync(workspace, 0, sizeof(float) * 2 * C, S(stream));
   else
-    hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C / 4, rp.CQ), rp.chunks), dim3(256), 0, S(stream), y, g, (int)rows, C,
+    hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C / 4, rp.CQ), rp.chunks), dim3(256), 0, S(stream), y, g, beta, (int)rows, C,
                        rp.per_chunk, rp.CQ, (float*)workspace);
   hipLaunchKernelGGL(k_bn_fold, dim3(cdiv(C, 4)), dim3(256), 0, S(stream), (const float*)workspace,
                      rows == 0 ? 1 : rp.chunks, C, gamma, beta, dgamma, dbeta, accum);
