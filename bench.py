@@ -206,12 +206,50 @@ def cpu_baseline(cfg, model, tr, H, W, seed, steps=3, batch=1):
             "total_loss_last_step": float(sum(losses.values()))}
 
 
+def cpu_plumbing_config0(dev, steps=10, H=600, W=800):
+    """BASELINE.json configs[0] / BASELINE.md §3: Faster R-CNN + MobileNet-v1, VOC07 settings, batch 1, on the host
+    cores only — the CPU oracle of that configuration (oracle/model.py + oracle/optimizer.py) for `steps` full
+    training steps on a VOC-shaped synthetic image (500x375 resized by the 600/1024 resizer = 800x600)."""
+    import torch
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    from oracle import optimizer as oopt
+    from oracle.model import Oracle
+    path = os.path.join(ROOT, "configs", "frcnn_mobilenet_v1_voc_mtl.config")
+    cfg = config.parse_pipeline_config(open(path).read())
+    K = int(cfg.model.faster_rcnn.num_classes)
+    model = model_builder.build(cfg.model, True, dev, seed=0)         # only to draw the initial values
+    tr = trainer.Trainer(model, cfg.train_config, 1)
+    values = model.ps.state_dict()
+    wd = {s.name: s.weight_decay for s in model.ps.trainable_specs if s.weight_decay}
+    seed = model.seed
+    del model
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 64)
+    torch.set_num_threads(cores)
+    hp = hyper_params_for_oracle(cfg)
+    b = synthetic.make_batch(1, H, W, K, seed=4321, device="cpu")
+    b["images"] = b["images"].numpy()
+    accum = {}
+    Oracle(hp, values).step(b, seed=seed, step=0)                     # warm-up (thread pools, allocator)
+    t0 = time.time()
+    for step in range(steps):
+        losses, grads, _ = Oracle(hp, values).step(b, seed=seed, step=step)
+        oopt.momentum_update(values, grads, accum, tr.lr_fn(step), tr.momentum, tr.clip, wd)
+    dt = (time.time() - t0) / steps
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "host_cores": host_cores, "kind": "port",
+            "sample": "configs[0] on the CPU oracle: Faster R-CNN MobileNet-v1, VOC07 settings (20 classes), batch 1, "
+                      "%dx%d, 1 warm-up + %d timed training steps (fwd + losses + bwd + clip + momentum), %.2f s/step on "
+                      "%d torch threads" % (W, H, steps, dt, cores),
+            "total_loss_last_step": float(sum(losses.values()))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)      # SURVEY.md §8d: >= 50 timed steps after >= 10 warm-up
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-config0-steps", type=int, default=10, help="timed CPU steps of configs[0] (0 = skip)")
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "frcnn_resnet101_coco_mtl.config"))
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1024)
@@ -369,6 +407,8 @@ def main():
         out["hbm_kernels"] = hbm_kernels(tr)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, model, tr, a.height, a.width, seed=1234, steps=a.cpu_steps)
+        if default_cfg and a.cpu_config0_steps > 0:
+            out["cpu_baseline_config0"] = cpu_plumbing_config0(dev, a.cpu_config0_steps)
     if comm is not None:
         with comm_mod._stdout_to_stderr():      # anything RCCL left in C stdio's stdout buffer goes to stderr,
             pass                                # so that stdout carries exactly the one JSON line
