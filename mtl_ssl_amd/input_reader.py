@@ -332,7 +332,7 @@ def collate(examples):
     shapes = {e["image"].shape for e in examples}
     if len(shapes) != 1:
         raise ValueError("images of one batch must share a shape, got %s" % sorted(shapes))
-    out = {"images": torch.from_numpy(np.stack([e["image"] for e in examples]))}
+    out = {"images": torch.from_numpy(np.ascontiguousarray(np.stack([e["image"] for e in examples]), np.float32))}
     for k in ("groundtruth_boxes", "groundtruth_classes", "groundtruth_closeness", "window_boxes", "window_classes",
               "groundtruth_edgemask"):
         if all(k in e for e in examples):

@@ -83,4 +83,4 @@ def resize_bilinear_legacy(image, out_h, out_w):
     xl = (xs - x0.astype(np.float32))[None, :, None]
     top = x[y0][:, x0] + (x[y0][:, x1] - x[y0][:, x0]) * xl
     bot = x[y1][:, x0] + (x[y1][:, x1] - x[y1][:, x0]) * xl
-    return (top + (bot - top) * yl).astype(np.float32)
+    return np.ascontiguousarray(top + (bot - top) * yl, dtype=np.float32)     # fancy indexing leaves a permuted layout

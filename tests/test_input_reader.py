@@ -143,6 +143,7 @@ def test_mixed_shape_records_are_bucketed_not_padded(tmp_path):
     got = sorted(tuple(b["images"].shape) for b in bs)
     assert got == [(1, 60, 85, 3), (2, 60, 80, 3), (2, 60, 80, 3), (2, 80, 60, 3)], got
     assert sum(b["images"].shape[0] for b in bs) == len(shapes)
+    assert all(b["images"].is_contiguous() for b in bs)          # resized images come out of fancy indexing
     assert len(list(R.batches([p], 3, 2, resized_shape=fn, drop_remainder=True))) == 3
     # without a resizer images can only be grouped by their raw shape
     raw = sorted(tuple(b["images"].shape) for b in R.batches([p], 3, 2))
