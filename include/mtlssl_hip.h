@@ -122,6 +122,16 @@ int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* 
                         const float* out_scale, float* dw, float* dbias, float beta,
                         void* workspace, mtlssl_stream_t stream);
 
+/* Grouped filter gradient: n problems of ONE descriptor in one launch — the 22 shape-identical bottleneck units of
+ * ResNet-101's block3 (slim/nets/resnet_v1.py:69-130 stacked by resnet_utils.py:126-200) each give a 4 864-pixel
+ * reduction at per-GPU batch 2, far too few tiles to fill 256 CUs one at a time. x_ptrs / dy_ptrs / dw_ptrs (and
+ * scale_ptrs, nullable as a whole or per entry) are DEVICE arrays of n pointers; dw[g] = beta*dw[g] + scale[g][k] *
+ * sum_pixels x[g]*dy[g]. MFMA-path problems only (C, K multiples of 4, >= 16); no dbias. */
+int64_t mtlssl_conv2d_wgrad_grouped_workspace_bytes(const mtlssl_conv_desc* d, int n);
+int mtlssl_conv2d_wgrad_grouped(const mtlssl_conv_desc* d, int n, const void* x_ptrs, const void* dy_ptrs,
+                                const void* scale_ptrs, const void* dw_ptrs, float beta, void* workspace,
+                                mtlssl_stream_t stream);
+
 /* Depthwise convolution (slim.separable_conv2d with num_outputs=None, depth_multiplier 1:
  * slim/nets/mobilenet_v1.py:229-245; models/faster_rcnn_mobilenet_v1_feature_extractor.py:145-184).
  * Descriptor with C == K; filter layout [R,S,C]. Epilogue flags BIAS / RELU / RELU6 (fwd) and

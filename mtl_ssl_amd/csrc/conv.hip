@@ -46,6 +46,31 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* ws, int nspli
   *d = beta != 0.f ? beta * *d + s : s;
 }
 
+// The same over n problems of one descriptor (grouped wgrad): blockIdx.y = problem, per-problem scale / dw pointers.
+__global__ void __launch_bounds__(256) k_wgrad_reduce_grouped(const float* ws, int nsplit, int64_t total4, int K,
+                                                              const float* const* scale_tab, float* const* dw_tab,
+                                                              float beta) {
+  const int g = blockIdx.y;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t i = t >> 2;
+  const int sl = (int)(t & 3);
+  const bool live = i < total4;
+  const floatx4* w4 = reinterpret_cast<const floatx4*>(ws) + (int64_t)g * nsplit * total4;
+  floatx4 s = {0.f, 0.f, 0.f, 0.f};
+  if (live)
+    for (int k = sl; k < nsplit; k += 4) s += w4[(int64_t)k * total4 + i];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s[e] += __shfl_xor(s[e], 1, 64);
+    s[e] += __shfl_xor(s[e], 2, 64);
+  }
+  if (!live || sl) return;
+  const float* scale = scale_tab ? scale_tab[g] : nullptr;
+  if (scale) s *= *reinterpret_cast<const floatx4*>(scale + (i * 4) % K);
+  floatx4* d = reinterpret_cast<floatx4*>(dw_tab[g]) + i;
+  *d = beta != 0.f ? beta * *d + s : s;
+}
+
 // ------------------------------------------------------------------------------ generic paths
 // Direct convolution for shapes the MFMA path does not take (the 7x7x3 stem, heads with a
 // handful of output channels). One thread per output element group; VALU only. These layers are
@@ -1122,6 +1147,56 @@ int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
   if (choose_wino(d, MODE_WGRAD, &wc)) return bias_part + wino_workspace_bytes(d, wc.variant, MODE_WGRAD);
   wgrad_plan(d, &cfg, &ns, &pps);
   return bias_part + align_up((int64_t)ns * d->R * d->S * d->C * d->K * 4, 256);
+}
+
+// Plan of a grouped wgrad: the tile and the split of the pixel range that fill the chip with n problems' tiles.
+static void wgrad_group_plan(const mtlssl_conv_desc* d, int n, int* cfg, int* nsplit, int* pps) {
+  const int64_t P = (int64_t)d->N * d->OH * d->OW;
+  const int RS = d->R * d->S;
+  double best_t = 1e30;
+  *cfg = 2; *nsplit = 1; *pps = (int)align_up(P, 16);
+  for (int c = 0; c < NCFG; ++c) {
+    const int ksteps = (int)cdiv(P, CFG_BK[c]);
+    const int64_t tiles = cdiv(d->C, CFG_BM[c]) * cdiv(d->K, CFG_BN[c]) * RS * n;
+    for (int s = 1; s <= 16; ++s) {
+      if (s > 1 && ksteps * CFG_BK[c] / s < 128) break;
+      const int per = (int)cdiv(ksteps, s), ns = (int)cdiv(ksteps, per);
+      if (ns != s) continue;
+      const double t = tile_time_us(c, tiles * ns, per) + 2.0 + (double)n * RS * d->C * d->K * 4.0 * (ns + 1) / 3.0e6;
+      if (t < best_t) { best_t = t; *cfg = c; *nsplit = ns; *pps = per * CFG_BK[c]; }
+    }
+  }
+}
+int64_t mtlssl_conv2d_wgrad_grouped_workspace_bytes(const mtlssl_conv_desc* d, int n) {
+  if (!d || n <= 0 || check_desc(d) || !mfma_wgrad_ok(d)) return 0;
+  int cfg, ns, pps;
+  wgrad_group_plan(d, n, &cfg, &ns, &pps);
+  return align_up((int64_t)n * ns * d->R * d->S * d->C * d->K * 4, 256);
+}
+int mtlssl_conv2d_wgrad_grouped(const mtlssl_conv_desc* d, int n, const void* x_ptrs, const void* dy_ptrs,
+                                const void* scale_ptrs, const void* dw_ptrs, float beta, void* workspace,
+                                mtlssl_stream_t stream) {
+  if (n <= 0) return MTLSSL_OK;
+  if (int rc = check_desc(d)) return rc;
+  MTLSSL_REQUIRE(mfma_wgrad_ok(d), "wgrad_grouped: the problem is not on the MFMA path (C, K multiples of 4 and >= 16)");
+  MTLSSL_REQUIRE(x_ptrs && dy_ptrs && dw_ptrs && workspace, "wgrad_grouped: null table / workspace");
+  MTLSSL_REQUIRE(n <= 1024, "wgrad_grouped: at most 1024 problems per launch");
+  hipStream_t st = S(stream);
+  ConvArgs p = make_args(d);
+  p.a_bytes = (unsigned)((int64_t)d->N * d->H * d->W * d->C * 4);
+  p.b_bytes = (unsigned)((int64_t)d->N * d->OH * d->OW * d->K * 4);
+  p.a_tab = (const float* const*)x_ptrs;
+  p.b_tab = (const float* const*)dy_ptrs;
+  int cfg, ns, pps;
+  wgrad_group_plan(d, n, &cfg, &ns, &pps);
+  MTLSSL_REQUIRE((int64_t)n * ns <= 65535, "wgrad_grouped: grid too large");
+  p.out = (float*)workspace;
+  p.M = d->C; p.NG = d->K; p.nsplit = ns; p.pix_per_split = pps;
+  launch_mfma<MODE_WGRAD>(cfg, p, dim3(1, d->R * d->S, n * ns), st);
+  const int64_t total4 = (int64_t)d->R * d->S * d->C * d->K / 4;
+  hipLaunchKernelGGL(k_wgrad_reduce_grouped, dim3(cdiv(total4 * 4, 256), n), dim3(256), 0, st, (const float*)workspace, ns,
+                     total4, d->K, (const float* const*)scale_ptrs, (float* const*)dw_ptrs, beta);
+  return check_launch("conv2d_wgrad_grouped");
 }
 
 int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,

@@ -46,6 +46,10 @@ struct ConvArgs {
   int tile_m0;           // first tile row covered by this launch (tail launches start past 0)
   int ws_m0;             // first GEMM row held by the split-K workspace of this launch
   int64_t a_bs, b_bs, o_bs;   // batched launches: element strides between the planes of a / b / out
+  // grouped wgrad (n problems of one descriptor in one launch): per-problem operand pointers, blockIdx.z =
+  // problem * nsplit + split; the partial tiles land in the workspace in that order
+  const float* const* a_tab;
+  const float* const* b_tab;
 };
 
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
@@ -214,6 +218,13 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     p.b += (int64_t)blockIdx.y * p.b_bs;
     if constexpr (MODE != MODE_WGRAD) p.out += (int64_t)blockIdx.y * p.o_bs;
   }
+  if constexpr (MODE == MODE_WGRAD && !BATCH) {
+    if (p.a_tab) {
+      const int grp = blockIdx.z / p.nsplit;
+      p.a = p.a_tab[grp];
+      p.b = p.b_tab[grp];
+    }
+  }
   const __amdgpu_buffer_rsrc_t rsrc_a =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b =
@@ -227,7 +238,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     ksteps = p.R * p.S * (p.K / BKT);
   } else {
     rs_fixed = BATCH ? 0 : blockIdx.y;
-    int split = blockIdx.z;
+    int split = (!BATCH && p.a_tab) ? blockIdx.z % p.nsplit : blockIdx.z;
     int P = p.N * p.OH * p.OW;
     pix0 = split * p.pix_per_split;
     pix1 = min(P, pix0 + p.pix_per_split);

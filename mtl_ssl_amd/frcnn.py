@@ -197,7 +197,8 @@ class FasterRCNNMetaArch:
         if self.ps.device.type != "cuda" or os.environ.get("MTLSSL_WGRAD_STREAM", "1") == "0":
             return nn.INLINE_WGRAD
         if getattr(self, "_wgrad_stream_obj", None) is None:
-            self._wgrad_stream_obj = nn.WgradStream(torch.cuda.Stream(device=self.ps.device))
+            self._wgrad_stream_obj = nn.WgradStream(torch.cuda.Stream(device=self.ps.device),
+                                                    group=os.environ.get("MTLSSL_WGRAD_GROUP", "0") == "1")
         return self._wgrad_stream_obj
 
     def compute_streams(self):

@@ -340,6 +340,36 @@ def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0):
     return dw
 
 
+_ptr_tables = {}
+
+
+def _ptr_table(tensors, device):
+    """Device array of the tensors' addresses. Cached by the address tuple: in steady state the caching allocator
+    hands every step the same addresses, so no host->device copy (a synchronising one) happens on the step."""
+    key = tuple(t.data_ptr() if t is not None else 0 for t in tensors)
+    tab = _ptr_tables.get(key)
+    if tab is None:
+        if len(_ptr_tables) > 4096:
+            _ptr_tables.clear()
+        tab = torch.tensor(key, dtype=torch.int64, device=device)
+        _ptr_tables[key] = tab
+    return tab
+
+
+def conv2d_wgrad_grouped(d, xs, dys, dws, scales=None, beta=0.0):
+    """n filter gradients of one descriptor in one launch (mtlssl_conv2d_wgrad_grouped): xs / dys / dws lists of
+    tensors, scales a list of per-output-channel scale tensors (or None)."""
+    n = len(xs)
+    dev = xs[0].device
+    for t in list(xs) + list(dys) + list(dws):
+        _chk(t)
+    nb = lib().conv2d_wgrad_grouped_workspace_bytes(ctypes.byref(d), n)
+    ws = workspace(nb, "wgrad_grouped", dev)
+    lib().conv2d_wgrad_grouped(ctypes.byref(d), n, ptr(_ptr_table(xs, dev)), ptr(_ptr_table(dys, dev)),
+                               ptr(_ptr_table(scales, dev)) if scales is not None else None,
+                               ptr(_ptr_table(dws, dev)), float(beta), ptr(ws), _stream())
+
+
 def depthwise_fwd(d, x, w, bias=None, epilogue=0):
     y = torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
     lib().depthwise_fwd(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(y), epilogue, _stream())

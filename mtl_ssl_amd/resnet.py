@@ -105,6 +105,7 @@ class FasterRCNNResnetV1FeatureExtractor:
         units = self.trunk.units
         for i in range(len(units) - 1, self.first_trainable - 1, -1):
             gp = units[i].backward(gp, ctxs[i], need_input_grad=(i > self.first_trainable), wgrad=wgrad)
+        wgrad.flush()
 
     def box_classifier_tower(self, scope, trainable):
         return BoxClassifierTower(self.ps, scope, self.arch, self.cout, trainable and self.is_training,

@@ -313,3 +313,34 @@ def test_scale_axpby_tanh(ops):
     assert relerr(ops.axpby(x.cuda(), y.cuda().clone(), 2.0, -0.5), 2 * x - 0.5 * y) < 1e-6
     t = torch.tanh(x); gy = torch.randn(1000)
     assert relerr(ops.tanh_bwd(t.cuda(), gy.cuda()), gy * (1 - t * t)) < 1e-6
+
+
+def test_grouped_wgrad_matches_per_problem_wgrad():
+    """mtlssl_conv2d_wgrad_grouped: n problems of one descriptor (block3's identical units) in one launch."""
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    for (N, H, W, C, K, R) in ((2, 38, 64, 256, 128, 1), (1, 19, 23, 64, 48, 3)):
+        n = 5
+        d = ops.conv_desc((N, H, W, C), (R, R, C, K), 1, 1, "SAME")
+        xs = [torch.randn(N, H, W, C, generator=gen).cuda() for _ in range(n)]
+        dys = [torch.randn(N, H, W, K, generator=gen).cuda() for _ in range(n)]
+        scales = [(torch.rand(K, generator=gen) + 0.5).cuda() for _ in range(n)]
+        base = [torch.randn(R, R, C, K, generator=gen).cuda() for _ in range(n)]
+        want = [b.clone() for b in base]
+        for i in range(n):
+            ops.conv2d_wgrad(d, xs[i], dys[i], want[i], out_scale=scales[i], beta=1.0)
+        got = [b.clone() for b in base]
+        ops.conv2d_wgrad_grouped(d, xs, dys, got, scales, beta=1.0)
+        torch.cuda.synchronize()
+        for i in range(n):
+            err = float((got[i] - want[i]).abs().max() / want[i].abs().max())
+            assert err < 1e-5, (i, err)
+        # without scales, overwriting
+        got2 = [torch.full_like(b, 7.0) for b in base]
+        ops.conv2d_wgrad_grouped(d, xs, dys, got2, None, beta=0.0)
+        ref = torch.zeros_like(base[0])
+        ops.conv2d_wgrad(d, xs[2], dys[2], ref, beta=0.0)
+        torch.cuda.synchronize()
+        assert float((got2[2] - ref).abs().max() / ref.abs().max()) < 1e-5
