@@ -310,6 +310,7 @@ def main():
     for _ in range(a.steps):
         losses = tr.step(batch)
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0          # this rank's own time, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -321,7 +322,7 @@ def main():
         # time was exposed, every rank's own step time, and a checksum of every rank's weights after the timed steps
         import zlib
         red = tr.reducer.timing_summary(a.steps)
-        mine = {"rank": rank, "ms_per_step": 1e3 * dt / a.steps, "comm": comm.info(),
+        mine = {"rank": rank, "ms_per_step": 1e3 * dt_local / a.steps, "comm": comm.info(),
                 "weights_crc32": zlib.crc32(model.ps.weights.cpu().numpy().tobytes()), **red}
         if world > 1:
             everyone = [None] * world
@@ -342,6 +343,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_loss = float(sum(v.item() for v in losses.values()))
+    if comm is not None:
+        comm.close()                     # ncclCommDestroy on every rank
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
