@@ -257,6 +257,8 @@ __global__ void __launch_bounds__(64) k_nms_mask(const float* sboxes, const int3
   int nv = nvalid ? min(nvalid[b], n) : n;
   int rc = rc0 + blockIdx.y, cc = blockIdx.x;
   if (cc < rc || rc * 64 >= nv || cc * 64 >= nv) return;
+  // the matrix holds only the rows of the current round: [image][row - 64*rc0][column chunk]
+  mask += (int64_t)b * gridDim.y * 64 * nchunks;
   __shared__ float4 s_col[64];
   const float* bx = sboxes + (int64_t)b * n * 4;
   int col = cc * 64 + threadIdx.x;
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(64) k_nms_mask(const float* sboxes, const int3
     int cj = cc * 64 + j;
     if (cj > row && nms_iou_gt(r, Box{v.x, v.y, v.z, v.w}, thr)) bits |= 1ull << j;
   }
-  mask[((int64_t)b * n + row) * nchunks + cc] = bits;
+  mask[(int64_t)(row - rc0 * 64) * nchunks + cc] = bits;
 }
 
 // Stage 4: greedy scan, one block per image. Chunk-wise: wave 0 resolves the 64 candidates of a chunk in
@@ -293,7 +295,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(const unsigned long l
   if (state[b * 2 + 1]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = nvalid ? min(nvalid[b], n) : n;
-  const unsigned long long* mk = mask + (int64_t)b * n * nchunks;
+  // rows of this round only (k_nms_mask): row r of the round's image slab is candidate c0*64 + r
+  const unsigned long long* mk = mask + ((int64_t)b * (c1 - c0) * 64 - (int64_t)c0 * 64) * nchunks;
   unsigned long long* rv = remv + (int64_t)b * nchunks;
   const int nch = (nv + 63) / 64;
   int nsel = c0 ? state[b * 2] : 0;
@@ -382,6 +385,7 @@ __global__ void k_emit_selected(const int32_t* sidx, const int32_t* sel_rank, co
   selected_out[k] = k < num[0] ? sidx[sel_rank[k]] : -1;
 }
 
+constexpr int NMS_ROUND_CHUNKS = 128;    // rows per round of the suppression matrix / 64 (8 192 rows)
 struct NmsWs {
   float* boxes;
   float* scores;
@@ -412,7 +416,9 @@ static int64_t nms_ws_layout(int batch, int n, int max_out, char* base, NmsWs* w
   w.sidx = (int32_t*)take((int64_t)batch * n * 4);
   w.nvalid = (int32_t*)take((int64_t)batch * 4);
   w.sel_rank = (int32_t*)take((int64_t)batch * max_out * 4);
-  w.mask = (unsigned long long*)take((int64_t)batch * n * nchunks * 8);
+  // suppression bit matrix of ONE round of rows (run_nms_sorted): at most NMS_ROUND_CHUNKS * 64 rows per image
+  const int64_t round_rows = (int64_t)(nchunks < NMS_ROUND_CHUNKS ? nchunks : NMS_ROUND_CHUNKS) * 64;
+  w.mask = (unsigned long long*)take((int64_t)batch * round_rows * nchunks * 8);
   w.remv = (unsigned long long*)take((int64_t)batch * nchunks * 8);
   w.state = (int32_t*)take((int64_t)batch * 2 * 4);
   if (ws) *ws = w;
@@ -421,18 +427,21 @@ static int64_t nms_ws_layout(int batch, int n, int max_out, char* base, NmsWs* w
 
 static int run_nms_sorted(const NmsWs& w, const int32_t* nvalid, int batch, int n, float thr,
                           int max_out, int32_t* num_out, hipStream_t st) {
-  // Rounds of row chunks: 2 048 rows, then 4 096, then the rest. Every round is launched; an image whose scan
-  // has its max_out survivors (or ran out of candidates) makes the later rounds' blocks return at once.
+  // Rounds of row chunks: 2 048 rows, then 4 096, then 8 192 at a time. Every round is launched; an image whose scan
+  // has its max_out survivors (or ran out of candidates) makes the later rounds' blocks return at once. The matrix
+  // buffer holds one round (<= 8 192 rows x n/64 words per image: 7.8 GB -> 256 MB for the 250 000 clipped anchors
+  // of a stride-8 inference pass).
   (void)hipMemsetAsync(w.state, 0, sizeof(int32_t) * 2 * batch, st);
   size_t lds = (size_t)w.nchunks * 8;
-  const int bounds[] = {0, 32, 96, w.nchunks};
-  for (int r = 0; r < 3; ++r) {
-    const int c0 = bounds[r], c1 = r == 2 ? w.nchunks : (bounds[r + 1] < w.nchunks ? bounds[r + 1] : w.nchunks);
-    if (c0 >= w.nchunks) break;
+  int c0 = 0;
+  for (int r = 0; c0 < w.nchunks; ++r) {
+    const int want = r == 0 ? 32 : (r == 1 ? 64 : NMS_ROUND_CHUNKS);
+    const int c1 = c0 + want < w.nchunks ? c0 + want : w.nchunks;
     hipLaunchKernelGGL(k_nms_mask, dim3(w.nchunks, c1 - c0, batch), dim3(64), 0, st, w.sboxes, nvalid, n, w.nchunks, thr,
                        c0, w.state, w.mask);
     hipLaunchKernelGGL(k_nms_scan, dim3(batch), dim3(SCAN_THREADS), lds, st, w.mask, nvalid, n, w.nchunks, max_out, c0,
                        c1, w.state, w.remv, w.sel_rank, num_out);
+    c0 = c1;
   }
   return check_launch("nms");
 }

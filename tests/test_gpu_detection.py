@@ -326,3 +326,21 @@ def test_dedup_windows_is_an_exact_regrouping():
     junk[0, E - 1] = torch.rand(n2, 4, device="cuda")
     ops.dedup_windows(junk, U, ovf)
     assert int(ovf.item()) == 1
+
+
+def test_nms_many_rounds_heavy_suppression(ops):
+    """Clustered candidates: only a few dozen survive, so the greedy scan must walk ALL rounds of the suppression
+    matrix (2 048 / 4 096 / 8 192-row rounds, a buffer that holds one round) — 20 000 candidates = 4 rounds."""
+    rng = np.random.RandomState(77)
+    n, clusters = 20000, 60
+    cy, cx = rng.uniform(50, 550, clusters), rng.uniform(50, 950, clusters)
+    h, w = rng.uniform(30, 120, clusters), rng.uniform(30, 120, clusters)
+    k = rng.randint(0, clusters, n)
+    jit = rng.normal(0, 1.5, (n, 4)).astype(np.float32)
+    bx = np.stack([cy[k] - h[k] / 2, cx[k] - w[k] / 2, cy[k] + h[k] / 2, cx[k] + w[k] / 2], 1).astype(np.float32) + jit
+    sc = rng.permutation(n).astype(np.float32) / n
+    sel, num = ops.nms(cu(bx), cu(sc), 0.5, 300)
+    ref = N.greedy_nms(bx, sc, 300, 0.5)
+    kk = int(num.item())
+    assert kk == len(ref) and 40 <= kk < 300
+    np.testing.assert_array_equal(sel.cpu().numpy()[:kk], ref)
