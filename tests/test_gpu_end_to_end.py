@@ -148,3 +148,42 @@ def test_mixed_aspect_ratio_records_train_from_a_tensorflow_checkpoint(tmp_path)
         cfg.train_config["fine_tune_checkpoint"] = str(tmp_path / "missing.ckpt")
         trainer.train(next_batch, lambda: model_builder.build(cfg.model, True, "cuda", seed=1), cfg.train_config,
                       train_dir=str(tmp_path / "run2"), num_steps=1, model_config=cfg.model)
+
+
+def test_trainer_state_saves_moving_averages_and_options(tmp_path):
+    """slim.learning.train's periodic Saver (trainer.py:464-466) as atomic state files; the optimizer's
+    use_moving_average option (builders/optimizer_builder.py:105-111); freeze_variables / bias_grad_multiplier
+    (trainer.py:389-410) acting on a real model."""
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    text = open(os.path.join(ROOT, "configs", "smoke_resnet50_mtl.config")).read()
+    text = text.replace("use_moving_average: false", "use_moving_average: true moving_average_decay: 0.9")
+    text = text.replace("train_config {", "train_config {\n  freeze_variables: 'FirstStageBoxPredictor/.*'\n  bias_grad_multiplier: 2.0\n", 1) \
+        if "train_config {" in text else text.replace("train_config: {", "train_config: {\n  freeze_variables: 'FirstStageBoxPredictor/.*'\n  bias_grad_multiplier: 2.0\n", 1)
+    cfg = config.parse_pipeline_config(text)
+    assert cfg.train_config.optimizer.use_moving_average and list(cfg.train_config.freeze_variables)
+    batch = synthetic.make_batch(2, 160, 224, 5, seed=3, device="cuda", max_gt=4, num_windows=6)
+    d = str(tmp_path / "run")
+    built = []
+
+    def model_fn():
+        built.append(model_builder.build(cfg.model, True, "cuda", seed=1))
+        return built[-1]
+    w0 = None
+    tr, log = trainer.train(lambda: batch, model_fn, cfg.train_config, train_dir=d, num_steps=4, model_config=cfg.model,
+                            log_every=1, save_interval_secs=1e-6)
+    state = np.load(os.path.join(d, "model.ckpt.npz"))
+    assert int(state["global_step"]) == 4 and not os.path.exists(os.path.join(d, "model.ckpt.npz.tmp.npz"))
+    name = "SecondStageBoxPredictor/ClassPredictor/weights"
+    assert name + "/Momentum" in state.files and name + "/ExponentialMovingAverage" in state.files
+    ema, w = state[name + "/ExponentialMovingAverage"], state[name]
+    assert np.abs(ema - w).max() > 0                      # the average lags the weights
+    # frozen scope: untouched by four updates; everything else moved
+    fresh = model_builder.build(cfg.model, True, "cuda", seed=1)
+    for sp in tr.ps.trainable_specs:
+        same = torch.equal(tr.ps.value(sp.name), fresh.ps.value(sp.name))
+        assert same == sp.name.startswith("FirstStageBoxPredictor/"), sp.name
+    # resuming picks the state (and the averages) up where it stopped
+    tr2, _ = trainer.train(lambda: batch, model_fn, cfg.train_config, train_dir=d, num_steps=5, model_config=cfg.model)
+    assert tr2.global_step == 5
