@@ -338,6 +338,7 @@ class FasterRCNNMetaArch:
         latency-bound kernels (a one-wavefront greedy scan among them) that leaves the chip idle."""
         x, mtl = preprocessed_inputs, self._mtl
         F, trunk_ctx = self._feature_extractor.extract_proposal_features(x, save=self._is_training)
+        ops.mark("trunk_forward")
 
         def aux_forward():
             t = {"rpn_features_to_crop": F}
@@ -741,6 +742,7 @@ class FasterRCNNMetaArch:
         gpF = self.rpn_conv.dgrad(F.shape, g_rf, out=dF, accum=True, mask_ref=F,
                                   mask6=getattr(self._feature_extractor, "output_relu6", False))
         pd["_gpF"] = gpF
+        ops.mark("heads_backward")
         if getattr(self._feature_extractor, "supports_wgrad_stream", False):
             self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"], wgrad=wg)
         else:

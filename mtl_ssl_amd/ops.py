@@ -114,6 +114,12 @@ class ConvProfiler:
 
 
 PROFILER = None
+PHASE_HOOK = None      # tools/phase_times.py: callable(name) invoked at the step's phase boundaries
+
+
+def mark(name):
+    if PHASE_HOOK is not None:
+        PHASE_HOOK(name)
 
 # ---- tile autotuning. The time model mis-ranks tiles on some small GEMMs, so tile choices are
 # measured: `conv_plans.json` (next to this file, generated on an MI355X by tools/tune_plans.py) pins

@@ -254,8 +254,10 @@ class Trainer:
         self.ps.grads.zero_()
         self.reducer.compute_streams = m.compute_streams()
         self.reducer.begin_step()
+        ops.mark("step_start")
         images = m.preprocess(batch["images"])
         pd = m.predict_for_training(images)       # predict + predict_with_window + predict_edgemask
+        ops.mark("predict")
         mtl = m._mtl
         side = m._aux_stream() if (mtl.refine and self.split_loss) else None
         if side is not None:
@@ -272,7 +274,9 @@ class Trainer:
             if mtl.refine:
                 pd = m.predict_with_mtl_results(pd)
             losses = m.loss(pd, loss_scale=1.0 / self.world)
+        ops.mark("refine_and_losses")
         m.backward(pd)
+        ops.mark("backward")
         self._pd = pd
         return losses
 
@@ -288,6 +292,7 @@ class Trainer:
         if self.ema is not None:
             ops.axpby(ps.weights, self.ema, 1.0 - self.ema_decay, self.ema_decay)
         self.model.refold()
+        ops.mark("update")
         self.global_step += 1
 
     def step(self, batch):
