@@ -73,7 +73,8 @@ int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float*
  * transform U = G g G^T depends on the weights only, which change once per optimizer step, while a layer is
  * convolved several times per step (forward, the refiner's second forward, dgrad). A caller may keep U:
  *   bytes   = mtlssl_conv2d_filter_xf_bytes(d, mode)      0 when the planned algorithm of (d, mode) is direct
- *   variant = mtlssl_conv2d_filter_xf_variant(d, mode)    the Winograd variant planned (0 F(4x4,3x3), 1 whole-7-span), -1 direct
+ *   variant = mtlssl_conv2d_filter_xf_variant(d, mode)    the Winograd variant planned (0 F(4x4,3x3), 1 whole-7-span), -1 direct;
+ *                                                         mode 0 / 1 / 2 (the wgrad plan has no filter to cache: see input_xf below)
  *   mtlssl_conv2d_transform_filter(d, mode, variant, w, filter_xf, stream)   mode 0 forward form, 1 dgrad (flipped) form
  * and hand it to the _xf entry points below together with the variant it was made for; a cache made for another
  * variant than the call's plan (or a null one) is ignored and the call transforms the filter itself.
@@ -92,6 +93,21 @@ int mtlssl_conv2d_fwd_xf(const mtlssl_conv_desc* d, const float* x, const float*
 int mtlssl_conv2d_dgrad_xf(const mtlssl_conv_desc* d, const float* dy, const float* w, const float* residual,
                            const float* mask_ref, float* dx, int epilogue, void* workspace, const float* filter_xf,
                            int xf_variant, mtlssl_stream_t stream);
+/* Transformed-input reuse within a training step: the Winograd forward and the Winograd filter gradient of one layer
+ * both start from V = B^T x B of the same activation x (slim.conv2d's forward and its Conv2DBackpropFilter see the
+ * same input tensor). A caller that keeps activations for backward may keep V as well:
+ *   variant = mtlssl_conv2d_filter_xf_variant(d, 0), and the same value from (d, 2), else there is nothing to share
+ *   bytes   = mtlssl_conv2d_input_xf_bytes(d, variant)
+ *   mtlssl_conv2d_fwd_keep(... input_xf, variant ...)   writes V there instead of into the workspace
+ *   mtlssl_conv2d_wgrad_xf(... input_xf, variant ...)   skips its own input transform
+ * As with the filter cache, a buffer made for another variant than the call's plan is ignored. */
+int64_t mtlssl_conv2d_input_xf_bytes(const mtlssl_conv_desc* d, int variant);
+int mtlssl_conv2d_fwd_keep(const mtlssl_conv_desc* d, const float* x, const float* w, const float* bias,
+                           const float* residual, float* y, int epilogue, void* workspace, const float* filter_xf,
+                           int xf_variant, float* input_xf, int input_variant, mtlssl_stream_t stream);
+int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const float* dy,
+                           const float* out_scale, float* dw, float* dbias, float beta,
+                           void* workspace, const float* input_xf, int input_variant, mtlssl_stream_t stream);
 /* dw[r,s,c,k] (beta=0: overwrite, beta=1: accumulate) = sum_pixels x*dy, optionally scaled
  * per output channel by out_scale[k] (frozen-BN fold) and dbias[k] = sum dy (nullable).
  * workspace: mtlssl_conv2d_wgrad_workspace_bytes(d) bytes. */

@@ -991,8 +991,12 @@ int64_t mtlssl_conv2d_filter_xf_bytes(const mtlssl_conv_desc* d, int mode) {
 }
 int mtlssl_conv2d_filter_xf_variant(const mtlssl_conv_desc* d, int mode) {
   WinoChoice wc;
-  if (!d || (mode != MODE_FWD && mode != MODE_DGRAD) || check_desc(d) || !choose_wino(d, mode, &wc)) return -1;
+  if (!d || mode < MODE_FWD || mode > MODE_WGRAD || check_desc(d) || !choose_wino(d, mode, &wc)) return -1;
   return wc.variant;
+}
+int64_t mtlssl_conv2d_input_xf_bytes(const mtlssl_conv_desc* d, int variant) {
+  if (!d || check_desc(d) || variant < 0 || variant >= WINO_VARIANTS || !wino_eligible(d, variant)) return 0;
+  return wino_input_bytes(d, variant);
 }
 int mtlssl_conv2d_transform_filter(const mtlssl_conv_desc* d, int mode, int variant, const float* w, float* filter_xf,
                                    mtlssl_stream_t stream) {
@@ -1023,6 +1027,12 @@ int mtlssl_conv2d_fwd(const mtlssl_conv_desc* d, const float* x, const float* w,
 int mtlssl_conv2d_fwd_xf(const mtlssl_conv_desc* d, const float* x, const float* w, const float* bias,
                          const float* residual, float* y, int epi, void* workspace, const float* filter_xf,
                          int xf_variant, mtlssl_stream_t stream) {
+  return mtlssl_conv2d_fwd_keep(d, x, w, bias, residual, y, epi, workspace, filter_xf, xf_variant, nullptr, -1, stream);
+}
+
+int mtlssl_conv2d_fwd_keep(const mtlssl_conv_desc* d, const float* x, const float* w, const float* bias,
+                           const float* residual, float* y, int epi, void* workspace, const float* filter_xf,
+                           int xf_variant, float* input_xf, int input_variant, mtlssl_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_BIAS) || bias, "conv_fwd: bias pointer required");
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_fwd: residual pointer required");
@@ -1035,7 +1045,8 @@ int mtlssl_conv2d_fwd_xf(const mtlssl_conv_desc* d, const float* x, const float*
   WinoChoice wc;
   if (workspace && choose_wino(d, MODE_FWD, &wc)) {
     wino_fwd(d, wc.variant, wc.tile, x, w, bias, residual, y, epi, workspace, S(stream),
-             (filter_xf && xf_variant == wc.variant) ? filter_xf : nullptr);
+             (filter_xf && xf_variant == wc.variant) ? filter_xf : nullptr,
+             (input_xf && input_variant == wc.variant) ? input_xf : nullptr);
   } else if (mfma_fwd_ok(d)) {
     Plan pl = plan_dir(d, MODE_FWD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
@@ -1202,6 +1213,12 @@ int mtlssl_conv2d_wgrad_grouped(const mtlssl_conv_desc* d, int n, const void* x_
 int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,
                         const float* out_scale, float* dw, float* dbias, float beta,
                         void* workspace, mtlssl_stream_t stream) {
+  return mtlssl_conv2d_wgrad_xf(d, x, dy, out_scale, dw, dbias, beta, workspace, nullptr, -1, stream);
+}
+
+int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const float* dy,
+                           const float* out_scale, float* dw, float* dbias, float beta,
+                           void* workspace, const float* input_xf, int input_variant, mtlssl_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   hipStream_t st = S(stream);
   ConvArgs p = make_args(d);
@@ -1213,7 +1230,8 @@ int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* 
   float* ws_main = (float*)((char*)workspace + align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256));
   WinoChoice wc;
   if (choose_wino(d, MODE_WGRAD, &wc)) {
-    wino_wgrad(d, wc.variant, wc.tile, x, dy, out_scale, dw, beta, ws_main, st);
+    wino_wgrad(d, wc.variant, wc.tile, x, dy, out_scale, dw, beta, ws_main, st,
+               (input_xf && input_variant == wc.variant) ? input_xf : nullptr);
   } else if (mfma_wgrad_ok(d)) {
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);

@@ -882,7 +882,9 @@ double wino_time_us(const mtlssl_conv_desc* d, int variant, int mode, int* tile)
 int64_t wino_workspace_bytes(const mtlssl_conv_desc* d, int variant, int mode);
 // filter_xf: the layer's transformed filter if the caller keeps it (wino_filter), else nullptr
 void wino_fwd(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* w, const float* bias,
-              const float* residual, float* y, int epi, void* workspace, hipStream_t st, const float* filter_xf = nullptr);
+              const float* residual, float* y, int epi, void* workspace, hipStream_t st, const float* filter_xf = nullptr,
+              float* input_xf_keep = nullptr);
+int64_t wino_input_bytes(const mtlssl_conv_desc* d, int variant);
 void wino_dgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* dy, const float* w,
                 const float* residual, const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st,
                 const float* filter_xf = nullptr);
@@ -891,6 +893,7 @@ void wino_filter(const mtlssl_conv_desc* d, int variant, int flip, const float* 
 void wino_filters_batched(int variant, int n, const void* w_ptrs, const void* u_ptrs, const int64_t* ck,
                           const int32_t* flip, int64_t max_ck, hipStream_t st);
 void wino_wgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* dy,
-                const float* out_scale, float* dw, float beta, void* workspace, hipStream_t st);
+                const float* out_scale, float* dw, float beta, void* workspace, hipStream_t st,
+                const float* input_xf = nullptr);
 
 }  // namespace mtlssl

@@ -529,7 +529,8 @@ int64_t workspace_bytes(const mtlssl_conv_desc* d, int mode) {
 
 template <typename S>
 void fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* w, const float* bias,
-         const float* residual, float* y, int epi, void* workspace, hipStream_t st, const float* U_pre = nullptr) {
+         const float* residual, float* y, int epi, void* workspace, hipStream_t st, const float* U_pre = nullptr,
+         float* V_keep = nullptr) {
   constexpr int PL = S::P * S::P;
   WinoGeom g = geom<S>(d);
   const int64_t CK = (int64_t)d->C * d->K;
@@ -537,6 +538,7 @@ void fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* w, co
   float* V = (float*)((char*)U + align_up(PL * CK * 4, 256));
   float* Mb = (float*)((char*)V + align_up((int64_t)PL * g.T * d->C * 4, 256));
   if (U_pre) U = const_cast<float*>(U_pre);       // transformed once per optimizer step by the caller
+  if (V_keep) V = V_keep;                         // the caller keeps B^T x B for this layer's filter gradient
   else run_filter<S>(w, U, CK, 0, st);
   run_input<S>(x, V, g, d->C, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
@@ -571,7 +573,7 @@ void dgrad(const mtlssl_conv_desc* d, int tile, const float* dy, const float* w,
 
 template <typename S>
 void wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float* dy, const float* out_scale,
-           float* dw, float beta, void* workspace, hipStream_t st) {
+           float* dw, float beta, void* workspace, hipStream_t st, const float* V_pre = nullptr) {
   constexpr int PL = S::P * S::P;
   WinoGeom g = geom<S>(d);
   const int64_t CK = (int64_t)d->C * d->K;
@@ -580,7 +582,8 @@ void wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float* dy,
   float* dU = (float*)((char*)dM + align_up((int64_t)PL * g.T * d->K * 4, 256));  // [ns][P^2][C][K]
   int ns, pps;
   wgrad_split(g.T, PL, d->C, d->K, tile, &ns, &pps);
-  run_input<S>(x, V, g, d->C, st);
+  if (V_pre) V = const_cast<float*>(V_pre);        // kept by the forward call of the same layer
+  else run_input<S>(x, V, g, d->C, st);
   run_dy<S>(dy, dM, g, d->K, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = dM; p.out = dU;
@@ -604,9 +607,17 @@ int64_t wino_workspace_bytes(const mtlssl_conv_desc* d, int variant, int mode) {
   return variant == WINO_M7 ? workspace_bytes<M7>(d, mode) : workspace_bytes<F43>(d, mode);
 }
 void wino_fwd(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* w, const float* bias,
-              const float* residual, float* y, int epi, void* workspace, hipStream_t st, const float* filter_xf) {
-  if (variant == WINO_M7) fwd<M7>(d, tile, x, w, bias, residual, y, epi, workspace, st, filter_xf);
-  else fwd<F43>(d, tile, x, w, bias, residual, y, epi, workspace, st, filter_xf);
+              const float* residual, float* y, int epi, void* workspace, hipStream_t st, const float* filter_xf,
+              float* input_xf_keep) {
+  if (variant == WINO_M7) fwd<M7>(d, tile, x, w, bias, residual, y, epi, workspace, st, filter_xf, input_xf_keep);
+  else fwd<F43>(d, tile, x, w, bias, residual, y, epi, workspace, st, filter_xf, input_xf_keep);
+}
+// The transformed input V = B^T x B of one layer ([P^2][T][C]): the forward and the filter-gradient pass of a layer
+// compute the same thing from the same x, so a training step may keep the forward's.
+int64_t wino_input_bytes(const mtlssl_conv_desc* d, int variant) {
+  if (variant == WINO_M7) { WinoGeom g = geom<M7>(d); return align_up((int64_t)M7::P * M7::P * g.T * d->C * 4, 256); }
+  WinoGeom g = geom<F43>(d);
+  return align_up((int64_t)F43::P * F43::P * g.T * d->C * 4, 256);
 }
 void wino_dgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* dy, const float* w,
                 const float* residual, const float* mask_ref, float* dx, int epi, void* workspace, hipStream_t st,
@@ -636,9 +647,9 @@ void wino_filter(const mtlssl_conv_desc* d, int variant, int flip, const float* 
   else run_filter<F43>(w, U, CK, flip, st);
 }
 void wino_wgrad(const mtlssl_conv_desc* d, int variant, int tile, const float* x, const float* dy,
-                const float* out_scale, float* dw, float beta, void* workspace, hipStream_t st) {
-  if (variant == WINO_M7) wgrad<M7>(d, tile, x, dy, out_scale, dw, beta, workspace, st);
-  else wgrad<F43>(d, tile, x, dy, out_scale, dw, beta, workspace, st);
+                const float* out_scale, float* dw, float beta, void* workspace, hipStream_t st, const float* input_xf) {
+  if (variant == WINO_M7) wgrad<M7>(d, tile, x, dy, out_scale, dw, beta, workspace, st, input_xf);
+  else wgrad<F43>(d, tile, x, dy, out_scale, dw, beta, workspace, st, input_xf);
 }
 
 }  // namespace mtlssl

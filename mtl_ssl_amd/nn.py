@@ -130,6 +130,7 @@ class ConvBN:
         self.mean = ps.add(bn + "moving_mean", (cout,), ("uniform", -0.1, 0.1), False)
         self.var = ps.add(bn + "moving_variance", (cout,), ("uniform", 0.8, 1.2), False)
         self._desc = {}
+        self._kept = {}          # x.data_ptr() -> (Winograd-transformed x, variant), between forward(keep=True) and wgrad
         self.w_eff = None
 
     def prepare(self):
@@ -165,19 +166,27 @@ class ConvBN:
             self._desc[tuple(shape)] = d
         return d
 
-    def forward(self, x, residual=None, relu=None):
+    def forward(self, x, residual=None, relu=None, keep=False):
+        """keep: this forward will be followed by wgrad(x, .) of the same x (training with saved activations) —
+        a Winograd layer then keeps its transformed input for the filter gradient."""
         act = self.act if relu is None else ("relu" if relu else None)
         epi = ops.EPI_BIAS | {None: 0, "relu": ops.EPI_RELU, "relu6": ops.EPI_RELU6}[act] \
             | (ops.EPI_RESIDUAL if residual is not None else 0)
         return ops.conv2d_fwd(self.desc(x.shape), x, self.w_eff, self.shift, residual, epi,
-                              xf_cache=self.ps.filter_cache)
+                              xf_cache=self.ps.filter_cache,
+                              keep_input_xf=self._keep_slot() if (keep and self.trainable and self.k == 3) else None)
+
+    def _keep_slot(self):
+        if len(self._kept) > 8:      # forwards whose backward never came (a caller that saves and then drops the step)
+            self._kept.clear()
+        return self._kept
 
     def wgrad(self, x, g):
         if self.trainable:
             # without a gamma, d(beta) is just the column sum of g: ride on the wgrad's dbias pass
             db = self.ps.grad(self.beta.name) if (self.bn_trainable and self.gamma is None) else None
             ops.conv2d_wgrad(self.desc(x.shape), x, g, self.ps.grad(self.w.name), out_scale=self.scale,
-                             dbias=db, beta=1.0)
+                             dbias=db, beta=1.0, input_xf=self._kept.pop(x.data_ptr(), None))
             self.ps.grad_ready(self.w, self.beta if db is not None else None)
 
     def dgrad(self, x_shape, g, residual=None, mask_ref=None, out=None, accum=False, mask6=False):
@@ -333,7 +342,7 @@ class Bottleneck:
         else:
             sc = x
         a1 = self.conv1.forward(x)
-        a2 = self.conv2.forward(a1)
+        a2 = self.conv2.forward(a1, keep=save)
         out = self.conv3.forward(a2, residual=sc)
         ctx = (x, a1, a2, sc if (self.shortcut is None and self.stride > 1) else None) if save else None
         return out, ctx

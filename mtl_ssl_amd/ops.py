@@ -286,7 +286,20 @@ class FilterXfCache:
             e["event"], e["waited"] = ev, {run_on.cuda_stream}
 
 
-def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None, xf_cache=None):
+KEEP_INPUT_XF = os.environ.get("MTLSSL_KEEP_INPUT_XF", "1") != "0"
+
+
+def _shared_input_variant(d):
+    """The Winograd variant both the forward and the filter gradient of `d` are planned with (-1: none in common)."""
+    if not (KEEP_INPUT_XF and d.R == 3 and d.S == 3):
+        return -1
+    v = lib().conv2d_filter_xf_variant(ctypes.byref(d), 0)
+    return v if (v >= 0 and v == lib().conv2d_filter_xf_variant(ctypes.byref(d), 2)) else -1
+
+
+def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None, xf_cache=None, keep_input_xf=None):
+    """keep_input_xf: a dict (owned by the layer) that receives {x.data_ptr(): (V, variant)} when the forward
+    and the filter gradient of this problem share a Winograd input transform; conv2d_wgrad takes it back."""
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
     if PROFILER is None:
         def run():
@@ -299,8 +312,14 @@ def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None, xf_cache
     nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 0)
     ws = workspace(nb, "splitk", x.device) if nb else None
     U, variant = xf_cache.get(d, 0, w) if (xf_cache is not None and d.R == 3 and d.S == 3) else (None, -1)
-    lib().conv2d_fwd_xf(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(residual),
-                        ptr(y), epilogue, ptr(ws), ptr(U), variant, _stream())
+    V, vvar = None, -1
+    if keep_input_xf is not None:
+        vvar = _shared_input_variant(d)
+        if vvar >= 0:
+            V = torch.empty(int(lib().conv2d_input_xf_bytes(ctypes.byref(d), vvar)) // 4, dtype=f32, device=x.device)
+            keep_input_xf[x.data_ptr()] = (V, vvar)
+    lib().conv2d_fwd_keep(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(residual),
+                          ptr(y), epilogue, ptr(ws), ptr(U), variant, ptr(V), vvar, _stream())
     if t0 is not None:
         PROFILER.end(d, 0, t0)
     return y
@@ -327,7 +346,8 @@ def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None, x
     return dx
 
 
-def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0):
+def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0, input_xf=None):
+    """input_xf: (V, variant) kept by this layer's conv2d_fwd(keep_input_xf=...) for the same x, or None."""
     if PROFILER is None:
         def run():                                    # scratch filter gradient, beta = 0
             tmp = workspace(4 * d.R * d.S * d.C * d.K, "tune_out", x.device)
@@ -339,8 +359,11 @@ def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0):
     nbytes = lib().conv2d_wgrad_workspace_bytes(ctypes.byref(d))
     ws = workspace(nbytes, "wgrad", x.device)
     t0 = PROFILER.begin(d, 2) if PROFILER is not None else None
-    lib().conv2d_wgrad(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(dy)), ptr(out_scale), ptr(dw),
-                       ptr(dbias), float(beta), ptr(ws), _stream())
+    V, vvar = input_xf if input_xf is not None else (None, -1)
+    if V is not None:
+        V.record_stream(torch.cuda.current_stream())     # made on the forward's stream, read on this one
+    lib().conv2d_wgrad_xf(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(dy)), ptr(out_scale), ptr(dw),
+                          ptr(dbias), float(beta), ptr(ws), ptr(V), vvar, _stream())
     if t0 is not None:
         PROFILER.end(d, 2, t0)
     return dw

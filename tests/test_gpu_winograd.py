@@ -142,3 +142,42 @@ def test_winograd_full_size_round_trip(ops, wino_cfg):
     assert relerr(y, ops.conv2d_fwd(d, x, w)) < 1e-4
     for mode in (0, 1, 2):
         ops.force_conv_config(d, mode, -1)
+
+
+@pytest.mark.parametrize("case", [((2, 19, 23, 64, 64), 4), ((1, 38, 64, 256, 256), 6), ((130, 7, 7, 128, 256), 8)],
+                         ids=["f43-ragged", "f43-block3", "m7-rois"])
+def test_kept_input_transform_gives_the_same_filter_gradient(ops, case):
+    """mtlssl_conv2d_fwd_keep / _wgrad_xf: the forward's B^T x B handed to the filter gradient of the same layer.
+    Same kernels on the same numbers, so y and dw are bit-identical to the calls that transform x themselves; a
+    buffer made for another variant than the wgrad's plan is ignored (dw still right)."""
+    (N, H, W, C, K), cfg = case
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g)
+    w = torch.randn(3, 3, C, K, device="cuda", generator=g) / np.sqrt(9 * C)
+    gy = torch.randn(N, H, W, K, device="cuda", generator=g)
+    d = ops.conv_desc(x.shape, w.shape, 1, 1, "SAME")
+    try:
+        for mode in (0, 2):
+            assert ops.force_conv_config(d, mode, cfg) == cfg
+        y0 = ops.conv2d_fwd(d, x, w)
+        dw0 = torch.zeros_like(w)
+        ops.conv2d_wgrad(d, x, gy, dw0)
+        kept = {}
+        y1 = ops.conv2d_fwd(d, x, w, keep_input_xf=kept)
+        assert list(kept) == [x.data_ptr()] and kept[x.data_ptr()][1] == (1 if cfg >= 8 else 0)
+        dw1 = torch.zeros_like(w)
+        ops.conv2d_wgrad(d, x, gy, dw1, input_xf=kept[x.data_ptr()])
+        assert torch.equal(y0, y1) and torch.equal(dw0, dw1)
+        # the wgrad re-planned as the direct algorithm: the kept buffer no longer applies and must be ignored
+        ops.force_conv_config(d, 2, 2)
+        dw2, dw3 = torch.zeros_like(w), torch.zeros_like(w)
+        ops.conv2d_wgrad(d, x, gy, dw2)
+        ops.conv2d_wgrad(d, x, gy, dw3, input_xf=kept[x.data_ptr()])
+        assert torch.equal(dw2, dw3) and relerr(dw2, dw0) < 1e-4
+        # and a forward whose plan differs from the wgrad's keeps nothing
+        kept2 = {}
+        ops.conv2d_fwd(d, x, w, keep_input_xf=kept2)
+        assert not kept2
+    finally:
+        for mode in (0, 2):
+            ops.force_conv_config(d, mode, -1)
