@@ -187,3 +187,37 @@ def test_trainer_state_saves_moving_averages_and_options(tmp_path):
     # resuming picks the state (and the averages) up where it stopped
     tr2, _ = trainer.train(lambda: batch, model_fn, cfg.train_config, train_dir=d, num_steps=5, model_config=cfg.model)
     assert tr2.global_step == 5
+
+
+def test_train_and_eval_launchers_with_the_reference_flags(tmp_path):
+    """object_detection/train.py:65-98 / eval.py:66-82 command lines against this build's launchers: records on
+    disk -> `python -m mtl_ssl_amd.train --train_dir --pipeline_config_path` -> state file + saved configuration ->
+    `python -m mtl_ssl_amd.eval --checkpoint_dir --eval_dir --pipeline_config_path` -> metrics JSON."""
+    import json
+    import subprocess
+    import sys
+    K, H, W = 5, 160, 224
+    rec = str(tmp_path / "voc.record")
+    _write_records(rec, 4, K, H, W, np.random.RandomState(5))
+    text = open(os.path.join(ROOT, "configs", "smoke_resnet50_mtl.config")).read()
+    text += '\ntrain_input_reader { tf_record_input_reader { input_path: "%s" } }\n' % str(tmp_path / "voc.rec*")
+    text += 'eval_config { num_examples: 3 }\neval_input_reader { shuffle: false tf_record_input_reader { input_path: "%s" } }\n' % rec
+    cfgp = str(tmp_path / "pipeline.config")
+    open(cfgp, "w").write(text)
+    run = str(tmp_path / "run")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "mtl_ssl_amd.train", "--logtostderr", "--train_dir=" + run,
+                        "--pipeline_config_path=" + cfgp, "--num_steps=3"], env=env, cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "global step 3" in r.stdout and os.path.exists(os.path.join(run, "model.ckpt.npz"))
+    assert os.path.exists(os.path.join(run, "pipeline.config"))
+    r = subprocess.run([sys.executable, "-m", "mtl_ssl_amd.train", "--train_dir=" + run, "--pipeline_config_path=" + cfgp,
+                        "--num_clones=2"], env=env, cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0 and "torch.distributed.run" in r.stderr
+    r = subprocess.run([sys.executable, "-m", "mtl_ssl_amd.eval", "--logtostderr", "--checkpoint_dir=" + run,
+                        "--eval_dir=" + str(tmp_path / "eval"), "--pipeline_config_path=" + cfgp],
+                       env=env, cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["global_step"] == 3 and out["num_images"] == 3 and len(out["ap_per_class"]) == K
+    assert json.load(open(str(tmp_path / "eval" / "metrics-3.json"))) == out
