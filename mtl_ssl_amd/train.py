@@ -92,8 +92,10 @@ def main(argv=None):
     model_config, train_config, input_config = read_configs(f)
     K = int(model_config.faster_rcnn.num_classes)
     B = int(train_config.batch_size)
-    if world > 1 and B % world == 0 and os.environ.get("MTLSSL_GLOBAL_BATCH", "1") != "0":
-        B //= world                                  # train_config.batch_size is the global batch (trainer.py:270)
+    if world > 1:                                    # train_config.batch_size is the GLOBAL batch: every clone of the
+        if B % world:                                # reference takes batch_size // num_clones images (trainer.py:270)
+            raise SystemExit("train_config.batch_size %d does not divide over %d ranks" % (B, world))
+        B //= world
     probe = model_builder.build(model_config, True, dev, seed=f.seed)
     rz = model_config.faster_rcnn.image_resizer
     stream = input_reader.batches(record_paths(input_config), K, B, train_config.data_augmentation_options,
