@@ -380,3 +380,46 @@ def test_random_horizontal_flip_known_answers_and_fork_extras():
     assert 150 < flips < 250
     with pytest.raises(ValueError, match="not supported"):
         preprocessor.preprocess(ex, [{"random_crop_image": {}}])
+
+
+def test_train_launcher_reads_the_reference_flag_forms(tmp_path):
+    """object_detection/train.py:101-155: one pipeline file, or --model/--train/--input config files; record
+    globs of tf_record_input_reader.input_path; clone / parameter-server flags are refused, not ignored."""
+    from mtl_ssl_amd import train
+    text = open(os.path.join(ROOT, "configs", "smoke_resnet50_mtl.config")).read()
+    for i in range(3):
+        (tmp_path / ("voc-%05d-of-00003.record" % i)).write_bytes(b"")
+    reader = 'tf_record_input_reader { input_path: "%s" }' % str(tmp_path / "voc-?????-of-00003.record")
+    pipe = tmp_path / "pipeline.config"
+    pipe.write_text(text + "\ntrain_input_reader { %s }\n" % reader)
+    f = train._flags(["--logtostderr", "--train_dir=/x", "--pipeline_config_path=%s" % pipe])
+    model_cfg, train_cfg, input_cfg = train.read_configs(f)
+    assert model_cfg.faster_rcnn.num_classes == 5 and int(train_cfg.batch_size) == 2
+    assert [os.path.basename(p) for p in train.record_paths(input_cfg)] == ["voc-%05d-of-00003.record" % i for i in range(3)]
+    # the three-file form gives the same messages
+    from mtl_ssl_amd import config
+    whole = config.parse_pipeline_config(pipe.read_text())
+
+    def body(field):
+        s = pipe.read_text()
+        a = s.index(field) + len(field)
+        a = s.index("{", a) + 1
+        depth, i = 1, a
+        while depth:
+            depth += {"{": 1, "}": -1}.get(s[i], 0)
+            i += 1
+        return s[a:i - 1]
+    for name, field in (("m.cfg", "model"), ("t.cfg", "train_config"), ("i.cfg", "train_input_reader")):
+        (tmp_path / name).write_text(body(field))
+    f3 = train._flags(["--train_dir", "/x", "--model_config_path", str(tmp_path / "m.cfg"),
+                       "--train_config_path", str(tmp_path / "t.cfg"), "--input_config_path", str(tmp_path / "i.cfg")])
+    m3, t3, i3 = train.read_configs(f3)
+    assert m3 == whole.model and t3 == whole.train_config and train.record_paths(i3) == train.record_paths(input_cfg)
+    with pytest.raises(FileNotFoundError):
+        train.record_paths(config.parse_pipeline_config('train_input_reader { tf_record_input_reader { input_path: "/nowhere/*.rec" } }').train_input_reader)
+    with pytest.raises(ValueError):
+        train.record_paths(config.Msg())
+    for bad in (["--num_clones=8"], ["--ps_tasks=1"], ["--worker_replicas=2"]):
+        with pytest.raises(SystemExit) as e:
+            train.main(["--train_dir=/x", "--pipeline_config_path=%s" % pipe] + bad)
+        assert "torch.distributed.run" in str(e.value)
