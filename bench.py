@@ -75,6 +75,19 @@ def pmc_traffic(default_cfg):
     return d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
 
 
+def pmc_traffic_provenance(default_cfg):
+    """Where `roofline.traffic` comes from and whether the counters were taken from the kernel sources being timed
+    (tools/pmc_summary.py stores a digest of conv_mfma.h + conv.hip with them)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not default_cfg or not os.path.exists(path):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_summary import kernel_source_sha16
+    d = json.load(open(path))
+    return {"file": "profiles/r02_pmc_traffic.json", "counters_from_sources": d.get("kernel_source_sha16"),
+            "current_sources": kernel_source_sha16(), "matches_current_kernel": d.get("kernel_source_sha16") == kernel_source_sha16()}
+
+
 HBM_PEAK = 8.0e12   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -389,6 +402,7 @@ def main():
                 "bound": "mfma", "achieved": dom["flops"] / dom["seconds"] / 1e12,
                 "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": dom["flops"] / dom["seconds"] / FP32_MFMA_PEAK, "traffic": pmc_traffic(default_cfg),
+                "traffic_provenance": pmc_traffic_provenance(default_cfg),
                 "kernel": "mtlssl::k_conv_mfma<128,128,0> (implicit-GEMM conv forward)",
                 # calls of mtlssl_conv2d_fwd that ran this kernel; some make two launches of it (whole
                 # waves + a K-split tail), so the per-launch average divides by the dispatch count —

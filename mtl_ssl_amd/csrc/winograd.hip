@@ -538,8 +538,8 @@ void fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* w, co
   float* V = (float*)((char*)U + align_up(PL * CK * 4, 256));
   float* Mb = (float*)((char*)V + align_up((int64_t)PL * g.T * d->C * 4, 256));
   if (U_pre) U = const_cast<float*>(U_pre);       // transformed once per optimizer step by the caller
-  if (V_keep) V = V_keep;                         // the caller keeps B^T x B for this layer's filter gradient
   else run_filter<S>(w, U, CK, 0, st);
+  if (V_keep) V = V_keep;                         // the caller keeps B^T x B for this layer's filter gradient
   run_input<S>(x, V, g, d->C, st);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = U; p.out = Mb;

@@ -47,3 +47,17 @@ def test_product_package_never_imports_the_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_committed_pmc_traffic_was_taken_from_the_current_roofline_kernel():
+    """bench.py's roofline.traffic is the committed result of separate PMC passes (counters cannot be read inside
+    the timed process): the file carries a digest of the kernel sources it was measured on, and a change to
+    conv_mfma.h / conv.hip without re-running tools/pmc_bench.sh + tools/pmc_summary.py fails here."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from pmc_summary import kernel_source_sha16
+    d = json.load(open(os.path.join(root, "profiles", "r02_pmc_traffic.json")))
+    assert d.get("kernel_source_sha16") == kernel_source_sha16(), \
+        "profiles/r02_pmc_traffic.json is stale: regenerate it with tools/pmc_bench.sh + tools/pmc_summary.py"

@@ -52,13 +52,25 @@ def main(root, top=14):
     return rows
 
 
+def kernel_source_sha16():
+    """Digest of the sources of the roofline kernel: stored with the counters so that bench.py can tell whether the
+    committed traffic figure was taken from the kernel it is timing."""
+    import hashlib
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mtl_ssl_amd", "csrc")
+    h = hashlib.sha256()
+    for name in ("conv_mfma.h", "conv.hip"):
+        h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 if __name__ == "__main__":
     rows = main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 14)
     if len(sys.argv) > 3:
         dom = next(r for r in rows if "k_conv_mfma<128, 128, 0" in r["kernel"])
         json.dump({"kernel": dom["kernel"], "launches": dom["launches"],
                    "hbm_read_bytes_per_launch": dom["fetch_bytes"], "hbm_write_bytes_per_launch": dom["write_bytes"],
-                   "mfma_util": dom["mfma_util"], "l2_hit": dom["l2_hit"],
+                   "mfma_util": dom["mfma_util"], "l2_hit": dom["l2_hit"], "kernel_source_sha16": kernel_source_sha16(),
                    "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py "
                              "(tools/pmc_bench.sh); FETCH_SIZE doubled (gfx950 wide-load correction)"},
                   open(sys.argv[3], "w"), indent=1)
