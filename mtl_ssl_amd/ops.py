@@ -29,8 +29,13 @@ def _chk(t, dtype=f32):
 _ws_cache = {}
 
 
+POISON_WS = os.environ.get("MTLSSL_POISON_WS") == "1"
+
+
 def workspace(nbytes, key="default", device=None):
-    """Grow-only device scratch buffers, one per key (caller-owned workspaces of the C ABI)."""
+    """Grow-only device scratch buffers, one per key (caller-owned workspaces of the C ABI).
+    MTLSSL_POISON_WS=1 (the test suite sets it) fills a buffer with NaN bit patterns every time it is handed out, so
+    that no entry point can get by on what an earlier call left in its workspace."""
     device = device or torch.device("cuda", torch.cuda.current_device())
     # one buffer per (purpose, device, stream): kernels on different streams may run concurrently
     k = (key, device.index, torch.cuda.current_stream().cuda_stream)
@@ -38,6 +43,8 @@ def workspace(nbytes, key="default", device=None):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _ws_cache[k] = buf
+    if POISON_WS:
+        buf.fill_(255)
     return buf
 
 

@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# every workspace is filled with NaN patterns when it is handed out (mtl_ssl_amd/ops.py:workspace): an entry point
+# that skips part of its work cannot pass on what an earlier call left behind
+os.environ.setdefault("MTLSSL_POISON_WS", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
