@@ -130,6 +130,14 @@ int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg);
  * initial value), 2 = Winograd F(4x4,3x3) for every eligible problem. Returns the previous mode; a mode
  * outside 0..2 only queries. Process-wide. */
 int mtlssl_conv2d_set_winograd(int mode);
+/* fp32 matrix engine of the large implicit GEMMs. 0 (default; MTLSSL_FP32_ENGINE unset): v_mfma_f32_32x32x2_f32,
+ * exact fp32 products with fp32 accumulation. 1 (MTLSSL_FP32_ENGINE=split): problems with at least 192 tiles of
+ * 256 x 256 run on the bf16 matrix datapath with every operand split EXACTLY into three bf16 pieces (hi + mid + lo
+ * = the fp32 value) and six of the nine piece products accumulated in fp32; the three dropped products are below
+ * 2^-23 of |a*b| (one fp32 rounding). Same error against fp64 as mode 0 (tests/test_gpu_split_engine.py), other
+ * summation order (not bit-identical), +-inf operands yield NaN. Returns the previous mode; any other value only
+ * queries. Process-wide. */
+int mtlssl_conv2d_set_fp32_engine(int mode);
 /* Number of launches of the implicit-GEMM kernel one call makes for this problem (2 when the planner
  * splits off a K-split tail launch) — lets a profiler relate per-call timings to
  * per-dispatch kernel traces. */

@@ -19,6 +19,7 @@
 #include <unordered_map>
 
 #include "conv_mfma.h"
+#include "conv_split.h"
 
 namespace mtlssl {
 
@@ -698,6 +699,11 @@ static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st, int ti
 template <int MODE>
 static void launch_planned(const Plan& pl, ConvArgs& p, float* ws, hipStream_t st) {
   p.splitk_ws = ws;
+  if (pl.nsplit == 1 && split_engine_takes(pl.cfg, p.M, p.NG, (int64_t)p.R * p.S * (MODE == MODE_FWD ? p.C : p.K))) {
+    p.nsplit = 1; p.ks_per_split = 0; p.tile_m0 = 0; p.ws_m0 = 0;     // one launch over every tile, no K-split tail
+    launch_split<MODE, false>(p, dim3(1, 1, 1), st);
+    return;
+  }
   if (pl.tail_rows == 0) {
     p.nsplit = pl.nsplit; p.ks_per_split = pl.ks_per_split;
     launch_mfma<MODE>(pl.cfg, p, dim3(1, 1, pl.nsplit), st);
@@ -781,6 +787,19 @@ static void wgrad_plan(const mtlssl_conv_desc* d, int* cfg, int* nsplit, int* pp
 // direct path.
 constexpr int WINO_CFG0 = 4;
 struct WinoChoice { int variant, tile; };
+static std::atomic<int>& fp32_engine_ref() {
+  static std::atomic<int> v{-1};
+  return v;
+}
+int fp32_engine() {
+  int v = fp32_engine_ref().load();
+  if (v < 0) {
+    const char* e = getenv("MTLSSL_FP32_ENGINE");
+    v = (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : 0;
+    fp32_engine_ref().store(v);
+  }
+  return v;
+}
 static std::atomic<int>& wino_mode_ref() {
   static std::atomic<int> v{-1};
   return v;
@@ -1127,6 +1146,12 @@ int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg) {
   }
   plans_clear();
   return MTLSSL_OK;
+}
+
+int mtlssl_conv2d_set_fp32_engine(int mode) {
+  const int prev = fp32_engine();
+  if (mode == 0 || mode == 1) fp32_engine_ref().store(mode);
+  return prev;
 }
 
 int mtlssl_conv2d_set_winograd(int mode) {

@@ -1,0 +1,330 @@
+// Second tile engine of the fp32 convolution family (opt-in, see mtlssl_conv2d_set_fp32_engine): the same
+// implicit GEMMs as conv_mfma.h, multiplied on the bf16 matrix-core datapath by EXACT operand splitting.
+//
+//   * every fp32 value is the exact sum of three bf16 numbers, x = hi + mid + lo, obtained by truncation
+//     (8 + 8 + 8 significant bits = the 24 of fp32; each remainder is formed by an exact subtraction);
+//   * a product of two bf16 pieces has 16 significant bits: exact in the fp32 accumulator of
+//     v_mfma_f32_32x32x16_bf16;
+//   * a*b is the sum of the 9 piece products; the 6 with weight >= 2^-16 are issued — (hi,hi) (hi,mid) (mid,hi)
+//     (mid,mid) (hi,lo) (lo,hi) — and the 3 dropped ones (mid,lo) (lo,mid) (lo,lo) are below 2^-23 |a*b|: one fp32
+//     rounding of the product, which the fp32 FMA chain of the native engine commits on every accumulation anyway.
+//     Measured against fp64 the two engines have the same error (tools/lab/split_gemm.hip, tests/test_gpu_split_engine.py).
+//
+// Six 32-cycle bf16 MFMAs replace eight 64-cycle fp32 MFMAs per 32x32x16 block-step (2.67x the matrix rate); the
+// operands still travel as fp32 (the split happens between the global load and the LDS store), so the tile is
+// 256 x 256 to keep the L2 -> LDS traffic per flop at half of the 128 x 128 fp32 tile's.
+//
+// Differences a caller can see: +-inf operands give NaN (inf - inf in the split) where the native engine gives
+// inf; sums are formed in another order (same fp32 products up to 2^-23, not bit-identical to the native engine).
+//
+// Geometry: 512 threads = 8 wavefronts as 4 (m) x 2 (n), 64 x 128 outputs each (2 x 4 MFMA blocks);
+// K-step 16 = one MFMA k extent; LDS image of an operand stage: [piece 3][k-group 2][row 256] x 16 B, the 16 B
+// being the 8 bf16 of one k-group — exactly one lane's MFMA operand (lane l: row l%32, k-group l/32), read with
+// one conflict-free ds_read_b128. Two stages (96 KB, dynamic LDS), register double-buffered global loads two
+// K-steps ahead, one barrier per K-step. Loaders, split-K / batched / grouped variants and the epilogue are the
+// native engine's (conv_mfma.h).
+#pragma once
+#include <mutex>
+
+#include "conv_mfma.h"
+
+namespace mtlssl {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SPLIT_BM = 256, SPLIT_BN = 256, SPLIT_THREADS = 512, SPLIT_LDS_BYTES = 2 * 2 * 1536 * 16;
+
+// x = h + m + l exactly; each returned as the upper 16 bits of its fp32 pattern (a bf16)
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned hb = __float_as_uint(x) & 0xFFFF0000u;
+  const float r1 = x - __uint_as_float(hb);
+  const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(mb);
+  h = hb >> 16; m = mb >> 16; l = __float_as_uint(r2) >> 16;
+}
+
+__device__ __forceinline__ float bufload1(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset, soffset, 0));
+}
+
+template <int MODE, bool BATCH>
+__device__ __forceinline__ void conv_split_body(ConvArgs p) {
+  constexpr int BM = SPLIT_BM, BN = SPLIT_BN, BKT = 16, NW = 8, TM = 2, TN = 4;
+  constexpr bool A_KC = (MODE != MODE_WGRAD);     // A rows are k-contiguous (else m-contiguous, k strided)
+  constexpr bool B_KC = (MODE == MODE_DGRAD);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char split_smem[];
+  uintx4* const lds = reinterpret_cast<uintx4*>(split_smem);        // [stage][operand][piece][k-group][row]
+  auto slot = [](int piece, int kg, int row) { return (piece * 2 + kg) * 256 + row; };
+
+  int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tile_m = bid / p.tiles_n + p.tile_m0, tile_n = bid % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int lo = lane & 31, hi = lane >> 5;
+
+  if constexpr (BATCH) {
+    p.a += (int64_t)blockIdx.y * p.a_bs;
+    p.b += (int64_t)blockIdx.y * p.b_bs;
+    if constexpr (MODE != MODE_WGRAD) p.out += (int64_t)blockIdx.y * p.o_bs;
+  }
+  if constexpr (MODE == MODE_WGRAD && !BATCH) {
+    if (p.a_tab) {
+      const int grp = blockIdx.z / p.nsplit;
+      p.a = p.a_tab[grp];
+      p.b = p.b_tab[grp];
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
+
+  int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps, ks_begin = 0;
+  if constexpr (MODE == MODE_FWD) {
+    ksteps = p.R * p.S * (p.C / BKT);
+  } else if constexpr (MODE == MODE_DGRAD) {
+    ksteps = p.R * p.S * (p.K / BKT);
+  } else {
+    rs_fixed = BATCH ? 0 : blockIdx.y;
+    int split = (!BATCH && p.a_tab) ? blockIdx.z % p.nsplit : blockIdx.z;
+    int P = p.N * p.OH * p.OW;
+    pix0 = split * p.pix_per_split;
+    pix1 = min(P, pix0 + p.pix_per_split);
+    ksteps = (max(pix1 - pix0, 0) + BKT - 1) / BKT;
+  }
+  if constexpr (MODE != MODE_WGRAD) {
+    if (p.nsplit > 1) {
+      ks_begin = blockIdx.z * p.ks_per_split;
+      ksteps = min(ksteps, ks_begin + p.ks_per_split);
+    }
+  }
+
+  // ---- thread -> element maps
+  // k-contiguous operand: row = tid / 2, the 8 k of k-group tid & 1 (two 16-byte loads, one LDS slot per piece)
+  const int kc_row = tid >> 1, kc_kg = tid & 1;
+  // strided operand ([k][cols] in memory): wave -> (k-group, 64-column block); lane -> (k pair, column % 16),
+  // four column sub-blocks of 16: eight dword loads, and per column one dword (two bf16) per piece into LDS —
+  // the 64 lanes of a store hit 64 different banks
+  const int mc_kg = wid & 1, mc_cb = (wid >> 1) * 64, mc_kq = lane >> 4, mc_cn = lane & 15;
+  const int mc_k0 = mc_kg * 8 + mc_kq * 2;
+
+  int a_base = 0, a_y = 0, a_x = 0, a_n = 0;
+  bool a_ok = false;
+  if constexpr (A_KC) {
+    int m = m0 + kc_row;
+    a_ok = m < p.M;
+    int mm = a_ok ? m : 0;
+    if constexpr (MODE == MODE_FWD) {
+      int ow = mm % p.OW, t = mm / p.OW;
+      a_x = ow * p.stride - p.pl;
+      a_y = (t % p.OH) * p.stride - p.pt;
+      a_n = t / p.OH;
+      a_base = ((a_n * p.H + a_y) * p.W + a_x) * p.C + kc_kg * 8;
+    } else {
+      int iw = mm % p.W, t = mm / p.W;
+      a_x = iw + p.pl;
+      a_y = (t % p.H) + p.pt;
+      a_n = t / p.H;
+      a_base = ((a_n * p.OH + a_y) * p.OW + a_x) * p.K + kc_kg * 8;     // stride-1 form
+    }
+  }
+  unsigned b_kc_base = OOB;
+  if constexpr (B_KC) {
+    int row = n0 + kc_row;
+    b_kc_base = row < p.NG ? (unsigned)(row * p.K + kc_kg * 8) * 4u : OOB;
+  }
+
+  float rA[2][8], rB[2][8];
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+
+  auto put4 = [](float (&r)[8], int at, floatx4 v) { r[at] = v.x; r[at + 1] = v.y; r[at + 2] = v.z; r[at + 3] = v.w; };
+
+  auto load_tile = [&](int ks, auto SET) {
+    float (&ra)[8] = rA[decltype(SET)::value];
+    float (&rb)[8] = rB[decltype(SET)::value];
+    if constexpr (MODE == MODE_FWD) {
+      int cpk = p.C / BKT;
+      int rs = ks / cpk, c0 = (ks - rs * cpk) * BKT;
+      int r = rs / p.S, s = rs - r * p.S;
+      int dy = r * p.dil, dx = s * p.dil;
+      int tapoff = (dy * p.W + dx) * p.C + c0;
+      int ih = a_y + dy, iw = a_x + dx;
+      bool ok = a_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      unsigned vo = ok ? (unsigned)(a_base + tapoff) * 4u : OOB;
+      put4(ra, 0, bufload4(rsrc_a, vo, 0));
+      put4(ra, 4, bufload4(rsrc_a, ok ? vo + 16u : OOB, 0));
+      unsigned so = (unsigned)(ks * BKT * p.K) * 4u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int col = n0 + mc_cb + mc_cn + 16 * j;
+        unsigned vo0 = col < p.NG ? (unsigned)(mc_k0 * p.K + col) * 4u : OOB;
+        rb[2 * j] = bufload1(rsrc_b, vo0, so);
+        rb[2 * j + 1] = bufload1(rsrc_b, col < p.NG ? vo0 + (unsigned)p.K * 4u : OOB, so);
+      }
+    } else if constexpr (MODE == MODE_DGRAD) {
+      int kpk = p.K / BKT;
+      int rs = ks / kpk, k0 = (ks - rs * kpk) * BKT;
+      int r = rs / p.S, s = rs - r * p.S;
+      int dy = r * p.dil, dx = s * p.dil;
+      unsigned vo;
+      if (p.stride == 1) {
+        int tapoff = k0 - (dy * p.OW + dx) * p.K;
+        int oh = a_y - dy, ow = a_x - dx;
+        bool ok = a_ok && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
+        vo = ok ? (unsigned)(a_base + tapoff) * 4u : OOB;
+      } else {
+        int ny = a_y - dy, nx = a_x - dx;
+        bool ok = a_ok && ny >= 0 && nx >= 0 && (ny % p.stride == 0) && (nx % p.stride == 0);
+        int oh = ny / p.stride, ow = nx / p.stride;
+        ok = ok && oh < p.OH && ow < p.OW;
+        int off = ((a_n * p.OH + oh) * p.OW + ow) * p.K + k0 + kc_kg * 8;
+        vo = ok ? (unsigned)off * 4u : OOB;
+      }
+      put4(ra, 0, bufload4(rsrc_a, vo, 0));
+      put4(ra, 4, bufload4(rsrc_a, vo != OOB ? vo + 16u : OOB, 0));
+      unsigned so = (unsigned)(rs * p.C * p.K + k0) * 4u;
+      put4(rb, 0, bufload4(rsrc_b, b_kc_base, so));
+      put4(rb, 4, bufload4(rsrc_b, b_kc_base != OOB ? b_kc_base + 16u : OOB, so));
+    } else {
+      int r = rs_fixed / p.S, s = rs_fixed - r * p.S;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        int pix = pix0 + ks * BKT + mc_k0 + e;
+        bool ok = pix < pix1;
+        int off = 0;
+        if (p.R == 1 && p.S == 1 && p.stride == 1) {
+          off = pix * p.C;
+        } else {
+          int ow = pix % p.OW, t = pix / p.OW;
+          int oh = t % p.OH, n = t / p.OH;
+          int ih = oh * p.stride - p.pt + r * p.dil, iw = ow * p.stride - p.pl + s * p.dil;
+          ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          off = ((n * p.H + ih) * p.W + iw) * p.C;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int m = m0 + mc_cb + mc_cn + 16 * j;
+          ra[2 * j + e] = bufload1(rsrc_a, (ok && m < p.M) ? (unsigned)(off + m) * 4u : OOB, 0);
+          int col = n0 + mc_cb + mc_cn + 16 * j;
+          rb[2 * j + e] = bufload1(rsrc_b, (pix < pix1 && col < p.NG) ? (unsigned)(pix * p.K + col) * 4u : OOB, 0);
+        }
+      }
+    }
+  };
+
+  // k-contiguous operand: 8 consecutive k of one row -> one 16-byte slot per piece
+  auto store_kc = [&](uintx4* s, const float (&r)[8]) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3(r[e], h[e], m[e], l[e]);
+    s[slot(0, kc_kg, kc_row)] = uintx4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    s[slot(1, kc_kg, kc_row)] = uintx4{m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16)};
+    s[slot(2, kc_kg, kc_row)] = uintx4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+  };
+  // strided operand: r[2j], r[2j+1] = the k pair of column block j -> one dword per piece and column
+  auto store_mc = [&](uintx4* s, const float (&r)[8]) {
+    unsigned* sw = reinterpret_cast<unsigned*>(s);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned h0, m0_, l0, h1, m1, l1;
+      split3(r[2 * j], h0, m0_, l0);
+      split3(r[2 * j + 1], h1, m1, l1);
+      const int c = mc_cb + mc_cn + 16 * j;
+      sw[slot(0, mc_kg, c) * 4 + mc_kq] = h0 | (h1 << 16);
+      sw[slot(1, mc_kg, c) * 4 + mc_kq] = m0_ | (m1 << 16);
+      sw[slot(2, mc_kg, c) * 4 + mc_kq] = l0 | (l1 << 16);
+    }
+  };
+  auto store_tile = [&](int buf, auto SET) {
+    uintx4* sa = lds + buf * 3072;
+    uintx4* sb = sa + 1536;
+    if constexpr (A_KC) store_kc(sa, rA[decltype(SET)::value]); else store_mc(sa, rA[decltype(SET)::value]);
+    if constexpr (B_KC) store_kc(sb, rB[decltype(SET)::value]); else store_mc(sb, rB[decltype(SET)::value]);
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = ksteps - ks_begin;
+  if (nk > 0) {
+    load_tile(ks_begin, Set0{});
+    store_tile(0, Set0{});
+  }
+  if (nk > 1) load_tile(ks_begin + 1, Set1{});
+  __syncthreads();
+  auto kstep = [&](int it, auto next, auto spare) {
+    if (it + 2 < nk) load_tile(ks_begin + it + 2, spare);
+    const uintx4* sa = lds + (it & 1) * 3072;
+    const uintx4* sb = sa + 1536;
+    bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[pc][i] = __builtin_bit_cast(bf16x8, sa[slot(pc, hi, wr * 64 + i * 32 + lo)]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[pc][j] = __builtin_bit_cast(bf16x8, sb[slot(pc, hi, wc * 128 + j * 32 + lo)]);
+    }
+    // the six piece products, in the order their operands arrive from LDS
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
+    constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
+    if (it + 1 < nk) store_tile((it & 1) ^ 1, next);
+    __syncthreads();
+  };
+  for (int it = 0; it < nk; it += 2) {
+    kstep(it, Set1{}, Set0{});
+    if (it + 1 < nk) kstep(it + 1, Set0{}, Set1{});
+  }
+
+  conv_epilogue<BM, BN, MODE, NW>(p, acc, reinterpret_cast<float*>(split_smem), m0, n0);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(SPLIT_THREADS, 1) k_conv_split(ConvArgs p) {
+  conv_split_body<MODE, false>(p);
+}
+template <int MODE>
+__global__ void __launch_bounds__(SPLIT_THREADS, 1) k_wino_split(ConvArgs p) {
+  conv_split_body<MODE, true>(p);
+}
+
+// 0: native fp32 MFMA engine only (default), 1: large problems run on the split-bf16 engine
+int fp32_engine();
+// problems the split engine takes over from the 128x128 / 256x128 native tiles
+inline bool split_engine_takes(int cfg, int64_t rows, int64_t cols, int64_t depth) {
+  return fp32_engine() == 1 && (cfg == 0 || cfg == 3) && cols >= 256 && depth >= 64 &&
+         cdiv(rows, SPLIT_BM) * cdiv(cols, SPLIT_BN) >= 192;        // enough 256 x 256 tiles for 256 CUs
+}
+template <int MODE, bool BATCH>
+inline void launch_split(ConvArgs& p, dim3 extra, hipStream_t st, int tile_rows = -1) {
+  void (*kern)(ConvArgs) = BATCH ? k_wino_split<MODE> : k_conv_split<MODE>;
+  static std::once_flag once;               // one per instantiation: the kernel asks for more than 64 KB of LDS
+  std::call_once(once, [&] {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES);
+  });
+  p.tiles_m = tile_rows >= 0 ? tile_rows : (int)cdiv(p.M, SPLIT_BM);
+  p.tiles_n = (int)cdiv(p.NG, SPLIT_BN);
+  dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
+  hipLaunchKernelGGL(kern, grid, dim3(SPLIT_THREADS), SPLIT_LDS_BYTES, st, p);
+}
+
+}  // namespace mtlssl

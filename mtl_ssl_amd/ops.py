@@ -189,6 +189,12 @@ def set_winograd(mode):
     return lib().conv2d_set_winograd(int(mode))
 
 
+def set_fp32_engine(mode):
+    """0: the native fp32 MFMA engine (default), 1: large implicit GEMMs on the exact split-bf16 engine
+    (csrc/conv_split.h; MTLSSL_FP32_ENGINE=split sets the initial value). Returns the previous mode; -1 only queries."""
+    return lib().conv2d_set_fp32_engine(int(mode))
+
+
 def _autotune(d, mode, run):
     key = _plan_key(d, mode)
     if key in _tuned:
