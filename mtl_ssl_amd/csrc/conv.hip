@@ -1182,6 +1182,8 @@ int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
   WinoChoice wc;
   if (choose_wino(d, MODE_WGRAD, &wc)) return bias_part + wino_workspace_bytes(d, wc.variant, MODE_WGRAD);
   wgrad_plan(d, &cfg, &ns, &pps);
+  int sns = 0, spps;
+  if (split_wgrad_plan((int64_t)d->N * d->OH * d->OW, d->C, d->K, d->R * d->S, &sns, &spps) && sns > ns) ns = sns;
   return bias_part + align_up((int64_t)ns * d->R * d->S * d->C * d->K * 4, 256);
 }
 
@@ -1260,9 +1262,12 @@ int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const floa
   } else if (mfma_wgrad_ok(d)) {
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);
+    const bool split = fp32_engine() == 1 && (cfg == 0 || cfg == 3) &&
+                       split_wgrad_plan(P, d->C, d->K, d->R * d->S, &ns, &pps);
     p.out = ws_main;
     p.M = d->C; p.NG = d->K; p.nsplit = ns; p.pix_per_split = pps;
-    launch_mfma<MODE_WGRAD>(cfg, p, dim3(1, d->R * d->S, ns), st);
+    if (split) launch_split<MODE_WGRAD, false>(p, dim3(1, d->R * d->S, ns), st);
+    else launch_mfma<MODE_WGRAD>(cfg, p, dim3(1, d->R * d->S, ns), st);
     int64_t total4 = (int64_t)d->R * d->S * d->C * d->K / 4;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(total4 * 4, 256)), dim3(256), 0, st,
                        (const float*)ws_main, ns, total4, d->K, out_scale, dw, beta);

@@ -314,6 +314,22 @@ inline bool split_engine_takes(int cfg, int64_t rows, int64_t cols, int64_t dept
   return fp32_engine() == 1 && (cfg == 0 || cfg == 3) && cols >= 256 && depth >= 64 &&
          cdiv(rows, SPLIT_BM) * cdiv(cols, SPLIT_BN) >= 192;        // enough 256 x 256 tiles for 256 CUs
 }
+// Filter gradients on the split engine: 256 x 256 tiles over [C, K] (x planes), the pixel range cut so that about two
+// blocks per CU exist (one block is resident per CU) with at least 256 pixels per cut. The workspace queries size for
+// this plan as well as for the native one, whatever the engine switch says, so the switch may change between calls.
+inline bool split_wgrad_plan(int64_t P, int64_t C, int64_t K, int64_t planes, int* ns, int* pps) {
+  if (C < 256 || K < 256) return false;
+  const int64_t tiles = cdiv(C, SPLIT_BM) * cdiv(K, SPLIT_BN) * planes, ksteps = cdiv(P, 16);
+  int64_t want = cdiv(512, tiles);
+  want = want > 64 ? 64 : want;
+  const int64_t cap = ksteps / 16 > 1 ? ksteps / 16 : 1;
+  want = want > cap ? cap : want;
+  const int64_t per = cdiv(ksteps, want), n = cdiv(ksteps, per);
+  if (tiles * n < 192) return false;
+  *ns = (int)n; *pps = (int)(per * 16);
+  return true;
+}
+
 template <int MODE, bool BATCH>
 inline void launch_split(ConvArgs& p, dim3 extra, hipStream_t st, int tile_rows = -1) {
   void (*kern)(ConvArgs) = BATCH ? k_wino_split<MODE> : k_conv_split<MODE>;

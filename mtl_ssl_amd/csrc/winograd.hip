@@ -22,6 +22,7 @@
 // coefficients dropped at compile time). fp32 throughout; the matrices are exact in binary except the
 // 1/6, 1/12, 1/24 (F43) and 1/6, 1/3, 2/3 (F33) entries of G.
 #include "conv_mfma.h"
+#include "conv_split.h"
 
 namespace mtlssl {
 
@@ -428,6 +429,11 @@ void run_wgrad_out(const float* dU, int ns, int64_t CK, int K, const float* scal
 
 template <int MODE>
 void launch_gemm(int cfg, ConvArgs& p, int planes, int nz, hipStream_t st) {
+  if (MODE != MODE_WGRAD && fp32_engine() == 1 && (cfg == 0 || cfg == 3) && p.NG >= 256 && p.C >= 64 &&
+      cdiv(p.M, SPLIT_BM) * cdiv(p.NG, SPLIT_BN) * planes >= 192) {
+    launch_split<MODE, true>(p, dim3(1, planes, nz), st);
+    return;
+  }
   p.tiles_m = (int)cdiv(p.M, CFG_BM[cfg]);
   p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
   dim3 grid(p.tiles_m * p.tiles_n, planes, nz);
@@ -522,6 +528,7 @@ int64_t workspace_bytes(const mtlssl_conv_desc* d, int mode) {
     int ns = 1, pps;
     int64_t mx = 1;    // the split depends on the tile; size for the largest split any tile would ask for
     for (int cfg = 0; cfg < NCFG; ++cfg) { wgrad_split(g.T, PL, d->C, d->K, cfg, &ns, &pps); if (ns > mx) mx = ns; }
+    if (split_wgrad_plan(g.T, d->C, d->K, PL, &ns, &pps) && ns > mx) mx = ns;   // the split engine's plan
     return planes + align_up(mx * PL * d->C * d->K * 4, 256);
   }
   return planes + align_up((int64_t)PL * d->C * d->K * 4, 256);
@@ -582,6 +589,7 @@ void wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float* dy,
   float* dU = (float*)((char*)dM + align_up((int64_t)PL * g.T * d->K * 4, 256));  // [ns][P^2][C][K]
   int ns, pps;
   wgrad_split(g.T, PL, d->C, d->K, tile, &ns, &pps);
+  const bool split = fp32_engine() == 1 && (tile == 0 || tile == 3) && split_wgrad_plan(g.T, d->C, d->K, PL, &ns, &pps);
   if (V_pre) V = const_cast<float*>(V_pre);        // kept by the forward call of the same layer
   else run_input<S>(x, V, g, d->C, st);
   run_dy<S>(dy, dM, g, d->K, st);
@@ -590,7 +598,8 @@ void wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float* dy,
   p.M = d->C; p.NG = d->K; p.nsplit = ns; p.pix_per_split = pps;
   p.a_bytes = (unsigned)(g.T * d->C * 4); p.b_bytes = (unsigned)(g.T * d->K * 4);
   p.a_bs = g.T * d->C; p.b_bs = g.T * d->K;
-  launch_gemm<MODE_WGRAD>(tile, p, PL, ns, st);
+  if (split) launch_split<MODE_WGRAD, true>(p, dim3(1, PL, ns), st);
+  else launch_gemm<MODE_WGRAD>(tile, p, PL, ns, st);
   run_wgrad_out<S>(dU, ns, CK, d->K, out_scale, dw, beta, st);
 }
 

@@ -35,17 +35,19 @@ def _err(y, ref, scale):
 
 
 CASES = [
-    # N, H, W, C, K, ksize      ROI-tower shapes of config[1] (enough 256x256 tiles for the engine to take them)
-    (600, 7, 7, 512, 2048, 1),
-    (600, 7, 7, 2048, 512, 1),
-    (1300, 7, 7, 256, 256, 3),
-    (2, 151, 256, 256, 256, 1),     # a feature-map shaped problem: 77 312 pixels, ragged last row tile
+    # (N, H, W, C, K, ksize), forced plan      ROI-tower shapes of config[1] (enough 256x256 tiles for the engine)
+    ((600, 7, 7, 512, 2048, 1), 0),
+    ((600, 7, 7, 2048, 512, 1), 0),
+    ((1300, 7, 7, 256, 256, 3), 0),            # direct 3x3: the nine taps of the implicit GEMM
+    ((2, 151, 256, 256, 256, 1), 0),           # a feature-map shaped problem: 77 312 pixels, ragged last row tile
+    ((600, 7, 7, 512, 512, 3), 8),             # whole-7-span Winograd: 81 batched GEMMs per pass
+    ((40, 28, 40, 256, 256, 3), 4),            # F(4x4,3x3) Winograd: 36 batched GEMMs over 2 800 tiles
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c[0])) + "-plan%d" % c[1])
 def test_split_engine_is_as_accurate_as_the_native_engine(ops, case):
-    N, H, W, C, K, ks = case
+    (N, H, W, C, K, ks), plan = case
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.rand(N, H, W, C, device="cuda", generator=g) * 2 - 0.6          # post-ReLU-like: mostly positive
     w = (torch.rand(ks, ks, C, K, device="cuda", generator=g) - 0.5) * (2.0 / np.sqrt(ks * ks * C))
@@ -53,32 +55,48 @@ def test_split_engine_is_as_accurate_as_the_native_engine(ops, case):
     gy = torch.rand(N, H, W, K, device="cuda", generator=g) - 0.5
     d = ops.conv_desc(x.shape, w.shape, 1, 1, "SAME")
     try:
-        for mode in (0, 1):
-            assert ops.force_conv_config(d, mode, 0) == 0            # the direct 128x128 plan: the one the engine replaces
+        for mode in (0, 1, 2):
+            assert ops.force_conv_config(d, mode, plan) == plan      # the big-tile plan the engine replaces
         y0, y1 = _both(ops, lambda: ops.conv2d_fwd(d, x, w, b, None, ops.EPI_BIAS))
         dx0, dx1 = _both(ops, lambda: ops.conv2d_dgrad(d, gy, w))
-        assert not torch.equal(y0, y1) and not torch.equal(dx0, dx1)          # the other engine really ran
-        # fp64 reference on a subset of images (the convolution is per image)
+
+        def wgrad():
+            dw = torch.zeros_like(w)
+            ops.conv2d_wgrad(d, x, gy, dw)
+            return dw
+        dw0, dw1 = _both(ops, wgrad)
+        assert not torch.equal(y0, y1) and not torch.equal(dx0, dx1)                 # the other engine ran
+        if plan >= 4 or C * K > 256 * 256:      # a single 256x256 filter tile cannot fill the chip: that wgrad stays native
+            assert not torch.equal(dw0, dw1)
+        # fp64 references: forward / dgrad on a subset of images (the convolution is per image), wgrad on everything
         sub = slice(0, min(N, 6))
-        xd, wd, gd = x[sub].double().cpu(), w.double().cpu(), gy[sub].double().cpu()
+        xd, wd, gd = x.double().cpu(), w.double().cpu(), gy.double().cpu()
         xn, gn = xd.permute(0, 3, 1, 2), gd.permute(0, 3, 1, 2)
         wt = wd.permute(3, 2, 0, 1)
-        ref = torch.nn.functional.conv2d(xn, wt, b.double().cpu(), padding=ks // 2).permute(0, 2, 3, 1)
-        mag = torch.nn.functional.conv2d(xn.abs(), wt.abs(), b.double().cpu().abs(), padding=ks // 2).permute(0, 2, 3, 1)
+        bd = b.double().cpu()
+        F = torch.nn.functional
+        ref = F.conv2d(xn[sub], wt, bd, padding=ks // 2).permute(0, 2, 3, 1)
+        mag = F.conv2d(xn[sub].abs(), wt.abs(), bd.abs(), padding=ks // 2).permute(0, 2, 3, 1)
         e0, e1 = _err(y0[sub], ref, mag), _err(y1[sub], ref, mag)
-        refd = torch.nn.functional.conv_transpose2d(gn, wt, padding=ks // 2).permute(0, 2, 3, 1)
-        magd = torch.nn.functional.conv_transpose2d(gn.abs(), wt.abs(), padding=ks // 2).permute(0, 2, 3, 1)
+        refd = F.conv_transpose2d(gn[sub], wt, padding=ks // 2).permute(0, 2, 3, 1)
+        magd = F.conv_transpose2d(gn[sub].abs(), wt.abs(), padding=ks // 2).permute(0, 2, 3, 1)
         f0, f1 = _err(dx0[sub], refd, magd), _err(dx1[sub], refd, magd)
+        refw = torch.nn.grad.conv2d_weight(xn, wt.shape, gn, padding=ks // 2).permute(2, 3, 1, 0)
+        magw = torch.nn.grad.conv2d_weight(xn.abs(), wt.shape, gn.abs(), padding=ks // 2).permute(2, 3, 1, 0)
+        g0, g1 = _err(dw0, refw, magw), _err(dw1, refw, magw)
         from tests import parity_report
-        parity_report.LINES.append("split-bf16 engine %s: error in units of 2^-24*sum|ab| — fwd native %.2f split %.2f, "
-                                   "dgrad native %.2f split %.2f" % ("x".join(map(str, case)), e0, e1, f0, f1))
-        # both engines sit at the fp32 rounding level; the split engine is allowed the three dropped products
-        # (2 units) on top of what the native engine shows
-        assert e0 < 8 and f0 < 8
-        assert e1 <= max(e0, 1.0) + 2.5 and f1 <= max(f0, 1.0) + 2.5
+        parity_report.LINES.append("split-bf16 engine %s plan %d: error in units of 2^-24*sum|ab| — fwd native %.2f split %.2f, "
+                                   "dgrad native %.2f split %.2f, wgrad native %.2f split %.2f"
+                                   % ("x".join(map(str, case[0])), plan, e0, e1, f0, f1, g0, g1))
+        # direct plans sit at the fp32 rounding level on both engines; Winograd adds its transform rounding to both.
+        # The split engine is allowed the three dropped products (2 units) on top of what the native engine shows.
+        lim = 8 if plan < 4 else 400
+        assert e0 < lim and f0 < lim and g0 < lim
+        for nat, spl in ((e0, e1), (f0, f1), (g0, g1)):
+            assert spl <= 1.25 * max(nat, 1.0) + 2.5
     finally:
         ops.set_fp32_engine(0)
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             ops.force_conv_config(d, mode, -1)
 
 
