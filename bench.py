@@ -267,6 +267,8 @@ def main():
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-engine-steps", type=int, default=10,
+                    help="after the timed region, time this many steps on the opt-in split-bf16 fp32 engine (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--conv-breakdown", action="store_true",
                     help="time every conv launch (adds ~2%% to the step) and report the per-kernel table")
@@ -423,6 +425,23 @@ def main():
                                             "ms_per_step": 1e3 * v["seconds"] / a.steps}
                           for k, v in sorted(s.items()) if v["seconds"] > 0},
         }
+    out["fp32_engine"] = "split-bf16x3" if ops.set_fp32_engine(-1) == 1 else "native fp32 MFMA"
+    if world == 1 and a.split_engine_steps > 0 and ops.set_fp32_engine(-1) == 0:
+        # NOT part of `value`: the same step with the large GEMMs on the opt-in engine (exact three-way bf16 split of
+        # every fp32 operand, six bf16 MFMA products, fp32 accumulation; csrc/conv_split.h, tests/test_gpu_split_engine.py)
+        ops.set_fp32_engine(1)
+        for _ in range(3):
+            tr.step(batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.split_engine_steps):
+            tr.step(batch)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t1) / a.split_engine_steps
+        ops.set_fp32_engine(0)
+        out["split_engine"] = {"ms_per_step": ms, "images_per_sec": 1e3 * B / ms, "steps": a.split_engine_steps,
+                               "speedup_over_native": (1e3 * dt / a.steps) / ms,
+                               "note": "opt-in (MTLSSL_FP32_ENGINE=split); not the headline value"}
     if world == 1 and not a.no_roofline:
         out["hbm_kernels"] = hbm_kernels(tr)
     if world == 1 and not a.no_cpu_baseline:

@@ -11,10 +11,12 @@ import __graft_entry__ as g  # noqa: E402
 g.build()
 from mtl_ssl_amd import ops  # noqa: E402
 
-SHAPES = [(2560, 7, 7, 512, 2048), (2560, 7, 7, 2048, 512), (2560, 7, 7, 1024, 2048), (2560, 7, 7, 1024, 512),
+SHAPES = [(2064, 7, 7, 512, 2048), (2064, 7, 7, 2048, 512), (2064, 7, 7, 1024, 2048), (2064, 7, 7, 1024, 512),
           (512, 7, 7, 512, 2048), (512, 7, 7, 2048, 512), (512, 7, 7, 1024, 2048), (2, 38, 64, 1024, 256),
           (2, 38, 64, 256, 1024)]
-print("%-26s %-6s %s" % ("N,H,W,C,K (1x1)", "mode", "  ".join("cfg%d us / TF" % c for c in range(4))))
+if len(sys.argv) > 1:
+    SHAPES = SHAPES[:int(sys.argv[1])]
+print("%-26s %-6s %s  split-bf16 engine" % ("N,H,W,C,K (1x1)", "mode", "  ".join("cfg%d us / TF" % c for c in range(4))))
 for N, H, W, C, K in SHAPES:
     x = torch.randn(N, H, W, C, device="cuda")
     w = torch.randn(1, 1, C, K, device="cuda") / C ** 0.5
@@ -38,5 +40,16 @@ for N, H, W, C, K in SHAPES:
             e.record(); e.synchronize()
             us = s.elapsed_time(e) * 100
             cells.append("%7.1f / %5.1f" % (us, fl / us / 1e6))
+        ops.force_conv_config(d, mode, 0)              # the split engine replaces the 128x128 plan
+        ops.set_fp32_engine(1)
+        runs[mode](); runs[mode]()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            runs[mode]()
+        e.record(); e.synchronize()
+        ops.set_fp32_engine(0)
+        us = s.elapsed_time(e) * 100
+        cells.append("%7.1f / %5.1f" % (us, fl / us / 1e6))
         ops.force_conv_config(d, mode, -1)
         print("%-26s %-6s %s" % ((N, H, W, C, K), ("fwd", "dgrad", "wgrad")[mode], "  ".join(cells)))
