@@ -77,7 +77,7 @@ def pmc_traffic(default_cfg):
 
 def pmc_traffic_provenance(default_cfg):
     """Where `roofline.traffic` comes from and whether the counters were taken from the kernel sources being timed
-    (tools/pmc_summary.py stores a digest of conv_mfma.h + conv.hip with them)."""
+    (tools/pmc_summary.py stores a digest of the tile engine, conv_mfma.h, with them)."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if not default_cfg or not os.path.exists(path):
         return None

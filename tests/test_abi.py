@@ -52,7 +52,7 @@ def test_product_package_never_imports_the_oracle():
 def test_committed_pmc_traffic_was_taken_from_the_current_roofline_kernel():
     """bench.py's roofline.traffic is the committed result of separate PMC passes (counters cannot be read inside
     the timed process): the file carries a digest of the kernel sources it was measured on, and a change to
-    conv_mfma.h / conv.hip without re-running tools/pmc_bench.sh + tools/pmc_summary.py fails here."""
+    conv_mfma.h without re-running tools/pmc_bench.sh + tools/pmc_summary.py fails here."""
     import json
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

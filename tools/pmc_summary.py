@@ -53,13 +53,13 @@ def main(root, top=14):
 
 
 def kernel_source_sha16():
-    """Digest of the sources of the roofline kernel: stored with the counters so that bench.py can tell whether the
-    committed traffic figure was taken from the kernel it is timing."""
+    """Digest of the source of the roofline kernel (the tile engine, conv_mfma.h): stored with the counters so that
+    bench.py can tell whether the committed traffic figure was taken from the kernel it is timing."""
     import hashlib
     import os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mtl_ssl_amd", "csrc")
     h = hashlib.sha256()
-    for name in ("conv_mfma.h", "conv.hip"):
+    for name in ("conv_mfma.h",):
         h.update(open(os.path.join(root, name), "rb").read())
     return h.hexdigest()[:16]
 
