@@ -31,7 +31,10 @@ def _both(ops, fn):
 
 def _err(y, ref, scale):
     """max |y - ref| in units of 2^-24 * (sum over the reduction of |a*b|) — the natural unit of an fp32 dot product."""
-    return float(((y.double().cpu() - ref).abs() / (scale * 2.0 ** -24)).max())
+    yd = y.double().cpu()
+    live = scale > 0
+    assert bool((yd[~live] == 0).all())                 # e.g. the input pixels a strided convolution never reads
+    return float(((yd - ref).abs()[live] / (scale[live] * 2.0 ** -24)).max())
 
 
 CASES = [
@@ -42,18 +45,22 @@ CASES = [
     ((2, 151, 256, 256, 256, 1), 0),           # a feature-map shaped problem: 77 312 pixels, ragged last row tile
     ((600, 7, 7, 512, 512, 3), 8),             # whole-7-span Winograd: 81 batched GEMMs per pass
     ((40, 28, 40, 256, 256, 3), 4),            # F(4x4,3x3) Winograd: 36 batched GEMMs over 2 800 tiles
+    ((16, 38, 64, 512, 512, 3, 1, 2), 0),      # atrous 3x3 (rate 2: R-FCN's block4 on the stride-16 map)
+    ((8, 76, 128, 256, 1024, 1, 2, 1), 0),     # stride-2 1x1 (a block's projection shortcut): the strided dgrad gather
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c[0])) + "-plan%d" % c[1])
 def test_split_engine_is_as_accurate_as_the_native_engine(ops, case):
-    (N, H, W, C, K, ks), plan = case
+    (N, H, W, C, K, ks), plan = case[0][:6], case[1]
+    stride, dil = (case[0] + (1, 1))[6:8]
+    pad = dil * (ks // 2)
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.rand(N, H, W, C, device="cuda", generator=g) * 2 - 0.6          # post-ReLU-like: mostly positive
     w = (torch.rand(ks, ks, C, K, device="cuda", generator=g) - 0.5) * (2.0 / np.sqrt(ks * ks * C))
     b = torch.rand(K, device="cuda", generator=g) - 0.5
-    gy = torch.rand(N, H, W, K, device="cuda", generator=g) - 0.5
-    d = ops.conv_desc(x.shape, w.shape, 1, 1, "SAME")
+    d = ops.conv_desc(x.shape, w.shape, stride, dil, "SAME")
+    gy = torch.rand(N, d.OH, d.OW, K, device="cuda", generator=g) - 0.5
     try:
         for mode in (0, 1, 2):
             assert ops.force_conv_config(d, mode, plan) == plan      # the big-tile plan the engine replaces
@@ -66,7 +73,7 @@ def test_split_engine_is_as_accurate_as_the_native_engine(ops, case):
             return dw
         dw0, dw1 = _both(ops, wgrad)
         assert not torch.equal(y0, y1) and not torch.equal(dx0, dx1)                 # the other engine ran
-        if plan >= 4 or C * K > 256 * 256:      # a single 256x256 filter tile cannot fill the chip: that wgrad stays native
+        if plan >= 4 or C * K * ks * ks > 9 * 256 * 256:   # too few 256x256 filter tiles to fill the chip: that wgrad stays native
             assert not torch.equal(dw0, dw1)
         # fp64 references: forward / dgrad on a subset of images (the convolution is per image), wgrad on everything
         sub = slice(0, min(N, 6))
@@ -75,14 +82,16 @@ def test_split_engine_is_as_accurate_as_the_native_engine(ops, case):
         wt = wd.permute(3, 2, 0, 1)
         bd = b.double().cpu()
         F = torch.nn.functional
-        ref = F.conv2d(xn[sub], wt, bd, padding=ks // 2).permute(0, 2, 3, 1)
-        mag = F.conv2d(xn[sub].abs(), wt.abs(), bd.abs(), padding=ks // 2).permute(0, 2, 3, 1)
+        kw = dict(stride=stride, dilation=dil, padding=pad)
+        ref = F.conv2d(xn[sub], wt, bd, **kw).permute(0, 2, 3, 1)
+        mag = F.conv2d(xn[sub].abs(), wt.abs(), bd.abs(), **kw).permute(0, 2, 3, 1)
         e0, e1 = _err(y0[sub], ref, mag), _err(y1[sub], ref, mag)
-        refd = F.conv_transpose2d(gn[sub], wt, padding=ks // 2).permute(0, 2, 3, 1)
-        magd = F.conv_transpose2d(gn[sub].abs(), wt.abs(), padding=ks // 2).permute(0, 2, 3, 1)
+        op = (H - ((d.OH - 1) * stride - 2 * pad + dil * (ks - 1) + 1), W - ((d.OW - 1) * stride - 2 * pad + dil * (ks - 1) + 1))
+        refd = F.conv_transpose2d(gn[sub], wt, output_padding=op, **kw).permute(0, 2, 3, 1)
+        magd = F.conv_transpose2d(gn[sub].abs(), wt.abs(), output_padding=op, **kw).permute(0, 2, 3, 1)
         f0, f1 = _err(dx0[sub], refd, magd), _err(dx1[sub], refd, magd)
-        refw = torch.nn.grad.conv2d_weight(xn, wt.shape, gn, padding=ks // 2).permute(2, 3, 1, 0)
-        magw = torch.nn.grad.conv2d_weight(xn.abs(), wt.shape, gn.abs(), padding=ks // 2).permute(2, 3, 1, 0)
+        refw = torch.nn.grad.conv2d_weight(xn, wt.shape, gn, **kw).permute(2, 3, 1, 0)
+        magw = torch.nn.grad.conv2d_weight(xn.abs(), wt.shape, gn.abs(), **kw).permute(2, 3, 1, 0)
         g0, g1 = _err(dw0, refw, magw), _err(dw1, refw, magw)
         from tests import parity_report
         parity_report.LINES.append("split-bf16 engine %s plan %d: error in units of 2^-24*sum|ab| — fwd native %.2f split %.2f, "
