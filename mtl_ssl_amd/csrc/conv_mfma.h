@@ -64,7 +64,9 @@ __device__ __forceinline__ floatx4 bufload4(__amdgpu_buffer_rsrc_t rsrc, unsigne
 // Epilogue shared by the tile engines: split-K partial store, or bias / residual / activation (fwd),
 // residual / accumulate / activation mask (dgrad), or the wgrad partial-tile store. `smem` is the
 // block's LDS (free once the last K-step's barrier has been passed).
-template <int BM, int BN, int MODE, int NW>
+// PREFETCH_RES: fetch the residual operand of the next 32x32 tile during the current tile's LDS transpose (for engines
+// with one block per CU, where nothing else hides those loads).
+template <int BM, int BN, int MODE, int NW, bool PREFETCH_RES = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)[BM / (16 * NW)][BN / 64], float* smem,
                                               int m0, int n0) {
   constexpr int WR = NW / 2, TM = BM / (32 * WR), TN = BN / 64, LDT = 36;
@@ -97,10 +99,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
     // stores, and the bias / residual / mask / accumulate operands come in as 16-byte loads too.
     float* tile = smem + wid * (32 * LDT);                 // LDT: 16-byte aligned rows, conflict-light
     const int r_in = lane >> 3, c4 = (lane & 7) * 4;      // this lane's row (mod 8) and first column in the tile
+    // The residual operand of tile t+1 is fetched while tile t goes through its LDS transpose: the epilogue of a
+    // wave is a chain of (LDS write, LDS read, operand load, store) per 32x32 tile, and with few blocks resident per
+    // CU nothing else hides those loads (the 512 -> 2048 layers add their shortcut here: M x N x 4 bytes).
+    const bool use_res = PREFETCH_RES && !raw && (MODE == MODE_FWD || MODE == MODE_DGRAD) && (p.epi & MTLSSL_EPI_RESIDUAL);
+    floatx4 res_cur[4], res_nxt[4];
+    auto fetch_res = [&](int t, floatx4 (&dst)[4]) {
+      const int i = t / TN, j = t % TN;
+      const int col = n0 + wc * (BN / 2) + j * 32 + c4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = m0 + wr * (BM / WR) + i * 32 + r_in + 8 * k;
+        dst[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (use_res && row < p.M && col < p.NG) dst[k] = *reinterpret_cast<const floatx4*>(p.residual + (int64_t)row * ldo + col);
+      }
+    };
+    if constexpr (PREFETCH_RES) fetch_res(0, res_cur);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
+        if constexpr (PREFETCH_RES)
+          if (i * TN + j + 1 < TM * TN) fetch_res(i * TN + j + 1, res_nxt);
 #pragma unroll
         for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hi) * LDT + lo] = acc[i][j][e];
         const int col = n0 + wc * (BN / 2) + j * 32 + c4;
@@ -120,7 +140,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
           const int64_t o = (int64_t)row * ldo + col;
           if constexpr (MODE == MODE_FWD) {
             v += bv;
-            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
+            if (p.epi & MTLSSL_EPI_RESIDUAL) v += PREFETCH_RES ? res_cur[k] : *reinterpret_cast<const floatx4*>(p.residual + o);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               if (p.epi & MTLSSL_EPI_RELU) v[q] = fmaxf(v[q], 0.f);
@@ -128,7 +148,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
               if (p.epi & MTLSSL_EPI_TANH) v[q] = tanhf(v[q]);
             }
           } else if constexpr (MODE == MODE_DGRAD) {
-            if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
+            if (p.epi & MTLSSL_EPI_RESIDUAL) v += PREFETCH_RES ? res_cur[k] : *reinterpret_cast<const floatx4*>(p.residual + o);
             if (p.epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const floatx4*>(outp + o);
             if (p.epi & MASK_ANY) {
               floatx4 mk = *reinterpret_cast<const floatx4*>(p.mask + o);
@@ -137,6 +157,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
             }
           }
           *reinterpret_cast<floatx4*>(outp + o) = v;
+        }
+        if constexpr (PREFETCH_RES) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) res_cur[k] = res_nxt[k];
         }
       }
     }

@@ -295,7 +295,7 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
     if (it + 1 < nk) kstep(it + 1, Set0{}, Set1{});
   }
 
-  conv_epilogue<BM, BN, MODE, NW>(p, acc, reinterpret_cast<float*>(split_smem), m0, n0);
+  conv_epilogue<BM, BN, MODE, NW, true>(p, acc, reinterpret_cast<float*>(split_smem), m0, n0);
 }
 
 template <int MODE>
