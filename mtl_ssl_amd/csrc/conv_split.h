@@ -32,7 +32,8 @@ namespace mtlssl {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int SPLIT_BM = 256, SPLIT_BN = 256, SPLIT_THREADS = 512, SPLIT_LDS_BYTES = 2 * 2 * 1536 * 16;
+constexpr int SPLIT_BM = 256, SPLIT_BN = 256;
+constexpr int split_lds_bytes(int bn) { return 2 * (6 * SPLIT_BM + 6 * bn) * 16; }
 
 // x = h + m + l exactly; each returned as the upper 16 bits of its fp32 pattern (a bf16)
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
@@ -43,19 +44,37 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
   h = hb >> 16; m = mb >> 16; l = __float_as_uint(r2) >> 16;
 }
 
+// offset of a guarded load: x, or the out-of-range offset (the buffer load then returns 0) — as mask arithmetic, so
+// that hipcc keeps the loads of a tile unconditional and back to back instead of wrapping each in an exec branch
+__device__ __forceinline__ unsigned guard_off(bool keep, unsigned x) {
+  const unsigned k = 0u - (unsigned)keep;
+  return (x & k) | (0xFFFFFFF0u & ~k);
+}
+
 __device__ __forceinline__ float bufload1(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset, soffset, 0));
 }
 
-template <int MODE, bool BATCH>
+// The body is written for two geometries; the library builds the first (see split_tile_for for the second's numbers):
+//   BN = 256, NW = 8: 256 x 256 tile, 8 wavefronts as 4 (m) x 2 (n) with 64 x 128 outputs each, 96 KB of LDS, one block
+//                     per CU — the least operand traffic per flop;
+//   BN = 128, NW = 4: 256 x 128 tile, 4 wavefronts as 2 x 2 with 128 x 64 outputs each, 72 KB of LDS, two blocks per CU.
+template <int MODE, bool BATCH, int BN, int NW>
 __device__ __forceinline__ void conv_split_body(ConvArgs p) {
-  constexpr int BM = SPLIT_BM, BN = SPLIT_BN, BKT = 16, NW = 8, TM = 2, TN = 4;
+  constexpr int BM = SPLIT_BM, BKT = 16, NT = 64 * NW, WR = NW / 2;
+  constexpr int TM = BM / (32 * WR), TN = BN / 64;
   constexpr bool A_KC = (MODE != MODE_WGRAD);     // A rows are k-contiguous (else m-contiguous, k strided)
   constexpr bool B_KC = (MODE == MODE_DGRAD);
   constexpr unsigned OOB = 0xFFFFFFF0u;
+  constexpr int A_SLOTS = 6 * BM, B_SLOTS = 6 * BN, STAGE = A_SLOTS + B_SLOTS;
+  // elements per thread and K-step
+  constexpr int KCA = 2 * BM / NT, KCB = 2 * BN / NT;          // k-contiguous: (row, k-group) units of 8 floats
+  constexpr int MCA = 2 * (BM / 16) / NW, MCB = 2 * (BN / 16) / NW;   // strided: (k-group, 16-column block) units of 2 floats
+  constexpr int NA = A_KC ? 8 * KCA : 2 * MCA, NB = B_KC ? 8 * KCB : 2 * MCB;
   extern __shared__ __attribute__((aligned(16))) unsigned char split_smem[];
-  uintx4* const lds = reinterpret_cast<uintx4*>(split_smem);        // [stage][operand][piece][k-group][row]
-  auto slot = [](int piece, int kg, int row) { return (piece * 2 + kg) * 256 + row; };
+  uintx4* const lds = reinterpret_cast<uintx4*>(split_smem);        // [stage][A: piece, k-group, row | B: piece, k-group, row]
+  auto slot_a = [](int piece, int kg, int row) { return (piece * 2 + kg) * BM + row; };
+  auto slot_b = [](int piece, int kg, int row) { return (piece * 2 + kg) * BN + row; };
 
   int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
@@ -107,92 +126,111 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
   }
 
   // ---- thread -> element maps
-  // k-contiguous operand: row = tid / 2, the 8 k of k-group tid & 1 (two 16-byte loads, one LDS slot per piece)
-  const int kc_row = tid >> 1, kc_kg = tid & 1;
-  // strided operand ([k][cols] in memory): wave -> (k-group, 64-column block); lane -> (k pair, column % 16),
-  // four column sub-blocks of 16: eight dword loads, and per column one dword (two bf16) per piece into LDS —
+  // k-contiguous operand: unit u = tid + NT*i -> row u / 2, the 8 k of k-group u & 1 (two 16-byte loads, one LDS
+  // slot per piece)
+  // strided operand ([k][cols] in memory): wave -> k-group wave & 1 and a block of cols / (NW/2) columns, cut into units of 16;
+  // lane -> (k pair, column % 16): two dword loads per unit, and per column one dword (two bf16) per piece into LDS —
   // the 64 lanes of a store hit 64 different banks
-  const int mc_kg = wid & 1, mc_cb = (wid >> 1) * 64, mc_kq = lane >> 4, mc_cn = lane & 15;
+  const int mc_kg = wid & 1, mc_kq = lane >> 4, mc_cn = lane & 15;
   const int mc_k0 = mc_kg * 8 + mc_kq * 2;
+  // a wave's units are ADJACENT 16-column blocks (its loads of one k row cover whole cache lines between them)
+  auto mc_col_a = [&](int j) { return (wid >> 1) * (BM / (NW / 2)) + 16 * j + mc_cn; };
+  auto mc_col_b = [&](int j) { return (wid >> 1) * (BN / (NW / 2)) + 16 * j + mc_cn; };
 
-  int a_base = 0, a_y = 0, a_x = 0, a_n = 0;
-  bool a_ok = false;
+  int a_base[A_KC ? KCA : 1], a_y[A_KC ? KCA : 1], a_x[A_KC ? KCA : 1], a_n[A_KC ? KCA : 1];
+  bool a_ok[A_KC ? KCA : 1];
   if constexpr (A_KC) {
-    int m = m0 + kc_row;
-    a_ok = m < p.M;
-    int mm = a_ok ? m : 0;
-    if constexpr (MODE == MODE_FWD) {
-      int ow = mm % p.OW, t = mm / p.OW;
-      a_x = ow * p.stride - p.pl;
-      a_y = (t % p.OH) * p.stride - p.pt;
-      a_n = t / p.OH;
-      a_base = ((a_n * p.H + a_y) * p.W + a_x) * p.C + kc_kg * 8;
-    } else {
-      int iw = mm % p.W, t = mm / p.W;
-      a_x = iw + p.pl;
-      a_y = (t % p.H) + p.pt;
-      a_n = t / p.H;
-      a_base = ((a_n * p.OH + a_y) * p.OW + a_x) * p.K + kc_kg * 8;     // stride-1 form
+#pragma unroll
+    for (int i = 0; i < KCA; ++i) {
+      const int u = tid + NT * i, kg = u & 1;
+      int m = m0 + (u >> 1);
+      a_ok[i] = m < p.M;
+      int mm = a_ok[i] ? m : 0;
+      if constexpr (MODE == MODE_FWD) {
+        int ow = mm % p.OW, t = mm / p.OW;
+        a_x[i] = ow * p.stride - p.pl;
+        a_y[i] = (t % p.OH) * p.stride - p.pt;
+        a_n[i] = t / p.OH;
+        a_base[i] = ((a_n[i] * p.H + a_y[i]) * p.W + a_x[i]) * p.C + kg * 8;
+      } else {
+        int iw = mm % p.W, t = mm / p.W;
+        a_x[i] = iw + p.pl;
+        a_y[i] = (t % p.H) + p.pt;
+        a_n[i] = t / p.H;
+        a_base[i] = ((a_n[i] * p.OH + a_y[i]) * p.OW + a_x[i]) * p.K + kg * 8;     // stride-1 form
+      }
     }
   }
-  unsigned b_kc_base = OOB;
+  unsigned b_kc_base[B_KC ? KCB : 1];
   if constexpr (B_KC) {
-    int row = n0 + kc_row;
-    b_kc_base = row < p.NG ? (unsigned)(row * p.K + kc_kg * 8) * 4u : OOB;
+#pragma unroll
+    for (int i = 0; i < KCB; ++i) {
+      const int u = tid + NT * i;
+      int row = n0 + (u >> 1);
+      b_kc_base[i] = row < p.NG ? (unsigned)(row * p.K + (u & 1) * 8) * 4u : OOB;
+    }
   }
 
-  float rA[2][8], rB[2][8];
+  float rA[2][NA], rB[2][NB];
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
 
-  auto put4 = [](float (&r)[8], int at, floatx4 v) { r[at] = v.x; r[at + 1] = v.y; r[at + 2] = v.z; r[at + 3] = v.w; };
-
   auto load_tile = [&](int ks, auto SET) {
-    float (&ra)[8] = rA[decltype(SET)::value];
-    float (&rb)[8] = rB[decltype(SET)::value];
+    float (&ra)[NA] = rA[decltype(SET)::value];
+    float (&rb)[NB] = rB[decltype(SET)::value];
+    auto put4 = [](float* r, floatx4 v) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; };
     if constexpr (MODE == MODE_FWD) {
       int cpk = p.C / BKT;
       int rs = ks / cpk, c0 = (ks - rs * cpk) * BKT;
       int r = rs / p.S, s = rs - r * p.S;
       int dy = r * p.dil, dx = s * p.dil;
       int tapoff = (dy * p.W + dx) * p.C + c0;
-      int ih = a_y + dy, iw = a_x + dx;
-      bool ok = a_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      unsigned vo = ok ? (unsigned)(a_base + tapoff) * 4u : OOB;
-      put4(ra, 0, bufload4(rsrc_a, vo, 0));
-      put4(ra, 4, bufload4(rsrc_a, ok ? vo + 16u : OOB, 0));
+#pragma unroll
+      for (int i = 0; i < KCA; ++i) {
+        int ih = a_y[i] + dy, iw = a_x[i] + dx;
+        const bool ok = a_ok[i] & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+        const unsigned x = (unsigned)(a_base[i] + tapoff) * 4u;
+        put4(ra + 8 * i, bufload4(rsrc_a, guard_off(ok, x), 0));
+        put4(ra + 8 * i + 4, bufload4(rsrc_a, guard_off(ok, x + 16u), 0));
+      }
       unsigned so = (unsigned)(ks * BKT * p.K) * 4u;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int col = n0 + mc_cb + mc_cn + 16 * j;
-        unsigned vo0 = col < p.NG ? (unsigned)(mc_k0 * p.K + col) * 4u : OOB;
-        rb[2 * j] = bufload1(rsrc_b, vo0, so);
-        rb[2 * j + 1] = bufload1(rsrc_b, col < p.NG ? vo0 + (unsigned)p.K * 4u : OOB, so);
+      for (int j = 0; j < MCB; ++j) {
+        int col = n0 + mc_col_b(j);
+        const unsigned x0 = (unsigned)(mc_k0 * p.K + col) * 4u;
+        rb[2 * j] = bufload1(rsrc_b, guard_off(col < p.NG, x0), so);
+        rb[2 * j + 1] = bufload1(rsrc_b, guard_off(col < p.NG, x0 + (unsigned)p.K * 4u), so);
       }
     } else if constexpr (MODE == MODE_DGRAD) {
       int kpk = p.K / BKT;
       int rs = ks / kpk, k0 = (ks - rs * kpk) * BKT;
       int r = rs / p.S, s = rs - r * p.S;
       int dy = r * p.dil, dx = s * p.dil;
-      unsigned vo;
-      if (p.stride == 1) {
-        int tapoff = k0 - (dy * p.OW + dx) * p.K;
-        int oh = a_y - dy, ow = a_x - dx;
-        bool ok = a_ok && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
-        vo = ok ? (unsigned)(a_base + tapoff) * 4u : OOB;
-      } else {
-        int ny = a_y - dy, nx = a_x - dx;
-        bool ok = a_ok && ny >= 0 && nx >= 0 && (ny % p.stride == 0) && (nx % p.stride == 0);
-        int oh = ny / p.stride, ow = nx / p.stride;
-        ok = ok && oh < p.OH && ow < p.OW;
-        int off = ((a_n * p.OH + oh) * p.OW + ow) * p.K + k0 + kc_kg * 8;
-        vo = ok ? (unsigned)off * 4u : OOB;
+#pragma unroll
+      for (int i = 0; i < KCA; ++i) {
+        unsigned vo;
+        if (p.stride == 1) {
+          int tapoff = k0 - (dy * p.OW + dx) * p.K;
+          int oh = a_y[i] - dy, ow = a_x[i] - dx;
+          bool ok = a_ok[i] && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
+          vo = ok ? (unsigned)(a_base[i] + tapoff) * 4u : OOB;
+        } else {
+          int ny = a_y[i] - dy, nx = a_x[i] - dx;
+          bool ok = a_ok[i] && ny >= 0 && nx >= 0 && (ny % p.stride == 0) && (nx % p.stride == 0);
+          int oh = ny / p.stride, ow = nx / p.stride;
+          ok = ok && oh < p.OH && ow < p.OW;
+          int off = ((a_n[i] * p.OH + oh) * p.OW + ow) * p.K + k0 + ((tid + NT * i) & 1) * 8;
+          vo = ok ? (unsigned)off * 4u : OOB;
+        }
+        put4(ra + 8 * i, bufload4(rsrc_a, vo, 0));
+        put4(ra + 8 * i + 4, bufload4(rsrc_a, vo != OOB ? vo + 16u : OOB, 0));
       }
-      put4(ra, 0, bufload4(rsrc_a, vo, 0));
-      put4(ra, 4, bufload4(rsrc_a, vo != OOB ? vo + 16u : OOB, 0));
       unsigned so = (unsigned)(rs * p.C * p.K + k0) * 4u;
-      put4(rb, 0, bufload4(rsrc_b, b_kc_base, so));
-      put4(rb, 4, bufload4(rsrc_b, b_kc_base != OOB ? b_kc_base + 16u : OOB, so));
+#pragma unroll
+      for (int i = 0; i < KCB; ++i) {
+        put4(rb + 8 * i, bufload4(rsrc_b, b_kc_base[i], so));
+        put4(rb + 8 * i + 4, bufload4(rsrc_b, b_kc_base[i] != OOB ? b_kc_base[i] + 16u : OOB, so));
+      }
     } else {
       int r = rs_fixed / p.S, s = rs_fixed - r * p.S;
 #pragma unroll
@@ -210,44 +248,56 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
           off = ((n * p.H + ih) * p.W + iw) * p.C;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int m = m0 + mc_cb + mc_cn + 16 * j;
-          ra[2 * j + e] = bufload1(rsrc_a, (ok && m < p.M) ? (unsigned)(off + m) * 4u : OOB, 0);
-          int col = n0 + mc_cb + mc_cn + 16 * j;
-          rb[2 * j + e] = bufload1(rsrc_b, (pix < pix1 && col < p.NG) ? (unsigned)(pix * p.K + col) * 4u : OOB, 0);
+        for (int j = 0; j < MCA; ++j) {
+          int m = m0 + mc_col_a(j);
+          ra[2 * j + e] = bufload1(rsrc_a, guard_off(ok & (m < p.M), (unsigned)(off + m) * 4u), 0);
+        }
+#pragma unroll
+        for (int j = 0; j < MCB; ++j) {
+          int col = n0 + mc_col_b(j);
+          rb[2 * j + e] = bufload1(rsrc_b, guard_off((pix < pix1) & (col < p.NG), (unsigned)(pix * p.K + col) * 4u), 0);
         }
       }
     }
   };
 
   // k-contiguous operand: 8 consecutive k of one row -> one 16-byte slot per piece
-  auto store_kc = [&](uintx4* s, const float (&r)[8]) {
-    unsigned h[8], m[8], l[8];
+  auto store_kc = [&](uintx4* s, const float* r, auto UNITS, auto ROWS) {
+    constexpr int units = decltype(UNITS)::value, rows = decltype(ROWS)::value;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split3(r[e], h[e], m[e], l[e]);
-    s[slot(0, kc_kg, kc_row)] = uintx4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-    s[slot(1, kc_kg, kc_row)] = uintx4{m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16)};
-    s[slot(2, kc_kg, kc_row)] = uintx4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    for (int i = 0; i < units; ++i) {
+      const int u = tid + NT * i, row = u >> 1, kg = u & 1;
+      unsigned h[8], m[8], l[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split3(r[8 * i + e], h[e], m[e], l[e]);
+      s[(0 * 2 + kg) * rows + row] = uintx4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+      s[(1 * 2 + kg) * rows + row] = uintx4{m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16)};
+      s[(2 * 2 + kg) * rows + row] = uintx4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    }
   };
-  // strided operand: r[2j], r[2j+1] = the k pair of column block j -> one dword per piece and column
-  auto store_mc = [&](uintx4* s, const float (&r)[8]) {
+  // strided operand: r[2j], r[2j+1] = the k pair of unit j -> one dword per piece and column
+  auto store_mc = [&](uintx4* s, const float* r, auto UNITS, auto ROWS) {
+    constexpr int units = decltype(UNITS)::value, rows = decltype(ROWS)::value;
+    const int cb = (wid >> 1) * (rows / (NW / 2));
     unsigned* sw = reinterpret_cast<unsigned*>(s);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < units; ++j) {
       unsigned h0, m0_, l0, h1, m1, l1;
       split3(r[2 * j], h0, m0_, l0);
       split3(r[2 * j + 1], h1, m1, l1);
-      const int c = mc_cb + mc_cn + 16 * j;
-      sw[slot(0, mc_kg, c) * 4 + mc_kq] = h0 | (h1 << 16);
-      sw[slot(1, mc_kg, c) * 4 + mc_kq] = m0_ | (m1 << 16);
-      sw[slot(2, mc_kg, c) * 4 + mc_kq] = l0 | (l1 << 16);
+      const int c = cb + 16 * j + mc_cn;
+      sw[((0 * 2 + mc_kg) * rows + c) * 4 + mc_kq] = h0 | (h1 << 16);
+      sw[((1 * 2 + mc_kg) * rows + c) * 4 + mc_kq] = m0_ | (m1 << 16);
+      sw[((2 * 2 + mc_kg) * rows + c) * 4 + mc_kq] = l0 | (l1 << 16);
     }
   };
   auto store_tile = [&](int buf, auto SET) {
-    uintx4* sa = lds + buf * 3072;
-    uintx4* sb = sa + 1536;
-    if constexpr (A_KC) store_kc(sa, rA[decltype(SET)::value]); else store_mc(sa, rA[decltype(SET)::value]);
-    if constexpr (B_KC) store_kc(sb, rB[decltype(SET)::value]); else store_mc(sb, rB[decltype(SET)::value]);
+    uintx4* sa = lds + buf * STAGE;
+    uintx4* sb = sa + A_SLOTS;
+    if constexpr (A_KC) store_kc(sa, rA[decltype(SET)::value], std::integral_constant<int, KCA>{}, std::integral_constant<int, BM>{});
+    else store_mc(sa, rA[decltype(SET)::value], std::integral_constant<int, MCA>{}, std::integral_constant<int, BM>{});
+    if constexpr (B_KC) store_kc(sb, rB[decltype(SET)::value], std::integral_constant<int, KCB>{}, std::integral_constant<int, BN>{});
+    else store_mc(sb, rB[decltype(SET)::value], std::integral_constant<int, MCB>{}, std::integral_constant<int, BN>{});
   };
 
   floatx16 acc[TM][TN];
@@ -267,26 +317,38 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
   __syncthreads();
   auto kstep = [&](int it, auto next, auto spare) {
     if (it + 2 < nk) load_tile(ks_begin + it + 2, spare);
-    const uintx4* sa = lds + (it & 1) * 3072;
-    const uintx4* sb = sa + 1536;
-    bf16x8 fa[3][TM], fb[3][TN];
+    const uintx4* sa = lds + (it & 1) * STAGE;
+    const uintx4* sb = sa + A_SLOTS;
+    auto read_piece = [&](int pc, bf16x8 (&fa)[TM], bf16x8 (&fb)[TN]) {
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
+      for (int i = 0; i < TM; ++i) fa[i] = __builtin_bit_cast(bf16x8, sa[slot_a(pc, hi, wr * (BM / WR) + i * 32 + lo)]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[pc][i] = __builtin_bit_cast(bf16x8, sa[slot(pc, hi, wr * 64 + i * 32 + lo)]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[pc][j] = __builtin_bit_cast(bf16x8, sb[slot(pc, hi, wc * 128 + j * 32 + lo)]);
-    }
-    // the six piece products, in the order their operands arrive from LDS
-    constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
-    constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
+      for (int j = 0; j < TN; ++j) fb[j] = __builtin_bit_cast(bf16x8, sb[slot_b(pc, hi, wc * (BN / 2) + j * 32 + lo)]);
+    };
+    auto group = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fb)[TN]) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    if constexpr (NW == 8) {
+      // all three pieces of both operands in registers, the six piece products in the order the operands arrive
+      bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) read_piece(pc, fa[pc], fb[pc]);
+      group(fa[0], fb[0]); group(fa[0], fb[1]); group(fa[1], fb[0]);
+      group(fa[1], fb[1]); group(fa[0], fb[2]); group(fa[2], fb[0]);
+    } else {
+      // the 128-wide tile stages twice as many A values per thread: the hi pieces stay, the lo and then the mid
+      // pieces pass through one more register set (48 fragment registers instead of 72)
+      bf16x8 fah[TM], fbh[TN], fax[TM], fbx[TN];
+      read_piece(0, fah, fbh);
+      read_piece(2, fax, fbx);
+      group(fah, fbh); group(fax, fbh); group(fah, fbx);
+      read_piece(1, fax, fbx);
+      group(fax, fbh); group(fah, fbx); group(fax, fbx);
+    }
     if (it + 1 < nk) store_tile((it & 1) ^ 1, next);
     __syncthreads();
   };
@@ -298,21 +360,25 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
   conv_epilogue<BM, BN, MODE, NW, true>(p, acc, reinterpret_cast<float*>(split_smem), m0, n0);
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(SPLIT_THREADS, 1) k_conv_split(ConvArgs p) {
-  conv_split_body<MODE, false>(p);
-}
-template <int MODE>
-__global__ void __launch_bounds__(SPLIT_THREADS, 1) k_wino_split(ConvArgs p) {
-  conv_split_body<MODE, true>(p);
+template <int MODE, bool BATCH>
+__global__ void __launch_bounds__(512, 1) k_split256(ConvArgs p) {
+  conv_split_body<MODE, BATCH, 256, 8>(p);
 }
 
 // 0: native fp32 MFMA engine only (default), 1: large problems run on the split-bf16 engine
 int fp32_engine();
+// Tile width for a problem of rows x cols outputs (x planes): 256 when there are enough 256 x 256 tiles for the 256 CUs
+// (one block per CU), else 0 = leave it to the native engine. The body also instantiates as a 256 x 128 tile with four
+// wavefronts and two blocks per CU (conv_split_body<.., 128, 4>, 72 KB of LDS); measured on the ROI-tower shapes that
+// geometry reaches 113-143 TFLOP/s fp32-equivalent against 152-180 for the 256-wide tile and 123-137 for the native
+// engine — twice the staging per thread and 1.5x the operand traffic per flop cost more than the second resident
+// block hides — so it is not built into the library.
+inline int split_tile_for(int64_t rows, int64_t cols, int64_t planes = 1) {
+  return (cols >= 256 && cdiv(rows, SPLIT_BM) * cdiv(cols, 256) * planes >= 192) ? 256 : 0;
+}
 // problems the split engine takes over from the 128x128 / 256x128 native tiles
-inline bool split_engine_takes(int cfg, int64_t rows, int64_t cols, int64_t depth) {
-  return fp32_engine() == 1 && (cfg == 0 || cfg == 3) && cols >= 256 && depth >= 64 &&
-         cdiv(rows, SPLIT_BM) * cdiv(cols, SPLIT_BN) >= 192;        // enough 256 x 256 tiles for 256 CUs
+inline bool split_engine_takes(int cfg, int64_t rows, int64_t cols, int64_t depth, int64_t planes = 1) {
+  return fp32_engine() == 1 && (cfg == 0 || cfg == 3) && depth >= 64 && split_tile_for(rows, cols, planes) != 0;
 }
 // Filter gradients on the split engine: 256 x 256 tiles over [C, K] (x planes), the pixel range cut so that about two
 // blocks per CU exist (one block is resident per CU) with at least 256 pixels per cut. The workspace queries size for
@@ -332,15 +398,14 @@ inline bool split_wgrad_plan(int64_t P, int64_t C, int64_t K, int64_t planes, in
 
 template <int MODE, bool BATCH>
 inline void launch_split(ConvArgs& p, dim3 extra, hipStream_t st, int tile_rows = -1) {
-  void (*kern)(ConvArgs) = BATCH ? k_wino_split<MODE> : k_conv_split<MODE>;
-  static std::once_flag once;               // one per instantiation: the kernel asks for more than 64 KB of LDS
+  static std::once_flag once;               // one per instantiation: the kernels ask for more than 64 KB of LDS
   std::call_once(once, [&] {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)k_split256<MODE, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, split_lds_bytes(256));
   });
   p.tiles_m = tile_rows >= 0 ? tile_rows : (int)cdiv(p.M, SPLIT_BM);
   p.tiles_n = (int)cdiv(p.NG, SPLIT_BN);
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
-  hipLaunchKernelGGL(kern, grid, dim3(SPLIT_THREADS), SPLIT_LDS_BYTES, st, p);
+  hipLaunchKernelGGL((k_split256<MODE, BATCH>), grid, dim3(512), split_lds_bytes(256), st, p);
 }
 
 }  // namespace mtlssl

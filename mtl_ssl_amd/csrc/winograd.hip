@@ -429,8 +429,7 @@ void run_wgrad_out(const float* dU, int ns, int64_t CK, int K, const float* scal
 
 template <int MODE>
 void launch_gemm(int cfg, ConvArgs& p, int planes, int nz, hipStream_t st) {
-  if (MODE != MODE_WGRAD && fp32_engine() == 1 && (cfg == 0 || cfg == 3) && p.NG >= 256 && p.C >= 64 &&
-      cdiv(p.M, SPLIT_BM) * cdiv(p.NG, SPLIT_BN) * planes >= 192) {
+  if (MODE != MODE_WGRAD && split_engine_takes(cfg, p.M, p.NG, p.C, planes)) {
     launch_split<MODE, true>(p, dim3(1, planes, nz), st);
     return;
   }
