@@ -432,7 +432,7 @@ def main():
                           for k, v in sorted(s.items()) if v["seconds"] > 0},
         }
     out["fp32_engine"] = "split-bf16x3" if ops.set_fp32_engine(-1) == 1 else "native fp32 MFMA"
-    if world == 1 and a.split_engine_steps > 0 and ops.set_fp32_engine(-1) == 0:
+    if world == 1 and comm is None and a.split_engine_steps > 0 and ops.set_fp32_engine(-1) == 0:
         # NOT part of `value`: the same step with the large GEMMs on the opt-in engine (exact three-way bf16 split of
         # every fp32 operand, six bf16 MFMA products, fp32 accumulation; csrc/conv_split.h, tests/test_gpu_split_engine.py)
         ops.set_fp32_engine(1)

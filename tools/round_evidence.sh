@@ -13,6 +13,12 @@ MTLSSL_COMM_SELFTEST=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline >
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --config configs/rfcn_resnet101_voc_mtl.config > $E/bench_rfcn.json 2> $E/bench_rfcn.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --config configs/frcnn_mobilenet_v1_voc_mtl.config > $E/bench_mobilenet.json 2> $E/bench_mobilenet.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --config configs/frcnn_inception_resnet_v2_coco_mtl.config --height 800 --width 1333 > $E/bench_inception.json 2> $E/bench_inception.err
+MTLSSL_FP32_ENGINE=split python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_split_engine.json 2> $E/bench_split_engine.err
+(cd /tmp && export TMPDIR=/tmp && MTLSSL_FP32_ENGINE=split rocprofv3 --kernel-trace --stats -d $E/prof_split -o ev -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $E/bench_split_profiled.err)
+DBS=$(find $E/prof_split -name "*.db" | head -1)
+python tools/rocprof_summary.py $DBS 30 > $E/kernel_stats_split_engine.md
+rm -rf $E/prof_split
+python tools/bench_tiles.py 7 > $E/bench_tiles.txt 2>/dev/null
 python tools/phase_times.py > $E/phase_times.txt 2>/dev/null
 python tools/phase_times.py --config configs/frcnn_mobilenet_v1_voc_mtl.config --steps 30 >> $E/phase_times.txt 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $E/prof -o ev -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $E/bench_profiled.json 2> $E/bench_profiled.err)
