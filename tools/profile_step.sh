@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 P=$R/gpurun_out/prof
 rm -rf $P; mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $P/raw -o ev -- python $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline "$@" > $P/bench.json 2> $P/bench.err
+rocprofv3 --kernel-trace --stats -d $P/raw -o ev -- python $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline --split-engine-steps 0 "$@" > $P/bench.json 2> $P/bench.err
 DB=$(find $P/raw -name "*.db" | head -1)
 cp $DB $P/trace.db
 cd $R

@@ -21,7 +21,7 @@ rm -rf $E/prof_split
 python tools/bench_tiles.py 7 > $E/bench_tiles.txt 2>/dev/null
 python tools/phase_times.py > $E/phase_times.txt 2>/dev/null
 python tools/phase_times.py --config configs/frcnn_mobilenet_v1_voc_mtl.config --steps 30 >> $E/phase_times.txt 2>/dev/null
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $E/prof -o ev -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $E/bench_profiled.json 2> $E/bench_profiled.err)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $E/prof -o ev -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --split-engine-steps 0 > $E/bench_profiled.json 2> $E/bench_profiled.err)
 DB=$(find $E/prof -name "*.db" | head -1)
 python tools/rocprof_summary.py $DB 45 > $E/kernel_stats.md
 python tools/step_timeline.py $DB 1 > $E/step_timeline.txt
