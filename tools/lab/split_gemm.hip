@@ -26,7 +26,8 @@ constexpr int TM = 2, TN = 4;                       // 32x32 blocks per wave: 8 
 #endif
 #ifndef ABL
 #define ABL 0      // ablation bits (timing only, results wrong): 1 no global loads in the loop, 2 no LDS stores in the loop,
-#endif             // 4 no barrier in the loop, 8 fragments read once, 16 no split arithmetic (pieces = raw bit fields)
+#endif             // 4 no barrier in the loop, 8 fragments read once, 16 no split arithmetic (pieces = raw bit fields),
+                   // 32 no A loads in the loop, 64 no B loads in the loop, 128 no A stores, 256 no B stores
 
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
   if (ABL & 16) { h = __float_as_uint(x) >> 16; m = __float_as_uint(x) & 0xFFFFu; l = (__float_as_uint(x) >> 8) & 0xFFFFu; return; }
@@ -61,11 +62,15 @@ __global__ void __launch_bounds__(NT, 1) k_split_gemm(const float* __restrict__ 
     floatx4 (&ra)[2] = rA[set];
     float (&rb)[4][2] = rB[set];
     const float* a = a_src + ks * BK;
-    ra[0] = a_ok ? *reinterpret_cast<const floatx4*>(a) : floatx4{0, 0, 0, 0};
-    ra[1] = a_ok ? *reinterpret_cast<const floatx4*>(a + 4) : floatx4{0, 0, 0, 0};
+    if (!(ABL & 32) || ks < 2) {
+      ra[0] = a_ok ? *reinterpret_cast<const floatx4*>(a) : floatx4{0, 0, 0, 0};
+      ra[1] = a_ok ? *reinterpret_cast<const floatx4*>(a + 4) : floatx4{0, 0, 0, 0};
+    }
     const float* b = b_src + (size_t)ks * BK * N;
+    if (!(ABL & 64) || ks < 2) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { rb[j][0] = b[16 * j]; rb[j][1] = b[16 * j + N]; }
+      for (int j = 0; j < 4; ++j) { rb[j][0] = b[16 * j]; rb[j][1] = b[16 * j + N]; }
+    }
   };
   auto store = [&](int stage, int set) {
     floatx4 (&ra)[2] = rA[set];
@@ -73,11 +78,14 @@ __global__ void __launch_bounds__(NT, 1) k_split_gemm(const float* __restrict__ 
     uintx4* sa = lds + stage * 3072;
     uintx4* sb = sa + 1536;
     unsigned h[8], m[8], l[8];
+    if (!(ABL & 128) || stage == 0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) split3(ra[e >> 2][e & 3], h[e], m[e], l[e]);
     sa[slot(0, a_half, a_row)] = uintx4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
     sa[slot(1, a_half, a_row)] = uintx4{m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16)};
     sa[slot(2, a_half, a_row)] = uintx4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    }
+    if ((ABL & 256) && stage != 0) return;
     unsigned* sbw = reinterpret_cast<unsigned*>(sb);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
