@@ -59,7 +59,9 @@ __device__ __forceinline__ float bufload1(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 //   BN = 256, NW = 8: 256 x 256 tile, 8 wavefronts as 4 (m) x 2 (n) with 64 x 128 outputs each, 96 KB of LDS, one block
 //                     per CU — the least operand traffic per flop;
 //   BN = 128, NW = 4: 256 x 128 tile, 4 wavefronts as 2 x 2 with 128 x 64 outputs each, 72 KB of LDS, two blocks per CU.
-template <int MODE, bool BATCH, int BN, int NW>
+// PW: the problem is pointwise (1x1, stride 1, no padding — the ROI-tower GEMMs and every Winograd-domain GEMM):
+// the A gather needs no tap / bounds state, which pays for the native engine's four-lanes-per-row load map.
+template <int MODE, bool BATCH, int BN, int NW, bool PW>
 __device__ __forceinline__ void conv_split_body(ConvArgs p) {
   constexpr int BM = SPLIT_BM, BKT = 16, NT = 64 * NW, WR = NW / 2;
   constexpr int TM = BM / (32 * WR), TN = BN / 64;
@@ -68,9 +70,10 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
   constexpr unsigned OOB = 0xFFFFFFF0u;
   constexpr int A_SLOTS = 6 * BM, B_SLOTS = 6 * BN, STAGE = A_SLOTS + B_SLOTS;
   // elements per thread and K-step
-  constexpr int KCA = 2 * BM / NT, KCB = 2 * BN / NT;          // k-contiguous: (row, k-group) units of 8 floats
+  constexpr bool QUAD = PW && A_KC;               // A units of 4 floats (row, k quad) instead of 8 (row, k-group)
+  constexpr int KCA = (QUAD ? 4 : 2) * BM / NT, KCB = 2 * BN / NT;   // k-contiguous units per thread
   constexpr int MCA = 2 * (BM / 16) / NW, MCB = 2 * (BN / 16) / NW;   // strided: (k-group, 16-column block) units of 2 floats
-  constexpr int NA = A_KC ? 8 * KCA : 2 * MCA, NB = B_KC ? 8 * KCB : 2 * MCB;
+  constexpr int NA = A_KC ? (QUAD ? 4 : 8) * KCA : 2 * MCA, NB = B_KC ? 8 * KCB : 2 * MCB;
   extern __shared__ __attribute__((aligned(16))) unsigned char split_smem[];
   uintx4* const lds = reinterpret_cast<uintx4*>(split_smem);        // [stage][A: piece, k-group, row | B: piece, k-group, row]
   auto slot_a = [](int piece, int kg, int row) { return (piece * 2 + kg) * BM + row; };
@@ -139,7 +142,15 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
 
   int a_base[A_KC ? KCA : 1], a_y[A_KC ? KCA : 1], a_x[A_KC ? KCA : 1], a_n[A_KC ? KCA : 1];
   bool a_ok[A_KC ? KCA : 1];
-  if constexpr (A_KC) {
+  if constexpr (QUAD) {
+#pragma unroll
+    for (int i = 0; i < KCA; ++i) {
+      const int u = tid + NT * i;
+      const int m = m0 + (u >> 2);
+      a_ok[i] = m < p.M;
+      a_base[i] = (a_ok[i] ? m : 0) * (MODE == MODE_FWD ? p.C : p.K) + (u & 3) * 4;
+    }
+  } else if constexpr (A_KC) {
 #pragma unroll
     for (int i = 0; i < KCA; ++i) {
       const int u = tid + NT * i, kg = u & 1;
@@ -185,13 +196,19 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
       int r = rs / p.S, s = rs - r * p.S;
       int dy = r * p.dil, dx = s * p.dil;
       int tapoff = (dy * p.W + dx) * p.C + c0;
+      if constexpr (QUAD) {
 #pragma unroll
-      for (int i = 0; i < KCA; ++i) {
-        int ih = a_y[i] + dy, iw = a_x[i] + dx;
-        const bool ok = a_ok[i] & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
-        const unsigned x = (unsigned)(a_base[i] + tapoff) * 4u;
-        put4(ra + 8 * i, bufload4(rsrc_a, guard_off(ok, x), 0));
-        put4(ra + 8 * i + 4, bufload4(rsrc_a, guard_off(ok, x + 16u), 0));
+        for (int i = 0; i < KCA; ++i)
+          put4(ra + 4 * i, bufload4(rsrc_a, guard_off(a_ok[i], (unsigned)(a_base[i] + ks * BKT) * 4u), 0));
+      } else {
+#pragma unroll
+        for (int i = 0; i < KCA; ++i) {
+          int ih = a_y[i] + dy, iw = a_x[i] + dx;
+          const bool ok = a_ok[i] & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+          const unsigned x = (unsigned)(a_base[i] + tapoff) * 4u;
+          put4(ra + 8 * i, bufload4(rsrc_a, guard_off(ok, x), 0));
+          put4(ra + 8 * i + 4, bufload4(rsrc_a, guard_off(ok, x + 16u), 0));
+        }
       }
       unsigned so = (unsigned)(ks * BKT * p.K) * 4u;
 #pragma unroll
@@ -206,6 +223,11 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
       int rs = ks / kpk, k0 = (ks - rs * kpk) * BKT;
       int r = rs / p.S, s = rs - r * p.S;
       int dy = r * p.dil, dx = s * p.dil;
+      if constexpr (QUAD) {
+#pragma unroll
+        for (int i = 0; i < KCA; ++i)
+          put4(ra + 4 * i, bufload4(rsrc_a, guard_off(a_ok[i], (unsigned)(a_base[i] + ks * BKT) * 4u), 0));
+      } else {
 #pragma unroll
       for (int i = 0; i < KCA; ++i) {
         unsigned vo;
@@ -224,6 +246,7 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
         }
         put4(ra + 8 * i, bufload4(rsrc_a, vo, 0));
         put4(ra + 8 * i + 4, bufload4(rsrc_a, vo != OOB ? vo + 16u : OOB, 0));
+      }
       }
       unsigned so = (unsigned)(rs * p.C * p.K + k0) * 4u;
 #pragma unroll
@@ -275,6 +298,22 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
       s[(2 * 2 + kg) * rows + row] = uintx4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
     }
   };
+  // k-contiguous operand, quad map: 4 consecutive k of one row -> half a slot (8 bytes) per piece
+  typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+  auto store_kq = [&](uintx4* s, const float* r, auto UNITS, auto ROWS) {
+    constexpr int units = decltype(UNITS)::value, rows = decltype(ROWS)::value;
+    uintx2* s2 = reinterpret_cast<uintx2*>(s);
+#pragma unroll
+    for (int i = 0; i < units; ++i) {
+      const int u = tid + NT * i, row = u >> 2, kg = (u >> 1) & 1, half = u & 1;
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3(r[4 * i + e], h[e], m[e], l[e]);
+      s2[((0 * 2 + kg) * rows + row) * 2 + half] = uintx2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+      s2[((1 * 2 + kg) * rows + row) * 2 + half] = uintx2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
+      s2[((2 * 2 + kg) * rows + row) * 2 + half] = uintx2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    }
+  };
   // strided operand: r[2j], r[2j+1] = the k pair of unit j -> one dword per piece and column
   auto store_mc = [&](uintx4* s, const float* r, auto UNITS, auto ROWS) {
     constexpr int units = decltype(UNITS)::value, rows = decltype(ROWS)::value;
@@ -294,7 +333,8 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
   auto store_tile = [&](int buf, auto SET) {
     uintx4* sa = lds + buf * STAGE;
     uintx4* sb = sa + A_SLOTS;
-    if constexpr (A_KC) store_kc(sa, rA[decltype(SET)::value], std::integral_constant<int, KCA>{}, std::integral_constant<int, BM>{});
+    if constexpr (QUAD) store_kq(sa, rA[decltype(SET)::value], std::integral_constant<int, KCA>{}, std::integral_constant<int, BM>{});
+    else if constexpr (A_KC) store_kc(sa, rA[decltype(SET)::value], std::integral_constant<int, KCA>{}, std::integral_constant<int, BM>{});
     else store_mc(sa, rA[decltype(SET)::value], std::integral_constant<int, MCA>{}, std::integral_constant<int, BM>{});
     if constexpr (B_KC) store_kc(sb, rB[decltype(SET)::value], std::integral_constant<int, KCB>{}, std::integral_constant<int, BN>{});
     else store_mc(sb, rB[decltype(SET)::value], std::integral_constant<int, MCB>{}, std::integral_constant<int, BN>{});
@@ -360,9 +400,9 @@ __device__ __forceinline__ void conv_split_body(ConvArgs p) {
   conv_epilogue<BM, BN, MODE, NW, true>(p, acc, reinterpret_cast<float*>(split_smem), m0, n0);
 }
 
-template <int MODE, bool BATCH>
+template <int MODE, bool BATCH, bool PW>
 __global__ void __launch_bounds__(512, 1) k_split256(ConvArgs p) {
-  conv_split_body<MODE, BATCH, 256, 8>(p);
+  conv_split_body<MODE, BATCH, 256, 8, PW>(p);
 }
 
 // 0: native fp32 MFMA engine only (default), 1: large problems run on the split-bf16 engine
@@ -400,12 +440,17 @@ template <int MODE, bool BATCH>
 inline void launch_split(ConvArgs& p, dim3 extra, hipStream_t st, int tile_rows = -1) {
   static std::once_flag once;               // one per instantiation: the kernels ask for more than 64 KB of LDS
   std::call_once(once, [&] {
-    (void)hipFuncSetAttribute((const void*)k_split256<MODE, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, split_lds_bytes(256));
+    (void)hipFuncSetAttribute((const void*)k_split256<MODE, BATCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, split_lds_bytes(256));
+    (void)hipFuncSetAttribute((const void*)k_split256<MODE, BATCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, split_lds_bytes(256));
   });
   p.tiles_m = tile_rows >= 0 ? tile_rows : (int)cdiv(p.M, SPLIT_BM);
   p.tiles_n = (int)cdiv(p.NG, SPLIT_BN);
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
-  hipLaunchKernelGGL((k_split256<MODE, BATCH>), grid, dim3(512), split_lds_bytes(256), st, p);
+  static const bool quad_ok = [] { const char* e = getenv("MTLSSL_SPLIT_QUAD"); return !e || atoi(e) != 0; }();
+  const bool pw = quad_ok && MODE != MODE_WGRAD && p.R == 1 && p.S == 1 && p.stride == 1 && p.pt == 0 && p.pl == 0 &&
+                  p.OH == p.H && p.OW == p.W;
+  if (pw) hipLaunchKernelGGL((k_split256<MODE, BATCH, true>), grid, dim3(512), split_lds_bytes(256), st, p);
+  else hipLaunchKernelGGL((k_split256<MODE, BATCH, false>), grid, dim3(512), split_lds_bytes(256), st, p);
 }
 
 }  // namespace mtlssl
