@@ -317,7 +317,10 @@ def main():
             # the proposal chain and the ROI scatter are data dependent (how many candidates a suppression round
             # needs, how many atomics collide): time them once on the freshly initialised detector too — the entry
             # after the timed steps sees a detector over-fitted to one batch, whose proposals pile onto the groundtruth
-            hbm_first = {r["kernel"]: r["avg_us"] for r in hbm_kernels(tr)}
+            try:
+                hbm_first = {r["kernel"]: r["avg_us"] for r in hbm_kernels(tr)}
+            except Exception:
+                hbm_first = None
     if comm is not None:
         tr.reducer.timing = True
     if not a.no_roofline:
@@ -435,29 +438,43 @@ def main():
     if world == 1 and comm is None and a.split_engine_steps > 0 and ops.set_fp32_engine(-1) == 0:
         # NOT part of `value`: the same step with the large GEMMs on the opt-in engine (exact three-way bf16 split of
         # every fp32 operand, six bf16 MFMA products, fp32 accumulation; csrc/conv_split.h, tests/test_gpu_split_engine.py)
-        ops.set_fp32_engine(1)
-        for _ in range(3):
-            tr.step(batch)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(a.split_engine_steps):
-            tr.step(batch)
-        torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t1) / a.split_engine_steps
-        ops.set_fp32_engine(0)
-        out["split_engine"] = {"ms_per_step": ms, "images_per_sec": 1e3 * B / ms, "steps": a.split_engine_steps,
-                               "speedup_over_native": (1e3 * dt / a.steps) / ms,
-                               "note": "opt-in (MTLSSL_FP32_ENGINE=split); not the headline value"}
+        try:
+            ops.set_fp32_engine(1)
+            for _ in range(3):
+                tr.step(batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.split_engine_steps):
+                tr.step(batch)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t1) / a.split_engine_steps
+            out["split_engine"] = {"ms_per_step": ms, "images_per_sec": 1e3 * B / ms, "steps": a.split_engine_steps,
+                                   "speedup_over_native": (1e3 * dt / a.steps) / ms,
+                                   "note": "opt-in (MTLSSL_FP32_ENGINE=split); not the headline value"}
+        except Exception as e:                       # the side measurement must never take the headline line down
+            out["split_engine"] = {"error": repr(e)}
+        finally:
+            ops.set_fp32_engine(0)
+    # the secondary blocks below never take the headline line down: a failure is reported in place of the block
     if world == 1 and not a.no_roofline:
-        out["hbm_kernels"] = hbm_kernels(tr)
-        for r in out["hbm_kernels"]:
-            r["state"] = "after the warm-up and timed steps on one fixed batch"
-            if hbm_first and r["kernel"] in hbm_first:
-                r["avg_us_random_init"] = hbm_first[r["kernel"]]
+        try:
+            out["hbm_kernels"] = hbm_kernels(tr)
+            for r in out["hbm_kernels"]:
+                r["state"] = "after the warm-up and timed steps on one fixed batch"
+                if hbm_first and r["kernel"] in hbm_first:
+                    r["avg_us_random_init"] = hbm_first[r["kernel"]]
+        except Exception as e:
+            out["hbm_kernels"] = {"error": repr(e)}
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, model, tr, a.height, a.width, seed=1234, steps=a.cpu_steps)
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, model, tr, a.height, a.width, seed=1234, steps=a.cpu_steps)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
         if default_cfg and a.cpu_config0_steps > 0:
-            out["cpu_baseline_config0"] = cpu_plumbing_config0(dev, a.cpu_config0_steps)
+            try:
+                out["cpu_baseline_config0"] = cpu_plumbing_config0(dev, a.cpu_config0_steps)
+            except Exception as e:
+                out["cpu_baseline_config0"] = {"error": repr(e)}
     if comm is not None:
         with comm_mod._stdout_to_stderr():      # anything RCCL left in C stdio's stdout buffer goes to stderr,
             pass                                # so that stdout carries exactly the one JSON line
