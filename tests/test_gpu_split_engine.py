@@ -117,3 +117,39 @@ def test_small_problems_stay_on_the_native_engine(ops):
     d = ops.conv_desc(x.shape, w.shape, 1, 1, "SAME")
     y0, y1 = _both(ops, lambda: ops.conv2d_fwd(d, x, w))
     assert torch.equal(y0, y1)
+
+
+def test_split_engine_on_wide_dynamic_range_and_cancelling_sums(ops):
+    """Operands spanning twelve decades with random signs (heavy cancellation inside every dot product), plus exact
+    powers of two and values with all 24 mantissa bits set: the split must stay exact where fp32 is exact and lose
+    nothing relative to sum|a*b| elsewhere."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    N, H, W, C, K = 600, 7, 7, 512, 2048
+    mag = 10.0 ** (torch.rand(N, H, W, C, device="cuda", generator=g) * 12 - 6)
+    x = mag * (torch.randint(0, 2, mag.shape, device="cuda", generator=g) * 2 - 1)
+    x[0, 0, 0, :8] = torch.tensor([1.0, -2.0, 0.5, 16777215.0, -16777215.0, 3.0, 2.0 ** -20, 0.0], device="cuda")
+    wm = 10.0 ** (torch.rand(1, 1, C, K, device="cuda", generator=g) * 6 - 3)
+    w = wm * (torch.randint(0, 2, wm.shape, device="cuda", generator=g) * 2 - 1)
+    d = ops.conv_desc(x.shape, w.shape, 1, 1, "SAME")
+    try:
+        assert ops.force_conv_config(d, 0, 0) == 0
+        y0, y1 = _both(ops, lambda: ops.conv2d_fwd(d, x, w))
+        assert bool(torch.isfinite(y1).all())
+        xs, ws = x[:4].double().cpu().reshape(-1, C), w.double().cpu().reshape(C, K)
+        ref, scale = xs @ ws, xs.abs() @ ws.abs()
+        e0 = _err(y0[:4].reshape(-1, K), ref, scale)
+        e1 = _err(y1[:4].reshape(-1, K), ref, scale)
+        from tests import parity_report
+        parity_report.LINES.append("split-bf16 engine, 12 decades of magnitude + random signs: error / (2^-24 sum|ab|) native %.2f split %.2f"
+                                   % (e0, e1))
+        # with twelve decades inside one sum both engines sit at ~17-20 units (one rounding of the few dominant terms
+        # is many units of the small ones); the split engine stays within the same band
+        assert e0 < 64 and e1 <= 1.25 * max(e0, 1.0) + 2.5
+        # a product of two powers of two is exact on both engines: a one-hot row picks out a single weight
+        x2 = torch.zeros(N, H, W, C, device="cuda")
+        x2[..., 5] = 2.0 ** -3
+        yy0, yy1 = _both(ops, lambda: ops.conv2d_fwd(d, x2, w))
+        assert torch.equal(yy0, yy1) and torch.equal(yy1[0, 0, 0], w[0, 0, 5] * 2.0 ** -3)
+    finally:
+        ops.set_fp32_engine(0)
+        ops.force_conv_config(d, 0, -1)
