@@ -663,6 +663,29 @@ static bool is_pointwise(const mtlssl_conv_desc* d) {
   return d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->OH == d->H &&
          d->OW == d->W;
 }
+// Pointwise dgrad whose reduction width K is not a multiple of the 16-deep K-step (the 91- / 364-wide class and box
+// heads of a 90-class detector, core/box_predictor.py:215-337): dy [M, K] and w [C, K] are copied into zero-padded
+// [*, Kp] images in the workspace (Kp = K rounded up to 16) and the padded problem runs on the MFMA engine — the zero
+// columns add nothing to any sum. Replaces the scalar fallback (85 us per head at 512 ROIs, now ~25 us).
+static bool padded_dgrad_ok(const mtlssl_conv_desc* d) {
+  return is_pointwise(d) && d->K % BK != 0 && d->K >= 32 && d->C % 4 == 0 && d->C >= 16;
+}
+static mtlssl_conv_desc padded_desc(const mtlssl_conv_desc* d) {
+  mtlssl_conv_desc q = *d;
+  q.K = (int)align_up(d->K, BK);
+  return q;
+}
+static int64_t padded_dgrad_bytes(const mtlssl_conv_desc* d) {
+  const int64_t Kp = align_up(d->K, BK), M = (int64_t)d->N * d->H * d->W;
+  return align_up(M * Kp * 4, 256) + align_up((int64_t)d->C * Kp * 4, 256);
+}
+__global__ void __launch_bounds__(256) k_pad_rows(const float* src, int64_t rows, int K, int Kp, float* dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * Kp) return;
+  const int64_t r = i / Kp;
+  const int k = (int)(i - r * Kp);
+  dst[i] = k < K ? src[r * K + k] : 0.f;
+}
 static size_t stem_lds_bytes(const mtlssl_conv_desc* d) {
   int PH = (STEM_T - 1) * d->stride + (d->R - 1) * d->dilation + 1;
   int PW = (STEM_T - 1) * d->stride + (d->S - 1) * d->dilation + 1;
@@ -991,6 +1014,10 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
   if (mode == MODE_WGRAD) return mtlssl_conv2d_wgrad_workspace_bytes(d);
   int64_t M = mode == MODE_FWD ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W;
   int64_t NG = mode == MODE_FWD ? d->K : d->C;
+  if (mode == MODE_DGRAD && !mfma_dgrad_ok(d) && padded_dgrad_ok(d)) {
+    const mtlssl_conv_desc q = padded_desc(d);
+    return padded_dgrad_bytes(d) + mtlssl_conv2d_workspace_bytes(&q, MODE_DGRAD);
+  }
   if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : mfma_dgrad_ok(d))) return 0;
   WinoChoice wc;
   if (choose_wino(d, mode, &wc)) return wino_workspace_bytes(d, wc.variant, mode);
@@ -1112,6 +1139,22 @@ int mtlssl_conv2d_dgrad_xf(const mtlssl_conv_desc* d, const float* dy, const flo
     Plan pl = plan_dir(d, MODE_DGRAD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
     launch_planned<MODE_DGRAD>(pl, p, (float*)workspace, S(stream));
+  } else if (workspace && padded_dgrad_ok(d)) {
+    const mtlssl_conv_desc q = padded_desc(d);
+    const int64_t M = p.M;
+    float* dy_pad = (float*)workspace;
+    float* w_pad = (float*)((char*)workspace + align_up(M * q.K * 4, 256));
+    void* ws_conv = (char*)workspace + padded_dgrad_bytes(d);
+    hipLaunchKernelGGL(k_pad_rows, dim3(cdiv(M * q.K, 256)), dim3(256), 0, S(stream), dy, M, d->K, q.K, dy_pad);
+    hipLaunchKernelGGL(k_pad_rows, dim3(cdiv((int64_t)d->C * q.K, 256)), dim3(256), 0, S(stream), w, (int64_t)d->C, d->K, q.K, w_pad);
+    ConvArgs pq = make_args(&q);
+    pq.a = dy_pad; pq.b = w_pad; pq.out = dx; pq.residual = residual; pq.mask = mask_ref; pq.epi = epi;
+    pq.a_bytes = (unsigned)(M * q.K * 4);
+    pq.b_bytes = (unsigned)((int64_t)q.C * q.K * 4);
+    pq.M = (int)M;
+    pq.NG = q.C;
+    Plan pl = plan_dir(&q, MODE_DGRAD);
+    launch_planned<MODE_DGRAD>(pl, pq, (float*)ws_conv, S(stream));
   } else if (is_pointwise(d)) {
     GemmArgs g{dy, w, dx, nullptr, residual, mask_ref, p.M, d->C, d->K, epi, 0};
     hipLaunchKernelGGL(k_gemm_small<GM_DGRAD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, S(stream), g);
