@@ -679,6 +679,16 @@ static int64_t padded_dgrad_bytes(const mtlssl_conv_desc* d) {
   const int64_t Kp = align_up(d->K, BK), M = (int64_t)d->N * d->H * d->W;
   return align_up(M * Kp * 4, 256) + align_up((int64_t)d->C * Kp * 4, 256);
 }
+// The same for a pointwise forward whose input width C is not a multiple of 16 (the refiner's first FC layer reads the
+// tower features concatenated with the expanded class predictions): x -> [M, Cp] with zero columns, w -> [Cp, K] with
+// zero rows.
+static bool padded_fwd_ok(const mtlssl_conv_desc* d) {
+  return is_pointwise(d) && d->C % BK != 0 && d->C >= 32 && d->K >= 16;
+}
+static int64_t padded_fwd_bytes(const mtlssl_conv_desc* d) {
+  const int64_t Cp = align_up(d->C, BK), M = (int64_t)d->N * d->H * d->W;
+  return align_up(M * Cp * 4, 256) + align_up(Cp * d->K * 4, 256);
+}
 __global__ void __launch_bounds__(256) k_pad_rows(const float* src, int64_t rows, int K, int Kp, float* dst) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * Kp) return;
@@ -1014,6 +1024,11 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
   if (mode == MODE_WGRAD) return mtlssl_conv2d_wgrad_workspace_bytes(d);
   int64_t M = mode == MODE_FWD ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W;
   int64_t NG = mode == MODE_FWD ? d->K : d->C;
+  if (mode == MODE_FWD && !mfma_fwd_ok(d) && padded_fwd_ok(d)) {
+    mtlssl_conv_desc q = *d;
+    q.C = (int)align_up(d->C, BK);
+    return padded_fwd_bytes(d) + mtlssl_conv2d_workspace_bytes(&q, MODE_FWD);
+  }
   if (mode == MODE_DGRAD && !mfma_dgrad_ok(d) && padded_dgrad_ok(d)) {
     const mtlssl_conv_desc q = padded_desc(d);
     return padded_dgrad_bytes(d) + mtlssl_conv2d_workspace_bytes(&q, MODE_DGRAD);
@@ -1097,6 +1112,24 @@ int mtlssl_conv2d_fwd_keep(const mtlssl_conv_desc* d, const float* x, const floa
     Plan pl = plan_dir(d, MODE_FWD);
     if ((pl.nsplit > 1 || pl.tail_rows > 0) && !workspace) pl = Plan{pick_tile(p.M, p.NG, 1), 1, 0, 0, 1, 0};
     launch_planned<MODE_FWD>(pl, p, (float*)workspace, S(stream));
+  } else if (workspace && padded_fwd_ok(d)) {
+    mtlssl_conv_desc q = *d;
+    q.C = (int)align_up(d->C, BK);
+    const int64_t M = p.M;
+    float* x_pad = (float*)workspace;
+    float* w_pad = (float*)((char*)workspace + align_up(M * q.C * 4, 256));
+    void* ws_conv = (char*)workspace + padded_fwd_bytes(d);
+    hipLaunchKernelGGL(k_pad_rows, dim3(cdiv(M * q.C, 256)), dim3(256), 0, S(stream), x, M, d->C, q.C, x_pad);
+    (void)hipMemcpyAsync(w_pad, w, (size_t)d->C * d->K * 4, hipMemcpyDeviceToDevice, S(stream));
+    (void)hipMemsetAsync(w_pad + (int64_t)d->C * d->K, 0, (size_t)(q.C - d->C) * d->K * 4, S(stream));
+    ConvArgs pq = make_args(&q);
+    pq.a = x_pad; pq.b = w_pad; pq.out = y; pq.bias = bias; pq.residual = residual; pq.epi = epi;
+    pq.a_bytes = (unsigned)(M * q.C * 4);
+    pq.b_bytes = (unsigned)((int64_t)q.C * q.K * 4);
+    pq.M = (int)M;
+    pq.NG = q.K;
+    Plan pl = plan_dir(&q, MODE_FWD);
+    launch_planned<MODE_FWD>(pl, pq, (float*)ws_conv, S(stream));
   } else if (is_pointwise(d)) {
     GemmArgs g{x, w, y, bias, residual, nullptr, p.M, d->K, d->C, epi, 0};
     hipLaunchKernelGGL(k_gemm_small<GM_FWD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, S(stream), g);

@@ -38,6 +38,7 @@ CONV_CASES = [
     (2, 33, 41, 3, 64, 7, 2, 1, "RESNET_SAME"),  # stem 7x7/2: direct path (C = 3)
     (100, 1, 1, 2048, 91, 1, 1, 1, "VALID"),     # FC head as 1x1 conv (dgrad: zero-padded to K = 96 for the MFMA engine)
     (512, 1, 1, 2048, 364, 1, 1, 1, "VALID"),    # box-encoding head of a 90-class detector (4 x 91), a full second-stage batch
+    (300, 1, 1, 2503, 512, 1, 1, 1, "VALID"),    # FC over a concatenation (C % 16 != 0): forward zero-padded to C = 2512
     # Inception-ResNet-v2 shapes: channel counts that are not multiples of the 64-wide tile,
     # asymmetric filters, VALID stride-2 reductions (slim/nets/inception_resnet_v2.py:33-262)
     (2, 17, 21, 32, 48, 3, 1, 1, "SAME"),        # block35 branch_2 3x3 32->48
