@@ -668,7 +668,7 @@ static bool is_pointwise(const mtlssl_conv_desc* d) {
 // [*, Kp] images in the workspace (Kp = K rounded up to 16) and the padded problem runs on the MFMA engine — the zero
 // columns add nothing to any sum. Replaces the scalar fallback (85 us per head at 512 ROIs, now ~25 us).
 static bool padded_dgrad_ok(const mtlssl_conv_desc* d) {
-  return is_pointwise(d) && d->K % BK != 0 && d->K >= 32 && d->C % 4 == 0 && d->C >= 16;
+  return is_pointwise(d) && d->K % BK != 0 && d->K >= 8 && d->C % 4 == 0 && d->C >= 16;
 }
 static mtlssl_conv_desc padded_desc(const mtlssl_conv_desc* d) {
   mtlssl_conv_desc q = *d;

@@ -38,6 +38,7 @@ CONV_CASES = [
     (2, 33, 41, 3, 64, 7, 2, 1, "RESNET_SAME"),  # stem 7x7/2: direct path (C = 3)
     (100, 1, 1, 2048, 91, 1, 1, 1, "VALID"),     # FC head as 1x1 conv (dgrad: zero-padded to K = 96 for the MFMA engine)
     (512, 1, 1, 2048, 364, 1, 1, 1, "VALID"),    # box-encoding head of a 90-class detector (4 x 91), a full second-stage batch
+    (2, 38, 64, 512, 24, 1, 1, 1, "SAME"),       # RPN objectness head (2 x 12 anchors): dgrad zero-padded to K = 32
     (300, 1, 1, 2503, 512, 1, 1, 1, "VALID"),    # FC over a concatenation (C % 16 != 0): forward zero-padded to C = 2512
     # Inception-ResNet-v2 shapes: channel counts that are not multiples of the 64-wide tile,
     # asymmetric filters, VALID stride-2 reductions (slim/nets/inception_resnet_v2.py:33-262)
