@@ -175,3 +175,58 @@ def test_host_resize_matches_the_oracle_restatement():
         ref = T.resize_bilinear_legacy(torch.from_numpy(x)[None], oh, ow)[0].numpy()
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4)
     assert preprocessor.resize_bilinear_legacy(x, 50, 50) is not None
+
+
+def test_pascal_converter_writes_records_the_input_path_reads(tmp_path):
+    """create_records/create_pascal_tf_record.py:52-62,66-497 as `python -m mtl_ssl_amd.create_pascal_tf_record`: a tiny
+    VOC tree (XML annotations + JPEGs) -> TFRecord -> input_reader. Boxes come back normalised, class ids 1-based,
+    and the window / closeness / edge-mask labels are what labels.py computes from the same annotations (three-decimal
+    text round trip)."""
+    from PIL import Image
+    from mtl_ssl_amd import create_pascal_tf_record as C
+    from mtl_ssl_amd import input_reader as R
+    from mtl_ssl_amd import labels
+    root = tmp_path / "VOCdevkit" / "VOC2007"
+    for d in ("Annotations", "JPEGImages", "ImageSets/Main"):
+        (root / d).mkdir(parents=True)
+    rng = np.random.RandomState(0)
+    anns = {"000001": (120, 160, [("dog", 10, 20, 90, 100, 0), ("person", 60, 30, 150, 110, 1)]),
+            "000002": (100, 80, [("cat", 5, 5, 70, 90, 0)])}
+    for name, (H, W, objs) in anns.items():
+        Image.fromarray(rng.randint(0, 256, (H, W, 3)).astype(np.uint8)).save(str(root / "JPEGImages" / (name + ".jpg")), quality=95)
+        xml = "<annotation><folder>VOC2007</folder><filename>%s.jpg</filename><size><width>%d</width><height>%d</height><depth>3</depth></size>" % (name, W, H)
+        for cls, x0, y0, x1, y1, diff in objs:
+            xml += ("<object><name>%s</name><pose>Left</pose><truncated>0</truncated><difficult>%d</difficult><bndbox><xmin>%d</xmin>"
+                    "<ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>" % (cls, diff, x0, y0, x1, y1))
+        (root / "Annotations" / (name + ".xml")).write_text(xml + "</annotation>")
+    (root / "ImageSets" / "Main" / "aeroplane_trainval.txt").write_text("000001 -1\n000002 -1\n")
+    lm = tmp_path / "label_map.pbtxt"
+    lm.write_text("".join("item {\n  id: %d\n  name: '%s'\n}\n\n" % (i + 1, n) for i, n in enumerate(C.VOC_CLASSES)))
+    out = str(tmp_path / "voc.record")
+    assert C.main(["--data_dir", str(tmp_path / "VOCdevkit"), "--year=VOC2007", "--set=trainval", "--output_path=" + out,
+                   "--label_map_path=" + str(lm), "--seed=3"]) == 2
+    K = 20
+    got = [R.decode_example(r, K) for r in R.read_tfrecord(out, verify=True)]
+    pyr = labels.PyRandom(3)
+    for ex, (name, (H, W, objs)) in zip(got, anns.items()):
+        assert ex["image"].shape == (H, W, 3) and ex["filename"] == name + ".jpg"
+        b = np.array([[o[2], o[1], o[4], o[3]] for o in objs], np.float64)
+        cls = np.array([C.VOC_CLASSES.index(o[0]) + 1 for o in objs])
+        np.testing.assert_allclose(ex["groundtruth_boxes"], b / [H, W, H, W], rtol=0, atol=1e-6)
+        assert ex["groundtruth_classes"].argmax(1).tolist() == (cls - 1).tolist()
+        assert ex["groundtruth_difficult"].tolist() == [bool(o[5]) for o in objs]
+        wb, wl = labels.random_windows(b, cls, W, H, K, pyr, 64)
+        np.testing.assert_allclose(ex["window_boxes"], wb, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(ex["window_classes"], wl, rtol=0, atol=5e-4)       # three decimals in the record text
+        np.testing.assert_allclose(ex["groundtruth_closeness"], labels.closeness_labels(b, cls, W, H, K), rtol=0, atol=5e-4)
+        np.testing.assert_array_equal(ex["groundtruth_edgemask"], labels.edgemask(b, W, H).astype(np.float32))
+    # the expanding-window branch and the difficult filter
+    out2 = str(tmp_path / "voc2.record")
+    C.main(["--data_dir", str(tmp_path / "VOCdevkit"), "--set=trainval", "--output_path=" + out2,
+            "--random_multi_object=false", "--ignore_difficult_instances=true"])
+    ex = R.decode_example(next(iter(R.read_tfrecord(out2))), K)
+    assert len(ex["groundtruth_boxes"]) == 1 and len(ex["groundtruth_closeness"]) == 1      # the difficult person is dropped
+    b = np.array([[20, 10, 100, 90], [30, 60, 110, 150]], np.float64)
+    wb, _ = labels.expanding_windows(b, np.array([12, 15]), 160, 120, K)
+    np.testing.assert_allclose(ex["window_boxes"], wb, rtol=0, atol=1e-6)
+    assert C.label_text([1.0, 0.0, 0.3333, 0.25]) == b"1 0 0.333 0.25"
