@@ -66,12 +66,33 @@ def parse_annotation(path):
                 height=int(txt(size, "height", "0")) if size is not None else 0, objects=objs)
 
 
+def aux_label_features(boxes, classes, W, H, num_classes, rng, random_windows=True, num_windows=64, keep=None):
+    """The recycled-annotation fields of a record from absolute [ymin, xmin, ymax, xmax] boxes and 1-based classes:
+    window boxes + soft labels, per-object closeness (rows `keep`), the 2 x 64 x 64 foreground mask."""
+    from . import labels
+    if random_windows:
+        wb, wl = labels.random_windows(boxes, classes, W, H, num_classes, rng, num_windows)
+    else:
+        wb, wl = labels.expanding_windows(boxes, classes, W, H, num_classes)
+    clo = labels.closeness_labels(boxes, classes, W, H, num_classes)
+    em = labels.edgemask(boxes, W, H).astype(np.float32)
+    keep = range(len(clo)) if keep is None else keep
+    return {
+        "image/window/bbox/ymin": wb[:, 0], "image/window/bbox/xmin": wb[:, 1],
+        "image/window/bbox/ymax": wb[:, 2], "image/window/bbox/xmax": wb[:, 3],
+        "image/window/labels/text": [label_text(row) for row in wl],
+        "image/object/closeness/text": [label_text(clo[i]) for i in keep],
+        "image/edgemask/masks": em.reshape(-1), "image/edgemask/height": np.array([em.shape[1]], np.int64),
+        "image/edgemask/width": np.array([em.shape[2]], np.int64),
+    }
+
+
 def example_from_annotation(ann, image_bytes, label_map, num_classes, rng, ignore_difficult=False, random_windows=True,
                             num_windows=64):
     """-> serialized tf.Example (create_pascal_tf_record.py:66-497: boxes normalised by the image size, 1-based class
     ids, difficult / truncated / pose, the window, closeness and edge-mask labels)."""
     from PIL import Image
-    from . import input_reader, labels
+    from . import input_reader
     image = Image.open(io.BytesIO(image_bytes))
     if image.format != "JPEG":
         raise ValueError("Image format not JPEG: %s" % ann["filename"])
@@ -80,13 +101,8 @@ def example_from_annotation(ann, image_bytes, label_map, num_classes, rng, ignor
     # the auxiliary labels see every annotated object, like the reference (it builds them from data['object'])
     all_boxes = np.array([[o["ymin"], o["xmin"], o["ymax"], o["xmax"]] for o in ann["objects"]], np.float64).reshape(-1, 4)
     all_cls = np.array([label_map[o["name"]] for o in ann["objects"]], np.int64)
-    if random_windows:
-        wb, wl = labels.random_windows(all_boxes, all_cls, W, H, num_classes, rng, num_windows)
-    else:
-        wb, wl = labels.expanding_windows(all_boxes, all_cls, W, H, num_classes)
-    clo = labels.closeness_labels(all_boxes, all_cls, W, H, num_classes)
     keep = [i for i, o in enumerate(ann["objects"]) if not (ignore_difficult and o["difficult"])]
-    em = labels.edgemask(all_boxes, W, H).astype(np.float32)
+    aux = aux_label_features(all_boxes, all_cls, W, H, num_classes, rng, random_windows, num_windows, keep)
     f32 = lambda v: np.asarray(v, np.float32)
     name = ann["filename"].encode("utf-8")
     return input_reader.serialize_example({
@@ -101,12 +117,7 @@ def example_from_annotation(ann, image_bytes, label_map, num_classes, rng, ignor
         "image/object/difficult": np.array([o["difficult"] for o in objs], np.int64),
         "image/object/truncated": np.array([o["truncated"] for o in objs], np.int64),
         "image/object/view": [o["pose"].encode("utf-8") for o in objs],
-        "image/window/bbox/ymin": wb[:, 0], "image/window/bbox/xmin": wb[:, 1],
-        "image/window/bbox/ymax": wb[:, 2], "image/window/bbox/xmax": wb[:, 3],
-        "image/window/labels/text": [label_text(row) for row in wl],
-        "image/object/closeness/text": [label_text(clo[i]) for i in keep],
-        "image/edgemask/masks": em.reshape(-1), "image/edgemask/height": np.array([em.shape[1]], np.int64),
-        "image/edgemask/width": np.array([em.shape[2]], np.int64),
+        **aux,
     })
 
 

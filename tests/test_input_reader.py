@@ -230,3 +230,44 @@ def test_pascal_converter_writes_records_the_input_path_reads(tmp_path):
     wb, _ = labels.expanding_windows(b, np.array([12, 15]), 160, 120, K)
     np.testing.assert_allclose(ex["window_boxes"], wb, rtol=0, atol=1e-6)
     assert C.label_text([1.0, 0.0, 0.3333, 0.25]) == b"1 0 0.333 0.25"
+
+
+def test_mscoco_converter_writes_records_the_input_path_reads(tmp_path):
+    """create_records/create_mscoco_tf_record.py:56-66,87-474 as `python -m mtl_ssl_amd.create_mscoco_tf_record`: an
+    instances JSON + images -> one record file per set; boxes [x, y, w, h] clipped to the image and normalised,
+    category ids as classes, crowd flags, an image without annotations skipped, aux labels from labels.py."""
+    import json
+    from PIL import Image
+    from mtl_ssl_amd import create_mscoco_tf_record as C
+    from mtl_ssl_amd import input_reader as R
+    from mtl_ssl_amd import labels
+    root = tmp_path / "mscoco"
+    (root / "annotations").mkdir(parents=True)
+    (root / "images" / "val2017").mkdir(parents=True)
+    rng = np.random.RandomState(1)
+    images = [{"id": 7, "file_name": "000000000007.jpg", "height": 90, "width": 120},
+              {"id": 9, "file_name": "000000000009.jpg", "height": 64, "width": 64}]
+    for im in images:
+        Image.fromarray(rng.randint(0, 256, (im["height"], im["width"], 3)).astype(np.uint8)).save(
+            str(root / "images" / "val2017" / im["file_name"]), quality=95)
+    anns = [{"id": 1, "image_id": 7, "category_id": 18, "bbox": [10.5, 20.0, 50.0, 40.0], "iscrowd": 0},
+            {"id": 2, "image_id": 7, "category_id": 1, "bbox": [100.0, 5.0, 40.0, 30.0], "iscrowd": 1},      # runs past the right edge
+            {"id": 3, "image_id": 7, "category_id": 90, "bbox": [130.0, 5.0, 10.0, 10.0], "iscrowd": 0}]     # outside: dropped
+    json.dump({"images": images, "annotations": anns,
+               "categories": [{"id": 1, "name": "person"}, {"id": 18, "name": "dog"}, {"id": 90, "name": "toothbrush"}]},
+              open(str(root / "annotations" / "instances_val2017.json"), "w"))
+    done = C.main(["--data_dir", str(root), "--set=val", "--year=2017", "--output_name=coco", "--seed=5"])
+    assert done == {"val": (1, 1)}                           # image 9 has no annotation
+    K = 90
+    (rec,) = list(R.read_tfrecord(str(root / "coco_2017_val.record"), verify=True))
+    ex = R.decode_example(rec, K)
+    f = R.parse_example(rec)
+    b = np.array([[20.0, 10.5, 60.0, 60.5], [5.0, 100.0, 35.0, 120.0]])
+    np.testing.assert_allclose(ex["groundtruth_boxes"], b / [90, 120, 90, 120], rtol=0, atol=1e-6)
+    assert ex["groundtruth_classes"].argmax(1).tolist() == [17, 0] and list(f["image/object/is_crowd"]) == [0, 1]
+    assert f["image/source_id"][0] == b"7" and [t for t in f["image/object/class/text"]] == [b"dog", b"person"]
+    wb, wl = labels.random_windows(b, np.array([18, 1]), 120, 90, K, labels.PyRandom(5), 64)
+    np.testing.assert_allclose(ex["window_boxes"], wb, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ex["window_classes"], wl, rtol=0, atol=5e-4)
+    np.testing.assert_allclose(ex["groundtruth_closeness"], labels.closeness_labels(b, np.array([18, 1]), 120, 90, K), rtol=0, atol=5e-4)
+    np.testing.assert_array_equal(ex["groundtruth_edgemask"], labels.edgemask(b, 120, 90).astype(np.float32))
