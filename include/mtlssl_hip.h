@@ -389,6 +389,17 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              int64_t max_var_size, float lr, float momentum, float clip_norm,
                              float grad_scale, const float* var_weight_decay, const float* var_grad_mult,
                              float* norms_ws, mtlssl_stream_t stream);
+/* The other two optimizers of builders/optimizer_builder.py:40-62 behind the same gradient pipeline (L2 term,
+ * multipliers / frozen variables, per-variable clip; same tables and workspace as above). kind 1 =
+ * tf.train.RMSPropOptimizer: slot0 = mean square (TensorFlow initialises it to ONE), slot1 = momentum;
+ * p0 = decay, p1 = momentum, p2 = epsilon: ms <- p0*ms + (1-p0)*g^2; mom <- p1*mom + lr*g/sqrt(ms+p2); w <- w - mom.
+ * kind 2 = tf.train.AdamOptimizer: slot0 = m, slot1 = v; p0 = beta1, p1 = beta2, p2 = epsilon; `lr` is the
+ * bias-corrected rate lr*sqrt(1-beta2^t)/(1-beta1^t) of step t: w <- w - lr*m/(sqrt(v)+p2). */
+int mtlssl_adaptive_update_clip(int kind, float* weights, const float* grads, float* slot0, float* slot1,
+                                const int32_t* var_offsets, int num_vars, int64_t total, int64_t max_var_size,
+                                float lr, float p0, float p1, float p2, float clip_norm, float grad_scale,
+                                const float* var_weight_decay, const float* var_grad_mult, float* norms_ws,
+                                mtlssl_stream_t stream);
 
 /* Batched fold of per-output-channel scales into a shadow copy of the flat parameter buffer, one
  * launch for every convolution of the model: eff[i] = weights[i] * scale_v[(i - var_offsets[v]) %

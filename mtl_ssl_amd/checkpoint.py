@@ -130,12 +130,22 @@ def open_checkpoint(path):
                                 "TensorFlow V2 prefix (<path>.index + .data-*) or a V1 checkpoint file" % (path, e))
 
 
+def _slot_names(trainer):
+    """TensorFlow's slot variable suffixes: MomentumOptimizer '<var>/Momentum'; RMSPropOptimizer '<var>/RMSProp' (mean
+    square) + '<var>/RMSProp_1' (momentum); AdamOptimizer '<var>/Adam' (m) + '<var>/Adam_1' (v)."""
+    kind = trainer.opt["kind"] if trainer is not None and hasattr(trainer, "opt") else "momentum"
+    return {"momentum": ("/Momentum", None), "rms_prop": ("/RMSProp", "/RMSProp_1"), "adam": ("/Adam", "/Adam_1")}[kind]
+
+
 def save(path, ps, global_step=0, trainer=None):
     """Full training state: every variable under its reference name, momentum slots, moving averages
     (when the trainer keeps them), step."""
     out = {s.name: ps.value(s.name).detach().cpu().numpy() for s in ps.specs}
+    slot0, slot1 = _slot_names(trainer)
     for s in ps.trainable_specs:
-        out[s.name + "/Momentum"] = ps._view(ps.accum, s).detach().cpu().numpy()
+        out[s.name + slot0] = ps._view(ps.accum, s).detach().cpu().numpy()
+        if slot1 is not None:
+            out[s.name + slot1] = ps._view(trainer.slot1, s).detach().cpu().numpy()
         if trainer is not None and trainer.ema is not None:
             out[s.name + "/ExponentialMovingAverage"] = ps._view(trainer.ema, s).detach().cpu().numpy()
     out["global_step"] = np.asarray(global_step, np.int64)
@@ -148,9 +158,12 @@ def load(path, ps, trainer=None):
     for s in ps.specs:
         if s.name in ck.files:
             ps.value(s.name).copy_(torch.as_tensor(ck[s.name]).to(ps.device))
+    slot0, slot1 = _slot_names(trainer)
     for s in ps.trainable_specs:
-        if s.name + "/Momentum" in ck.files:
-            ps._view(ps.accum, s).copy_(torch.as_tensor(ck[s.name + "/Momentum"]).to(ps.device))
+        if s.name + slot0 in ck.files:
+            ps._view(ps.accum, s).copy_(torch.as_tensor(ck[s.name + slot0]).to(ps.device))
+        if slot1 is not None and s.name + slot1 in ck.files:
+            ps._view(trainer.slot1, s).copy_(torch.as_tensor(ck[s.name + slot1]).to(ps.device))
         if trainer is not None and trainer.ema is not None and s.name + "/ExponentialMovingAverage" in ck.files:
             ps._view(trainer.ema, s).copy_(torch.as_tensor(ck[s.name + "/ExponentialMovingAverage"]).to(ps.device))
     return int(ck["global_step"]) if "global_step" in ck.files else 0

@@ -126,6 +126,10 @@ DEFAULTS = {
     # protos/optimizer.proto
     "Optimizer": {"use_moving_average": True, "moving_average_decay": 0.9999},
     "MomentumOptimizer": {"momentum_optimizer_value": 0.9, "learning_rate": "@LearningRate"},
+    "RMSPropOptimizer": {"momentum_optimizer_value": 0.9, "decay": 0.9, "epsilon": 1.0, "learning_rate": "@LearningRate"},
+    "AdamOptimizer": {"beta1": 0.9, "beta2": 0.999, "epsilon": 1e-8, "learning_rate": "@LearningRate"},
+    "ExponentialDecayLearningRate": {"initial_learning_rate": 0.002, "decay_steps": 4000000, "decay_factor": 0.95,
+                                     "staircase": True},
     "ManualStepLearningRate": {"initial_learning_rate": 0.002, "schedule": []},
     "LearningRateSchedule": {"learning_rate": 0.002},
     "ConstantLearningRate": {"learning_rate": 0.002},

@@ -453,6 +453,56 @@ __global__ void __launch_bounds__(256)
   *reinterpret_cast<float4*>(w + i) = wv;
 }
 
+// RMSProp (KIND 1) / Adam (KIND 2) behind the same gradient pipeline (L2 term, multipliers, per-variable clip):
+//   RMSProp, tf.train.RMSPropOptimizer (training_ops ApplyRMSProp): ms = decay*ms + (1-decay)*g^2;
+//            mom = momentum*mom + lr*g / sqrt(ms + eps); w -= mom          (s0 = ms, s1 = mom; p0 decay, p1 momentum, p2 eps)
+//   Adam, tf.train.AdamOptimizer (ApplyAdam): m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g^2; w -= lr_t * m / (sqrt(v) + eps)
+//            with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) formed by the caller  (s0 = m, s1 = v; p0 b1, p1 b2, p2 eps)
+template <int KIND>
+__global__ void __launch_bounds__(256)
+    k_adaptive_update(float* w, const float* g, float* s0, float* s1, const int32_t* off, int num_vars,
+                      int64_t total4, float lr, float p0, float p1, float p2, float clip, float gscale,
+                      const float* norms, const float* var_wd, const float* var_mult) {
+  int64_t i4 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i4 >= total4) return;
+  int64_t i = i4 * 4;
+  int lo = 0, hi = num_vars;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if ((int64_t)off[mid] <= i) lo = mid; else hi = mid;
+  }
+  const float mult = var_mult ? var_mult[lo] : 1.f;
+  if (mult < 0.f) return;
+  float f = 1.f;
+  if (clip > 0.f) {
+    float nrm = sqrtf(norms[lo]);
+    if (nrm > clip) f = clip / nrm;
+  }
+  const float wd = var_wd ? var_wd[lo] : 0.f;
+  float4 gv = *reinterpret_cast<const float4*>(g + i);
+  float4 a = *reinterpret_cast<float4*>(s0 + i);
+  float4 b = *reinterpret_cast<float4*>(s1 + i);
+  float4 wv = *reinterpret_cast<float4*>(w + i);
+  float gq[4] = {gv.x, gv.y, gv.z, gv.w}, aq[4] = {a.x, a.y, a.z, a.w}, bq[4] = {b.x, b.y, b.z, b.w};
+  float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gg = (gq[e] * gscale + wd * wq[e]) * mult * f;
+    if (KIND == 1) {
+      aq[e] = p0 * aq[e] + (1.f - p0) * gg * gg;
+      bq[e] = p1 * bq[e] + lr * gg / sqrtf(aq[e] + p2);
+      wq[e] -= bq[e];
+    } else {
+      aq[e] = p0 * aq[e] + (1.f - p0) * gg;
+      bq[e] = p1 * bq[e] + (1.f - p1) * gg * gg;
+      wq[e] -= lr * aq[e] / (sqrtf(bq[e]) + p2);
+    }
+  }
+  *reinterpret_cast<float4*>(s0 + i) = float4{aq[0], aq[1], aq[2], aq[3]};
+  *reinterpret_cast<float4*>(s1 + i) = float4{bq[0], bq[1], bq[2], bq[3]};
+  *reinterpret_cast<float4*>(w + i) = float4{wq[0], wq[1], wq[2], wq[3]};
+}
+
 // ------------------------------------------------------------------------------ elementwise
 __global__ void k_axpby(const float* x, float* y, int64_t n, float a, float b) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -673,6 +723,38 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                      accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
                      norms_ws, var_weight_decay, var_grad_mult);
   return check_launch("sgd_momentum_clip");
+}
+
+int mtlssl_adaptive_update_clip(int kind, float* weights, const float* grads, float* slot0, float* slot1,
+                                const int32_t* var_offsets, int num_vars, int64_t total, int64_t max_var_size,
+                                float lr, float p0, float p1, float p2, float clip_norm, float grad_scale,
+                                const float* var_weight_decay, const float* var_grad_mult, float* norms_ws,
+                                mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(kind == 1 || kind == 2, "adaptive_update: kind %d (1 RMSProp, 2 Adam)", kind);
+  MTLSSL_REQUIRE(total % 4 == 0 && total < (1ll << 31), "adaptive_update: bad flat buffer size");
+  MTLSSL_REQUIRE(slot0 && slot1, "adaptive_update: both slot buffers are required");
+  if (!total) return MTLSSL_OK;
+  hipStream_t st = S(stream);
+  if (clip_norm > 0.f) {
+    MTLSSL_REQUIRE(norms_ws != nullptr, "adaptive_update: norms workspace required when clipping");
+    int chunks = (int)cdiv(max_var_size > 0 ? max_var_size : total, NORM_CHUNK);
+    float* part = norms_ws + num_vars;
+    if (hipMemsetAsync(part, 0, sizeof(float) * (size_t)num_vars * chunks, st) != hipSuccess)
+      return check_launch("adaptive_update memset");
+    hipLaunchKernelGGL(k_var_sumsq, dim3(chunks, num_vars), dim3(256), 0, st, grads, weights,
+                       var_weight_decay, var_grad_mult, var_offsets, grad_scale, chunks, part);
+    hipLaunchKernelGGL(k_var_norm_fold, dim3(cdiv(num_vars, 256)), dim3(256), 0, st, (const float*)part, chunks,
+                       num_vars, norms_ws);
+  }
+  if (kind == 1)
+    hipLaunchKernelGGL(k_adaptive_update<1>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads, slot0, slot1,
+                       var_offsets, num_vars, total / 4, lr, p0, p1, p2, clip_norm, grad_scale, norms_ws,
+                       var_weight_decay, var_grad_mult);
+  else
+    hipLaunchKernelGGL(k_adaptive_update<2>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads, slot0, slot1,
+                       var_offsets, num_vars, total / 4, lr, p0, p1, p2, clip_norm, grad_scale, norms_ws,
+                       var_weight_decay, var_grad_mult);
+  return check_launch("adaptive_update_clip");
 }
 
 int mtlssl_fold_scales(const float* weights, float* eff, const int32_t* var_offsets, int num_vars,

@@ -794,6 +794,18 @@ def sgd_momentum_clip(weights, grads, accum, var_offsets, max_var_size, lr, mome
                             ptr(var_weight_decay), ptr(var_grad_mult), ptr(norms), _stream())
 
 
+def adaptive_update_clip(kind, weights, grads, slot0, slot1, var_offsets, max_var_size, lr, p0, p1, p2, clip_norm,
+                         grad_scale=1.0, var_weight_decay=None, var_grad_mult=None):
+    """kind 1: RMSProp (slot0 mean square, slot1 momentum; p0 decay, p1 momentum, p2 epsilon);
+    kind 2: Adam (slot0 m, slot1 v; p0 beta1, p1 beta2, p2 epsilon; lr already bias-corrected)."""
+    nv = var_offsets.numel() - 1
+    norms = workspace(lib().sgd_workspace_bytes(max(nv, 1), int(max_var_size)), "norms", weights.device)
+    lib().adaptive_update_clip(int(kind), ptr(_chk(weights)), ptr(_chk(grads)), ptr(_chk(slot0)), ptr(_chk(slot1)),
+                               ptr(_chk(var_offsets, i32)), nv, weights.numel(), int(max_var_size), float(lr),
+                               float(p0), float(p1), float(p2), float(clip_norm), float(grad_scale),
+                               ptr(var_weight_decay), ptr(var_grad_mult), ptr(norms), _stream())
+
+
 def fold_scales(ps):
     """Refresh ParamStore.eff (all registered BatchNorm / residual-scale folds) in one launch."""
     if ps.eff is None:

@@ -17,26 +17,50 @@ def manual_stepping(global_step, boundaries, rates):
     return rates[idx]
 
 
-def learning_rate_fn(optimizer_cfg):
-    """builders/optimizer_builder.py:24-118 (momentum / manual_step or constant)."""
+def exponential_decay(global_step, initial, decay_steps, decay_factor, staircase=True):
+    """tf.train.exponential_decay (builders/optimizer_builder.py:94-101): initial * factor ** (step / steps), the
+    exponent floored when `staircase`."""
+    e = global_step / float(decay_steps)
+    return initial * decay_factor ** (float(int(e)) if staircase else e)
+
+
+def optimizer_from_config(optimizer_cfg):
+    """builders/optimizer_builder.py:24-118 -> dict(kind, lr_fn, + the optimizer's hyper-parameters).
+    kind: 'momentum' (momentum), 'rms_prop' (decay, momentum, epsilon), 'adam' (beta1, beta2, epsilon)."""
     which = optimizer_cfg.which_oneof(["momentum_optimizer", "rms_prop_optimizer", "adam_optimizer"])
-    if which != "momentum_optimizer":
-        raise ValueError("Optimizer %s not supported (the paper configs use momentum_optimizer)." % which)
-    mo = optimizer_cfg.momentum_optimizer
-    lr = mo.learning_rate
-    kind = lr.which_oneof(["manual_step_learning_rate", "constant_learning_rate",
-                           "exponential_decay_learning_rate"])
+    if which is None:
+        raise ValueError("Optimizer None not supported.")
+    oc = optimizer_cfg[which]
+    lr = oc.learning_rate
+    kind = lr.which_oneof(["manual_step_learning_rate", "constant_learning_rate", "exponential_decay_learning_rate"])
     if kind == "constant_learning_rate":
         v = float(lr.constant_learning_rate.learning_rate)
-        return (lambda step: v), float(mo.momentum_optimizer_value)
-    if kind == "manual_step_learning_rate":
+        lr_fn = lambda step: v
+    elif kind == "manual_step_learning_rate":
         ms = lr.manual_step_learning_rate
         if not ms.schedule:
             raise ValueError("Empty learning rate schedule.")
         bounds = [int(s.step) for s in ms.schedule]
         rates = [float(ms.initial_learning_rate)] + [float(s.learning_rate) for s in ms.schedule]
-        return (lambda step: manual_stepping(step, bounds, rates)), float(mo.momentum_optimizer_value)
-    raise ValueError("Learning_rate %s not supported." % kind)
+        lr_fn = lambda step: manual_stepping(step, bounds, rates)
+    elif kind == "exponential_decay_learning_rate":
+        ed = lr.exponential_decay_learning_rate
+        args = (float(ed.initial_learning_rate), int(ed.decay_steps), float(ed.decay_factor), bool(ed.staircase))
+        lr_fn = lambda step: exponential_decay(step, *args)
+    else:
+        raise ValueError("Learning_rate %s not supported." % kind)
+    if which == "momentum_optimizer":
+        return dict(kind="momentum", lr_fn=lr_fn, momentum=float(oc.momentum_optimizer_value))
+    if which == "rms_prop_optimizer":
+        return dict(kind="rms_prop", lr_fn=lr_fn, momentum=float(oc.momentum_optimizer_value), decay=float(oc.decay),
+                    epsilon=float(oc.epsilon))
+    return dict(kind="adam", lr_fn=lr_fn, beta1=float(oc.beta1), beta2=float(oc.beta2), epsilon=float(oc.epsilon))
+
+
+def learning_rate_fn(optimizer_cfg):
+    """(lr_fn, momentum) of a momentum optimizer — kept for callers of the round-1 interface."""
+    o = optimizer_from_config(optimizer_cfg)
+    return o["lr_fn"], o.get("momentum", 0.0)
 
 
 class GradientReducer:
@@ -186,7 +210,15 @@ class Trainer:
 
     def __init__(self, model, train_config, world_size=1, comm=None, reduce_always=False):
         self.model, self.ps, self.cfg = model, model.ps, train_config
-        self.lr_fn, self.momentum = learning_rate_fn(train_config.optimizer)
+        self.opt = optimizer_from_config(train_config.optimizer)
+        self.lr_fn, self.momentum = self.opt["lr_fn"], self.opt.get("momentum", 0.0)
+        # second optimizer slot (RMSProp: momentum next to the mean square in ps.accum, which TensorFlow starts at
+        # one; Adam: v next to m)
+        self.slot1 = None
+        if self.opt["kind"] != "momentum":
+            self.slot1 = torch.zeros_like(self.ps.accum)
+            if self.opt["kind"] == "rms_prop":
+                self.ps.accum.fill_(1.0)
         self.clip = float(train_config.gradient_clipping_by_norm)
         self.world = world_size
         self.global_step = 0
@@ -221,6 +253,8 @@ class Trainer:
         self.comm.broadcast(self.ps.weights, root)
         self.comm.broadcast(self.ps.frozen, root)
         self.comm.broadcast(self.ps.accum, root)
+        if self.slot1 is not None:
+            self.comm.broadcast(self.slot1, root)
         if self.ps.device.type == "cuda":
             torch.cuda.current_stream().synchronize()
         self.model.prepare()
@@ -287,8 +321,18 @@ class Trainer:
         self.reducer.finish()
         lr = self.lr_fn(self.global_step)
         ps = self.ps
-        ops.sgd_momentum_clip(ps.weights, ps.grads, ps.accum, ps.var_offsets, ps.max_var_size, lr,
-                              self.momentum, self.clip, 1.0, self.var_wd, self.var_mult)
+        o = self.opt
+        if o["kind"] == "momentum":
+            ops.sgd_momentum_clip(ps.weights, ps.grads, ps.accum, ps.var_offsets, ps.max_var_size, lr,
+                                  self.momentum, self.clip, 1.0, self.var_wd, self.var_mult)
+        elif o["kind"] == "rms_prop":
+            ops.adaptive_update_clip(1, ps.weights, ps.grads, ps.accum, self.slot1, ps.var_offsets, ps.max_var_size, lr,
+                                     o["decay"], o["momentum"], o["epsilon"], self.clip, 1.0, self.var_wd, self.var_mult)
+        else:
+            t = self.global_step + 1                        # AdamOptimizer's beta powers after t updates
+            lr_t = lr * (1.0 - o["beta2"] ** t) ** 0.5 / (1.0 - o["beta1"] ** t)
+            ops.adaptive_update_clip(2, ps.weights, ps.grads, ps.accum, self.slot1, ps.var_offsets, ps.max_var_size, lr_t,
+                                     o["beta1"], o["beta2"], o["epsilon"], self.clip, 1.0, self.var_wd, self.var_mult)
         if self.ema is not None:
             ops.axpby(ps.weights, self.ema, 1.0 - self.ema_decay, self.ema_decay)
         self.model.refold()

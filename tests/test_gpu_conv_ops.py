@@ -347,3 +347,39 @@ def test_grouped_wgrad_matches_per_problem_wgrad():
         ops.conv2d_wgrad(d, xs[2], dys[2], ref, beta=0.0)
         torch.cuda.synchronize()
         assert float((got2[2] - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["rms_prop", "adam"])
+def test_rmsprop_and_adam_match_the_oracle(ops, kind):
+    """mtlssl_adaptive_update_clip (builders/optimizer_builder.py:40-62) against oracle/optimizer.py over three
+    steps: L2 term, a gradient multiplier, a frozen variable and per-variable clipping in front of the update."""
+    from oracle import optimizer as O
+    rng = np.random.RandomState(4)
+    sizes = [64, 4096, 8, 70000]
+    names = ["a", "b", "c", "d"]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    w = rng.randn(offs[-1]).astype(np.float32)
+    wd = torch.tensor([0.0, 1e-3, 0.0, 1e-4]).cuda()
+    mult = torch.tensor([1.0, 2.0, -1.0, 1.0]).cuda()
+    vals = {n: w[offs[i]:offs[i + 1]].copy() for i, n in enumerate(names)}
+    s0, s1 = {}, {}
+    wdev = torch.from_numpy(w).cuda()
+    d0 = torch.ones_like(wdev) if kind == "rms_prop" else torch.zeros_like(wdev)
+    d1 = torch.zeros_like(wdev)
+    for step in range(1, 4):
+        g = (rng.randn(offs[-1]) * (3.0 if step == 2 else 0.1)).astype(np.float32)          # step 2 gets clipped
+        grads = {n: g[offs[i]:offs[i + 1]] for i, n in enumerate(names)}
+        kw = dict(clip_norm=10.0, weight_decay={"b": 1e-3, "d": 1e-4}, multipliers={"b": 2.0, "c": -1.0})
+        if kind == "rms_prop":
+            O.rmsprop_update(vals, grads, s0, s1, lr=0.01, decay=0.9, momentum=0.9, epsilon=1.0, **kw)
+            ops.adaptive_update_clip(1, wdev, torch.from_numpy(g).cuda(), d0, d1, torch.from_numpy(offs).cuda(), max(sizes),
+                                     0.01, 0.9, 0.9, 1.0, 10.0, 1.0, wd, mult)
+        else:
+            O.adam_update(vals, grads, s0, s1, step=step, lr=0.01, beta1=0.9, beta2=0.999, epsilon=1e-8, **kw)
+            lr_t = 0.01 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+            ops.adaptive_update_clip(2, wdev, torch.from_numpy(g).cuda(), d0, d1, torch.from_numpy(offs).cuda(), max(sizes),
+                                     lr_t, 0.9, 0.999, 1e-8, 10.0, 1.0, wd, mult)
+    got = wdev.cpu().numpy()
+    for i, n in enumerate(names):
+        np.testing.assert_allclose(got[offs[i]:offs[i + 1]], vals[n], rtol=2e-5, atol=2e-6)
+    assert np.array_equal(got[offs[2]:offs[3]], w[offs[2]:offs[3]])                         # the frozen variable

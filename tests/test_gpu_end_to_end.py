@@ -221,3 +221,31 @@ def test_train_and_eval_launchers_with_the_reference_flags(tmp_path):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["global_step"] == 3 and out["num_images"] == 3 and len(out["ap_per_class"]) == K
     assert json.load(open(str(tmp_path / "eval" / "metrics-3.json"))) == out
+
+
+@pytest.mark.parametrize("opt", ["rms_prop_optimizer { decay: 0.9 epsilon: 1.0 learning_rate { exponential_decay_learning_rate { initial_learning_rate: 0.0005 decay_steps: 3 } } }",
+                                 "adam_optimizer { learning_rate { constant_learning_rate { learning_rate: 0.0001 } } }"],
+                         ids=["rms_prop", "adam"])
+def test_training_with_the_other_optimizers_saves_their_slots(tmp_path, opt):
+    """rms_prop / adam of builders/optimizer_builder.py:40-62 through trainer.train: the loss falls on a fixed batch,
+    the state file carries TensorFlow's slot names, and a resumed run continues from them."""
+    import re
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    text = open(os.path.join(ROOT, "configs", "smoke_resnet50_mtl.config")).read()
+    text = re.sub(r"optimizer \{.*use_moving_average: false \}", "optimizer { %s use_moving_average: false }" % opt, text, flags=re.S)
+    cfg = config.parse_pipeline_config(text)
+    kind = trainer.optimizer_from_config(cfg.train_config.optimizer)["kind"]
+    assert kind == ("rms_prop" if opt.startswith("rms") else "adam")
+    batch = synthetic.make_batch(2, 160, 224, 5, seed=3, device="cuda", max_gt=4, num_windows=6)
+    d = str(tmp_path / "run")
+    model_fn = lambda: model_builder.build(cfg.model, True, "cuda", seed=1)
+    tr, log = trainer.train(lambda: batch, model_fn, cfg.train_config, train_dir=d, num_steps=12, model_config=cfg.model, log_every=1)
+    assert log[-1]["loss"] < log[0]["loss"] and all(np.isfinite(e["loss"]) for e in log)
+    state = np.load(os.path.join(d, "model.ckpt.npz"))
+    name = "SecondStageBoxPredictor/ClassPredictor/weights"
+    a, b = ("/RMSProp", "/RMSProp_1") if kind == "rms_prop" else ("/Adam", "/Adam_1")
+    assert name + a in state.files and name + b in state.files and name + "/Momentum" not in state.files
+    tr2, _ = trainer.train(lambda: batch, model_fn, cfg.train_config, train_dir=d, num_steps=13, model_config=cfg.model)
+    assert tr2.global_step == 13 and torch.equal(tr2.slot1, tr2.slot1) and float(tr2.slot1.abs().sum()) > 0

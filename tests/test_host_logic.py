@@ -423,3 +423,35 @@ def test_train_launcher_reads_the_reference_flag_forms(tmp_path):
         with pytest.raises(SystemExit) as e:
             train.main(["--train_dir=/x", "--pipeline_config_path=%s" % pipe] + bad)
         assert "torch.distributed.run" in str(e.value)
+
+
+def test_optimizer_builder_covers_the_three_optimizers_and_learning_rates():
+    """builders/optimizer_builder.py:24-118 + protos/optimizer.proto defaults: momentum / rms_prop / adam with
+    constant, manual-step and exponential-decay rates (tf.train.exponential_decay, staircase on by default)."""
+    from mtl_ssl_amd import config, trainer
+
+    def opt(text):
+        return trainer.optimizer_from_config(config.parse_pipeline_config("train_config { optimizer { %s } }" % text).train_config.optimizer)
+    o = opt("rms_prop_optimizer { learning_rate { exponential_decay_learning_rate { initial_learning_rate: 0.004 decay_steps: 100 decay_factor: 0.5 } } }")
+    assert o["kind"] == "rms_prop" and (o["decay"], o["momentum"], o["epsilon"]) == (0.9, 0.9, 1.0)
+    assert [o["lr_fn"](s) for s in (0, 99, 100, 250)] == [0.004, 0.004, 0.002, 0.001]           # staircase
+    o = opt("adam_optimizer { beta2: 0.99 learning_rate { exponential_decay_learning_rate { decay_steps: 100 decay_factor: 0.5 staircase: false } } }")
+    assert o["kind"] == "adam" and (o["beta1"], o["beta2"], o["epsilon"]) == (0.9, 0.99, 1e-8)
+    assert abs(o["lr_fn"](50) - 0.002 * 0.5 ** 0.5) < 1e-12
+    o = opt("momentum_optimizer { momentum_optimizer_value: 0.8 learning_rate { constant_learning_rate { learning_rate: 0.01 } } }")
+    assert o["kind"] == "momentum" and o["momentum"] == 0.8 and o["lr_fn"](12345) == 0.01
+    with pytest.raises(ValueError):
+        opt("")
+
+
+def test_oracle_rmsprop_and_adam_known_answers():
+    """Hand-computed single steps of tf.train.RMSPropOptimizer (mean square starts at one) and AdamOptimizer."""
+    from oracle import optimizer as O
+    v, ms, mom = {"w": np.array([1.0, -2.0], np.float32)}, {}, {}
+    O.rmsprop_update(v, {"w": np.array([0.5, -1.0], np.float32)}, ms, mom, lr=0.1, decay=0.9, momentum=0.0, epsilon=1.0, clip_norm=0.0)
+    s = 0.9 + 0.1 * np.array([0.25, 1.0])
+    np.testing.assert_allclose(ms["w"], s, rtol=1e-6)
+    np.testing.assert_allclose(v["w"], np.array([1.0, -2.0]) - 0.1 * np.array([0.5, -1.0]) / np.sqrt(s + 1.0), rtol=1e-6)
+    v, m, vv = {"w": np.array([1.0, -2.0], np.float32)}, {}, {}
+    O.adam_update(v, {"w": np.array([0.5, -1.0], np.float32)}, m, vv, step=1, lr=0.1, beta1=0.9, beta2=0.999, epsilon=1e-8, clip_norm=0.0)
+    np.testing.assert_allclose(v["w"], np.array([0.9, -1.9]), rtol=1e-5)      # the first Adam step moves every weight by lr
