@@ -133,8 +133,8 @@ int mtlssl_conv2d_set_winograd(int mode);
 /* fp32 matrix engine of the large implicit GEMMs. 0 (default; MTLSSL_FP32_ENGINE unset): v_mfma_f32_32x32x2_f32,
  * exact fp32 products with fp32 accumulation. 1 (MTLSSL_FP32_ENGINE=split): problems with at least 192 tiles of
  * 256 x 256 run on the bf16 matrix datapath with every operand split EXACTLY into three bf16 pieces (hi + mid + lo
- * = the fp32 value) and six of the nine piece products accumulated in fp32; the three dropped products are below
- * 2^-23 of |a*b| (one fp32 rounding). Same error against fp64 as mode 0 (tests/test_gpu_split_engine.py), other
+ * = the fp32 value) and six of the nine piece products accumulated in fp32; the three dropped products are each below
+ * 2^-21 |a*b| in the worst case, about 2^-24 |a*b| on average (the size of one fp32 accumulation rounding). Same error against fp64 as mode 0 (tests/test_gpu_split_engine.py), other
  * summation order (not bit-identical), +-inf operands yield NaN. Returns the previous mode; any other value only
  * queries. Process-wide. */
 int mtlssl_conv2d_set_fp32_engine(int mode);

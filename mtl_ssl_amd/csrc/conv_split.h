@@ -5,9 +5,10 @@
 //     (8 + 8 + 8 significant bits = the 24 of fp32; each remainder is formed by an exact subtraction);
 //   * a product of two bf16 pieces has 16 significant bits: exact in the fp32 accumulator of
 //     v_mfma_f32_32x32x16_bf16;
-//   * a*b is the sum of the 9 piece products; the 6 with weight >= 2^-16 are issued — (hi,hi) (hi,mid) (mid,hi)
-//     (mid,mid) (hi,lo) (lo,hi) — and the 3 dropped ones (mid,lo) (lo,mid) (lo,lo) are below 2^-23 |a*b|: one fp32
-//     rounding of the product, which the fp32 FMA chain of the native engine commits on every accumulation anyway.
+//   * a*b is the sum of the 9 piece products. With |mid| < 2^-7 |x| and |lo| < 2^-14 |x| the six largest are issued —
+//     (hi,hi) (hi,mid) (mid,hi) (mid,mid) (hi,lo) (lo,hi) — and the three dropped ones, (mid,lo) (lo,mid) (lo,lo),
+//     are each below 2^-21 |a*b| in the worst case and about 2^-24 |a*b| on average: the size of the roundings the
+//     native engine's fp32 accumulation commits on every one of its K steps anyway.
 //     Measured against fp64 the two engines have the same error (tools/lab/split_gemm.hip, tests/test_gpu_split_engine.py).
 //
 // Six 32-cycle bf16 MFMAs replace eight 64-cycle fp32 MFMAs per 32x32x16 block-step (2.67x the matrix rate); the
@@ -15,7 +16,7 @@
 // 256 x 256 to keep the L2 -> LDS traffic per flop at half of the 128 x 128 fp32 tile's.
 //
 // Differences a caller can see: +-inf operands give NaN (inf - inf in the split) where the native engine gives
-// inf; sums are formed in another order (same fp32 products up to 2^-23, not bit-identical to the native engine).
+// inf; sums are formed in another order (not bit-identical to the native engine).
 //
 // Geometry: 512 threads = 8 wavefronts as 4 (m) x 2 (n), 64 x 128 outputs each (2 x 4 MFMA blocks);
 // K-step 16 = one MFMA k extent; LDS image of an operand stage: [piece 3][k-group 2][row 256] x 16 B, the 16 B

@@ -1,8 +1,8 @@
 // Kernel lab: fp32 GEMM on the bf16 matrix-core datapath by exact operand splitting.
 // Every fp32 value is the exact sum of three bf16 numbers (truncation: 8 + 8 + 8 significant bits = fp32's 24),
 // products of bf16 pieces are exact in fp32, and v_mfma_f32_32x32x16_bf16 accumulates in fp32 — so
-//   a*b = sum over the 9 piece pairs, of which the 6 pairs with weight >= 2^-16 are issued (the dropped
-//   mid*lo + lo*mid + lo*lo are < 2^-23 |a*b|, the size of ONE fp32 rounding).
+//   a*b = sum over the 9 piece pairs, of which the 6 largest are issued (with |mid| < 2^-7 |x|, |lo| < 2^-14 |x| each
+//   dropped pair — mid*lo, lo*mid, lo*lo — is < 2^-21 |a*b| worst case, ~2^-24 |a*b| on average: one accumulation rounding).
 // 6 bf16 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles per 32x32x16 block-step: 2.67x the fp32 matrix rate.
 // This file measures what a plain GEMM tile engine gets out of that (C[M,N] = A[M,K] B[K,N], fp32 in and out)
 // and its error against fp64. Stand-alone:  hipcc --offload-arch=gfx950 -O3 -std=c++17 split_gemm.hip -o split_gemm
