@@ -517,7 +517,7 @@ int mtlssl_comm_broadcast(mtlssl_comm_t comm, void* buf, int64_t bytes, int root
 int mtlssl_comm_destroy(mtlssl_comm_t comm);
 
 /* CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start): the checksum of the reference's
- * data containers — TFRecord framing (tensorflow/core/lib/io/record_writer.cc; create_records/*.py write them,
+ * data containers — TFRecord framing (tensorflow/core/lib/io/record_writer.cc; the create_records scripts write them,
  * builders/input_reader_builder.py:34-65 reads them) and TensorFlow checkpoint tables / tensors
  * (trainer.py:309-356). Plain host code, no GPU work; returns the 32-bit value. */
 int64_t mtlssl_crc32c_host(const void* data, int64_t nbytes, int64_t crc);
