@@ -333,6 +333,24 @@ int mtlssl_roi_crop_pool_fwd(const float* feat, int B, int H, int W, int C, cons
 int mtlssl_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax, int B, int H, int W, int C,
                              const float* boxes, const int32_t* box_ind, int R, int crop,
                              int pool_k, int pool_stride, float* dfeat, mtlssl_stream_t stream);
+/* The same gradient (tf.image.crop_and_resize + max_pool2d backward, faster_rcnn_meta_arch.py:1340-1348) with the
+ * accumulation behaviour and the algorithm selectable:
+ *   accumulate  1: dfeat += scatter(dout) (the entry point above); 0: dfeat = scatter(dout), every element of
+ *               dfeat [B,H,W,C] is written, so the caller needs no memset;
+ *   algo        0: auto — the LDS-resident kernel whenever C % 16 == 0 and a workspace is given: one block per
+ *               (image, 16-channel slice, band of rows) keeps its piece of the map in LDS as 64-bit fixed-point
+ *               sums (step = max|dout| * 2^-30, integer adds commute), walks the image's RoIs and writes the piece
+ *               once — no HBM atomics, run-to-run bit-identical; else HBM fp32 atomics;
+ *               1: require the LDS-resident kernel (MTLSSL_EINVAL if the shape does not fit it);
+ *               2: force the HBM-atomics kernel (order of additions, hence the last bits, varies between runs;
+ *               this is what mtlssl_roi_crop_pool_bwd runs).
+ *   workspace   mtlssl_roi_crop_pool_bwd_workspace_bytes() bytes of device memory (may be NULL for algo 2).
+ * box_ind may be in any order. A non-finite value in dout turns the whole map into NaN (LDS kernel). */
+int64_t mtlssl_roi_crop_pool_bwd_workspace_bytes(void);
+int mtlssl_roi_crop_pool_bwd_ex(const float* dout, const uint8_t* argmax, int B, int H, int W, int C,
+                                const float* boxes, const int32_t* box_ind, int R, int crop, int pool_k,
+                                int pool_stride, float* dfeat, int accumulate, int algo, void* workspace,
+                                mtlssl_stream_t stream);
 
 /* ops.position_sensitive_crop_regions(global_pool=True) (utils/ops.py:462-609; call sites
  * core/box_predictor.py:228-264,312-330): fmap [B,H,W,C] with C = bins_y*bins_x*Cc; out [R,Cc].

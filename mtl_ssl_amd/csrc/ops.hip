@@ -112,6 +112,186 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Deterministic form of the scatter above, without HBM atomics. One block owns a (image, 16-channel
+// slice, band of map rows): that piece of the gradient map lives in LDS for the whole kernel, the
+// block walks the cell rows of the image's RoIs that can touch its band and adds every bilinear corner
+// that falls into it, then writes (or accumulates) its piece of dfeat ONCE with 64-byte segments. HBM
+// traffic = dout + argmax read (64-byte segments) + dfeat written once; no pre-zeroed dfeat needed.
+//
+// Accumulation is FIXED POINT in 64-bit LDS cells, not float: `ds_add_f32` retires 0.33 lane-adds per
+// clock per CU on gfx950 whatever the address pattern, `ds_add_u64` 8 (tools/lab/lds_atomic_lab.hip,
+// profiles/r03_lds_atomic_lab.txt) — the float form made this kernel as slow as the L2 atomics it
+// replaces. A contribution c = weight * dout (|c| <= M = max |dout|, found by a 25 us pass over dout)
+// is added as rint(c * 2^(30-e)), 2^(e-1) <= M < 2^e: 30 significant bits for the largest
+// contributions (fp32 carries 24), an absolute step of M * 2^-30 for the small ones, and integer
+// addition is associative, so the sums do not depend on the order in which lanes, waves or blocks
+// arrive: run-to-run bit-identical by construction (tests/test_gpu_conv_ops.py re-runs it), which the
+// float atomics in L2 were not. 2^33 addends fit before a cell could overflow.
+constexpr int kRoiSlice = 16;          // channels per block (one 64-byte segment of a dout row)
+constexpr int kRoiPass = 512;          // RoIs of one image handled per pass of the LDS lists
+struct RoiItem { float y1, x1, hs, ws; };
+
+// |x| of finite floats orders like the bit pattern; NaN / Inf patterns order above every finite one,
+// so the maximum also tells whether dout holds a non-finite value.
+__global__ void __launch_bounds__(256) k_absmax_bits(const float* __restrict__ x, int64_t n4, uint32_t* out) {
+  uint32_t m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
+        max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+template <int PK>    // pool kernel size known at compile time (1 or 2), 0 = any
+__global__ void __launch_bounds__(256)
+    k_roi_crop_pool_bwd_lds(const float* __restrict__ dout, const uint8_t* __restrict__ argmax, int H,
+                            int W, int C, const float* __restrict__ boxes,
+                            const int32_t* __restrict__ box_ind, int R, int crop, int pk_rt, int ps, int PH,
+                            int PW, int band_rows, int nbands, int accumulate,
+                            const uint32_t* __restrict__ absmax_bits, float* __restrict__ dfeat) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  const int pk = PK ? PK : pk_rt;
+  const int NP = band_rows * W;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(s_raw);   // [kRoiSlice][NP] channel-major
+  RoiItem* s_geom = reinterpret_cast<RoiItem*>(acc + (size_t)kRoiSlice * NP); // [kRoiPass]
+  int* s_roi = reinterpret_cast<int*>(s_geom + kRoiPass);                     // [kRoiPass]
+  uint16_t* s_entry = reinterpret_cast<uint16_t*>(s_roi + kRoiPass);          // [kRoiPass * PH]: slot * 64 + py
+  __shared__ int s_n;
+  // XCD-aware decode: the blocks that read the same dout rows (the bands and the two 16-channel
+  // slices of one 128-byte line) get consecutive LOGICAL ids, and logical ids are dealt to XCDs in
+  // contiguous ranges (hardware deals blockIdx round-robin over the 8 XCDs).
+  int nblk = gridDim.x, bid = blockIdx.x;
+  if (nblk % 8 == 0) bid = (bid % 8) * (nblk / 8) + bid / 8;
+  const int band = bid % nbands;
+  const int slice = (bid / nbands) % (C / kRoiSlice);
+  const int img = bid / nbands / (C / kRoiSlice);
+  const int row0 = band * band_rows;
+  const int rows = min(band_rows, H - row0);
+  const int tid = threadIdx.x;
+  // scale: contributions are added as rint(c * 2^(30-e)), M < 2^e
+  const uint32_t mbits = *absmax_bits;
+  const bool finite = mbits < 0x7f800000u;
+  int e = (int)(mbits >> 23) - 126;                      // M in [2^(e-1), 2^e)  (denormal M: e = -126)
+  e = max(e, -90);
+  const float scale = __uint_as_float((uint32_t)(30 - e + 127) << 23);       // 2^(30-e), e in [-90, 128]
+  const double descale = __longlong_as_double((long long)(e - 30 + 1023) << 52);
+  for (int i = tid; i < kRoiSlice * NP; i += 256) acc[i] = 0ull;
+  const int quad = tid & 3;                              // which 4 of the slice's 16 channels
+  const int cslot = tid >> 2;                            // cell slot of this lane inside a pass of 64 cells
+  unsigned long long* qacc = acc + (size_t)(quad * 4) * NP;
+  const float inv_pw = 1.0f / (float)PW;
+  const int cells = PH * PW;
+  const float Hm1 = (float)(H - 1), Wm1 = (float)(W - 1);
+  for (int base = 0; base < R; base += kRoiPass) {
+    // ---- list of (RoI, cell row) pairs of this image whose samples can touch the band (any order:
+    // integer accumulation commutes)
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    int lim = min(R, base + kRoiPass);
+    for (int r = base + tid; r < lim; r += 256) {
+      if (box_ind[r] != img) continue;
+      CropGeom g = crop_geom(boxes, box_ind, r, H, W, crop);
+      // cell row py samples crop rows py*ps .. py*ps+pk-1; in_y is monotonic in the crop row
+      int lo = PH, hi = -1;
+      for (int py = 0; py < PH; ++py) {
+        float ya = g.y1 + (float)(py * ps) * g.hs, yb = g.y1 + (float)(py * ps + pk - 1) * g.hs;
+        float mn = fminf(ya, yb), mx = fmaxf(ya, yb);
+        if (floorf(mn) < (float)(row0 + rows) && ceilf(mx) >= (float)row0) { lo = min(lo, py); hi = max(hi, py); }
+      }
+      if (hi < lo) continue;                               // (NaN boxes compare false: dropped)
+      int slot = r - base;
+      s_geom[slot] = RoiItem{g.y1, g.x1, g.hs, g.ws};
+      s_roi[slot] = r;
+      int pos = atomicAdd(&s_n, hi - lo + 1);
+      for (int py = lo; py <= hi; ++py) s_entry[pos + py - lo] = (uint16_t)(slot * 64 + py);
+    }
+    __syncthreads();
+    const int ncell = s_n * PW;
+    for (int c0 = 0; c0 < ncell; c0 += 64) {
+      int ci = c0 + cslot;
+      if (ci >= ncell) continue;
+      int ei = (int)(((float)ci + 0.5f) * inv_pw);
+      int px = ci - ei * PW;
+      int ent = s_entry[ei];
+      int slot = ent >> 6, py = ent & 63;
+      RoiItem g = s_geom[slot];
+      int64_t o = ((int64_t)s_roi[slot] * cells + py * PW + px) * C + slice * kRoiSlice + quad * 4;
+      float4 gr4 = *reinterpret_cast<const float4*>(dout + o);
+      uint32_t am4 = argmax ? *reinterpret_cast<const uint32_t*>(argmax + o) : 0u;
+      if (PK == 1) {
+        // no pooling: one sample per cell, shared by the 4 channels
+        float in_y = g.y1 + (float)(py * ps) * g.hs, in_x = g.x1 + (float)(px * ps) * g.ws;
+        if (in_y < 0.f || in_y > Hm1 || in_x < 0.f || in_x > Wm1) continue;
+        int ty = (int)floorf(in_y), by = (int)ceilf(in_y), lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+        float yl = in_y - (float)ty, xl = in_x - (float)lx;
+        int t = ty - row0, b = by - row0;
+        bool okt = t >= 0 && t < rows, okb = b >= 0 && b < rows;
+        float grv[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float dtop = (1.f - yl) * grv[k], dbot = yl * grv[k];
+          unsigned long long* a = qacc + (size_t)k * NP;
+          if (okt) {
+            atomicAdd(a + t * W + lx, (unsigned long long)(long long)(int)rintf((1.f - xl) * dtop * scale));
+            atomicAdd(a + t * W + rx, (unsigned long long)(long long)(int)rintf(xl * dtop * scale));
+          }
+          if (okb) {
+            atomicAdd(a + b * W + lx, (unsigned long long)(long long)(int)rintf((1.f - xl) * dbot * scale));
+            atomicAdd(a + b * W + rx, (unsigned long long)(long long)(int)rintf(xl * dbot * scale));
+          }
+        }
+        continue;
+      }
+      float grv[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int s = (int)((am4 >> (8 * k)) & 0xffu);
+        int dy = PK == 2 ? (s >> 1) : s / pk, dx = PK == 2 ? (s & 1) : s - dy * pk;
+        float in_y = g.y1 + (float)(py * ps + dy) * g.hs;
+        float in_x = g.x1 + (float)(px * ps + dx) * g.ws;
+        if (in_y < 0.f || in_y > Hm1 || in_x < 0.f || in_x > Wm1) continue;
+        int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
+        int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+        float yl = in_y - (float)ty, xl = in_x - (float)lx;
+        float dtop = (1.f - yl) * grv[k], dbot = yl * grv[k];
+        unsigned long long* a = qacc + (size_t)k * NP;
+        int t = ty - row0, b = by - row0;
+        if (t >= 0 && t < rows) {
+          atomicAdd(a + t * W + lx, (unsigned long long)(long long)(int)rintf((1.f - xl) * dtop * scale));
+          atomicAdd(a + t * W + rx, (unsigned long long)(long long)(int)rintf(xl * dtop * scale));
+        }
+        if (b >= 0 && b < rows) {
+          atomicAdd(a + b * W + lx, (unsigned long long)(long long)(int)rintf((1.f - xl) * dbot * scale));
+          atomicAdd(a + b * W + rx, (unsigned long long)(long long)(int)rintf(xl * dbot * scale));
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- one pass over the band: 4 adjacent lanes write the slice's 64 bytes of a pixel
+  const int np = rows * W;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  for (int i = tid; i < np * 4; i += 256) {
+    int p = i >> 2, q = i & 3;
+    const unsigned long long* a = acc + (size_t)(q * 4) * NP + p;
+    float4 v;
+    v.x = (float)((double)(long long)a[0] * descale);
+    v.y = (float)((double)(long long)a[NP] * descale);
+    v.z = (float)((double)(long long)a[2 * (size_t)NP] * descale);
+    v.w = (float)((double)(long long)a[3 * (size_t)NP] * descale);
+    if (!finite) v = make_float4(qnan, qnan, qnan, qnan);      // a NaN / Inf in dout poisons the map, as it would in float
+    float* dst = dfeat + (((int64_t)img * H + row0) * W + p) * C + slice * kRoiSlice + q * 4;
+    if (accumulate) {
+      float4 old = *reinterpret_cast<const float4*>(dst);
+      v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+    }
+    *reinterpret_cast<float4*>(dst) = v;
+  }
+}
+
 // ------------------------------------------------------------------------------ PS-RoI pooling
 // ops.position_sensitive_crop_regions(global_pool=True) (utils/ops.py:462-609): the box is cut
 // into bins_y x bins_x sub-boxes; bin g crops (crop_and_resize, bs x bs samples) ITS OWN channel
@@ -580,12 +760,68 @@ int mtlssl_roi_crop_pool_fwd(const float* feat, int B, int H, int W, int C, cons
 int mtlssl_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax, int B, int H, int W, int C,
                              const float* boxes, const int32_t* box_ind, int R, int crop, int pk,
                              int ps, float* dfeat, mtlssl_stream_t stream) {
+  return mtlssl_roi_crop_pool_bwd_ex(dout, argmax, B, H, W, C, boxes, box_ind, R, crop, pk, ps, dfeat, 1, 2, nullptr,
+                                     stream);
+}
+
+// LDS budget of one block of the deterministic kernel: the band's 64-bit accumulators + the RoI lists.
+static size_t roi_bwd_lds_bytes(int band_rows, int W, int PH) {
+  return sizeof(unsigned long long) * kRoiSlice * (size_t)(band_rows * W) +
+         kRoiPass * (sizeof(RoiItem) + sizeof(int) + sizeof(uint16_t) * (size_t)PH);
+}
+
+int64_t mtlssl_roi_crop_pool_bwd_workspace_bytes(void) { return 256; }
+
+int mtlssl_roi_crop_pool_bwd_ex(const float* dout, const uint8_t* argmax, int B, int H, int W, int C,
+                                const float* boxes, const int32_t* box_ind, int R, int crop, int pk, int ps,
+                                float* dfeat, int accumulate, int algo, void* workspace, mtlssl_stream_t stream) {
   MTLSSL_REQUIRE(argmax != nullptr || pk == 1, "roi_crop_bwd: argmax required when pooling");
-  if (R == 0) return MTLSSL_OK;
+  MTLSSL_REQUIRE(algo >= 0 && algo <= 2, "roi_crop_bwd: algo must be 0 (auto), 1 (LDS-resident, deterministic) or 2 (HBM atomics)");
+  MTLSSL_REQUIRE(pk >= 1 && ps >= 1 && crop >= pk, "roi_crop_bwd: bad pool geometry");
   int PH = (crop - pk) / ps + 1;
-  hipLaunchKernelGGL(k_roi_crop_pool_bwd, dim3(PH * PH, R), dim3(256), 0, S(stream), dout, argmax, H,
-                     W, C, boxes, box_ind, crop, pk, ps, PH, PH, dfeat);
-  return check_launch("roi_crop_pool_bwd");
+  // band height: the map rows whose 16-channel, 64-bit accumulators fit next to the lists in 76 KB (two blocks per CU)
+  size_t lists = roi_bwd_lds_bytes(0, W, PH);
+  int band_rows = lists < 76 * 1024 ? (int)((76 * 1024 - lists) / (sizeof(unsigned long long) * kRoiSlice * (size_t)W)) : 0;
+  if (band_rows > H) band_rows = H;
+  bool lds_ok = C % kRoiSlice == 0 && band_rows >= 1 && B >= 1 && PH <= 64 && workspace != nullptr;
+  MTLSSL_REQUIRE(algo != 1 || lds_ok, "roi_crop_bwd: the LDS-resident kernel needs C %% 16 == 0, a workspace, at most 64 cell rows and a "
+                                      "map row that fits its LDS budget (W = %d)", W);
+  if (algo == 2 || !lds_ok) {
+    if (!accumulate)
+      if (hipMemsetAsync(dfeat, 0, sizeof(float) * (size_t)B * H * W * C, S(stream)) != hipSuccess) {
+        set_error("roi_crop_pool_bwd: memset failed");
+        return MTLSSL_ELAUNCH;
+      }
+    if (R == 0) return MTLSSL_OK;
+    hipLaunchKernelGGL(k_roi_crop_pool_bwd, dim3(PH * PH, R), dim3(256), 0, S(stream), dout, argmax, H,
+                       W, C, boxes, box_ind, crop, pk, ps, PH, PH, dfeat);
+    return check_launch("roi_crop_pool_bwd");
+  }
+  if (R == 0 && accumulate) return MTLSSL_OK;
+  uint32_t* amax = reinterpret_cast<uint32_t*>(workspace);
+  if (hipMemsetAsync(amax, 0, sizeof(uint32_t), S(stream)) != hipSuccess) {
+    set_error("roi_crop_pool_bwd: memset failed");
+    return MTLSSL_ELAUNCH;
+  }
+  int64_t n4 = (int64_t)R * PH * PH * C / 4;
+  if (n4 > 0)
+    hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)(n4 < 2048 * 256 ? cdiv(n4, 256) : 2048)), dim3(256), 0, S(stream),
+                       dout, n4, amax);
+  int nbands = (int)cdiv(H, band_rows);
+  band_rows = (int)cdiv(H, nbands);                        // even bands
+  size_t lds = roi_bwd_lds_bytes(band_rows, W, PH);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_roi_crop_pool_bwd_lds<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_roi_crop_pool_bwd_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_roi_crop_pool_bwd_lds<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  int grid = nbands * (C / kRoiSlice) * B;
+  auto kern = pk == 1 ? k_roi_crop_pool_bwd_lds<1> : pk == 2 ? k_roi_crop_pool_bwd_lds<2> : k_roi_crop_pool_bwd_lds<0>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, S(stream), dout, argmax, H, W, C, boxes, box_ind, R, crop, pk, ps,
+                     PH, PH, band_rows, nbands, accumulate, amax, dfeat);
+  return check_launch("roi_crop_pool_bwd_lds");
 }
 
 int mtlssl_psroi_fwd(const float* fmap, int B, int H, int W, int C, const float* boxes,

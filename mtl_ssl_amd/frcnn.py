@@ -202,12 +202,16 @@ class FasterRCNNMetaArch:
         return self._wgrad_stream_obj
 
     def compute_streams(self):
+        """Every side stream a gradient may be produced on. Created HERE if they do not exist yet: the data-parallel
+        reducer takes this list before the first backward, and a stream that only appeared inside backward() would
+        be missing from the events a bucket's all-reduce waits for (its filter gradients would then land, with
+        beta = 1, on top of already reduced values)."""
         out = []
-        s = getattr(self, "_aux_stream_obj", None)
+        s = self._aux_stream()
         if s is not None:
             out.append(s)
-        w = getattr(self, "_wgrad_stream_obj", None)
-        if w is not None:
+        w = self._wgrad_exec()
+        if getattr(w, "stream", None) is not None:
             out.append(w.stream)
         return out
 
@@ -667,7 +671,7 @@ class FasterRCNNMetaArch:
         d = pd["_d"]
         F = pd["rpn_features_to_crop"]
         B = F.shape[0]
-        dF = torch.zeros_like(F)
+        dF = torch.empty_like(F)         # first written IN FULL by the main head's RoI-crop backward below (no memset)
         d_cls = d["class_predictions"]
         # refine: gradient reaches the refiner weights and, through the residual, the class logits
         if mtl.refine:
@@ -684,7 +688,7 @@ class FasterRCNNMetaArch:
         g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True, masked=True)
         ops.roi_crop_pool_bwd(g_crops, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
                               pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
-                              int(c.maxpool_stride), dfeat=dF)
+                              int(c.maxpool_stride), dfeat=dF, accumulate=False)
         stop = bool(mtl.stop_gradient_for_aux_tasks)
 
         def aux_backward():

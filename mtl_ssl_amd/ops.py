@@ -714,12 +714,20 @@ def roi_crop_pool_fwd(feat, boxes, box_ind, crop, pool_k=1, pool_stride=1, want_
 
 
 def roi_crop_pool_bwd(dout, argmax, feat_shape, boxes, box_ind, crop, pool_k, pool_stride,
-                      dfeat=None):
+                      dfeat=None, accumulate=None, algo=0):
+    """dfeat (+)= gradient of roi_crop_pool_fwd. Without `dfeat` a fresh map is returned (written in full by the
+    kernel, no memset); with one, the gradient is added to it unless accumulate=False (then it is overwritten).
+    algo: 0 auto, 1 the LDS-resident deterministic kernel, 2 HBM atomics (mtlssl_roi_crop_pool_bwd_ex)."""
     B, H, W, C = feat_shape
     if dfeat is None:
-        dfeat = torch.zeros(feat_shape, dtype=f32, device=dout.device)
-    lib().roi_crop_pool_bwd(ptr(_chk(dout)), ptr(argmax), B, H, W, C, ptr(boxes), ptr(box_ind),
-                            boxes.shape[0], crop, pool_k, pool_stride, ptr(dfeat), _stream())
+        dfeat = torch.empty(feat_shape, dtype=f32, device=dout.device)
+        accumulate = False
+    elif accumulate is None:
+        accumulate = True
+    ws = workspace(lib().roi_crop_pool_bwd_workspace_bytes(), "roi_bwd", dout.device)
+    lib().roi_crop_pool_bwd_ex(ptr(_chk(dout)), ptr(argmax), B, H, W, C, ptr(boxes), ptr(box_ind),
+                               boxes.shape[0], crop, pool_k, pool_stride, ptr(dfeat), 1 if accumulate else 0,
+                               int(algo), ptr(ws), _stream())
     return dfeat
 
 

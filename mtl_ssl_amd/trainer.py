@@ -97,6 +97,7 @@ class GradientReducer:
             self.buckets[-1] = (self.buckets[-1][0], ps.n_train)
         self.stream = torch.cuda.Stream() if (self.active and ps.device.type == "cuda") else None
         self.compute_streams = []          # extra compute streams whose work a bucket may depend on
+        self.compute_streams_fn = None     # asked at every bucket launch (a model may create streams lazily)
         self.main_stream = None
         self.pending, self.done, self.seen = [], [], set()
         self.launch_order = []             # bucket ids in the order they were issued (diagnostics/tests)
@@ -130,8 +131,10 @@ class GradientReducer:
             self.comm.allreduce(g[s:e])
             return
         # the bucket's variables may have been produced on any compute stream (main or auxiliary)
-        streams = {id(cs): cs for cs in [self.main_stream, torch.cuda.current_stream()] + self.compute_streams
-                   if cs is not None}
+        extra = list(self.compute_streams)
+        if self.compute_streams_fn is not None:
+            extra += list(self.compute_streams_fn())
+        streams = {id(cs): cs for cs in [self.main_stream, torch.cuda.current_stream()] + extra if cs is not None}
         for cs in streams.values():
             ev = torch.cuda.Event()
             ev.record(cs)
@@ -287,6 +290,7 @@ class Trainer:
         self.provide(batch)
         self.ps.grads.zero_()
         self.reducer.compute_streams = m.compute_streams()
+        self.reducer.compute_streams_fn = m.compute_streams
         self.reducer.begin_step()
         ops.mark("step_start")
         images = m.preprocess(batch["images"])

@@ -22,10 +22,13 @@ MEANS = (123.68, 116.779, 103.939)
 
 
 class Oracle:
-    def __init__(self, hp, values):
-        """hp: dict of hyper-parameters (see tests/test_gpu_model.py); values: {name: ndarray}."""
+    def __init__(self, hp, values, dtype=np.float32):
+        """hp: dict of hyper-parameters (see tests/test_gpu_model.py); values: {name: ndarray}.
+        dtype=np.float64 evaluates the same graph in double precision (the integer decisions still come from the
+        fp32 numpy oracle): the yardstick tests use to tell rounding of an fp32 implementation from a defect."""
         self.hp = hp
-        self.v = {k: torch.tensor(np.asarray(a, F), requires_grad=True) for k, a in values.items()}
+        self.dtype = np.dtype(dtype).type
+        self.v = {k: torch.tensor(np.asarray(a, self.dtype), requires_grad=True) for k, a in values.items()}
 
     # ------------------------------------------------------------------ building blocks
     def conv_bn(self, x, scope, stride=1, rate=1, relu=True, same="SAME"):
@@ -222,7 +225,7 @@ class Oracle:
         Returns (detection_boxes, scores, classes, num, aux)."""
         hp, mtl = self.hp, self.hp["mtl"]
         with torch.no_grad():
-            img = torch.as_tensor(np.asarray(images, F))
+            img = torch.as_tensor(np.asarray(images, self.dtype))
             Bn, H, W, _ = img.shape
             K = hp["num_classes"]
             K1 = K + 1
@@ -284,11 +287,18 @@ class Oracle:
         return ob, os_, oc, on, aux
 
     # ------------------------------------------------------------------ one training step
-    def step(self, batch, seed, step=0):
-        """Returns (losses {name: float}, grads {name: ndarray}, aux dict)."""
+    def step(self, batch, seed, step=0, forced=None):
+        """Returns (losses {name: float}, grads {name: ndarray}, aux dict).
+        forced: optional dict that replaces this run's own input to the (discrete, discontinuous) proposal chain:
+          * proposal_boxes [B,N2,4] abs + num_proposals [B]: the sampled second-stage boxes of another run (a
+            float64 run then evaluates exactly the graph of the fp32 run it is the yardstick for), or
+          * rpn_box_encodings [B,Nv,4] + rpn_objectness [B,Nv,2]: another implementation's RPN outputs, from which
+            THIS oracle's decode -> sort -> NMS -> sampling chain draws the boxes (a sort over 14 453 scores that
+            differ by 1e-7 between two fp32 convolutions is not a function either can be held to; the chain on
+            identical floats is)."""
         hp = self.hp
         mtl = hp["mtl"]
-        img = torch.as_tensor(np.asarray(batch["images"], F))
+        img = torch.as_tensor(np.asarray(batch["images"], self.dtype))
         Bn, H, W, _ = img.shape
         K = hp["num_classes"]
         K1 = K + 1
@@ -312,11 +322,18 @@ class Oracle:
         gt_cls_bg = [np.pad(np.asarray(c, F), [[0, 0], [1, 0]]) for c in batch["groundtruth_classes"]]
         gt_clo = [np.asarray(c, F) for c in batch["groundtruth_closeness"]] if mtl["closeness"] else None
         # proposals (no gradient: tf.stop_gradient, faster_rcnn_meta_arch.py:1117)
-        pb, _, _, pn = N.rpn_proposals(enc.detach().numpy(), obj.detach().numpy(), anchors, (H, W),
-                                       hp["nms_score_threshold"], hp["nms_iou_threshold"], hp["max_proposals"])
         N2 = hp["second_stage_batch_size"]
-        boxes_abs, num, _ = L.sample_box_classifier_batch(pb, pn, gt_abs, gt_cls_bg, N2,
-                                                          hp["second_stage_balance_fraction"], seed, step)
+        if forced is not None and "proposal_boxes" in forced:
+            boxes_abs = np.asarray(forced["proposal_boxes"], F)
+            num = np.asarray(forced["num_proposals"], np.int32)
+        else:
+            e_np, o_np = enc.detach().numpy().astype(F), obj.detach().numpy().astype(F)
+            if forced is not None:
+                e_np, o_np = np.asarray(forced["rpn_box_encodings"], F), np.asarray(forced["rpn_objectness"], F)
+            pb, _, _, pn = N.rpn_proposals(e_np, o_np, anchors, (H, W), hp["nms_score_threshold"],
+                                           hp["nms_iou_threshold"], hp["max_proposals"])
+            boxes_abs, num, _ = L.sample_box_classifier_batch(pb, pn, gt_abs, gt_cls_bg, N2,
+                                                              hp["second_stage_balance_fraction"], seed, step)
         boxes_norm = np.stack([B.to_normalized(boxes_abs[b], H, W) for b in range(Bn)])
         box_ind = np.repeat(np.arange(Bn), N2)
         rfcn = hp.get("rfcn")
@@ -372,7 +389,7 @@ class Oracle:
             em = self.conv(Fm, "EdgeMaskPredictor/BoxEncodingPredictor", "tanh")
             losses.update(L.loss_edgemask(em, np.stack(batch["groundtruth_edgemask"]),
                                           mtl["edgemask_loss_weight"]))
-        refined = None
+        refined = net = None
         if mtl["refine"]:
             src = [cls]
             if mtl["window"]:
@@ -412,7 +429,8 @@ class Oracle:
         grads = {k: t.grad.numpy() for k, t in self.v.items() if t.grad is not None}
         aux = dict(proposal_boxes=boxes_abs, num_proposals=num, rpn_match=tg["match"],
                    rpn_sampled=tg["samp"], det_match=dt["match"], rpn_box_encodings=enc.detach().numpy(),
-                   class_predictions=cls.detach().numpy(), features=Fm.detach().numpy(),
+                   rpn_objectness=obj.detach().numpy(), class_predictions=cls.detach().numpy(), features=Fm.detach().numpy(),
                    refined=None if refined is None else refined.detach().numpy(),
+                   refine_in=None if net is None else net.numpy(),
                    d_features=Fm.grad.numpy())
         return {k: float(v.detach()) for k, v in losses.items()}, grads, aux

@@ -213,6 +213,66 @@ def test_roi_crop_pool(ops, crop, pk, ps):
     ref.backward(gy)
     df = ops.roi_crop_pool_bwd(gy.cuda(), am, feat.shape, boxes.cuda(), bi.cuda(), crop, pk, ps)
     assert relerr(df, fr.grad) < 1e-4
+    # both algorithms behind mtlssl_roi_crop_pool_bwd_ex: the LDS-resident one (1) is what `auto` picked above for
+    # C % 16 == 0; HBM atomics (2) is the fallback. Accumulating and overwriting forms agree.
+    d1 = ops.roi_crop_pool_bwd(gy.cuda(), am, feat.shape, boxes.cuda(), bi.cuda(), crop, pk, ps, algo=1)
+    assert torch.equal(d1, df)
+    d2 = ops.roi_crop_pool_bwd(gy.cuda(), am, feat.shape, boxes.cuda(), bi.cuda(), crop, pk, ps, algo=2)
+    assert relerr(d2, fr.grad) < 1e-4
+    base = torch.randn(feat.shape, generator=g).cuda()
+    for algo in (1, 2):
+        acc = ops.roi_crop_pool_bwd(gy.cuda(), am, feat.shape, boxes.cuda(), bi.cuda(), crop, pk, ps,
+                                    dfeat=base.clone(), algo=algo)
+        assert relerr(acc - base, fr.grad) < 1e-4
+        over = ops.roi_crop_pool_bwd(gy.cuda(), am, feat.shape, boxes.cuda(), bi.cuda(), crop, pk, ps,
+                                     dfeat=torch.full(feat.shape, float("nan"), device="cuda"), accumulate=False, algo=algo)
+        assert relerr(over, fr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("H,W,C,R,crop,pk", [(38, 64, 1024, 512, 14, 2), (50, 84, 1088, 300, 7, 1), (19, 25, 48, 2300, 7, 1)])
+def test_roi_crop_bwd_lds_kernel_is_bit_reproducible_and_matches_the_atomic_kernel(ops, H, W, C, R, crop, pk):
+    """The LDS-resident scatter (no HBM atomics): at configs[1]'s full shape (two images, 38x64x1024, 512 RoIs of
+    14 -> 7 cells), on a map whose rows do not divide into equal bands (50x84, 1088 channels), and with more RoIs
+    per image than one pass of its RoI list holds (2300 > 1024), RoIs piled onto a few pixels (every cell of a tiny
+    box hits the same LDS cell from many lanes of one instruction), box_ind in arbitrary order and an image without
+    any RoI. Two runs are bit-identical; the result equals the oracle and the HBM-atomics kernel to rounding."""
+    g = torch.Generator().manual_seed(H * 7 + R)
+    B = 3
+    feat_shape = (B, H, W, C)
+    yx = torch.rand(R, 2, generator=g) * 0.9 - 0.05
+    hw = torch.rand(R, 2, generator=g) * 0.5 + 0.01
+    boxes = torch.cat([yx, yx + hw], 1)
+    boxes[: R // 4, 2:] = boxes[: R // 4, :2] + 0.004 * torch.rand(R // 4, 2, generator=g)   # sub-pixel boxes
+    boxes[R // 4: R // 2] = boxes[0]                                                      # piled onto one box
+    bi = (torch.randint(0, 2, (R,), generator=g) * 2).int()          # images 0 and 2; image 1 has no RoI
+    ps = pk
+    feat = torch.randn(feat_shape, generator=g).cuda()
+    out, am = ops.roi_crop_pool_fwd(feat, boxes.cuda(), bi.cuda(), crop, pk, ps)
+    gy = torch.randn(out.shape, generator=g).cuda()
+    a = ops.roi_crop_pool_bwd(gy, am, feat_shape, boxes.cuda(), bi.cuda(), crop, pk, ps, algo=1)
+    b = ops.roi_crop_pool_bwd(gy, am, feat_shape, boxes.cuda(), bi.cuda(), crop, pk, ps, algo=1)
+    assert torch.equal(a, b)
+    assert float(a[1].abs().max()) == 0.0
+    c = ops.roi_crop_pool_bwd(gy, am, feat_shape, boxes.cuda(), bi.cuda(), crop, pk, ps, algo=2)
+    assert relerr(a, c) < 1e-5
+    if R <= 512 and C <= 1024:                     # the torch-CPU oracle of the same gradient
+        fr = feat.cpu().requires_grad_()
+        ref = T.crop_and_resize(fr, boxes, bi, crop)
+        if pk > 1:
+            ref = T.max_pool(ref, pk, ps, "VALID")
+        ref.backward(gy.cpu())
+        assert relerr(a, fr.grad) < 1e-4
+
+
+def test_roi_crop_bwd_rejects_shapes_the_lds_kernel_cannot_take(ops):
+    from mtl_ssl_amd.lib import MtlsslError
+    gy = torch.zeros(1, 1, 1, 8, device="cuda")
+    boxes = torch.tensor([[0.1, 0.1, 0.5, 0.5]], device="cuda")
+    bi = torch.zeros(1, dtype=torch.int32, device="cuda")
+    with pytest.raises(MtlsslError):
+        ops.roi_crop_pool_bwd(gy, None, (1, 4, 4, 8), boxes, bi, 1, 1, 1, algo=1)      # C % 16 != 0
+    out = ops.roi_crop_pool_bwd(gy + 1.0, None, (1, 4, 4, 8), boxes, bi, 1, 1, 1)       # auto falls back to atomics
+    assert abs(float(out.sum()) - 8.0) < 1e-5
 
 
 def test_resize_bilinear_legacy(ops):

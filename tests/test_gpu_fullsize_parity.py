@@ -1,0 +1,122 @@
+"""Whole-step oracle parity at the FULL sizes the benchmark quotes, one image per case (what the CPU oracle
+finishes in seconds on the GPU box's host cores):
+
+  configs[1]  Faster R-CNN ResNet-101, 90 classes, crop 14 -> pool 2, three aux heads + refine, 600x1024
+              (configs/frcnn_resnet101_coco_mtl.config — bench.py's workload; 14 453 anchors inside the window)
+  configs[0]  Faster R-CNN MobileNet-v1, VOC07 settings, 600x800 (a 500x375 VOC image through the 600/1024 resizer)
+  configs[2]  R-FCN ResNet-101 (block4 on the whole 38x64 map, PS-RoI pooling), 600x1024
+
+`Trainer.forward_backward` (HIP path through the C ABI) against `Oracle.step` (torch-CPU fp32 + numpy) on the same
+synthetic image, weights and sampler seed: every loss <= 1e-3 relative, anchor matches / sampler picks / detector
+matches / proposal counts bit-exact, proposal boxes <= 1e-3, per-variable gradient error reported through
+tests/parity_report.py. Reference: faster_rcnn_meta_arch.py:507-609 (predict), :1514-1589 (loss);
+rfcn_meta_arch.py:208-381.
+
+The proposal chain (decode -> sort by score -> greedy NMS -> balanced sampling) is a discontinuous function of the RPN's
+floats: with a freshly initialised RPN the 14 453 objectness scores of an image lie within ~0.5 of each other, so
+two fp32 convolutions that agree to 1e-6 still order a handful of near-tied candidates differently (first GPU run of
+this test: two adjacent proposals swapped on the MobileNet case). The comparison is therefore staged the way the
+claim is staged: (1) the RPN's floats agree to 1e-3 relative; (2) the oracle's chain evaluated ON THE GPU'S RPN
+FLOATS yields bit-identical proposal counts / detector matches and the same boxes — integer work on identical inputs
+is exact at 14 453 anchors; (3) losses and gradients are compared with both sides looking at those boxes. How many of
+the oracle's free-running sampled boxes coincide with the GPU's is reported, not asserted."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    "configs1_frcnn_resnet101_coco": dict(config="frcnn_resnet101_coco_mtl.config", H=600, W=1024, n_inside=14453,
+                                          n_all=29184),
+    "configs0_frcnn_mobilenet_voc": dict(config="frcnn_mobilenet_v1_voc_mtl.config", H=600, W=800, n_inside=None,
+                                         n_all=38 * 50 * 12),
+    "configs2_rfcn_resnet101_voc": dict(config="rfcn_resnet101_voc_mtl.config", H=600, W=1024, n_inside=14453,
+                                        n_all=29184),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_full_size_step_matches_the_oracle(name):
+    import __graft_entry__ as g
+    g.build()
+    import bench
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    from oracle.model import Oracle
+    from tests import parity_report
+    case = CASES[name]
+    cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", case["config"])).read())
+    K = int(cfg.model.faster_rcnn.num_classes)
+    H, W = case["H"], case["W"]
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    model = model_builder.build(cfg.model, True, "cuda", seed=0)
+    tr = trainer.Trainer(model, cfg.train_config, 1)
+    batch = synthetic.make_batch(1, H, W, K, seed=1234, device="cuda")
+    values = model.ps.state_dict()
+    losses = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    model.check_device_flags()
+    got = {k: float(v.item()) for k, v in losses.items()}
+    pd = tr._pd
+    hb = dict(batch)
+    hb["images"] = batch["images"].cpu().numpy()
+    from oracle import frcnn_losses as OL
+    from oracle import nms as ON
+    hp = bench.hyper_params_for_oracle(cfg)
+    gpu_enc = pd["rpn_box_encodings"].cpu().numpy()
+    gpu_obj = pd["rpn_objectness_predictions_with_background"].cpu().numpy()
+    ref, rgrads, aux = Oracle(hp, values).step(hb, seed=model.seed, step=0,
+                                               forced=dict(rpn_box_encodings=gpu_enc, rpn_objectness=gpu_obj))
+    # (1) the RPN's own floats
+    for mine, theirs in ((gpu_enc, aux["rpn_box_encodings"]), (gpu_obj, aux["rpn_objectness"])):
+        assert float(np.abs(mine - theirs).max()) <= 1e-3 * float(np.abs(theirs).max())
+    rpn_err = float(np.abs(gpu_obj - aux["rpn_objectness"]).max() / np.abs(aux["rpn_objectness"]).max())
+    # free-running oracle (its own RPN floats through its own chain): how many sampled boxes coincide
+    gt_abs = [np.asarray(b, np.float32) * np.array([H, W, H, W], np.float32) for b in hb["groundtruth_boxes"]]
+    gt_cls = [np.pad(np.asarray(c, np.float32), [[0, 0], [1, 0]]) for c in hb["groundtruth_classes"]]
+    pb, _, _, pn = ON.rpn_proposals(aux["rpn_box_encodings"], aux["rpn_objectness"], pd["anchors"].cpu().numpy(), (H, W),
+                                    hp["nms_score_threshold"], hp["nms_iou_threshold"], hp["max_proposals"])
+    free_boxes, free_num, _ = OL.sample_box_classifier_batch(pb, pn, gt_abs, gt_cls, hp["second_stage_batch_size"],
+                                                            hp["second_stage_balance_fraction"], model.seed, 0)
+    mine = pd["proposal_boxes"].cpu().numpy()
+    same_rows = int((np.abs(free_boxes - mine).max(-1) <= 1e-3 * max(H, W)).sum())
+    # ---- shapes of the reference's prediction_dict at this size
+    assert pd["_n_all"] == case["n_all"]
+    if case["n_inside"]:
+        assert pd["anchors"].shape[0] == case["n_inside"]
+    # ---- integer work: bit-exact
+    np.testing.assert_array_equal(pd["_rpn_targets"]["match"].cpu().numpy(), aux["rpn_match"])
+    np.testing.assert_array_equal(pd["_rpn_targets"]["sampled"].cpu().numpy(), aux["rpn_sampled"])
+    np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
+    np.testing.assert_array_equal(pd["_det_targets"]["match"].cpu().numpy(), aux["det_match"])
+    # ---- floats: 1e-3 relative
+    feat_err = float(np.abs(pd["rpn_features_to_crop"].cpu().numpy() - aux["features"]).max()
+                     / np.abs(aux["features"]).max())
+    assert feat_err < 1e-3, feat_err
+    box_err = float(np.abs(pd["proposal_boxes"].cpu().numpy() - aux["proposal_boxes"]).max() / max(H, W))
+    assert box_err < 1e-3, box_err
+    assert set(got) == set(ref), (sorted(got), sorted(ref))
+    worst_loss = 0.0
+    for k in ref:
+        err = abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-3)
+        worst_loss = max(worst_loss, err)
+        assert err <= 1e-3, (k, got[k], ref[k])
+    # ---- gradients: every trainable variable, relative L2 against the oracle's autograd
+    grads = model.ps.grads_dict()
+    for n, gval in grads.items():
+        if n not in rgrads:
+            assert not np.any(gval), n
+    l2 = parity_report.gradients("%s FULL SIZE %dx%d batch 1, K=%d (anchors %d, proposals %s)" % (
+        name, W, H, K, pd["anchors"].shape[0], aux["num_proposals"].tolist()), grads, rgrads, got, ref)
+    parity_report.add("    %s: feature map rel err %.2e, RPN objectness rel err %.2e, proposal boxes err %.2e of the image "
+                      "side, worst loss rel err %.2e; rpn_match / rpn_sampled / num_proposals / det_match bit-exact "
+                      "(proposal chain on identical RPN floats); free-running oracle: %d of %d sampled boxes in the "
+                      "same slot" % (name, feat_err, rpn_err, box_err, worst_loss, same_rows, mine.shape[0] * mine.shape[1]))
+    assert len(l2) == len(set(grads) & set(rgrads)) > 50
+    assert np.median(l2) < 1e-3, np.median(l2)
+    assert l2[-1] < 5e-3, l2[-1]
+    del model, tr, batch
+    torch.cuda.empty_cache()

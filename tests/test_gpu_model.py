@@ -125,28 +125,43 @@ def test_step_losses_and_gradients_match_oracle(refine, aux, crop, pk, conv_algo
     assert set(got) == set(ref), (sorted(got), sorted(ref))
     for k in ref:
         assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
-    # Gradients. A ReLU pre-activation (or a max-pool tie) within one fp32 ulp of zero can take the
-    # other branch on the two implementations; such flips are sparse, discrete and unavoidable
-    # between any two fp32 implementations, so the bound per variable is on the relative L2 error,
-    # with a loose cap on the worst element and a tight one on the median over variables.
-    gF, F_ref = pd["_gpF"].cpu().numpy(), aux_o["features"]
-    gF_ref = aux_o["d_features"] * (F_ref > 0)
+    # Gradients, judged against a float64 evaluation of the same graph (same sampled boxes forced): the torch-CPU
+    # fp32 oracle is itself up to ~1e-3 away from it on the trunk variables — a ReLU pre-activation within an ulp of
+    # zero takes the other branch and one flipped element of a 286 720-element map moves a filter gradient by ~1e-3 of
+    # its norm (tools/grad_error_study.py: 14 such flips in the oracle's d_features against fp64, 1 in the HIP path's).
+    # So the claim "gradients within 1e-3" is asserted against the better yardstick, per variable:
+    #   direct implicit GEMM : every variable within 1e-3 relative L2 of float64 (observed worst 1.6e-4)
+    #   Winograd F(4x4,3x3) forced on EVERY 3x3 layer: the transforms' rounding (intermediates ~100x the operands,
+    #     cancelled by the output transform) is dense, ~8e-5 per layer and adds up along the backward chain
+    #     (observed worst 1.8e-3 at this depth; the shipped plan table mixes both and measures 3e-4 at full size,
+    #     tests/test_gpu_fullsize_parity.py) — bounded at 2.5e-3 per variable, 1e-3 in the median.
+    ref64, g64, aux64 = Oracle(hp, values, np.float64).step(_host_batch(batch), seed=model.seed, step=0, forced=aux_o)
+    np.testing.assert_array_equal(aux64["det_match"], aux_o["det_match"])
+    gF, F_ref = pd["_gpF"].cpu().numpy(), aux64["features"]
+    gF_ref = aux64["d_features"] * (F_ref > 0)
     bad = np.abs(gF - gF_ref) > 1e-3 * np.abs(gF_ref).max()
-    assert bad.mean() < 5e-4, bad.sum()                       # sparse, not systematic
+    assert bad.mean() < 5e-5, bad.sum()                       # branch flips: a handful of elements, not a pattern
     grads = model.ps.grads_dict()
-    l2errs = []
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+    cap = 1e-3 if conv_algorithm == 0 else 2.5e-3
+    e_gpu, e_cpu, l2errs = [], [], []
     for name, g in grads.items():
         r = rgrads.get(name)
         if r is None:
             assert np.abs(g).max() == 0, name
             continue
-        scale = max(np.abs(r).max(), 1e-8)
-        assert np.abs(g - r).max() / scale < 1e-2, (name, np.abs(g - r).max() / scale)
-        l2 = np.linalg.norm((g - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-12)
-        assert l2 < 5e-3, (name, l2)
+        e64 = rel(g, g64[name])
+        assert e64 < cap, (name, e64, rel(r, g64[name]))
+        e_gpu.append(e64)
+        e_cpu.append(rel(r, g64[name]))
+        l2 = rel(g, r)
+        assert l2 < 5e-3, (name, l2)                          # fp32 vs fp32: two sets of flips
         l2errs.append(l2)
-    assert len(l2errs) > 50 and np.median(l2errs) < 1e-3, np.median(l2errs)
+    assert len(l2errs) > 50 and np.median(l2errs) < 1e-3 and np.median(e_gpu) < 1e-3, (np.median(l2errs), np.median(e_gpu))
     from tests import parity_report
+    parity_report.add("    vs float64 (ResNet-50 160x224 refine=%s conv=%s): HIP path worst %.2e median %.2e; torch-CPU "
+                      "fp32 oracle worst %.2e median %.2e" % (refine, "winograd" if conv_algorithm == 2 else "direct",
+                                                               max(e_gpu), np.median(e_gpu), max(e_cpu), np.median(e_cpu)))
     parity_report.gradients("Faster R-CNN ResNet-50 160x224 refine=%s aux=%s crop=%d conv=%s" % (
         refine, aux, crop, "winograd" if conv_algorithm == 2 else "direct"), grads, rgrads, got, ref)
     # frozen variables get no gradient slot: conv1 + block1 + every BatchNorm
