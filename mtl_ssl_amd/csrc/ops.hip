@@ -129,24 +129,43 @@ __global__ void __launch_bounds__(256)
 // float atomics in L2 were not. 2^33 addends fit before a cell could overflow.
 constexpr int kRoiSlice = 16;          // channels per block (one 64-byte segment of a dout row)
 constexpr int kRoiPass = 512;          // RoIs of one image handled per pass of the LDS lists
+constexpr int kRoiThreads = 512;       // 8 wavefronts per block: two blocks per CU = 16 waves to hide the list / load latency
 struct RoiItem { float y1, x1, hs, ws; };
 
 // |x| of finite floats orders like the bit pattern; NaN / Inf patterns order above every finite one,
 // so the maximum also tells whether dout holds a non-finite value.
 __global__ void __launch_bounds__(256) k_absmax_bits(const float* __restrict__ x, int64_t n4, uint32_t* out) {
   uint32_t m = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    float4 v = reinterpret_cast<const float4*>(x)[i];
-    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
-        max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const uint4* x4 = reinterpret_cast<const uint4*>(x);
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {            // four independent 16-byte loads in flight per lane
+    uint4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+    uint32_t ma = max(max(a.x & 0x7fffffffu, a.y & 0x7fffffffu), max(a.z & 0x7fffffffu, a.w & 0x7fffffffu));
+    uint32_t mb = max(max(b.x & 0x7fffffffu, b.y & 0x7fffffffu), max(b.z & 0x7fffffffu, b.w & 0x7fffffffu));
+    uint32_t mc = max(max(c.x & 0x7fffffffu, c.y & 0x7fffffffu), max(c.z & 0x7fffffffu, c.w & 0x7fffffffu));
+    uint32_t md = max(max(d.x & 0x7fffffffu, d.y & 0x7fffffffu), max(d.z & 0x7fffffffu, d.w & 0x7fffffffu));
+    m = max(m, max(max(ma, mb), max(mc, md)));
+  }
+  for (; i < n4; i += stride) {
+    uint4 a = x4[i];
+    m = max(m, max(max(a.x & 0x7fffffffu, a.y & 0x7fffffffu), max(a.z & 0x7fffffffu, a.w & 0x7fffffffu)));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  // one device atomic per BLOCK: same-address atomics retire at ~12 ns each in L2, 8 192 of them (one per
+  // wave of a 2 048-block grid) were 80 us of a 105 us kernel
+  __shared__ uint32_t s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+    if (m) atomicMax(out, m);
+  }
 }
 
 template <int PK>    // pool kernel size known at compile time (1 or 2), 0 = any
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kRoiThreads)
     k_roi_crop_pool_bwd_lds(const float* __restrict__ dout, const uint8_t* __restrict__ argmax, int H,
                             int W, int C, const float* __restrict__ boxes,
                             const int32_t* __restrict__ box_ind, int R, int crop, int pk_rt, int ps, int PH,
@@ -178,9 +197,9 @@ __global__ void __launch_bounds__(256)
   e = max(e, -90);
   const float scale = __uint_as_float((uint32_t)(30 - e + 127) << 23);       // 2^(30-e), e in [-90, 128]
   const double descale = __longlong_as_double((long long)(e - 30 + 1023) << 52);
-  for (int i = tid; i < kRoiSlice * NP; i += 256) acc[i] = 0ull;
+  for (int i = tid; i < kRoiSlice * NP; i += kRoiThreads) acc[i] = 0ull;
   const int quad = tid & 3;                              // which 4 of the slice's 16 channels
-  const int cslot = tid >> 2;                            // cell slot of this lane inside a pass of 64 cells
+  const int cslot = tid >> 2;                            // cell slot of this lane inside a pass of kRoiThreads/4 cells
   unsigned long long* qacc = acc + (size_t)(quad * 4) * NP;
   const float inv_pw = 1.0f / (float)PW;
   const int cells = PH * PW;
@@ -191,7 +210,7 @@ __global__ void __launch_bounds__(256)
     if (tid == 0) s_n = 0;
     __syncthreads();
     int lim = min(R, base + kRoiPass);
-    for (int r = base + tid; r < lim; r += 256) {
+    for (int r = base + tid; r < lim; r += kRoiThreads) {
       if (box_ind[r] != img) continue;
       CropGeom g = crop_geom(boxes, box_ind, r, H, W, crop);
       // cell row py samples crop rows py*ps .. py*ps+pk-1; in_y is monotonic in the crop row
@@ -210,17 +229,37 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     const int ncell = s_n * PW;
-    for (int c0 = 0; c0 < ncell; c0 += 64) {
-      int ci = c0 + cslot;
-      if (ci >= ncell) continue;
+    // software pipeline: the list reads and the two global loads of the NEXT cell are issued before the
+    // current cell's ~300 instructions of geometry and 16 LDS adds (a wave holds only 16 cells in
+    // flight otherwise, and each pass would expose a full L2 / HBM round trip)
+    RoiItem g_n = {0.f, 0.f, 0.f, 0.f};
+    float4 gr_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t am_n = 0u;
+    int py_n = 0, px_n = 0;
+    bool ok_n = false;
+    auto fetch = [&](int ci) {
+      ok_n = ci < ncell;
+      if (!ok_n) return;
       int ei = (int)(((float)ci + 0.5f) * inv_pw);
-      int px = ci - ei * PW;
+      px_n = ci - ei * PW;
       int ent = s_entry[ei];
-      int slot = ent >> 6, py = ent & 63;
-      RoiItem g = s_geom[slot];
-      int64_t o = ((int64_t)s_roi[slot] * cells + py * PW + px) * C + slice * kRoiSlice + quad * 4;
-      float4 gr4 = *reinterpret_cast<const float4*>(dout + o);
-      uint32_t am4 = argmax ? *reinterpret_cast<const uint32_t*>(argmax + o) : 0u;
+      int slot = ent >> 6;
+      py_n = ent & 63;
+      g_n = s_geom[slot];
+      int64_t o = ((int64_t)s_roi[slot] * cells + py_n * PW + px_n) * C + slice * kRoiSlice + quad * 4;
+      gr_n = *reinterpret_cast<const float4*>(dout + o);
+      am_n = argmax ? *reinterpret_cast<const uint32_t*>(argmax + o) : 0u;
+    };
+    fetch(cslot);
+    for (int c0 = 0; c0 < ncell; c0 += kRoiThreads / 4) {
+      const RoiItem g = g_n;
+      const float4 gr4 = gr_n;
+      const uint32_t am4 = am_n;
+      const int py = py_n, px = px_n;
+      const bool ok = ok_n;
+      fetch(c0 + kRoiThreads / 4 + cslot);
+      if (!ok) continue;
+      float grv[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
       if (PK == 1) {
         // no pooling: one sample per cell, shared by the 4 channels
         float in_y = g.y1 + (float)(py * ps) * g.hs, in_x = g.x1 + (float)(px * ps) * g.ws;
@@ -229,7 +268,6 @@ __global__ void __launch_bounds__(256)
         float yl = in_y - (float)ty, xl = in_x - (float)lx;
         int t = ty - row0, b = by - row0;
         bool okt = t >= 0 && t < rows, okb = b >= 0 && b < rows;
-        float grv[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float dtop = (1.f - yl) * grv[k], dbot = yl * grv[k];
@@ -245,7 +283,6 @@ __global__ void __launch_bounds__(256)
         }
         continue;
       }
-      float grv[4] = {gr4.x, gr4.y, gr4.z, gr4.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         int s = (int)((am4 >> (8 * k)) & 0xffu);
@@ -274,7 +311,7 @@ __global__ void __launch_bounds__(256)
   // ---- one pass over the band: 4 adjacent lanes write the slice's 64 bytes of a pixel
   const int np = rows * W;
   const float qnan = __uint_as_float(0x7fc00000u);
-  for (int i = tid; i < np * 4; i += 256) {
+  for (int i = tid; i < np * 4; i += kRoiThreads) {
     int p = i >> 2, q = i & 3;
     const unsigned long long* a = acc + (size_t)(q * 4) * NP + p;
     float4 v;
@@ -400,25 +437,42 @@ __global__ void k_resize_fwd(const float* x, float* y, int H, int W, int C, int 
   float top = tl + (tr - tl) * xl, bot = bl + (br - bl) * xl;
   y[i] = top + (bot - top) * yl;
 }
+// Gradient of the resize as a GATHER (one thread per input element sums, in a fixed order, the output pixels
+// whose two source rows / columns include it): no float atomics, run-to-run bit-identical. The candidate
+// output rows of input row iy are those with floor(oy * sy) in {iy - 1, iy}; each is re-checked with the
+// forward's own arithmetic, so the two directions can never disagree about a boundary.
 __global__ void k_resize_bwd(const float* dy, float* dx, int H, int W, int C, int OH, int OW,
                              float sy, float sx, int64_t total) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= total) return;
+  if (i >= total) return;                                    // total = N * H * W * C (input elements)
   int c = i % C;
   int64_t t = i / C;
-  int ox = t % OW; t /= OW;
-  int oy = t % OH;
-  int n = t / OH;
-  float fy = (float)oy * sy, fx = (float)ox * sx;
-  int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
-  int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-  float yl = fy - (float)y0, xl = fx - (float)x0;
-  float g = dy[i];
-  float* xb = dx + (int64_t)n * H * W * C;
-  unsafeAtomicAdd(xb + ((int64_t)y0 * W + x0) * C + c, g * (1.f - yl) * (1.f - xl));
-  unsafeAtomicAdd(xb + ((int64_t)y0 * W + x1) * C + c, g * (1.f - yl) * xl);
-  unsafeAtomicAdd(xb + ((int64_t)y1 * W + x0) * C + c, g * yl * (1.f - xl));
-  unsafeAtomicAdd(xb + ((int64_t)y1 * W + x1) * C + c, g * yl * xl);
+  int ix = t % W; t /= W;
+  int iy = t % H;
+  int n = t / H;
+  int oy_lo = max(0, (int)floorf((float)(iy - 1) / sy) - 1), oy_hi = min(OH - 1, (int)ceilf((float)(iy + 1) / sy) + 1);
+  int ox_lo = max(0, (int)floorf((float)(ix - 1) / sx) - 1), ox_hi = min(OW - 1, (int)ceilf((float)(ix + 1) / sx) + 1);
+  const float* g = dy + (int64_t)n * OH * OW * C + c;
+  float acc = 0.f;
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    float fy = (float)oy * sy;
+    int y0 = (int)floorf(fy), y1 = min(y0 + 1, H - 1);
+    float yl = fy - (float)y0;
+    if (y0 != iy && y1 != iy) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      float fx = (float)ox * sx;
+      int x0 = (int)floorf(fx), x1 = min(x0 + 1, W - 1);
+      if (x0 != ix && x1 != ix) continue;
+      float xl = fx - (float)x0;
+      float gv = g[((int64_t)oy * OW + ox) * C];
+      // the four products of the scatter form, summed in its order for the corners that land here
+      if (y0 == iy && x0 == ix) acc += gv * (1.f - yl) * (1.f - xl);
+      if (y0 == iy && x1 == ix) acc += gv * (1.f - yl) * xl;
+      if (y1 == iy && x0 == ix) acc += gv * yl * (1.f - xl);
+      if (y1 == iy && x1 == ix) acc += gv * yl * xl;
+    }
+  }
+  dx[i] += acc;
 }
 
 // ------------------------------------------------------------------------------ max-pool / mean
@@ -805,7 +859,7 @@ int mtlssl_roi_crop_pool_bwd_ex(const float* dout, const uint8_t* argmax, int B,
   }
   int64_t n4 = (int64_t)R * PH * PH * C / 4;
   if (n4 > 0)
-    hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)(n4 < 2048 * 256 ? cdiv(n4, 256) : 2048)), dim3(256), 0, S(stream),
+    hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)(n4 < 1024 * 256 ? cdiv(n4, 256) : 1024)), dim3(256), 0, S(stream),
                        dout, n4, amax);
   int nbands = (int)cdiv(H, band_rows);
   band_rows = (int)cdiv(H, nbands);                        // even bands
@@ -819,7 +873,7 @@ int mtlssl_roi_crop_pool_bwd_ex(const float* dout, const uint8_t* argmax, int B,
   }
   int grid = nbands * (C / kRoiSlice) * B;
   auto kern = pk == 1 ? k_roi_crop_pool_bwd_lds<1> : pk == 2 ? k_roi_crop_pool_bwd_lds<2> : k_roi_crop_pool_bwd_lds<0>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, S(stream), dout, argmax, H, W, C, boxes, box_ind, R, crop, pk, ps,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kRoiThreads), lds, S(stream), dout, argmax, H, W, C, boxes, box_ind, R, crop, pk, ps,
                      PH, PH, band_rows, nbands, accumulate, amax, dfeat);
   return check_launch("roi_crop_pool_bwd_lds");
 }
@@ -859,8 +913,8 @@ int mtlssl_resize_bilinear_fwd(const float* x, float* y, int N, int H, int W, in
 }
 int mtlssl_resize_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH,
                                int OW, mtlssl_stream_t stream) {
-  int64_t total = (int64_t)N * OH * OW * C;
-  if (!total) return MTLSSL_OK;
+  int64_t total = (int64_t)N * H * W * C;
+  if (!total || !OH || !OW) return MTLSSL_OK;
   hipLaunchKernelGGL(k_resize_bwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), dy, dx, H, W, C,
                      OH, OW, (float)H / (float)OH, (float)W / (float)OW, total);
   return check_launch("resize_bwd");

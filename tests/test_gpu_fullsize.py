@@ -61,18 +61,26 @@ def test_full_size_step_invariants_and_determinism(setup):
         assert all(n.startswith(("SecondStageBoxPredictor/BoxEncodingPredictor", "ClosenessBoxPredictor/"))
                    for n in dead), dead[:5]
         assert l1["second_stage_localization_loss"] == 0.0 and l1["closeness_classification_loss"] == 0.0
-    # same weights, same batch, same step counter -> same integer decisions and (up to the order of
-    # fp32 atomic adds in the ROI-crop / max-pool backward) the same floats
+    # same weights, same batch, same step counter -> same integer decisions
+    losses2 = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    pd2 = tr._pd
+    # (the very first evaluation may time tile candidates for a problem that is not in conv_plans.json and keep the
+    # output of the last candidate — another summation order, 1e-7 away; from the second evaluation on the plan is
+    # fixed, so bit-identity is asserted between evaluations two and three)
+    l1 = {k: float(v.item()) for k, v in losses2.items()}
+    g1 = model.ps.grads.clone()
     losses2 = tr.forward_backward(batch)
     torch.cuda.synchronize()
     pd2 = tr._pd
     np.testing.assert_array_equal(pd2["_rpn_targets"]["sampled"].cpu().numpy(), samp)
     np.testing.assert_array_equal(pd2["_det_targets"]["match"].cpu().numpy(), dm)
     np.testing.assert_array_equal(pd2["proposal_boxes"].cpu().numpy(), pd["proposal_boxes"].cpu().numpy())
+    # ... and, since the RoI-crop backward accumulates in fixed point instead of with fp32 atomics in L2
+    # (mtlssl_roi_crop_pool_bwd_ex), the same floats to the last bit: losses and the whole gradient buffer
     for k, v in losses2.items():
-        assert abs(float(v.item()) - l1[k]) <= 1e-6 * max(abs(l1[k]), 1.0), k
-    rel = float((model.ps.grads - g1).norm() / g1.norm())
-    assert rel < 1e-5, rel
+        assert float(v.item()) == l1[k], k
+    assert torch.equal(model.ps.grads, g1), float((model.ps.grads - g1).norm() / g1.norm())
 
 
 def test_full_size_training_reduces_the_loss_and_keeps_the_fold_consistent(setup):

@@ -39,6 +39,10 @@ CASES = {
 }
 
 
+def oracle_rerun(Oracle, hp, values, hb, seed, boxes, num):
+    return Oracle(hp, values).step(hb, seed=seed, step=0, forced=dict(proposal_boxes=boxes, num_proposals=num))
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_full_size_step_matches_the_oracle(name):
     import __graft_entry__ as g
@@ -68,12 +72,32 @@ def test_full_size_step_matches_the_oracle(name):
     hp = bench.hyper_params_for_oracle(cfg)
     gpu_enc = pd["rpn_box_encodings"].cpu().numpy()
     gpu_obj = pd["rpn_objectness_predictions_with_background"].cpu().numpy()
-    ref, rgrads, aux = Oracle(hp, values).step(hb, seed=model.seed, step=0,
-                                               forced=dict(rpn_box_encodings=gpu_enc, rpn_objectness=gpu_obj))
+    oracle = Oracle(hp, values)
+    ref, rgrads, aux = oracle.step(hb, seed=model.seed, step=0,
+                                   forced=dict(rpn_box_encodings=gpu_enc, rpn_objectness=gpu_obj))
     # (1) the RPN's own floats
     for mine, theirs in ((gpu_enc, aux["rpn_box_encodings"]), (gpu_obj, aux["rpn_objectness"])):
         assert float(np.abs(mine - theirs).max()) <= 1e-3 * float(np.abs(theirs).max())
     rpn_err = float(np.abs(gpu_obj - aux["rpn_objectness"]).max() / np.abs(aux["rpn_objectness"]).max())
+    # (2) the chain on identical RPN floats. One more float stands between them and the sort: the foreground
+    # softmax, whose exp() is the device's in one chain and numpy's in the other. A freshly initialised MobileNet
+    # RPN emits logits of ~1e-3, so thousands of scores sit within a few ulp of 0.5 and a last-bit difference of
+    # exp() reorders two of them (seen: proposals 13 and 14 swapped). When that happens the chains must still
+    # agree as SETS up to a handful of boxes, and the float comparison continues on the device's boxes.
+    chain = "proposal chain on identical RPN floats bit-exact"
+    mine_boxes = pd["proposal_boxes"].cpu().numpy()
+    same = (np.array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
+            and np.array_equal(pd["_det_targets"]["match"].cpu().numpy(), aux["det_match"])
+            and float(np.abs(mine_boxes - aux["proposal_boxes"]).max()) <= 1e-3 * max(H, W))
+    if not same:
+        a = aux["proposal_boxes"].reshape(-1, 4)
+        b = mine_boxes.reshape(-1, 4)
+        hit = (np.abs(a[:, None, :] - b[None, :, :]).max(-1) <= 1e-3 * max(H, W)).any(1)
+        assert hit.mean() >= 0.97, hit.mean()              # the same boxes, a few in another slot / swapped in or out
+        chain = ("proposal chain on identical RPN floats: %d of %d sampled boxes found in the device's set (softmax "
+                 "last-bit near-ties at ~0.5); losses / gradients compared on the device's boxes" % (hit.sum(), len(hit)))
+        ref, rgrads, aux2 = oracle_rerun(Oracle, hp, values, hb, model.seed, mine_boxes, pd["num_proposals"].cpu().numpy())
+        aux = dict(aux, **{k: aux2[k] for k in ("proposal_boxes", "num_proposals", "det_match", "features")})
     # free-running oracle (its own RPN floats through its own chain): how many sampled boxes coincide
     gt_abs = [np.asarray(b, np.float32) * np.array([H, W, H, W], np.float32) for b in hb["groundtruth_boxes"]]
     gt_cls = [np.pad(np.asarray(c, np.float32), [[0, 0], [1, 0]]) for c in hb["groundtruth_classes"]]
@@ -112,9 +136,9 @@ def test_full_size_step_matches_the_oracle(name):
     l2 = parity_report.gradients("%s FULL SIZE %dx%d batch 1, K=%d (anchors %d, proposals %s)" % (
         name, W, H, K, pd["anchors"].shape[0], aux["num_proposals"].tolist()), grads, rgrads, got, ref)
     parity_report.add("    %s: feature map rel err %.2e, RPN objectness rel err %.2e, proposal boxes err %.2e of the image "
-                      "side, worst loss rel err %.2e; rpn_match / rpn_sampled / num_proposals / det_match bit-exact "
-                      "(proposal chain on identical RPN floats); free-running oracle: %d of %d sampled boxes in the "
-                      "same slot" % (name, feat_err, rpn_err, box_err, worst_loss, same_rows, mine.shape[0] * mine.shape[1]))
+                      "side, worst loss rel err %.2e; rpn_match / rpn_sampled bit-exact; %s; free-running oracle: %d of %d "
+                      "sampled boxes in the same slot" % (name, feat_err, rpn_err, box_err, worst_loss, chain, same_rows,
+                                                          mine.shape[0] * mine.shape[1]))
     assert len(l2) == len(set(grads) & set(rgrads)) > 50
     assert np.median(l2) < 1e-3, np.median(l2)
     assert l2[-1] < 5e-3, l2[-1]
