@@ -696,6 +696,64 @@ __global__ void __launch_bounds__(256) k_pad_rows(const float* src, int64_t rows
   const int k = (int)(i - r * Kp);
   dst[i] = k < K ? src[r * K + k] : 0.f;
 }
+// Stride-2 stems with 3 (or up to 4) input channels on the matrix cores — ResNet's 7x7/2 root convolution
+// (slim/nets/resnet_v1.py:216-219; 0.5 ms per step as a VALU kernel), MobileNet's and Inception-ResNet-v2's 3x3/2 first
+// layers. A stride-2 convolution over C channels is a stride-1 convolution over the 2x2 space-to-depth image with 4C
+// channels and a ceil(R/2) x ceil(S/2) filter:
+//   y[oh,ow] = sum_{r,s,c} xp[2oh+r, 2ow+s, c] w[r,s,c]          (xp = x with its zero padding made explicit)
+//            = sum_{r',s'} sum_{dy,dx,c} X'[oh+r', ow+s', (dy,dx,c)] W'[r',s',(dy,dx,c)],   r = 2r'+dy, s = 2s'+dx,
+// X'[y',x',(dy,dx,c)] = xp[2y'+dy, 2x'+dx, c], W' = w re-indexed (taps past R / S and the channels 4C..15 are zero).
+// X' has 16 channels = one 16-deep K-step of the tile engine per tap, so the layer runs as an ordinary VALID stride-1
+// problem (16 taps of 16 channels for the 7x7 root: 256 multiplies per output where 147 are real — on the MFMA pipe
+// that is still 4x faster than the 147 on the VALU). The same fp32 products in another order plus exact zeros.
+static bool s2d_fwd_ok(const mtlssl_conv_desc* d) {
+  return d->stride == 2 && d->dilation == 1 && d->C * 4 <= BK && d->K >= 16 && d->K % 4 == 0 && d->R <= 8 && d->S <= 8;
+}
+static mtlssl_conv_desc s2d_desc(const mtlssl_conv_desc* d) {
+  mtlssl_conv_desc q = *d;
+  q.R = (d->R + 1) / 2; q.S = (d->S + 1) / 2;
+  q.H = d->OH + q.R - 1; q.W = d->OW + q.S - 1;
+  q.C = BK; q.stride = 1; q.dilation = 1; q.pad_t = 0; q.pad_l = 0;
+  return q;
+}
+static int64_t s2d_bytes(const mtlssl_conv_desc* d) {
+  const mtlssl_conv_desc q = s2d_desc(d);
+  return align_up((int64_t)q.N * q.H * q.W * q.C * 4, 256) + align_up((int64_t)q.R * q.S * q.C * q.K * 4, 256);
+}
+// one thread per (pixel of X', 2x2 phase): writes C (<= 4) channels; phase 0 also clears the channels 4C..15
+__global__ void __launch_bounds__(256) k_s2d_pack(const float* __restrict__ x, int N, int H, int W, int C, int pt, int pl,
+                                                   int H2, int W2, float* __restrict__ xs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)N * H2 * W2 * 4) return;
+  const int ph = (int)(i & 3);
+  int64_t t = i >> 2;
+  const int x2 = (int)(t % W2); t /= W2;
+  const int y2 = (int)(t % H2);
+  const int n = (int)(t / H2);
+  const int ih = 2 * y2 + (ph >> 1) - pt, iw = 2 * x2 + (ph & 1) - pl;
+  const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+  const float* src = x + (((int64_t)n * H + ih) * W + iw) * C;
+  float* dst = xs + (((int64_t)n * H2 + y2) * W2 + x2) * BK;
+  for (int c = 0; c < C; ++c) dst[ph * C + c] = ok ? src[c] : 0.f;
+  if (ph == 0)
+    for (int c = 4 * C; c < BK; ++c) dst[c] = 0.f;
+}
+__global__ void __launch_bounds__(256) k_s2d_filter(const float* __restrict__ w, int R, int S, int C, int K, int R2, int S2,
+                                                     float* __restrict__ ws) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R2 * S2 * BK * K) return;
+  const int k = i % K;
+  int t = i / K;
+  const int ch = t % BK; t /= BK;
+  const int s2 = t % S2, r2 = t / S2;
+  float v = 0.f;
+  if (ch < 4 * C) {
+    const int ph = ch / C, c = ch - ph * C;
+    const int r = 2 * r2 + (ph >> 1), sx = 2 * s2 + (ph & 1);
+    if (r < R && sx < S) v = w[((r * S + sx) * C + c) * K + k];
+  }
+  ws[i] = v;
+}
 static size_t stem_lds_bytes(const mtlssl_conv_desc* d) {
   int PH = (STEM_T - 1) * d->stride + (d->R - 1) * d->dilation + 1;
   int PW = (STEM_T - 1) * d->stride + (d->S - 1) * d->dilation + 1;
@@ -910,6 +968,10 @@ static bool choose_wino(const mtlssl_conv_desc* d, int mode, WinoChoice* wc) {
 // so the engine runs four dense problems on a quarter of the rows each (9 taps in total instead of 36);
 // the results go through a compact buffer and are interleaved into dX by a kernel that applies the epilogue.
 struct ParityProblem { int py, px, Hs, Ws, r0, s0, Rs, Ss, a, b; };
+static bool s2d_enabled() {          // MTLSSL_STEM_S2D=0: the VALU stem kernels (A/B switch)
+  static const bool on = [] { const char* e = getenv("MTLSSL_STEM_S2D"); return !(e && e[0] == '0'); }();
+  return on;
+}
 static bool parity_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MTLSSL_DGRAD_PARITY"); v = e ? atoi(e) : 1; }
@@ -1033,6 +1095,10 @@ int64_t mtlssl_conv2d_workspace_bytes(const mtlssl_conv_desc* d, int mode) {
     const mtlssl_conv_desc q = padded_desc(d);
     return padded_dgrad_bytes(d) + mtlssl_conv2d_workspace_bytes(&q, MODE_DGRAD);
   }
+  if (mode == MODE_FWD && !mfma_fwd_ok(d) && s2d_fwd_ok(d)) {
+    const mtlssl_conv_desc q = s2d_desc(d);
+    return s2d_bytes(d) + mtlssl_conv2d_workspace_bytes(&q, MODE_FWD);
+  }
   if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : mfma_dgrad_ok(d))) return 0;
   WinoChoice wc;
   if (choose_wino(d, mode, &wc)) return wino_workspace_bytes(d, wc.variant, mode);
@@ -1133,6 +1199,23 @@ int mtlssl_conv2d_fwd_keep(const mtlssl_conv_desc* d, const float* x, const floa
   } else if (is_pointwise(d)) {
     GemmArgs g{x, w, y, bias, residual, nullptr, p.M, d->K, d->C, epi, 0};
     hipLaunchKernelGGL(k_gemm_small<GM_FWD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, S(stream), g);
+  } else if (workspace && s2d_fwd_ok(d) && s2d_enabled()) {
+    const mtlssl_conv_desc q = s2d_desc(d);
+    float* xs = (float*)workspace;
+    float* wsf = (float*)((char*)workspace + align_up((int64_t)q.N * q.H * q.W * q.C * 4, 256));
+    void* ws_conv = (char*)workspace + s2d_bytes(d);
+    hipLaunchKernelGGL(k_s2d_pack, dim3(cdiv((int64_t)q.N * q.H * q.W * 4, 256)), dim3(256), 0, S(stream), x, d->N, d->H, d->W,
+                       d->C, d->pad_t, d->pad_l, q.H, q.W, xs);
+    hipLaunchKernelGGL(k_s2d_filter, dim3(cdiv((int64_t)q.R * q.S * q.C * q.K, 256)), dim3(256), 0, S(stream), w, d->R, d->S,
+                       d->C, d->K, q.R, q.S, wsf);
+    ConvArgs pq = make_args(&q);
+    pq.a = xs; pq.b = wsf; pq.out = y; pq.bias = bias; pq.residual = residual; pq.epi = epi;
+    pq.a_bytes = (unsigned)((int64_t)q.N * q.H * q.W * q.C * 4);
+    pq.b_bytes = (unsigned)((int64_t)q.R * q.S * q.C * q.K * 4);
+    pq.M = p.M;
+    pq.NG = q.K;
+    Plan pl = plan_dir(&q, MODE_FWD);
+    launch_planned<MODE_FWD>(pl, pq, (float*)ws_conv, S(stream));
   } else if (d->K == 64 && d->C <= 4 && !(epi & ~(MTLSSL_EPI_BIAS | MTLSSL_EPI_RELU)) &&
              stem_lds_bytes(d) <= 160 * 1024) {
     dim3 grid(cdiv(d->OW, STEM_T), cdiv(d->OH, STEM_T), d->N);

@@ -530,6 +530,29 @@ __global__ void k_spatial_mean_fwd(const float* x, float* y, int HW, int C) {
   for (int p = 0; p < HW; ++p) s += x[((int64_t)n * HW + p) * C + c];
   y[(int64_t)n * C + c] = s / (float)HW;
 }
+// C % 4 == 0: one lane owns 4 channels and keeps 7 independent 16-byte loads in flight (the scalar form above had
+// one 4-byte load per lane outstanding: 88 us for a 205 MB tower output = 2.3 TB/s). Sums stay in pixel order.
+__global__ void __launch_bounds__(256) k_spatial_mean_fwd4(const float* __restrict__ x, float* __restrict__ y, int HW, int C4) {
+  int n = blockIdx.y;
+  int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c4 >= C4) return;
+  const float4* xb = reinterpret_cast<const float4*>(x) + (int64_t)n * HW * C4 + c4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p = 0;
+  for (; p + 7 <= HW; p += 7) {
+    float4 v[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) v[u] = xb[(int64_t)(p + u) * C4];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; p < HW; ++p) {
+    float4 v = xb[(int64_t)p * C4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float inv = (float)HW;
+  reinterpret_cast<float4*>(y)[(int64_t)n * C4 + c4] = make_float4(s.x / inv, s.y / inv, s.z / inv, s.w / inv);
+}
 __global__ void k_spatial_mean_bwd(const float* dy, float* dx, int HW, int C, int64_t total) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -942,7 +965,12 @@ int mtlssl_maxpool_bwd(const float* x, const float* y, const float* dy, float* d
 }
 int mtlssl_spatial_mean_fwd(const float* x, float* y, int N, int HW, int C, mtlssl_stream_t stream) {
   if (!N) return MTLSSL_OK;
-  hipLaunchKernelGGL(k_spatial_mean_fwd, dim3(cdiv(C, 256), N), dim3(256), 0, S(stream), x, y, HW, C);
+  if (C % 4 == 0) {
+    int threads = C / 4 >= 256 ? 256 : (int)align_up(C / 4, 64);
+    hipLaunchKernelGGL(k_spatial_mean_fwd4, dim3(cdiv(C / 4, threads), N), dim3(threads), 0, S(stream), x, y, HW, C / 4);
+  } else {
+    hipLaunchKernelGGL(k_spatial_mean_fwd, dim3(cdiv(C, 256), N), dim3(256), 0, S(stream), x, y, HW, C);
+  }
   return check_launch("spatial_mean_fwd");
 }
 int mtlssl_spatial_mean_bwd(const float* dy, float* dx, int N, int HW, int C, mtlssl_stream_t stream) {

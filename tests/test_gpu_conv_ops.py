@@ -35,7 +35,11 @@ CONV_CASES = [
     (64, 7, 7, 1024, 512, 1, 1, 1, "SAME"),      # block4 on ROI crops: 128x128 tile
     (32, 7, 7, 512, 512, 3, 1, 1, "SAME"),       # block4 3x3
     (2, 9, 9, 512, 48, 1, 1, 1, "SAME"),         # RPN box head: direct path (K%64 != 0)
-    (2, 33, 41, 3, 64, 7, 2, 1, "RESNET_SAME"),  # stem 7x7/2: direct path (C = 3)
+    (2, 33, 41, 3, 64, 7, 2, 1, "RESNET_SAME"),  # ResNet stem 7x7/2 (C = 3): space-to-depth onto the MFMA engine, odd map
+    (2, 64, 96, 3, 64, 7, 2, 1, "RESNET_SAME"),  # the same, even map
+    (2, 33, 40, 3, 32, 3, 2, 1, "SAME"),         # MobileNet Conv2d_0 3x3/2 SAME (odd x even)
+    (1, 35, 37, 3, 32, 3, 2, 1, "VALID"),        # Inception-ResNet-v2 Conv2d_1a_3x3 3x3/2 VALID
+    (1, 20, 22, 4, 48, 5, 2, 1, "SAME"),         # 4 input channels fill the 16-deep K-step exactly; 5x5 -> 3x3 taps
     (100, 1, 1, 2048, 91, 1, 1, 1, "VALID"),     # FC head as 1x1 conv (dgrad: zero-padded to K = 96 for the MFMA engine)
     (512, 1, 1, 2048, 364, 1, 1, 1, "VALID"),    # box-encoding head of a 90-class detector (4 x 91), a full second-stage batch
     (2, 38, 64, 512, 24, 1, 1, 1, "SAME"),       # RPN objectness head (2 x 12 anchors): dgrad zero-padded to K = 32
