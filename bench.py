@@ -67,8 +67,8 @@ def pmc_traffic(default_cfg):
     """HBM bytes per launch of the roofline kernel. PMC counters cannot be read from inside the
     process being timed, so this is the committed result of the separate `rocprofv3 --pmc FETCH_SIZE`
     / `--pmc WRITE_SIZE` passes over this same command (tools/pmc_bench.sh -> tools/pmc_summary.py ->
-    profiles/r02_pmc_traffic.json); null when that file is absent or the config is not the default."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    profiles/r03_pmc_traffic.json); null when that file is absent or the config is not the default."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if not default_cfg or not os.path.exists(path):
         return None
     d = json.load(open(path))
@@ -78,13 +78,13 @@ def pmc_traffic(default_cfg):
 def pmc_traffic_provenance(default_cfg):
     """Where `roofline.traffic` comes from and whether the counters were taken from the kernel sources being timed
     (tools/pmc_summary.py stores a digest of the tile engine, conv_mfma.h, with them)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if not default_cfg or not os.path.exists(path):
         return None
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from pmc_summary import kernel_source_sha16
     d = json.load(open(path))
-    return {"file": "profiles/r02_pmc_traffic.json", "counters_from_sources": d.get("kernel_source_sha16"),
+    return {"file": "profiles/r03_pmc_traffic.json", "counters_from_sources": d.get("kernel_source_sha16"),
             "current_sources": kernel_source_sha16(), "matches_current_kernel": d.get("kernel_source_sha16") == kernel_source_sha16()}
 
 
@@ -93,9 +93,9 @@ HBM_PEAK = 8.0e12   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 def pmc_hbm_counters():
     """{kernel name fragment: {"fetch_bytes", "write_bytes"} per launch} from the separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes over tools/hbm_kernels.py (tools/pmc_hbm.sh -> profiles/r02_hbm_kernels_pmc.json);
+    FETCH_SIZE / WRITE_SIZE passes over tools/hbm_kernels.py (tools/pmc_hbm.sh -> profiles/r03_hbm_kernels_pmc.json);
     empty when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_kernels_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r03_hbm_kernels_pmc.json")
     return json.load(open(path))["kernels"] if os.path.exists(path) else {}
 
 
@@ -155,10 +155,15 @@ def hbm_kernels(tr, iters=10):
     _, argmax = ops.roi_crop_pool_fwd(F, boxes, bi, crop, pk, pst)
     if argmax is not None:
         g = torch.ones((R, P, P, C), dtype=torch.float32, device=F.device)
-        dF = torch.zeros_like(F)
-        sec = timed(lambda: ops.roi_crop_pool_bwd(g, argmax, F.shape, boxes, bi, crop, pk, pst, dfeat=dF))
-        add("k_roi_crop_pool_bwd", ["k_roi_crop_pool_bwd"], R * P * P * C * (4 + 1 + 4 * 4 * 2),
-            R * P * P * C * 5 + 2 * fmap, sec, "%d ROIs scattered with fp32 atomics into the %.1f MB gradient map" % (R, fmap / 1e6))
+        dF = torch.empty_like(F)
+        sec = timed(lambda: ops.roi_crop_pool_bwd(g, argmax, F.shape, boxes, bi, crop, pk, pst, dfeat=dF, accumulate=False))
+        # algorithmic: dout + argmax read, four bilinear corners of 64-bit LDS adds (not HBM), map written once;
+        # compulsory: dout read twice (the max|dout| pass that fixes the fixed-point scale, then the scatter),
+        # argmax once, the map written once
+        add("k_roi_crop_pool_bwd_lds (+ k_absmax_bits)", ["k_absmax_bits", "k_roi_crop_pool_bwd_lds"],
+            R * P * P * C * (4 + 4 + 1) + fmap, R * P * P * C * (4 + 4 + 1) + fmap, sec,
+            "%d RoIs scattered into the %.1f MB gradient map held in LDS as 64-bit fixed point (no HBM atomics, "
+            "bit-reproducible; the map is written once, no pre-zero)" % (R, fmap / 1e6))
     H, W = pd["image_shape"][1], pd["image_shape"][2]
     enc, obj, anc = pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"]
     Nv = anc.shape[0]
@@ -188,34 +193,50 @@ def hbm_kernels(tr, iters=10):
     return res
 
 
-def cpu_baseline(cfg, model, tr, H, W, seed, steps=3, batch=1):
+def cpu_baseline(cfg, model, tr, H, W, seed, steps=3, batch=1, threads_max=128):
     """The CPU oracle (torch-CPU fp32 + numpy: oracle/model.py + oracle/optimizer.py) of the identical
     training step — forward + losses + backward + per-variable clip + momentum update — timed on this
-    host's cores. Bounded sample: `steps` steps on `batch` image(s) (the reference's own TF-CPU path cannot
-    run here: no TensorFlow)."""
+    host's cores. Bounded sample: one step per thread count in a sweep over 32 / 64 / 128 threads
+    (SURVEY.md §8d asks for the host's cores; torch-CPU's convolutions stop scaling somewhere past 64 threads, so
+    the best setting is searched, not assumed), then `steps` timed steps at the best one, on `batch` image(s) (the
+    reference's own TF-CPU path cannot run here: no TensorFlow)."""
     import torch
     from mtl_ssl_amd import synthetic
     from oracle import optimizer as oopt
     from oracle.model import Oracle
     host_cores = os.cpu_count() or 1
-    cores = min(host_cores, 64)                # torch-CPU stops scaling well past ~64 threads
-    torch.set_num_threads(cores)
     K = int(cfg.model.faster_rcnn.num_classes)
     hp = hyper_params_for_oracle(cfg)
     b = synthetic.make_batch(batch, H, W, K, seed=seed, device="cpu")
     b["images"] = b["images"].numpy()
     values = model.ps.state_dict()
-    accum = {}
     wd = {s.name: s.weight_decay for s in model.ps.trainable_specs if s.weight_decay}
-    t0 = time.time()
-    for step in range(steps):
-        losses, grads, _ = Oracle(hp, values).step(b, seed=model.seed, step=step)
-        oopt.momentum_update(values, grads, accum, tr.lr_fn(step), tr.momentum, tr.clip, wd)
-    dt = (time.time() - t0) / steps
+
+    def run(n_steps, accum):
+        t0 = time.time()
+        for step in range(n_steps):
+            losses, grads, _ = Oracle(hp, values).step(b, seed=model.seed, step=step)
+            oopt.momentum_update(values, grads, accum, tr.lr_fn(step), tr.momentum, tr.clip, wd)
+        return (time.time() - t0) / n_steps, losses
+
+    # all of the host's cores is NOT the fastest setting: on the 256-core GPU box one step took 12.9 s with 64 threads,
+    # 20.3 s with 128 and 370 s with 256 (profiles/r03_bench_default_cpu_sweep_256.json) — oversubscribed torch-CPU
+    # convolutions. The default sweep therefore stops at 128; `--cpu-threads-max 0` sweeps up to every core.
+    cap = host_cores if threads_max == 0 else min(host_cores, threads_max)
+    sweep = {}
+    for n in sorted({min(32, cap), min(64, cap), min(128, cap), cap if threads_max == 0 else min(128, cap)}):
+        torch.set_num_threads(n)
+        sweep[n] = run(1, {})[0]
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    values = model.ps.state_dict()                       # the sweep's updates are not part of the sample
+    dt, losses = run(steps, {})
     return {"value": batch / dt, "unit": "images/sec", "cores": cores, "host_cores": host_cores, "kind": "port",
-            "sample": "CPU oracle (torch-CPU fp32 + numpy): %d full training steps (fwd + losses + bwd + clip + "
-                      "momentum update) on %d synthetic %dx%d image(s), %.1f s/step on %d torch threads (host has %d "
-                      "cores)" % (steps, batch, W, H, dt, cores, host_cores),
+            "thread_sweep_s_per_step": {str(k): round(v, 2) for k, v in sweep.items()},
+            "sample": "CPU oracle (torch-CPU fp32 + numpy; this build's restatement of the step, not TensorFlow): %d full "
+                      "training steps (fwd + losses + bwd + clip + momentum update) on %d synthetic %dx%d image(s), "
+                      "%.1f s/step on %d torch threads — the fastest of a one-step sweep over %s threads (host has %d "
+                      "cores)" % (steps, batch, W, H, dt, cores, "/".join(str(k) for k in sorted(sweep)), host_cores),
             "total_loss_last_step": float(sum(losses.values()))}
 
 
@@ -262,6 +283,11 @@ def main():
     ap.add_argument("--steps", type=int, default=50)      # >= 50 timed steps after >= 10 warm-up
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-threads-max", type=int, default=128,
+                    help="largest thread count of the CPU baseline's sweep (0 = up to every host core)")
+    ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches cycled through the steps")
+    ap.add_argument("--class-steps", type=int, default=4,
+                    help="after the timed region, time every conv call of this many steps for the per-class rows (0 = skip)")
     ap.add_argument("--cpu-config0-steps", type=int, default=10, help="timed CPU steps of configs[0] (0 = skip)")
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "frcnn_resnet101_coco_mtl.config"))
     ap.add_argument("--height", type=int, default=600)
@@ -308,11 +334,21 @@ def main():
     model = model_builder.build(cfg.model, True, dev, seed=0)
     tr = trainer.Trainer(model, cfg.train_config, world, comm=comm, reduce_always=comm is not None)
     tr.broadcast_weights(0)                                  # C2: identical weights on every replica
-    batch = tr.stage_batch(synthetic.make_batch(B, a.height, a.width, K, seed=1234 + rank, device=dev))
+    # SURVEY.md §8d "synthetic batches", plural: a ring of different batches (seeds 1234 + rank + 1000*i), staged in
+    # HBM before the timed region and cycled — one fixed batch would be memorised within the warm-up, and the
+    # data-dependent kernels (proposal chain, sampling) would then run on a degenerate proposal set
+    ring = [tr.stage_batch(synthetic.make_batch(B, a.height, a.width, K, seed=1234 + rank + 1000 * i, device=dev))
+            for i in range(max(a.batches, 1))]
+    batch = ring[0]
+    counter = [0]
+
+    def next_batch():
+        counter[0] += 1
+        return ring[counter[0] % len(ring)]
 
     hbm_first = None
     for i in range(a.warmup):
-        tr.step(batch)
+        tr.step(next_batch())
         if i == 0 and world == 1 and not a.no_roofline:
             # the proposal chain and the ROI scatter are data dependent (how many candidates a suppression round
             # needs, how many atomics collide): time them once on the freshly initialised detector too — the entry
@@ -329,10 +365,11 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    ops.ACCOUNT = ops.FlopAccount()              # executed MACs per launch class, from the library's plan registry
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        losses = tr.step(batch)
+        losses = tr.step(next_batch())
     dt_host = time.perf_counter() - t0           # the launch thread is done; the GPU is still working through its queue:
     # the difference to dt_local is how far ahead the host ran (it is bounded by the HIP queue depth, so over many
     # steps the host's own time converges to the GPU's; tools/phase_times.py has the un-throttled figure, 26 ms/step)
@@ -343,6 +380,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILER = ops.PROFILER, None
+    account, ops.ACCOUNT = ops.ACCOUNT, None
     dp = None
     if comm is not None:
         # what a reader needs to trust an N-GPU line: the ranks RCCL itself reports, how much of the all-reduce
@@ -399,14 +437,26 @@ def main():
     }
     if dp is not None:
         out["data_parallel"] = dp
-    if default_cfg:
-        # FLOPs of the DIRECT convolution algorithm per step over the step time. The 3x3 stride-1 layers
-        # run as Winograd F(4x4,3x3) (3.06x-4x fewer multiplies than counted here), so this is an
-        # effective rate for comparing step times, not an MFMA utilisation; `roofline` below is the
-        # executed-FLOP figure of one kernel.
-        out["whole_step"] = {"direct_algorithm_tflops": FLOP_PER_IMAGE * value / world / 1e12,
-                             "over_fp32_mfma_peak": FLOP_PER_IMAGE * value / world / FP32_MFMA_PEAK,
-                             "note": "direct-algorithm FLOPs / step time (effective; Winograd layers execute fewer)"}
+    step_s = dt / a.steps
+    # Executed FLOPs: what the launches of one step multiply on the matrix cores, summed from the plan registry
+    # (mtlssl_conv2d_executed_macs) — direct layers 2*M*N*K of the implicit GEMM, Winograd layers the transformed-domain
+    # GEMM stack, the refiner's de-duplicated RoI count as launched. `executed_over_fp32_mfma_peak` is the whole-step
+    # roofline fraction north_star asks for (< 1 by construction); `direct_algorithm_tflops` is the same step priced as
+    # direct convolutions (an effective rate for comparing step times across algorithms, it may exceed the peak).
+    ex_mfma = sum(r[1] for r in account.rows.values()) * 2.0 / a.steps
+    ex_valu = sum(r[2] for r in account.rows.values()) * 2.0 / a.steps
+    direct = sum(r[3] for r in account.rows.values()) * 2.0 / a.steps
+    out["whole_step"] = {
+        "executed_tflops": ex_mfma / step_s / 1e12,
+        "executed_over_fp32_mfma_peak": ex_mfma / step_s / FP32_MFMA_PEAK,
+        "executed_mfma_tflop_per_step": ex_mfma / 1e12, "executed_valu_tflop_per_step": ex_valu / 1e12,
+        "direct_algorithm_tflop_per_step": direct / 1e12, "direct_algorithm_tflops": direct / step_s / 1e12,
+        "by_class_tflop_per_step": {k: round(2.0 * r[1] / a.steps / 1e12, 4) for k, r in sorted(account.rows.items())},
+        "conv_calls_per_step": sum(r[0] for r in account.rows.values()) / a.steps,
+        "note": "executed = MACs the launch plans run on the matrix cores (Winograd: transformed-domain GEMM stacks; "
+                "zero-padded widths included; tile-padding rows not), per rank; direct_algorithm = the same layers priced "
+                "as direct convolutions (SURVEY.md §8d counts 4.93 TFLOP/image that way)",
+    }
     if prof is not None:
         s = prof.summary()
         dom = s.get(("fwd", 0))
@@ -441,11 +491,11 @@ def main():
         try:
             ops.set_fp32_engine(1)
             for _ in range(3):
-                tr.step(batch)
+                tr.step(next_batch())
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(a.split_engine_steps):
-                tr.step(batch)
+                tr.step(next_batch())
             torch.cuda.synchronize()
             ms = 1e3 * (time.perf_counter() - t1) / a.split_engine_steps
             out["split_engine"] = {"ms_per_step": ms, "images_per_sec": 1e3 * B / ms, "steps": a.split_engine_steps,
@@ -455,19 +505,53 @@ def main():
             out["split_engine"] = {"error": repr(e)}
         finally:
             ops.set_fp32_engine(0)
+    if world == 1 and comm is None and a.class_steps > 0:
+        # where the step's milliseconds go: every conv-family call of a few more steps bracketed by HIP events on the
+        # stream it is issued to, grouped by launch class and by main / side stream (the step time IS the main stream's
+        # busy time: side-stream work rides under it). ~2 % slower than the timed region because of the events.
+        try:
+            ops.PROFILER = ops.ConvProfiler(None)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.class_steps):
+                tr.step(next_batch())
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t1) / a.class_steps
+            rows = ops.PROFILER.class_summary(torch.cuda.current_stream().cuda_stream)
+            ops.PROFILER = None
+            conv_main = 0.0
+            for r in rows.values():
+                for k in ("main_ms", "side_ms", "calls", "executed_tflop"):
+                    r[k] = r[k] / a.class_steps
+                conv_main += r["main_ms"]
+                r["main_ms"], r["side_ms"] = round(r["main_ms"], 3), round(r["side_ms"], 3)
+                r["executed_tflop"] = round(r["executed_tflop"], 4)
+                r["tflops_on_main"] = None if r["tflops_on_main"] is None else round(r["tflops_on_main"], 1)
+            out["step_breakdown"] = {
+                "ms_per_step_with_events": ms, "conv_calls_main_stream_ms": round(conv_main, 3),
+                "non_conv_main_stream_ms": round(ms - conv_main, 3), "by_class": rows,
+                "note": "per step; main_ms / side_ms = wall time of the calls issued to the step's main stream / to the "
+                        "auxiliary and filter-gradient streams (a Winograd call = its transforms + its GEMM stack); "
+                        "non_conv_main_stream_ms = step time minus the main stream's conv calls (RoI crop, proposal "
+                        "chain, losses, optimizer, waits on side streams); kernel-level rows: profiles/r03_kernel_stats_bench.md",
+            }
+        except Exception as e:
+            ops.PROFILER = None
+            out["step_breakdown"] = {"error": repr(e)}
     # the secondary blocks below never take the headline line down: a failure is reported in place of the block
     if world == 1 and not a.no_roofline:
         try:
             out["hbm_kernels"] = hbm_kernels(tr)
             for r in out["hbm_kernels"]:
-                r["state"] = "after the warm-up and timed steps on one fixed batch"
+                r["state"] = "after the warm-up and timed steps on a ring of %d batches" % len(ring)
                 if hbm_first and r["kernel"] in hbm_first:
                     r["avg_us_random_init"] = hbm_first[r["kernel"]]
         except Exception as e:
             out["hbm_kernels"] = {"error": repr(e)}
     if world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(cfg, model, tr, a.height, a.width, seed=1234, steps=a.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(cfg, model, tr, a.height, a.width, seed=1234, steps=a.cpu_steps,
+                                               threads_max=a.cpu_threads_max)
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
         if default_cfg and a.cpu_config0_steps > 0:

@@ -142,6 +142,12 @@ int mtlssl_conv2d_set_fp32_engine(int mode);
  * splits off a K-split tail launch) — lets a profiler relate per-call timings to
  * per-dispatch kernel traces. */
 int mtlssl_conv2d_num_dispatches(const mtlssl_conv_desc* d, int mode);
+/* Multiply-accumulates the launch plan of (d, mode) executes on the matrix cores (on_mfma = 1) or in a VALU fallback
+ * kernel (on_mfma = 0): direct problems count M*N*K of the implicit GEMM, Winograd variants the transformed-domain
+ * GEMM stack, padded / space-to-depth forms their zero-padded width, the input-parity stride-2 dgrad a quarter of the
+ * taps. What `whole_step.executed_tflops` of bench.py is summed from (the reference has no counterpart: TensorFlow
+ * 1.7 reports no FLOP counts for its cuDNN / Eigen convolutions). */
+int64_t mtlssl_conv2d_executed_macs(const mtlssl_conv_desc* d, int mode, int on_mfma);
 int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* dy,
                         const float* out_scale, float* dw, float* dbias, float beta,
                         void* workspace, mtlssl_stream_t stream);

@@ -1294,6 +1294,40 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
   return plan_dir(d, mode).cfg;
 }
 
+// Multiply-accumulates the launch plan of (d, mode) executes, on the matrix cores (on_mfma = 1) or in a VALU
+// fallback kernel (on_mfma = 0): the branch ladder of mtlssl_conv2d_fwd / _dgrad / _wgrad (a workspace is assumed),
+// with the reduction widths the kernels really run — transformed-domain GEMM stacks for the Winograd variants
+// (36 or 121 products per tile, clipped tiles included), zero-padded channels / taps of the padded and
+// space-to-depth forms, a quarter of the taps for the input-parity stride-2 dgrad. Rows that only pad the last
+// MFMA tile are not counted. bench.py sums these over a step for `whole_step.executed_tflops`.
+int64_t mtlssl_conv2d_executed_macs(const mtlssl_conv_desc* d, int mode, int on_mfma) {
+  if (!d || mode < MODE_FWD || mode > MODE_WGRAD || check_desc(d)) return 0;
+  const int64_t P_out = (int64_t)d->N * d->OH * d->OW, P_in = (int64_t)d->N * d->H * d->W;
+  const int64_t taps = (int64_t)d->R * d->S;
+  const int64_t direct = (mode == MODE_DGRAD && d->stride == 1 ? P_in : P_out) * taps * d->C * d->K;
+  int64_t mfma = 0, valu = 0;
+  WinoChoice wc;
+  if (choose_wino(d, mode, &wc)) {
+    mfma = wino_input_bytes(d, wc.variant) / 4 * d->K;        // planes * tiles * C * K
+  } else if (mode == MODE_FWD) {
+    if (mfma_fwd_ok(d)) mfma = direct;
+    else if (padded_fwd_ok(d)) mfma = P_out * align_up(d->C, BK) * d->K;
+    else if (is_pointwise(d)) valu = direct;
+    else if (s2d_fwd_ok(d) && s2d_enabled()) mfma = P_out * ((d->R + 1) / 2) * ((d->S + 1) / 2) * BK * d->K;
+    else valu = direct;
+  } else if (mode == MODE_DGRAD) {
+    const int64_t gathered = P_in * taps * d->C * d->K;        // every tap visited for every input pixel
+    if (parity_ok(d)) mfma = gathered / ((int64_t)d->stride * d->stride);
+    else if (mfma_dgrad_ok(d)) mfma = gathered;
+    else if (padded_dgrad_ok(d)) mfma = P_in * d->C * align_up(d->K, BK);
+    else valu = direct;
+  } else {
+    if (mfma_wgrad_ok(d)) mfma = direct;
+    else valu = direct;
+  }
+  return on_mfma ? mfma : valu;
+}
+
 int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg) {
   MTLSSL_REQUIRE(d != nullptr && mode >= MODE_FWD && mode <= MODE_WGRAD, "force_config: bad arguments");
   MTLSSL_REQUIRE(cfg < WINO_CFG0 + 4 * WINO_VARIANTS && (cfg < 0 || cfg % 4 < NCFG),

@@ -89,6 +89,7 @@ class ConvProfiler:
         """only: optional (mode, tile config) — time just that kernel (two events per launch cost
         ~1 us of stream time each; timing every conv of the step costs ~2 % of the step)."""
         self.pending = []          # (key, flops, start_event, end_event)
+        self.calls = []            # (launch class, stream handle, executed MFMA flops, start_event, end_event)
         self.only = only
 
     def begin(self, d=None, mode=None):
@@ -106,6 +107,8 @@ class ConvProfiler:
         flops = 2.0 * d.N * d.OH * d.OW * d.K * d.C * d.R * d.S
         self.pending.append(((self.MODES[mode], cfg), flops, start, e,
                              lib().conv2d_num_dispatches(ctypes.byref(d), mode)))
+        mf = int(lib().conv2d_executed_macs(ctypes.byref(d), mode, 1))
+        self.calls.append((conv_class(cfg, mf), torch.cuda.current_stream().cuda_stream, 2.0 * mf, start, e))
 
     def summary(self):
         """{(mode, cfg): dict(launches, dispatches, seconds, flops)} — call after
@@ -120,8 +123,67 @@ class ConvProfiler:
         return out
 
 
+    def class_summary(self, main_stream):
+        """{class: {"main_ms", "side_ms", "calls", "executed_tflop", "tflops_on_main"}} — per-call wall time on the
+        stream the call was issued to (a Winograd call = its transforms + its GEMM stack), split by whether that
+        stream is the step's main stream. Call after torch.cuda.synchronize()."""
+        out = {}
+        for cls, st, fl, s, e in self.calls:
+            r = out.setdefault(cls, {"main_ms": 0.0, "side_ms": 0.0, "calls": 0, "executed_tflop": 0.0, "_fm": 0.0})
+            ms = s.elapsed_time(e)
+            r["main_ms" if st == main_stream else "side_ms"] += ms
+            r["calls"] += 1
+            r["executed_tflop"] += fl / 1e12
+            if st == main_stream:
+                r["_fm"] += fl
+        for r in out.values():
+            fm = r.pop("_fm")
+            r["tflops_on_main"] = (fm / (r["main_ms"] * 1e-3) / 1e12) if r["main_ms"] > 0 else None
+        return out
+
+
 PROFILER = None
 PHASE_HOOK = None      # tools/phase_times.py: callable(name) invoked at the step's phase boundaries
+
+
+def conv_class(cfg, mfma_macs):
+    """Launch class of a conv-family call from its plan code (mtlssl_conv2d_tile_config)."""
+    if cfg < 0:
+        return "mfma_padded_or_space_to_depth" if mfma_macs else "valu_fallback"
+    if cfg >= 8:
+        return "winograd_M7"
+    if cfg >= 4:
+        return "winograd_F43"
+    return "direct_128x128_256x128" if cfg in (0, 3) else "direct_small_tiles"
+
+
+class FlopAccount:
+    """Executed multiply-accumulates of the conv family per launch class, summed from the library's own plan
+    registry (mtlssl_conv2d_executed_macs: direct = M*N*K of the implicit GEMM, Winograd = the transformed-domain
+    GEMM stack, ...). Pure host arithmetic, memoised per problem: cheap enough to leave on during a timed region.
+    bench.py divides the sums by the step time for `whole_step.executed_tflops`."""
+
+    def __init__(self):
+        self.rows = {}            # class -> [calls, mfma_macs, valu_macs, direct_algorithm_macs]
+        self._memo = {}
+
+    def add(self, d, mode, times=1):
+        key = (d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.OH, d.OW, d.stride, d.dilation, d.pad_t, d.pad_l, mode)
+        rec = self._memo.get(key)
+        if rec is None:
+            mf = int(lib().conv2d_executed_macs(ctypes.byref(d), mode, 1))
+            va = int(lib().conv2d_executed_macs(ctypes.byref(d), mode, 0))
+            cfg = lib().conv2d_tile_config(ctypes.byref(d), mode)
+            direct = d.N * d.OH * d.OW * d.K * d.C * d.R * d.S
+            rec = self._memo[key] = (conv_class(cfg, mf), mf, va, direct)
+        r = self.rows.setdefault(rec[0], [0, 0, 0, 0])
+        r[0] += times
+        r[1] += rec[1] * times
+        r[2] += rec[2] * times
+        r[3] += rec[3] * times
+
+
+ACCOUNT = None         # a FlopAccount while bench.py counts executed FLOPs
 
 
 def mark(name):
@@ -322,6 +384,8 @@ def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None, xf_cache
                              ptr(ws_), _stream())
         _autotune(d, 0, run)
     t0 = PROFILER.begin(d, 0) if PROFILER is not None else None
+    if ACCOUNT is not None:
+        ACCOUNT.add(d, 0)
     nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 0)
     ws = workspace(nb, "splitk", x.device) if nb else None
     U, variant = xf_cache.get(d, 0, w) if (xf_cache is not None and d.R == 3 and d.S == 3) else (None, -1)
@@ -349,6 +413,8 @@ def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None, x
                                epilogue & ~EPI_ACCUM, ptr(ws_), _stream())
         _autotune(d, 1, run)
     t0 = PROFILER.begin(d, 1) if PROFILER is not None else None
+    if ACCOUNT is not None:
+        ACCOUNT.add(d, 1)
     nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 1)
     ws = workspace(nb, "splitk", dy.device) if nb else None
     U, variant = xf_cache.get(d, 1, w) if (xf_cache is not None and d.R == 3 and d.S == 3) else (None, -1)
@@ -372,6 +438,8 @@ def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0, input_xf=No
     nbytes = lib().conv2d_wgrad_workspace_bytes(ctypes.byref(d))
     ws = workspace(nbytes, "wgrad", x.device)
     t0 = PROFILER.begin(d, 2) if PROFILER is not None else None
+    if ACCOUNT is not None:
+        ACCOUNT.add(d, 2)
     V, vvar = input_xf if input_xf is not None else (None, -1)
     if V is not None:
         V.record_stream(torch.cuda.current_stream())     # made on the forward's stream, read on this one
@@ -405,6 +473,8 @@ def conv2d_wgrad_grouped(d, xs, dys, dws, scales=None, beta=0.0):
     dev = xs[0].device
     for t in list(xs) + list(dys) + list(dws):
         _chk(t)
+    if ACCOUNT is not None:
+        ACCOUNT.add(d, 2, n)
     nb = lib().conv2d_wgrad_grouped_workspace_bytes(ctypes.byref(d), n)
     ws = workspace(nb, "wgrad_grouped", dev)
     lib().conv2d_wgrad_grouped(ctypes.byref(d), n, ptr(_ptr_table(xs, dev)), ptr(_ptr_table(dys, dev)),
