@@ -167,3 +167,17 @@ def load(path, ps, trainer=None):
         if trainer is not None and trainer.ema is not None and s.name + "/ExponentialMovingAverage" in ck.files:
             ps._view(trainer.ema, s).copy_(torch.as_tensor(ck[s.name + "/ExponentialMovingAverage"]).to(ps.device))
     return int(ck["global_step"]) if "global_step" in ck.files else 0
+
+
+def load_moving_averages(path, ps):
+    """Overwrite every variable that has a `<name>/ExponentialMovingAverage` entry in the state file with it —
+    what evaluator.py:330-333 does with `variable_averages.variables_to_restore()` when
+    eval_config.use_moving_averages is set. Returns the number of variables replaced."""
+    ck = np.load(path)
+    n = 0
+    for s in ps.specs:
+        key = s.name + "/ExponentialMovingAverage"
+        if key in ck.files:
+            ps.value(s.name).copy_(torch.as_tensor(ck[key]).to(ps.device))
+            n += 1
+    return n

@@ -47,6 +47,13 @@ def main(argv=None):
     model = model_builder.build(cfg.model, False, dev, seed=0)
     state = os.path.join(f.checkpoint_dir, "model.ckpt.npz")
     step = checkpoint.load(state, model.ps)
+    if bool(ec.get("use_moving_averages", False)):
+        # evaluator.py:330-333: restore variable_averages.variables_to_restore(), i.e. every variable from its
+        # `<name>/ExponentialMovingAverage` shadow when the training run kept one
+        n_ema = checkpoint.load_moving_averages(state, model.ps)
+        if n_ema == 0:
+            raise ValueError("eval_config.use_moving_averages is set but %s holds no ExponentialMovingAverage values "
+                             "(train with optimizer.use_moving_average: true)" % state)
     model.prepare()
     coco = "coco" in str(ec.get("metrics_set", "pascal_voc_metrics"))
     limit = int(ec.get("num_examples", 5000))
@@ -60,12 +67,19 @@ def main(argv=None):
         if cfg.model.get("mtl") is not None and cfg.model.mtl.get("refine", False):
             pd = model.predict_with_mtl_results(pd)
         d = {k: v.cpu().numpy() for k, v in model.postprocess(pd).items()}
+        model.check_device_flags()             # e.g. the refiner's window de-duplication ran out of slots (NaN boxes)
         n = int(d["num_detections"][0])
         H, W = b["images"].shape[1:3]
         # evaluator.py:137-150 hands the COCO evaluator absolute boxes, the PASCAL one either (IoU is scale-free)
         scale = np.asarray([H, W, H, W], np.float64) if coco else 1.0
-        ev.add_single_ground_truth_image_info(n_img, np.asarray(b["groundtruth_boxes"][0], np.float64).reshape(-1, 4) * scale,
-                                              np.asarray(b["groundtruth_classes"][0]).argmax(1))
+        gt_boxes = np.asarray(b["groundtruth_boxes"][0], np.float64).reshape(-1, 4) * scale
+        gt_cls = np.asarray(b["groundtruth_classes"][0]).argmax(1)
+        if coco:
+            ev.add_single_ground_truth_image_info(n_img, gt_boxes, gt_cls)
+        else:     # evaluator.py:196-201 -> eval_util.py:332-334: PASCAL's difficult boxes are ignored, not missed
+            diff = b.get("groundtruth_difficult")
+            ev.add_single_ground_truth_image_info(n_img, gt_boxes, gt_cls,
+                                                  is_difficult=None if diff is None else np.asarray(diff[0], bool))
         ev.add_single_detected_image_info(n_img, np.asarray(d["detection_boxes"][0][:n], np.float64) * scale,
                                           d["detection_scores"][0][:n], d["detection_classes"][0][:n])
         n_img += 1

@@ -267,33 +267,45 @@ def examples(paths, num_classes, augmentation_options=(), rng=None, loop=False, 
     """Decoded + augmented examples of a list of TFRecord files (builders/input_reader_builder.py:34-65:
     parallel_reader with a shuffling RandomShuffleQueue, then core/preprocessor.preprocess). Data-parallel
     ranks read disjoint records (record i of the stream goes to rank i % world — the reference's clones each
-    dequeue their own images from one shuffled queue, trainer.py:269-279); `shuffle_buffer` > 0 draws from a
-    buffer of that many pending examples like the reference's min_after_dequeue queue."""
+    dequeue their own images from one shuffled queue, trainer.py:269-279). `shuffle_buffer` > 0 draws from a
+    buffer of that many pending SERIALIZED records, like the reference's RandomShuffleQueue of strings with
+    `min_after_dequeue` elements (protos/input_reader.proto: queue_capacity 2000, min_after_dequeue 1000): a record
+    is a few hundred KB of JPEG, a decoded and augmented example ~5 MB of float32 — decoding happens after the
+    draw, one example at a time, so the buffer costs megabytes and the first step does not wait for a thousand
+    JPEG decodes."""
     from . import preprocessor
     rng = rng if rng is not None else np.random.RandomState(0)
-    buf, i = [], 0
-    while True:
-        for p in paths:
-            for rec in read_tfrecord(p):
-                mine = (i % world) == rank
-                i += 1
-                if not mine:
-                    continue
-                ex = preprocessor.preprocess(decode_example(rec, num_classes), augmentation_options, rng)
-                if shuffle_buffer <= 0:
-                    yield ex
-                    continue
-                buf.append(ex)
-                if len(buf) > shuffle_buffer:
-                    j = int(rng.randint(len(buf)))
-                    buf[j], buf[-1] = buf[-1], buf[j]
-                    yield buf.pop()
-        if not loop:
-            break
-    while buf:
-        j = int(rng.randint(len(buf)))
-        buf[j], buf[-1] = buf[-1], buf[j]
-        yield buf.pop()
+
+    def records():
+        i = 0
+        while True:
+            for p in paths:
+                for rec in read_tfrecord(p):
+                    mine = (i % world) == rank
+                    i += 1
+                    if mine:
+                        yield rec
+            if not loop:
+                return
+
+    def shuffled():
+        if shuffle_buffer <= 0:
+            yield from records()
+            return
+        buf = []
+        for rec in records():
+            buf.append(rec)
+            if len(buf) > shuffle_buffer:
+                j = int(rng.randint(len(buf)))
+                buf[j], buf[-1] = buf[-1], buf[j]
+                yield buf.pop()
+        while buf:
+            j = int(rng.randint(len(buf)))
+            buf[j], buf[-1] = buf[-1], buf[j]
+            yield buf.pop()
+
+    for rec in shuffled():
+        yield preprocessor.preprocess(decode_example(rec, num_classes), augmentation_options, rng)
 
 
 def batches(paths, num_classes, batch_size, augmentation_options=(), rng=None, loop=False, rank=0, world=1,
@@ -305,7 +317,9 @@ def batches(paths, num_classes, batch_size, augmentation_options=(), rng=None, l
     the device would (preprocessor.resize_bilinear_legacy) and bucketed by its resized shape; a bucket is
     emitted when it holds `batch_size` images. Nothing is padded, so every image is computed exactly as the
     reference computes it. More than `max_pending` waiting images flush the fullest bucket as a smaller
-    batch; what is left at the end of a non-looping stream is emitted too unless `drop_remainder`."""
+    batch; what is left at the end of a non-looping stream is emitted too unless `drop_remainder`. Under data
+    parallelism such a short batch weighs its images 1/len instead of 1/batch_size on that rank for that step (every
+    loss is a batch mean) — a slightly re-weighted but valid step; raise `max_pending` to make it rarer."""
     from . import preprocessor
     buckets, pending = {}, 0
     for ex in examples(paths, num_classes, augmentation_options, rng, loop, rank, world, shuffle_buffer):
@@ -337,4 +351,10 @@ def collate(examples):
               "groundtruth_edgemask"):
         if all(k in e for e in examples):
             out[k] = [np.asarray(e[k], np.float32) for e in examples]
+    # evaluation-only fields (evaluator.py:196-201, eval_util.py:332-334: difficult boxes are neither hits nor misses)
+    if all("groundtruth_difficult" in e for e in examples):
+        out["groundtruth_difficult"] = [np.asarray(e["groundtruth_difficult"], bool) for e in examples]
+    for k in ("filename", "source_id"):
+        if all(k in e for e in examples):
+            out[k] = [e[k] for e in examples]
     return out

@@ -100,9 +100,12 @@ def main(argv=None):
     rz = model_config.faster_rcnn.image_resizer
     stream = input_reader.batches(record_paths(input_config), K, B, train_config.data_augmentation_options,
                                   np.random.RandomState(f.seed + rank), loop=True, rank=rank, world=world,
-                                  shuffle_buffer=int(input_config.get("shuffle_buffer_size", 2048) or 0)
+                                  # protos/input_reader.proto: shuffle (default true) draws from a queue that holds
+                                  # at least min_after_dequeue (default 1000) serialized records
+                                  shuffle_buffer=int(input_config.get("min_after_dequeue", 1000) or 0)
                                   if input_config.get("shuffle", True) else 0,
-                                  resized_shape=lambda h, w: probe.resized_shape(h, w, rz))
+                                  resized_shape=lambda h, w: probe.resized_shape(h, w, rz),
+                                  max_pending=64 if world == 1 else 256)
 
     def next_batch():
         b = next(stream)

@@ -361,6 +361,16 @@ class Trainer:
         return losses
 
 
+def collective_verdict(comm, code, device):
+    """max over the data-parallel ranks of a small non-negative failure code (0 = fine). Every rank must call it at
+    the same point of the step loop; with one rank (or no communicator) it is the identity."""
+    if comm is None or comm.world <= 1:
+        return int(code)
+    flag = torch.tensor([int(code)], dtype=torch.int32, device=device)
+    comm.allreduce(flag, op="max")
+    return int(flag.item())
+
+
 def train(create_tensor_dict_fn, create_model_fn, train_config, master="", task=0, num_clones=1,
           worker_replicas=1, clone_on_cpu=False, ps_tasks=0, worker_job_name="lonely_worker",
           is_chief=True, train_dir=None, num_examples=0, total_configs=None, model_config=None,
@@ -415,10 +425,26 @@ def train(create_tensor_dict_fn, create_model_fn, train_config, master="", task=
             if model.ps.device.type == "cuda":
                 torch.cuda.synchronize()
             total = float(sum(v.item() for v in losses.values()))
+            # tf.check_numerics (:207-209) and the device-side invariants, decided COLLECTIVELY: a rank that raised on
+            # its own would leave the others blocked in the next step's all-reduce for good, so every rank learns the
+            # worst verdict first (one 4-byte max all-reduce on the log steps only) and all of them raise together
+            bad, why = 0, None
             if not (total == total and abs(total) != float("inf")):
-                raise FloatingPointError("LossTensor is inf or nan")     # tf.check_numerics, :207-209
-            if hasattr(model, "check_device_flags"):
-                model.check_device_flags()
+                bad, why = 1, FloatingPointError("LossTensor is inf or nan")
+            elif hasattr(model, "check_device_flags"):
+                try:
+                    model.check_device_flags()
+                except RuntimeError as e:
+                    bad, why = 2, e
+            worst = collective_verdict(trainer.comm, bad, model.ps.device)
+            if worst and not bad:
+                why = RuntimeError("another data-parallel rank reported %s; stopping with it"
+                                   % ("a non-finite loss" if worst == 1 else "a device-side invariant violation"))
+            bad = worst
+            if bad:
+                if trainer.comm is not None:
+                    trainer.comm.close()
+                raise why
             dt = time.time() - t0
             log.append({"step": trainer.global_step, "loss": total, "sec_per_step": dt})
             if is_chief:

@@ -1,0 +1,142 @@
+"""More than one data-parallel rank on real hardware.
+
+* `test_two_rccl_ranks...`: two processes, one GPU each, gradients summed by the library's own collective
+  (mtlssl_comm_* = RCCL over xGMI). Needs two visible devices — RCCL refuses two ranks on one — and SKIPS otherwise;
+  on a multi-GPU box it is the first thing that tells whether the N > 1 path works: reduced gradient == sum of the
+  replicas' local gradients, every bucket issued from a `grad_ready` report during backward, weights bit-identical
+  across ranks after the FIRST step (the step on which the filter-gradient side stream used to be missing from the
+  reducer's event list) and after three.
+* `test_first_step_keeps_replicas_identical_on_one_gpu`: the same first-step check with the gloo stand-in, two
+  replicas sharing device 0 — runs on the single-GPU boxes.
+* `test_bench_two_ranks_under_torchrun`: the driver's own command line for N = 2 (`python -m torch.distributed.run
+  --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2`), RCCL when two devices are visible, else the gloo stand-in
+  with both ranks on device 0: one JSON line on rank 0's stdout, `n_gpus` 2, the `data_parallel` block filled in and
+  `replicas_identical` true — so that the first real multi-GPU run cannot die on plumbing.
+Reference contract: slim/deployment/model_deploy.py:221-223 (clone loss / N), :300-302 (regularisers once),
+:414-444 (gradient sum across clones)."""
+import json
+import os
+import subprocess
+import sys
+import zlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, backend, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = rank if backend == "rccl" else 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    from mtl_ssl_amd.comm import GlooComm, RcclComm
+    device = torch.device("cuda", dev)
+    cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", "smoke_resnet50_mtl.config")).read())
+    model = model_builder.build(cfg.model, True, device, seed=3)          # same seed -> same weights
+    comm = RcclComm(device, rank, world) if backend == "rccl" else GlooComm()
+    tr = trainer.Trainer(model, cfg.train_config, world, comm=comm)
+    tr.broadcast_weights(0)
+    batch = synthetic.make_batch(2, 160, 224, 5, seed=100 + rank, device=device, max_gt=4, num_windows=6)
+    res = {"info": comm.info()}
+
+    def crc():
+        torch.cuda.synchronize()
+        return zlib.crc32(model.ps.weights.cpu().numpy().tobytes())
+
+    # step 1 of a fresh trainer: every side stream is created inside this call
+    tr.step(batch)
+    res["crc_step1"] = crc()
+    res["early_step1"] = list(tr.reducer.launch_order)
+    # local (unreduced) gradients against the reduced ones
+    hook, model.ps.grad_ready_hook = model.ps.grad_ready_hook, None
+    tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    local = model.ps.grads.clone()
+    model.ps.grad_ready_hook = hook
+    tr.forward_backward(batch)
+    res["early"] = list(tr.reducer.launch_order)
+    tr.reducer.finish()
+    torch.cuda.synchronize()
+    reduced = model.ps.grads.clone()
+    gathered = [torch.zeros_like(local, device="cpu") for _ in range(world)]
+    dist.all_gather(gathered, local.cpu())
+    want = sum(gathered).to(device)
+    res["err"] = float((reduced - want).abs().max() / want.abs().max())
+    res["differs_from_local"] = float((reduced - local).abs().max())
+    res["nb"] = len(tr.reducer.buckets)
+    tr.apply_gradients()
+    tr.step(batch)
+    res["crc_step3"] = crc()
+    out[rank] = res
+    comm.close()
+    dist.destroy_process_group()
+
+
+def _run(backend):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29900 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(2, port, backend, out), nprocs=2, join=True)
+    return out[0], out[1]
+
+
+def _check(a, b):
+    assert a["crc_step1"] == b["crc_step1"], "replicas diverged on the first step"
+    assert a["crc_step3"] == b["crc_step3"]
+    assert a["crc_step1"] != a["crc_step3"]
+    for o in (a, b):
+        assert o["err"] < 1e-5, o
+        assert o["differs_from_local"] > 0
+        assert sorted(o["early"]) == list(range(o["nb"])), o        # every bucket went out during backward
+        assert sorted(o["early_step1"]) == list(range(o["nb"])), o  # ... on the very first step too
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank; this box shows one GPU")
+def test_two_rccl_ranks_reduce_gradients_and_keep_replicas_identical():
+    a, b = _run("rccl")
+    assert a["info"]["backend"] == "rccl" and a["info"]["ranks"] == 2 and {a["info"]["rank"], b["info"]["rank"]} == {0, 1}
+    assert {a["info"]["device"], b["info"]["device"]} == {0, 1}
+    _check(a, b)
+
+
+def test_first_step_keeps_replicas_identical_on_one_gpu():
+    a, b = _run("gloo")
+    _check(a, b)
+
+
+def test_bench_two_ranks_under_torchrun():
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not two:
+        env["MTLSSL_DIST_BACKEND"] = "gloo"       # both ranks on device 0: the stand-in transport, same code path
+    port = 29700 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "2", "--batches", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                        # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    dp = d["data_parallel"]
+    assert dp["ranks_reported"] == [2, 2] and len(dp["per_rank_ms_per_step"]) == 2
+    assert dp["replicas_identical"] and len(set(dp["weights_crc32"])) == 1
+    assert dp["gradient_bytes_per_step"] > 300e6 and dp["buckets"] >= 2
+    assert dp["backend"] == ("rccl" if two else "gloo")
+    from tests import parity_report
+    parity_report.add("bench.py --gpus 2 under torch.distributed.run (%s): %.1f images/s, per-rank %s ms/step, all-reduce "
+                      "%s ms/step of which exposed %s; replicas identical" % (
+                          "RCCL, two devices" if two else "gloo stand-in, both ranks on one GPU", d["value"],
+                          dp["per_rank_ms_per_step"], dp["allreduce_ms_per_step"], dp["allreduce_exposed_ms_per_step"]))

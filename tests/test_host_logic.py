@@ -324,6 +324,9 @@ def _dp_worker(rank, world, port, out):
         ps.grad_ready(ps.by_name[n])                           # a repeated report is ignored
     early = list(red.launch_order)
     red.finish()
+    # the step loop's collective failure verdict: rank 1 alone sees a problem, both ranks learn of it
+    res["verdict"] = trainer.collective_verdict(GlooComm(), 2 if rank == 1 else 0, "cpu")
+    res["verdict_ok"] = trainer.collective_verdict(GlooComm(), 0, "cpu")
     res["overlap"] = ps.grads.clone().numpy()
     res["early"] = early
     res["order"] = list(red.launch_order)
@@ -349,6 +352,8 @@ def test_data_parallel_gradient_sum_gloo_world2():
     # every bucket exactly once overall
     assert len(out[0]["early"]) >= 1 and out[0]["early"] == sorted(out[0]["early"], reverse=True)
     assert sorted(out[0]["order"]) == list(range(out[0]["nb"]))
+    # trainer.collective_verdict: a failure seen by one rank stops every rank (none is left waiting in an all-reduce)
+    assert out[0]["verdict"] == 2 and out[1]["verdict"] == 2 and out[0]["verdict_ok"] == 0 and out[1]["verdict_ok"] == 0
 
 
 def test_random_horizontal_flip_known_answers_and_fork_extras():

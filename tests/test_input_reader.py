@@ -164,6 +164,53 @@ def test_record_sharding_and_shuffle(tmp_path):
     assert ids(R.examples([p], 3, rng=np.random.RandomState(3), shuffle_buffer=4)) == sh      # seeded
 
 
+def test_shuffle_buffer_holds_serialized_records_not_decoded_images(tmp_path, monkeypatch):
+    """builders/input_reader_builder.py:34-65: the reference shuffles STRINGS (a RandomShuffleQueue of serialized
+    tf.Examples with min_after_dequeue elements) and decodes after the draw. Decoding first would keep
+    min_after_dequeue float32 images in host memory per rank and decode a thousand JPEGs before the first step."""
+    p = _record_with_images(tmp_path, [(8, 8)] * 12)
+    decoded = []
+    real = R.decode_example
+    monkeypatch.setattr(R, "decode_example", lambda rec, K: decoded.append(1) or real(rec, K))
+    it = R.examples([p], 3, rng=np.random.RandomState(0), shuffle_buffer=8)
+    first = next(it)
+    assert first["image"].shape == (8, 8, 3)
+    assert len(decoded) == 1                      # nine records were read to fill the buffer, ONE was decoded
+    rest = list(it)
+    assert len(decoded) == 12 and sorted(int(e["source_id"]) for e in [first] + rest) == list(range(12))
+
+
+def test_collate_carries_the_evaluation_fields(tmp_path):
+    """evaluator.py:196-201 / eval_util.py:332-334 need `groundtruth_difficult` per box (PASCAL: neither a hit nor a
+    miss); the record's filename / source id ride along."""
+    K = 3
+    img = np.zeros((6, 6, 3), np.uint8)
+    rec = R.serialize_example({
+        "image/encoded": _png(img), "image/format": b"png", "image/filename": "a.png", "image/source_id": "7",
+        "image/object/bbox/ymin": np.array([0.1, 0.2], np.float32), "image/object/bbox/xmin": np.array([0.0, 0.5], np.float32),
+        "image/object/bbox/ymax": np.array([0.6, 0.9], np.float32), "image/object/bbox/xmax": np.array([0.4, 1.0], np.float32),
+        "image/object/class/label": np.array([1, 3], np.int64), "image/object/difficult": np.array([0, 1], np.int64)})
+    p = str(tmp_path / "e.record")
+    R.write_tfrecord(p, [rec])
+    b = next(R.batches([p], K, 1))
+    assert b["groundtruth_difficult"][0].tolist() == [False, True] and b["groundtruth_difficult"][0].dtype == bool
+    assert b["filename"] == ["a.png"] and b["source_id"] == ["7"]
+    # and the PASCAL evaluator ignores the difficult box: one non-difficult box, found -> AP 1; without the flag the
+    # second box would count as a miss
+    from mtl_ssl_amd import evaluation
+    cls = b["groundtruth_classes"][0].argmax(1)
+    for flag, want in ((b["groundtruth_difficult"][0], 1.0), (None, None)):
+        ev = evaluation.PascalDetectionEvaluator(K, 0.5)
+        ev.add_single_ground_truth_image_info(0, b["groundtruth_boxes"][0], cls, is_difficult=flag)
+        ev.add_single_detected_image_info(0, b["groundtruth_boxes"][0][:1], np.array([0.9]), cls[:1])
+        res = ev.evaluate()
+        ap2 = res["per_class_ap"][2] if "per_class_ap" in res else None
+        if want is not None:
+            assert ev.num_gt[2] == 0 and ev.num_gt[0] == 1
+        else:
+            assert ev.num_gt[2] == 1                                  # counted as a groundtruth box that was missed
+
+
 def test_host_resize_matches_the_oracle_restatement():
     import torch
     from mtl_ssl_amd import preprocessor
