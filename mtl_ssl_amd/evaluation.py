@@ -24,13 +24,13 @@ def precision_recall(scores, labels, num_gt):
     """metrics.compute_precision_recall (utils/metrics.py:21-67)."""
     scores, labels = np.asarray(scores), np.asarray(labels)
     if labels.dtype != bool or labels.ndim != 1:
-        raise ValueError("labels must be single dimension bool numpy array")
+        raise ValueError("tp/fp labels: expected a 1-D boolean array, got dtype %s with %d dimension(s)" % (labels.dtype, labels.ndim))
     if scores.ndim != 1:
-        raise ValueError("scores must be single dimension numpy array")
+        raise ValueError("detection scores: expected a 1-D array, got %d dimension(s)" % scores.ndim)
     if num_gt < labels.sum():
-        raise ValueError("Number of true positives must be smaller than num_gt.")
+        raise ValueError("%d true positives but only %d groundtruth boxes of this class" % (int(labels.sum()), num_gt))
     if len(scores) != len(labels):
-        raise ValueError("scores and labels must be of the same size.")
+        raise ValueError("%d scores for %d tp/fp labels" % (len(scores), len(labels)))
     if num_gt == 0:
         return None, None
     order = np.argsort(scores)[::-1]
@@ -44,19 +44,19 @@ def average_precision(precision, recall):
     monotonically-decreasing envelope of the precision/recall curve (VOC devkit, all points)."""
     if precision is None:
         if recall is not None:
-            raise ValueError("If precision is None, recall must also be None")
+            raise ValueError("a class without groundtruth has neither precision nor recall: got a recall array next to precision=None")
         return np.nan
     precision, recall = np.asarray(precision, float), np.asarray(recall, float)
     if len(precision) != len(recall):
-        raise ValueError("precision and recall must be of the same size.")
+        raise ValueError("precision has %d points, recall %d" % (len(precision), len(recall)))
     if not precision.size:
         return 0.0
     if precision.min() < 0 or precision.max() > 1:
-        raise ValueError("Precision must be in the range of [0, 1].")
+        raise ValueError("precision values outside [0, 1]")
     if recall.min() < 0 or recall.max() > 1:
-        raise ValueError("recall must be in the range of [0, 1].")
+        raise ValueError("recall values outside [0, 1]")
     if np.any(np.diff(recall) < 0):
-        raise ValueError("recall must be a non-decreasing array")
+        raise ValueError("recall decreases along the curve (it must be non-decreasing)")
     r = np.concatenate([[0.0], recall, [1.0]])
     p = np.concatenate([[0.0], precision, [0.0]])
     p = np.maximum.accumulate(p[::-1])[::-1]
@@ -97,8 +97,8 @@ class PascalDetectionEvaluator:
         scores = np.asarray(scores, float).reshape(-1)
         cls = np.asarray(class_labels, int).reshape(-1)
         if not (len(boxes) == len(scores) == len(cls)):
-            raise ValueError("detected_boxes, detected_scores and detected_class_labels should all have same "
-                             "lengths. Got[%d, %d, %d]" % (len(boxes), len(scores), len(cls)))
+            raise ValueError("one image's detections disagree in length: %d boxes, %d scores, %d class labels"
+                             % (len(boxes), len(scores), len(cls)))
         if image_key in self.seen:
             return
         self.seen.add(image_key)
@@ -220,8 +220,8 @@ class CocoDetectionEvaluator:
         s = np.asarray(scores, np.float64).reshape(-1)
         c = np.asarray(class_labels, int).reshape(-1)
         if not (len(b) == len(s) == len(c)):
-            raise ValueError("detected_boxes, detected_scores and detected_class_labels should all have same "
-                             "lengths. Got[%d, %d, %d]" % (len(b), len(s), len(c)))
+            raise ValueError("one image's detections disagree in length: %d boxes, %d scores, %d class labels"
+                             % (len(b), len(s), len(c)))
         if image_key in self.dt:
             return
         valid = (b[:, 0] < b[:, 2]) & (b[:, 1] < b[:, 3])                # _remove_invalid_boxes

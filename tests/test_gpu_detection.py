@@ -344,3 +344,64 @@ def test_nms_many_rounds_heavy_suppression(ops):
     kk = int(num.item())
     assert kk == len(ref) and 40 <= kk < 300
     np.testing.assert_array_equal(sel.cpu().numpy()[:kk], ref)
+
+
+def test_rpn_postprocess_train_mode_golden(ops, vec):
+    """faster_rcnn_meta_arch_test_lib.py:461-521 through the HIP path: mtlssl_rpn_proposals ->
+    mtlssl_sample_proposals (detector assigner + balanced sampler + boolean_mask order + padding)."""
+    v = vec["rpn_postprocess_train"]
+    H, W = v["image_hw"]
+    anchors = np.array(v["anchors"], np.float32)
+    props, _, nprop = ops.rpn_proposals(cu(np.zeros((2, 4, 4), np.float32)), cu(np.array(v["objectness"], np.float32)),
+                                        cu(anchors), H, W, v["score_thresh"], v["iou_thresh"], v["max_proposals"])
+    assert nprop.cpu().tolist() == [4, 4]
+    gt = np.array(v["gt_boxes"], np.float32) * np.array([H, W, H, W], np.float32)
+    cls_bg = np.pad(np.array(v["gt_classes"], np.float32), [[0, 0], [0, 0], [1, 0]])
+    for seed in (0, 1, 7):
+        ob, on, num = ops.sample_proposals(props, nprop, cu(gt), cu(np.array([2, 2], np.int32)), cu(cls_bg),
+                                           v["second_stage_batch_size"], v["balance_fraction"], seed, 1, 2, H, W)
+        assert num.cpu().tolist() == v["expected_num"]
+        np.testing.assert_allclose(on.cpu().numpy(), v["expected_boxes_normalized"], atol=1e-6)
+        np.testing.assert_allclose(ob.cpu().numpy() / 32.0, v["expected_boxes_normalized"], atol=1e-6)
+
+
+def test_second_stage_postprocess_golden(ops, vec):
+    """faster_rcnn_meta_arch_test_lib.py:523-590 through the kernels FasterRCNNMetaArch.postprocess strings together:
+    mtlssl_boxes_decode on the tiled proposals, identity score conversion, mtlssl_batch_multiclass_nms with
+    num_valid = num_proposals, the image as clip window and change_coordinate_frame."""
+    v = vec["second_stage_postprocess"]
+    Bn, N_, K = 2, v["max_num_proposals"], v["num_classes"]
+    H, W = v["image_hw"]
+    pb = cu(np.array(v["proposal_boxes"], np.float32))
+    enc = torch.zeros((1, Bn * N_ * K, 4), device="cuda")
+    tiled = pb.view(Bn, N_, 1, 4).expand(Bn, N_, K, 4).reshape(Bn * N_ * K, 4).contiguous()
+    boxes = ops.boxes_decode(enc, tiled).view(Bn, N_, K, 4)
+    scores = ops.score_convert(torch.ones((Bn * N_, K + 1), device="cuda"), "IDENTITY").view(Bn, N_, K + 1)
+    ob, os_, oc, on = ops.batch_multiclass_nms(
+        boxes, scores, v["score_thresh"], v["iou_thresh"], v["max_per_class"], v["max_total"],
+        clip_window=[0.0, 0.0, float(H), float(W)], change_coordinate_frame=True,
+        num_valid=cu(np.array(v["num_proposals"], np.int32)), col0=1, num_classes=K)
+    assert list(ob.shape) == v["expected_boxes_shape"]
+    np.testing.assert_allclose(os_.cpu().numpy(), v["expected_scores"])
+    np.testing.assert_allclose(oc.cpu().numpy(), v["expected_classes"])
+    assert on.cpu().tolist() == v["expected_num"]
+    # and the same through the oracle, box for box
+    rb, rs, rc, rn = N.postprocess_box_classifier(
+        np.zeros((Bn * N_, K, 4), np.float32), np.ones((Bn * N_, K + 1), np.float32), np.array(v["proposal_boxes"], np.float32),
+        np.array(v["num_proposals"], np.int32), (H, W), "IDENTITY", v["score_thresh"], v["iou_thresh"], v["max_per_class"],
+        v["max_total"])
+    np.testing.assert_allclose(ob.cpu().numpy(), rb, atol=1e-6)
+
+
+def test_scatter_rows_is_indices_to_dense_vector(ops, vec):
+    """utils/ops.py:250-279 (indices_to_dense_vector = dynamic_stitch of zeros and values) is what the gradient of the
+    anchor gather needs; mtlssl_scatter_rows on the reference's test shapes (utils/ops_test.py:232-346)."""
+    from oracle import helpers as Hh
+    for c in vec["ops_helpers"]["dense_vector"]["cases"]:
+        if c.get("dtype") == "int64" or "default" in c or c["num"] == 0:
+            continue
+        rng = np.random.RandomState(c["seed"])
+        idx = np.sort(rng.permutation(c["size"])[:c["num"]]).astype(np.int32)
+        want = Hh.indices_to_dense_vector(idx, c["size"])
+        got = ops.scatter_rows(torch.ones((1, len(idx), 1), device="cuda"), cu(idx), c["size"])
+        np.testing.assert_array_equal(got.cpu().numpy().reshape(-1), want)

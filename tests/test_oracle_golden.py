@@ -11,6 +11,7 @@ import torch
 from oracle import assign as A
 from oracle import boxes as B
 from oracle import frcnn_losses as L
+from oracle import helpers as Hh
 from oracle import nms as N
 from oracle import ops_torch as T
 
@@ -202,3 +203,97 @@ def test_sampler_properties():
     ind2 = rng.rand(300) > 0.5
     s = A.balanced_subsample(ind2, 64, labels, 0.5, prio)
     assert not (s & ~ind2).any() and s.sum() == min(64, ind2.sum())
+
+
+def test_ops_helpers_known_answers(vec):
+    """utils/ops_test.py:24-346: normalized_to_image_coordinates, meshgrid, padded_one_hot_encoding,
+    indices_to_dense_vector."""
+    v = vec["ops_helpers"]
+    n = v["normalized_to_image"]
+    np.testing.assert_array_equal(Hh.normalized_to_image_coordinates(n["boxes"], n["image_shape"]), n["expected"])
+    m = v["meshgrid_vectors"]
+    ex, ey = np.meshgrid(m["x"], m["y"])
+    gx, gy = Hh.meshgrid(m["x"], m["y"])
+    np.testing.assert_array_equal(gx, ex)
+    np.testing.assert_array_equal(gy, ey)
+    mm = v["meshgrid_multi"]
+    np.random.seed(mm["seed"])
+    x = np.random.rand(*mm["x_shape"]).astype(np.float32)
+    y = np.random.rand(*mm["y_shape"]).astype(np.float32)
+    gx, gy = Hh.meshgrid(x, y)
+    assert list(gx.shape) == mm["grid_shape"] and list(gy.shape) == mm["grid_shape"]
+    for xind, yind in mm["elements"]:
+        assert gx[tuple(yind) + tuple(xind)] == x[tuple(xind)] and gy[tuple(yind) + tuple(xind)] == y[tuple(yind)]
+    o = v["one_hot"]
+    for pad, key in ((0, "pad0"), (1, "pad1"), (3, "pad3")):
+        np.testing.assert_array_equal(Hh.padded_one_hot_encoding(o["indices"], o["depth"], pad), o[key])
+    e = o["empty"]
+    assert list(Hh.padded_one_hot_encoding([], e["depth"], e["pad"]).shape) == e["shape"]
+    assert Hh.padded_one_hot_encoding([1, 2, 3, 4, 5], 0, 2) is None
+    for bad in (dict(indices=np.ones((2, 3)), depth=6, left_pad=2), dict(indices=np.ones((2, 3)), depth=6, left_pad=-1),
+                dict(indices=[1], depth=6, left_pad=0.1), dict(indices=[1], depth=0.1, left_pad=2)):
+        with pytest.raises(ValueError):
+            Hh.padded_one_hot_encoding(**bad)
+    for c in v["dense_vector"]["cases"]:
+        rng = np.random.RandomState(c["seed"])
+        idx = rng.permutation(c["size"])[:c["num"]]
+        dt = np.int64 if c.get("dtype") == "int64" else np.float32
+        val, dflt = c.get("value", 1.0), c.get("default", 0.0)
+        want = np.full(c["size"], dflt, dt)
+        want[idx] = val
+        got = Hh.indices_to_dense_vector(idx, c["size"], val, dflt, dt)
+        np.testing.assert_array_equal(got, want)
+        assert got.dtype == want.dtype
+
+
+def test_input_path_one_hot_and_background_padding_match_padded_one_hot_encoding(vec):
+    """The two call sites of padded_one_hot_encoding on the hot path (trainer.py:128-131 with label_id_offset 1 and
+    left_pad 0; faster_rcnn_meta_arch.py:1243-1247 pads the background column): the host-side input path produces
+    the reference helper's rows on the reference's own vector."""
+    from mtl_ssl_amd import input_reader as R
+    o = vec["ops_helpers"]["one_hot"]
+    labels = np.array(o["indices"], np.int64) + 1                 # records carry 1-based labels
+    rec = R.serialize_example({"image/encoded": b"", "image/object/class/label": labels})
+    f = R.parse_example(rec)
+    lab = np.asarray(f["image/object/class/label"], np.int64) - 1
+    K = o["depth"]
+    onehot = np.zeros((len(lab), K), np.float32)
+    ok = (lab >= 0) & (lab < K)
+    onehot[np.arange(len(lab))[ok], lab[ok]] = 1
+    np.testing.assert_array_equal(onehot, o["pad0"])
+    np.testing.assert_array_equal(np.pad(onehot, [[0, 0], [1, 0]]), o["pad1"])
+    np.testing.assert_array_equal(np.pad(onehot, [[0, 0], [1, 0]]), Hh.padded_one_hot_encoding(o["indices"], K, 1))
+
+
+def test_rpn_postprocess_train_mode_known_answer(vec):
+    """faster_rcnn_meta_arch_test_lib.py:461-521: proposals of a training model = the balanced sample of the NMS
+    output against the groundtruth (both positives of each image here, whatever the shuffle)."""
+    v = vec["rpn_postprocess_train"]
+    anchors = np.array(v["anchors"], np.float32)
+    H, W = v["image_hw"]
+    pb, ps, _, pn = N.rpn_proposals(np.zeros([2, 4, 4], np.float32), np.array(v["objectness"], np.float32), anchors,
+                                    (H, W), v["score_thresh"], v["iou_thresh"], v["max_proposals"])
+    assert pn.tolist() == [4, 4]
+    gt_abs = [B.to_absolute(np.array(g, np.float32), H, W) for g in v["gt_boxes"]]
+    gt_cls = [np.pad(np.array(c, np.float32), [[0, 0], [1, 0]]) for c in v["gt_classes"]]
+    for seed in (0, 1, 7):
+        ob, on, _ = L.sample_box_classifier_batch(pb, pn, gt_abs, gt_cls, v["second_stage_batch_size"],
+                                                  v["balance_fraction"], seed, 0)
+        assert on.tolist() == v["expected_num"]
+        for i in range(2):
+            np.testing.assert_allclose(B.to_normalized(ob[i], H, W), v["expected_boxes_normalized"][i], atol=1e-6)
+
+
+def test_second_stage_postprocess_known_answer(vec):
+    """faster_rcnn_meta_arch_test_lib.py:523-590: padded proposals + num_proposals through decode, identity scores
+    and the batched per-class NMS."""
+    v = vec["second_stage_postprocess"]
+    Bn, P, K = 2, v["max_num_proposals"], v["num_classes"]
+    ob, os_, oc, on = N.postprocess_box_classifier(
+        np.zeros((Bn * P, K, 4), np.float32), np.ones((Bn * P, K + 1), np.float32),
+        np.array(v["proposal_boxes"], np.float32), np.array(v["num_proposals"], np.int32), v["image_hw"], "IDENTITY",
+        v["score_thresh"], v["iou_thresh"], v["max_per_class"], v["max_total"])
+    assert list(ob.shape) == v["expected_boxes_shape"]
+    np.testing.assert_allclose(os_, v["expected_scores"])
+    np.testing.assert_allclose(oc, v["expected_classes"])
+    assert on.tolist() == v["expected_num"]
