@@ -35,12 +35,28 @@ def hyper_params_for_oracle(cfg):
         r = fr.second_stage_box_predictor.rfcn_box_predictor
         rf = dict(crop=(int(r.crop_height), int(r.crop_width)),
                   bins=(int(r.num_spatial_bins_height), int(r.num_spatial_bins_width)), depth=int(r.depth))
+    def predictor_spec(bp, slot0, cin):
+        if not bp.has("mask_rcnn_box_predictor"):
+            return {}
+        m = bp.mask_rcnn_box_predictor
+        depth = max(min(cin, int(m.max_depth)), int(m.min_depth))
+        n_extra = int(m.num_layers_before_predictor) if depth > 0 else 0
+        return dict(spatial_average=bool(m.spatial_average), n_extra=n_extra, depth=depth, slot0=slot0,
+                    keep_prob=float(m.dropout_keep_probability) if m.use_dropout else None)
+    tower_cout = {"faster_rcnn_resnet50": 2048, "faster_rcnn_resnet101": 2048, "faster_rcnn_resnet152": 2048,
+                  "frcnn_mobilenet_v1": 1024, "faster_rcnn_inception_resnet_v2": 1536,
+                  "faster_rcnn_inception_v2": 1536}[fr.feature_extractor.type]
+    predictors = {"SecondStageBoxPredictor": predictor_spec(fr.second_stage_box_predictor, 16, tower_cout),
+                  "ClosenessBoxPredictor": predictor_spec(mtl.closeness_box_predictor, 32, tower_cout),
+                  "WindowBoxPredictor": predictor_spec(mtl.window_box_predictor, 48, tower_cout)}
     return dict(
+        predictors=predictors, first_stage_only=bool(fr.first_stage_only),
         rfcn=rf, stride=int(fr.feature_extractor.first_stage_features_stride),
         first_stage_atrous_rate=int(fr.first_stage_atrous_rate), anchor_stride=int(g.height_stride),
         arch={"faster_rcnn_resnet50": "resnet_v1_50", "faster_rcnn_resnet101": "resnet_v1_101",
               "faster_rcnn_resnet152": "resnet_v1_152", "frcnn_mobilenet_v1": "mobilenet_v1",
-              "faster_rcnn_inception_resnet_v2": "inception_resnet_v2"}[fr.feature_extractor.type],
+              "faster_rcnn_inception_resnet_v2": "inception_resnet_v2",
+              "faster_rcnn_inception_v2": "inception_resnet_v2"}[fr.feature_extractor.type],
         num_classes=int(fr.num_classes), scales=list(g.scales), aspect_ratios=list(g.aspect_ratios),
         nms_score_threshold=fr.first_stage_nms_score_threshold,
         nms_iou_threshold=fr.first_stage_nms_iou_threshold, max_proposals=int(fr.first_stage_max_proposals),
@@ -60,7 +76,8 @@ def hyper_params_for_oracle(cfg):
                  closeness_loss_weight=mtl.closeness_loss_weight,
                  edgemask_loss_weight=mtl.edgemask_loss_weight, refine_residue=bool(mtl.refine_residue),
                  stop_gradient_for_aux_tasks=bool(mtl.stop_gradient_for_aux_tasks),
-                 global_closeness=bool(mtl.global_closeness)))
+                 global_closeness=bool(mtl.global_closeness), shared_feature=str(mtl.shared_feature),
+                 refine_num_fc_layers=int(mtl.refine_num_fc_layers), refine_dropout_rate=float(mtl.refine_dropout_rate)))
 
 
 def pmc_traffic(default_cfg):

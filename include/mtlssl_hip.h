@@ -501,6 +501,12 @@ int mtlssl_expand_windows(const float* proposals_norm, int batch, int n2, int n_
  * more than `capacity` distinct last windows (then results are wrong and the caller must fail). */
 int mtlssl_dedup_windows(const float* windows, int batch, int n_expand, int n2, int capacity, float* rois_out,
                          int32_t* src_row, int32_t* overflow, mtlssl_stream_t stream);
+/* slim.dropout (faster_rcnn_meta_arch.py:838-839 in the refiner's FC stack; core/box_predictor.py:484-488, 590-594 after
+ * the predictors' extra FC layers): y[i] = x[i] / keep_prob if element i is kept, else 0. The Bernoulli draw is the
+ * samplers' counter hash: kept iff mix32(seed, stream_id, i) < floor(keep_prob * 2^32) — reproducible and identical in
+ * the CPU oracle. The backward pass is the same call on the gradient with the same (seed, stream_id). x == y allowed. */
+int mtlssl_dropout(const float* x, float* y, int64_t n, float keep_prob, uint32_t seed, uint32_t stream_id,
+                   mtlssl_stream_t stream);
 /* Refiner input (faster_rcnn_meta_arch.py:817-831), per image: [cls (k1) | window predictions
  * win[B,n_expand,n2,k1] laid out proposal-major (nullable) | closeness (nullable; per-image mean
  * tiled when global_closeness)] -> out [B*n2, ld]. */

@@ -104,7 +104,8 @@ DEFAULTS = {
     "BoxPredictor": {"trainable": True},
     "MaskRCNNBoxPredictor": {"use_dropout": False, "dropout_keep_probability": 0.5, "box_code_size": 4,
                              "predict_instance_masks": False, "mask_prediction_conv_depth": 256,
-                             "predict_keypoints": False, "spatial_average": False,
+                             "predict_keypoints": False, "spatial_average": True,
+                             "min_depth": 0, "max_depth": 0, "num_layers_before_predictor": 0,
                              "fc_hyperparams": "@Hyperparams"},
     "RfcnBoxPredictor": {"num_spatial_bins_height": 3, "num_spatial_bins_width": 3, "depth": 1024,
                          "box_code_size": 4, "crop_height": 12, "crop_width": 12,

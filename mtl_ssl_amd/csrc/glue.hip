@@ -99,6 +99,23 @@ __global__ void k_edgemask_targets(const float* gt, int HW, float coef, float* t
   scale[i] = w * coef;
 }
 
+// slim.dropout / tf.nn.dropout (TF 1.7: ret = div(x, keep_prob) * floor(keep_prob + uniform)) with the uniform draw
+// replaced by the samplers' counter hash: element i is kept iff mix32(seed, stream, i) < keep_prob * 2^32 — the same
+// integer test in oracle/assign.py:dropout_mask, so the CPU oracle and the device drop the same elements. The backward
+// is the same map applied to the incoming gradient (same seed / stream).
+__device__ __forceinline__ uint32_t glue_mix32(uint32_t seed, uint32_t stream, uint32_t i) {
+  uint32_t x = i + 0x9E3779B9u * seed + 0x85EBCA6Bu * stream;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__global__ void __launch_bounds__(256)
+    k_dropout(const float* __restrict__ x, float* __restrict__ y, int64_t n, float keep_prob, uint64_t thr, uint32_t seed,
+              uint32_t stream) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  y[i] = (uint64_t)glue_mix32(seed, stream, (uint32_t)i) < thr ? x[i] / keep_prob : 0.f;
+}
+
 // faster_rcnn_meta_arch.py:776-803: window i = proposal pushed i/4 of the way to the full image.
 __global__ void k_expand_windows(const float* prop, int n2, int n_expand, float* out) {
   int b = blockIdx.y;
@@ -282,6 +299,17 @@ int mtlssl_expand_windows(const float* proposals_norm, int batch, int n2, int n_
   hipLaunchKernelGGL(k_expand_windows, dim3(cdiv(n_expand * n2, 256), batch), dim3(256), 0, S(stream),
                      proposals_norm, n2, n_expand, out);
   return check_launch("expand_windows");
+}
+
+int mtlssl_dropout(const float* x, float* y, int64_t n, float keep_prob, uint32_t seed, uint32_t stream_id,
+                   mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dropout: keep_prob must be in (0, 1], got %g", (double)keep_prob);
+  MTLSSL_REQUIRE(n < ((int64_t)1 << 32), "dropout: at most 2^32 elements per call");
+  if (n <= 0) return MTLSSL_OK;
+  double t = floor((double)keep_prob * 4294967296.0);
+  uint64_t thr = t >= 4294967296.0 ? 4294967296ull : (uint64_t)t;
+  hipLaunchKernelGGL(k_dropout, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), x, y, n, keep_prob, thr, seed, stream_id);
+  return check_launch("dropout");
 }
 
 int mtlssl_dedup_windows(const float* windows, int batch, int n_expand, int n2, int capacity, float* rois_out,

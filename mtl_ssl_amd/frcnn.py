@@ -35,50 +35,85 @@ def _l2_from_hyperparams(hp):
 
 
 class MaskRCNNBoxPredictor:
-    """core/box_predictor.py:339-611: spatial mean -> FC heads."""
+    """core/box_predictor.py:339-611: RoI features -> (spatial mean | flatten) -> optional FC_i_depth layers, each
+    followed by dropout when use_dropout -> FC heads. The depth of the extra layers is
+    max(min(feature depth, max_depth), min_depth) and they exist only when that depth and
+    num_layers_before_predictor are positive (:465-466, 479-488) — with the proto defaults (both 0) `use_dropout`
+    alone changes nothing in the reference, and nothing here."""
 
-    def __init__(self, ps, scope, cin, num_classes, cfg, is_training, class_only):
-        if not cfg.spatial_average:
-            raise ValueError("mask_rcnn_box_predictor without spatial_average is not supported "
-                             "(every paper config sets spatial_average: true)")
-        if cfg.use_dropout and is_training:
-            # core/box_predictor.py:484-488 (slim.dropout on the pooled features while training)
-            raise ValueError("mask_rcnn_box_predictor.use_dropout is not supported (no paper config enables it)")
+    def __init__(self, ps, scope, cin, num_classes, cfg, is_training, class_only, feat_hw=None, slot0=0):
+        if cfg.predict_instance_masks:
+            raise ValueError("Mask prediction is unimplemented.")          # core/box_predictor.py:418-421
+        if cfg.predict_keypoints:
+            raise ValueError("Keypoint prediction is unimplemented.")
         init, wd = _init_from_hyperparams(cfg.fc_hyperparams), _l2_from_hyperparams(cfg.fc_hyperparams)
         self.num_classes, self.class_only = num_classes, class_only
+        self.spatial_average = bool(cfg.spatial_average)
+        self.is_training = is_training
+        width = cin
+        if not self.spatial_average:
+            if feat_hw is None:
+                raise ValueError("mask_rcnn_box_predictor without spatial_average needs the tower's output size")
+            width = cin * int(feat_hw[0]) * int(feat_hw[1])                # slim.flatten of [R, h, w, C]
+        depth = max(min(cin, int(cfg.max_depth)), int(cfg.min_depth))
+        self.stack = None
+        n_extra = int(cfg.num_layers_before_predictor) if depth > 0 else 0
+        if n_extra > 0:
+            act = {"RELU": "relu", "NONE": None}.get(str(cfg.fc_hyperparams.activation))
+            if act is None and str(cfg.fc_hyperparams.activation) != "NONE":
+                raise ValueError("fc_hyperparams.activation %s is not supported in the predictor's extra layers"
+                                 % cfg.fc_hyperparams.activation)
+            self.stack = nn.FCStack(ps, ["%s/FC_%d_%d" % (scope, i, depth) for i in range(n_extra)], width,
+                                    [depth] * n_extra, init, is_training, wd, activation=act,
+                                    keep_prob=float(cfg.dropout_keep_probability) if cfg.use_dropout else None,
+                                    slot0=slot0)
+            width = depth
         self.box = None
         if not class_only:
-            self.box = nn.Conv(ps, scope + "/BoxEncodingPredictor", cin, num_classes * 4, 1, init,
+            self.box = nn.Conv(ps, scope + "/BoxEncodingPredictor", width, num_classes * 4, 1, init,
                                is_training, wd, fc=True)
-            self.cls = nn.Conv(ps, scope + "/ClassPredictor", cin, num_classes + 1, 1, init, is_training,
+            self.cls = nn.Conv(ps, scope + "/ClassPredictor", width, num_classes + 1, 1, init, is_training,
                                wd, fc=True)
         else:
-            self.cls = nn.Conv(ps, scope + "/ClassPredictor", cin, num_classes, 1, init, is_training, wd,
+            self.cls = nn.Conv(ps, scope + "/ClassPredictor", width, num_classes, 1, init, is_training, wd,
                                fc=True)
 
     def layers(self):
-        return [l for l in (self.box, self.cls) if l is not None]
+        extra = self.stack.layers if self.stack is not None else []
+        return extra + [l for l in (self.box, self.cls) if l is not None]
 
-    def predict(self, feat):
-        pooled = ops.spatial_mean_fwd(feat)
-        out = {"pooled": pooled, "class": self.cls.forward(pooled)}
+    def predict(self, feat, seed=0, step=0):
+        pooled = ops.spatial_mean_fwd(feat) if self.spatial_average else feat.reshape(feat.shape[0], -1)
+        net, sctx = pooled, None
+        if self.stack is not None:
+            net, sctx = self.stack.forward(pooled, self.is_training, seed, step)
+        out = {"pooled": net, "_stack_ctx": sctx, "class": self.cls.forward(net)}
         if self.box is not None:
-            out["box"] = self.box.forward(pooled)
+            out["box"] = self.box.forward(net)
         return out
 
     def backward(self, pred, d_class, d_box, feat_shape, need_feat_grad=True, mask_ref=None, mask6=False):
         """Returns dL/d(feat); with mask_ref (= feat, an activation output) the activation gradient
         is fused in, i.e. the result is dL/d(pre-activation of feat)."""
-        pooled = pred["pooled"]
-        self.cls.wgrad(pooled, d_class)
+        net = pred["pooled"]
+        self.cls.wgrad(net, d_class)
         if d_box is not None:
-            self.box.wgrad(pooled, d_box)
+            self.box.wgrad(net, d_box)
+        if not need_feat_grad and self.stack is None:
+            return None
+        dp = self.cls.dgrad(net.shape, d_class)
+        if d_box is not None:
+            self.box.dgrad(net.shape, d_box, out=dp, accum=True)
+        if self.stack is not None:
+            dp = self.stack.backward(pred["_stack_ctx"], dp, need_input_grad=need_feat_grad)
         if not need_feat_grad:
             return None
-        dp = self.cls.dgrad(pooled.shape, d_class)
-        if d_box is not None:
-            self.box.dgrad(pooled.shape, d_box, out=dp, accum=True)
-        return ops.spatial_mean_bwd(dp, feat_shape, mask_ref, mask6)
+        if self.spatial_average:
+            return ops.spatial_mean_bwd(dp, feat_shape, mask_ref, mask6)
+        g = dp.reshape(tuple(feat_shape))
+        if mask_ref is not None:
+            g = (ops.relu6_bwd if mask6 else ops.relu_bwd)(mask_ref, g.contiguous())
+        return g
 
 
 class FasterRCNNMetaArch:
@@ -101,13 +136,25 @@ class FasterRCNNMetaArch:
         ag = frcnn.first_stage_anchor_generator
         if not ag.has("grid_anchor_generator"):
             raise ValueError("first_stage_anchor_generator must be of type grid_anchor_generator.")
-        if frcnn.first_stage_only:
-            raise ValueError("first_stage_only is not supported by this build")
         if frcnn.has("hard_example_miner"):
             raise ValueError("hard_example_miner is not supported by this build (unused by the paper configs)")
-        if mtl.shared_feature != "proposal_feature_maps":
-            raise ValueError("mtl.shared_feature must be 'proposal_feature_maps' (the proto default; "
-                             "no paper config overrides it)")
+        if mtl.shared_feature not in ("proposal_feature_maps", "classifier_feature_maps"):
+            raise ValueError("mtl.shared_feature must be 'proposal_feature_maps' or 'classifier_feature_maps', got %r"
+                             % (mtl.shared_feature,))
+        # faster_rcnn_meta_arch.py:701-712, 735-747: with 'classifier_feature_maps' the aux heads read the MAIN tower's
+        # output — closeness predicts from box_classifier_features, the window crops go through the second-stage
+        # feature extractor's own scope (same variables: the extractors are built with reuse_weights=AUTO_REUSE,
+        # builders/model_builder.py:243) — so there are no ClosenessBoxPredictor / WindowBoxPredictor tower copies.
+        self._shared_classifier = mtl.shared_feature == "classifier_feature_maps"
+        # faster_rcnn_meta_arch.py:603, 1029-1039, 1549-1567: an RPN-only model — predict stops after the proposal
+        # heads, loss keeps the two RPN terms (+ the edge-mask term, which only needs the shared feature map),
+        # postprocess returns the proposals. The box-classifier heads are still built (their variables exist in the
+        # reference's graph too) but never run.
+        self._first_stage_only = bool(frcnn.first_stage_only)
+        if self._first_stage_only and is_training and (mtl.refine or mtl.window or mtl.closeness):
+            raise ValueError("first_stage_only trains the RPN alone: mtl.window / closeness / refine read second-stage "
+                             "predictions that such a model never computes (the reference fails on the missing "
+                             "prediction_dict keys)")
         self._anchor_cfg = ag.grid_anchor_generator
         self.seed = seed
         self.step = 0
@@ -125,22 +172,28 @@ class FasterRCNNMetaArch:
         self.rpn_cls = nn.Conv(ps, s + "/ClassPredictor", depth, A * 2, 1, init, rpn_tr, wd)
         # second stage (+ aux heads: builders/model_builder.py:287-315 give the aux predictors
         # num_classes+1 "classes")
-        self.tower = fe.box_classifier_tower(self.second_stage_feature_extractor_scope, True)
+        self.tower = fe.box_classifier_tower(self.second_stage_feature_extractor_scope, not self._first_stage_only)
         bp = frcnn.second_stage_box_predictor
-        self.box_predictor = self._make_predictor(self.second_stage_box_predictor_scope, K, bp, False)
+        self.box_predictor = self._make_predictor(self.second_stage_box_predictor_scope, K, bp, False, slot0=16)
         self.layers = fe.layers() + [self.rpn_conv, self.rpn_box, self.rpn_cls] + self.tower.layers() \
             + self.box_predictor.layers()
         self.closeness_tower = self.window_tower = None
         if mtl.closeness:
-            self.closeness_tower = fe.box_classifier_tower(self.closeness_box_predictor_scope, True)
+            if not self._shared_classifier:
+                self.closeness_tower = fe.box_classifier_tower(self.closeness_box_predictor_scope, True)
+                self.layers += self.closeness_tower.layers()
             self.closeness_predictor = self._make_predictor(self.closeness_box_predictor_scope, K + 1,
-                                                            mtl.closeness_box_predictor, True)
-            self.layers += self.closeness_tower.layers() + self.closeness_predictor.layers()
+                                                            mtl.closeness_box_predictor, True, slot0=32)
+            self.layers += self.closeness_predictor.layers()
         if mtl.window:
-            self.window_tower = fe.box_classifier_tower(self.window_box_predictor_scope, True)
+            if self._shared_classifier:
+                self.window_tower = self.tower                       # the same variables, not a copy
+            else:
+                self.window_tower = fe.box_classifier_tower(self.window_box_predictor_scope, True)
+                self.layers += self.window_tower.layers()
             self.window_predictor = self._make_predictor(self.window_box_predictor_scope, K + 1,
-                                                         mtl.window_box_predictor, True)
-            self.layers += self.window_tower.layers() + self.window_predictor.layers()
+                                                         mtl.window_box_predictor, True, slot0=48)
+            self.layers += self.window_predictor.layers()
         if mtl.edgemask:
             ep = mtl.edgemask_predictor
             self.edgemask_conv = nn.Conv(ps, self.edgemask_predictor_scope + "/BoxEncodingPredictor", fe.cout,
@@ -149,11 +202,20 @@ class FasterRCNNMetaArch:
                                          activation="tanh")
             self.layers.append(self.edgemask_conv)
         if mtl.refine:
-            if int(mtl.refine_num_fc_layers) != 0:
-                raise ValueError("refine_num_fc_layers > 0 is not supported (all paper configs use 0)")
+            # faster_rcnn_meta_arch.py:832-841: refine_num_fc_layers hidden layers fc1..fcN of the input's own width
+            # with ReLU (activation_fn=tf.nn.relu, whatever the hyperparams say), each followed by slim.dropout with
+            # keep probability refine_dropout_rate when that is < 1, then fc{N+1} -> K + 1 without activation
             n_feat = (K + 1) * (1 + (self.N_EXPAND if mtl.window else 0) + (1 if mtl.closeness else 0))
             rh = mtl.refiner_fc_hyperparams
-            self.refine_fc = nn.Conv(ps, self.mtl_refiner_scope + "/fc1", n_feat, K + 1, 1,
+            n_hidden = int(mtl.refine_num_fc_layers)
+            self.refine_stack = None
+            if n_hidden > 0:
+                self.refine_stack = nn.FCStack(ps, ["%s/fc%d" % (self.mtl_refiner_scope, i + 1) for i in range(n_hidden)],
+                                               n_feat, [n_feat] * n_hidden, _init_from_hyperparams(rh), is_training,
+                                               _l2_from_hyperparams(rh), activation="relu",
+                                               keep_prob=float(mtl.refine_dropout_rate), slot0=0)
+                self.layers += self.refine_stack.layers
+            self.refine_fc = nn.Conv(ps, "%s/fc%d" % (self.mtl_refiner_scope, n_hidden + 1), n_feat, K + 1, 1,
                                      _init_from_hyperparams(rh), is_training, _l2_from_hyperparams(rh),
                                      fc=True)
             self.layers.append(self.refine_fc)
@@ -163,14 +225,17 @@ class FasterRCNNMetaArch:
         self._window = None
         self._edgemask = None
 
-    def _make_predictor(self, scope, num_classes, bp_cfg, class_only):
+    def _make_predictor(self, scope, num_classes, bp_cfg, class_only, slot0=0):
         """builders/box_predictor_builder.py:23-110 (mask_rcnn_box_predictor branch)."""
         if not bp_cfg.has("mask_rcnn_box_predictor"):
             raise ValueError("FasterRCNNMetaArch needs mask_rcnn_box_predictor (RFCNMetaArch handles "
                              "rfcn_box_predictor)")
-        return MaskRCNNBoxPredictor(self.ps, scope, self.tower.cout, num_classes,
-                                    bp_cfg.mask_rcnn_box_predictor, self._is_training and bp_cfg.trainable,
-                                    class_only)
+        c = self.cfg
+        P = (int(c.initial_crop_size) - int(c.maxpool_kernel_size)) // int(c.maxpool_stride) + 1
+        hw = self.tower.out_hw(P) if hasattr(self.tower, "out_hw") else None
+        return MaskRCNNBoxPredictor(self.ps, scope, self.tower.cout, num_classes, bp_cfg.mask_rcnn_box_predictor,
+                                    self._is_training and bp_cfg.trainable and not self._first_stage_only,
+                                    class_only, feat_hw=hw, slot0=slot0)
 
     # ------------------------------------------------------------------ properties / plumbing
     @property
@@ -381,7 +446,8 @@ class FasterRCNNMetaArch:
             "rpn_objectness_predictions_with_background": logits, "anchors": anchors,
             "_trunk_ctx": trunk_ctx, "_keep": keep, "_n_all": n_all,
         }
-        pd.update(self._predict_second_stage(pd))
+        if not self._first_stage_only:
+            pd.update(self._predict_second_stage(pd))
         return pd
 
     def _format_groundtruth_data(self, H, W):
@@ -440,7 +506,7 @@ class FasterRCNNMetaArch:
         flat = boxes_norm.view(B * N2, 4)
         crops, argmax = self._crop(F, flat, box_ind, True)
         feat, tower_ctx = self.tower.forward(crops, self._is_training)
-        bp = self.box_predictor.predict(feat)
+        bp = self.box_predictor.predict(feat, self.seed, self.step)
         out = {
             "refined_box_encodings": bp["box"].view(B * N2, self.num_classes, 4),
             "class_predictions_with_background": bp["class"],
@@ -449,9 +515,12 @@ class FasterRCNNMetaArch:
             "_tower_ctx": tower_ctx, "_bp": bp,
         }
         if mtl.closeness:
-            # stop_gradient_for_aux_tasks only decides whether d(crops) is propagated (:668-673)
-            cfeat, cctx = self.closeness_tower.forward(crops, self._is_training)
-            cp = self.closeness_predictor.predict(cfeat)
+            if self._shared_classifier:          # :701-706, 713-714: the predictor reads the main tower's features
+                cfeat, cctx = feat, None
+            else:
+                # stop_gradient_for_aux_tasks only decides whether d(crops) is propagated (:668-673)
+                cfeat, cctx = self.closeness_tower.forward(crops, self._is_training)
+            cp = self.closeness_predictor.predict(cfeat, self.seed, self.step)
             out.update({"closeness_predictions": cp["class"], "_cfeat": cfeat, "_cctx": cctx, "_cp": cp})
         return out
 
@@ -463,10 +532,14 @@ class FasterRCNNMetaArch:
         Wn = wb.shape[1]
         flat = wb.reshape(B * Wn, 4)
         box_ind = self._box_ind(B, Wn, F.device)
-        need_crop_grad = not self._mtl.stop_gradient_for_aux_tasks
+        stop = bool(self._mtl.stop_gradient_for_aux_tasks)
+        need_crop_grad = not stop
         crops, argmax = self._crop(F, flat, box_ind, need_crop_grad)
-        feat, ctx = self.window_tower.forward(crops, self._is_training)
-        wp = self.window_predictor.predict(feat)
+        # with the shared tower and stop_gradient_for_aux_tasks the gradient stops at the tower's OUTPUT (:746-747):
+        # nothing of this pass is needed by backward but the pooled features
+        save = self._is_training and not (self._shared_classifier and stop)
+        feat, ctx = self.window_tower.forward(crops, save)
+        wp = self.window_predictor.predict(feat, self.seed, self.step)
         pd.update({"window_class_predictions": wp["class"], "_wfeat": feat, "_wctx": ctx, "_wp": wp,
                    "_wcrops": crops, "_wargmax": argmax, "_wboxes": flat, "_wbox_ind": box_ind})
         return pd
@@ -507,17 +580,21 @@ class FasterRCNNMetaArch:
                 R = rois.shape[1]
                 crops, _ = self._crop(F, rois.view(B * R, 4), self._box_ind(B, R, F.device), False)
                 feat, _ = self.window_tower.forward(crops, False)               # forward only (:834)
-                compact = self.window_predictor.predict(feat)["class"]         # [B*R, K1]
+                compact = self.window_predictor.predict(feat, self.seed, self.step)["class"]         # [B*R, K1]
                 win = ops.gather_rows(compact.view(1, B * R, K1), src_row)      # [1, B*5*N2, K1]
             else:
                 flat = ew.view(B * self.N_EXPAND * N2, 4)
                 crops, _ = self._crop(F, flat, self._box_ind(B, self.N_EXPAND * N2, F.device), False)
                 feat, _ = self.window_tower.forward(crops, False)
-                win = self.window_predictor.predict(feat)["class"]             # [B*5*N2, K1]
+                win = self.window_predictor.predict(feat, self.seed, self.step)["class"]             # [B*5*N2, K1]
             pd["expand_window_class_predictions"] = win.view(B, self.N_EXPAND, N2, K1)
         clo = pd["closeness_predictions"] if mtl.closeness else None
         net = ops.refine_concat(cls, win, clo, B, N2, self.N_EXPAND, bool(mtl.global_closeness))
-        refined = self.refine_fc.forward(net)
+        hidden, sctx = net, None
+        if self.refine_stack is not None:
+            hidden, sctx = self.refine_stack.forward(net, self._is_training, self.seed, self.step)
+        refined = self.refine_fc.forward(hidden)
+        pd["_refine_hidden"], pd["_refine_ctx"] = hidden, sctx
         if mtl.refine_residue:
             ops.axpby(cls, refined, 1.0, 1.0)
         pd["mtl_refined_class_predictions_with_background"] = refined
@@ -532,11 +609,21 @@ class FasterRCNNMetaArch:
         c = self.cfg
         B, H, W, _ = pd["image_shape"]
         if c.first_stage_only:
+            # :1029-1039 -> _postprocess_rpn (:1055-1132): proposals in NORMALISED coordinates; a training model
+            # returns its balanced sample of them against the groundtruth instead (:1117-1125)
             boxes, scores, num = ops.rpn_proposals(
                 pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"],
                 H, W, c.first_stage_nms_score_threshold, c.first_stage_nms_iou_threshold,
                 int(c.first_stage_max_proposals))
-            return {"detection_boxes": boxes, "detection_scores": scores, "num_detections": num}
+            if self._is_training:
+                gt = self._format_groundtruth_data(H, W)
+                _, norm, num = self._second_stage_proposals(boxes, num, gt, H, W)
+                return {"detection_boxes": norm, "num_detections": num}
+            key = ("inv_hw", H, W)
+            if key not in self._consts:
+                self._consts[key] = torch.tensor([1.0 / H, 1.0 / W, 1.0 / H, 1.0 / W], dtype=f32, device=boxes.device)
+            return {"detection_boxes": ops.scale_channels(boxes, self._consts[key]), "detection_scores": scores,
+                    "num_detections": num}
         key = "mtl_refined_class_predictions_with_background"
         cls = pd[key] if (self._mtl.refine and key in pd) else pd["class_predictions_with_background"]
         N, K = self.max_num_proposals, self.num_classes
@@ -568,6 +655,8 @@ class FasterRCNNMetaArch:
         g = float(loss_scale)
         if part == "late":
             losses, d = pd["_losses_early"], pd["_d"]
+            if self._first_stage_only:
+                return losses
             dt, cls_s = pd["_det_targets"], pd["_cls_s"]
             cls_targets = dt["cls_targets"].view(B * self.max_num_proposals, self.num_classes + 1)
             if mtl.refine:
@@ -604,6 +693,20 @@ class FasterRCNNMetaArch:
         losses["first_stage_objectness_loss"] = ops.reduce_sum(rl)
         d["rpn_box_encodings"], d["rpn_objectness"] = d_enc, d_obj
         pd["_rpn_targets"] = dict(tg, sampled=sampled)
+        if self._first_stage_only:
+            if mtl.edgemask:
+                em = self._edgemask
+                mh, mw = em.shape[2], em.shape[3]
+                tgt, sc = ops.edgemask_targets(em, mtl.edgemask_loss_weight / (B * mh * mw))
+                pr = ops.resize_bilinear_fwd(pd["edgemask_predictions"], mh, mw)
+                rl, d_pr = ops.softmax_ce(pr, tgt, sc.view(-1))
+                losses["edgemask_loss"] = ops.reduce_sum(rl)
+                d["edgemask_resized"] = d_pr
+            if g != 1.0:
+                for k in d:
+                    ops.axpby(d[k], d[k], g, 0.0)
+            pd["_d"], pd["_losses_early"], pd["_cls_s"] = d, losses, None
+            return losses
         # ---- _loss_box_classifier :1670-1793
         N2, K, K1 = self.max_num_proposals, self.num_classes, self.num_classes + 1
         um2 = self._consts["um2"]
@@ -671,12 +774,18 @@ class FasterRCNNMetaArch:
         d = pd["_d"]
         F = pd["rpn_features_to_crop"]
         B = F.shape[0]
+        if self._first_stage_only:
+            dF = torch.zeros_like(F)
+            return self._backward_first_stage(pd, d, F, dF, B)
         dF = torch.empty_like(F)         # first written IN FULL by the main head's RoI-crop backward below (no memset)
         d_cls = d["class_predictions"]
         # refine: gradient reaches the refiner weights and, through the residual, the class logits
         if mtl.refine:
             d_ref = d["refined_class_predictions"]
-            self.refine_fc.wgrad(pd["_refine_in"], d_ref)        # refiner input is stop_gradient (:834)
+            self.refine_fc.wgrad(pd["_refine_hidden"], d_ref)    # refiner input is stop_gradient (:834)
+            if self.refine_stack is not None:
+                g_h = self.refine_fc.dgrad(pd["_refine_hidden"].shape, d_ref)
+                self.refine_stack.backward(pd["_refine_ctx"], g_h, need_input_grad=False)
             if mtl.refine_residue and not mtl.stop_gradient_for_prediction_org:
                 ops.axpby(d_ref, d_cls, 1.0, 1.0)
         c = self.cfg
@@ -685,13 +794,42 @@ class FasterRCNNMetaArch:
         m6 = getattr(self.tower, "out_relu6", False)
         g_feat = self.box_predictor.backward(pd["_bp"], d_cls, d["refined_box_encodings"].view(feat.shape[0], -1),
                                              feat.shape, mask_ref=feat, mask6=m6)
+        stop = bool(mtl.stop_gradient_for_aux_tasks)
+        shared = self._shared_classifier
+        gw_shared = None
+        if shared:
+            # shared_feature: 'classifier_feature_maps' (:701-714, 735-747). The closeness predictor hangs off the
+            # main tower's output: its gradient joins the main head's before the tower's backward (or stops there).
+            if mtl.closeness:
+                gcl = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, feat.shape,
+                                                        need_feat_grad=not stop, mask_ref=feat, mask6=m6)
+                if not stop:
+                    ops.axpby(gcl, g_feat, 1.0, 1.0)
+            # The window crops went through the SAME tower variables. Without stop_gradient their gradient makes a
+            # second pass through the tower; it runs first, on this stream, with the "gradient final" reports held
+            # back — the variables report once, after the main pass that follows.
+            if mtl.window and not stop:
+                wfeat = pd["_wfeat"]
+                g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat.shape,
+                                                   mask_ref=wfeat, mask6=m6)
+                hook, self.ps.grad_ready_hook = self.ps.grad_ready_hook, None
+                gw_shared = self.tower.backward(g, wfeat, pd["_wctx"], need_input_grad=True, masked=True)
+                self.ps.grad_ready_hook = hook
         g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True, masked=True)
         ops.roi_crop_pool_bwd(g_crops, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
                               pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
                               int(c.maxpool_stride), dfeat=dF, accumulate=False)
-        stop = bool(mtl.stop_gradient_for_aux_tasks)
+        if gw_shared is not None:
+            ops.roi_crop_pool_bwd(gw_shared, pd["_wargmax"], F.shape, pd["_wboxes"], pd["_wbox_ind"],
+                                  int(c.initial_crop_size), int(c.maxpool_kernel_size), int(c.maxpool_stride), dfeat=dF)
 
         def aux_backward():
+            if shared:
+                if mtl.window and stop:          # the gradient stops at the shared tower's output: predictor only
+                    wfeat = pd["_wfeat"]
+                    self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat.shape,
+                                                   need_feat_grad=False)
+                return
             if mtl.closeness:
                 cfeat = pd["_cfeat"]
                 g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat.shape,
@@ -724,6 +862,12 @@ class FasterRCNNMetaArch:
                 aux_backward()
         else:
             aux_backward()
+        return self._backward_first_stage(pd, d, F, dF, B, side)
+
+    def _backward_first_stage(self, pd, d, F, dF, B, side=None):
+        """Edge-mask head, RPN heads and the trunk: dF holds what the second stage sent back (zeros for an RPN-only
+        model)."""
+        mtl = self._mtl
         if mtl.edgemask:
             em_pred = pd["edgemask_predictions"]
             g = ops.resize_bilinear_bwd(d["edgemask_resized"], em_pred.shape)

@@ -258,6 +258,12 @@ class InceptionTower:
     def layers(self):
         return self.mixed_7a.layers() + [l for b in self.blocks for l in b.layers()] + [self.conv_7b]
 
+    @staticmethod
+    def out_hw(p):
+        """Mixed_7a reduces with 3x3 / stride-2 VALID convolutions and pooling; block8 / Conv2d_7b keep the size."""
+        q = (p - 3) // 2 + 1
+        return (q, q)
+
     def forward(self, crops, save):
         x, c7 = self.mixed_7a.forward(crops, save)
         ctxs = []

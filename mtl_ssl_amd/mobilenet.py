@@ -60,6 +60,11 @@ class MobilenetTower:
     def layers(self):
         return [self.dw12, self.pw12, self.dw13, self.pw13]
 
+    @staticmethod
+    def out_hw(p):
+        """Conv2d_12 is a stride-2 SAME separable conv, Conv2d_13 stride 1: ceil(p / 2)."""
+        return (-(-p // 2), -(-p // 2))
+
     def forward(self, crops, save):
         d12 = self.dw12.forward(crops)
         a12 = self.pw12.forward(d12)

@@ -313,6 +313,56 @@ class Conv:
         return dx.view(x_shape) if self.fc else dx
 
 
+def dropout_stream(step, slot):
+    """Counter-hash stream id of a dropout layer: top bit set (the samplers use the streams below it), 23 bits of
+    step, 8 bits of layer slot. oracle/model.py restates the same formula."""
+    return (0x80000000 | ((int(step) & 0x7FFFFF) << 8) | (int(slot) & 0xFF)) & 0xFFFFFFFF
+
+
+class FCStack:
+    """A run of slim.fully_connected(activation) layers, each optionally followed by slim.dropout — the refiner's
+    `fc1..fcN` (faster_rcnn_meta_arch.py:835-839) and the predictors' `FC_i_depth` layers
+    (core/box_predictor.py:479-488, 585-594). Explicit forward / backward over nn.Conv(fc=True)."""
+
+    def __init__(self, ps, scopes, cin, widths, init, trainable, weight_decay, activation="relu", keep_prob=None,
+                 slot0=0):
+        if activation not in ("relu", None):
+            raise ValueError("fully connected stacks support RELU or NONE activations, got %r" % (activation,))
+        self.layers, self.activation = [], activation
+        for scope, cout in zip(scopes, widths):
+            self.layers.append(Conv(ps, scope, cin, cout, 1, init, trainable, weight_decay, activation=activation, fc=True))
+            cin = cout
+        self.cout = cin
+        self.keep_prob = None if (keep_prob is None or keep_prob >= 1.0) else float(keep_prob)
+        self.slot0 = slot0
+
+    def forward(self, x, training, seed, step):
+        """-> (output, ctx). Dropout acts only while training (slim.dropout's is_training)."""
+        ctx = []
+        for i, l in enumerate(self.layers):
+            a = l.forward(x)
+            drop = training and self.keep_prob is not None
+            y = ops.dropout(a, self.keep_prob, seed, dropout_stream(step, self.slot0 + i)) if drop else a
+            ctx.append((x, a, (seed, dropout_stream(step, self.slot0 + i)) if drop else None))
+            x = y
+        return x, ctx
+
+    def backward(self, ctx, g, need_input_grad=True):
+        """g: dL/d(output). Accumulates the layers' filter / bias gradients; returns dL/d(input) or None."""
+        for i in range(len(self.layers) - 1, -1, -1):
+            l = self.layers[i]
+            x, a, drop = ctx[i]
+            if drop is not None:
+                g = ops.dropout(g, self.keep_prob, drop[0], drop[1])
+            if self.activation == "relu":
+                g = ops.relu_bwd(a, g)
+            l.wgrad(x, g)
+            if i == 0 and not need_input_grad:
+                return None
+            g = l.dgrad(x.shape, g)
+        return g
+
+
 class Bottleneck:
     """slim/nets/resnet_v1.py:69-130 bottleneck (v1: BN after conv, stride in the 3x3)."""
 

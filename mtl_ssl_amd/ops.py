@@ -703,6 +703,15 @@ def batch_multiclass_nms(boxes, scores, score_thresh, iou_thresh, max_per_class,
     return ob, os_, oc, on
 
 
+def dropout(x, keep_prob, seed, stream_id, out=None):
+    """slim.dropout in training mode with counter-hash draws (mtlssl_dropout). Call it again on the gradient with the
+    same (seed, stream_id) for the backward pass."""
+    y = out if out is not None else torch.empty_like(x)
+    lib().dropout(ptr(_chk(x)), ptr(y), x.numel(), float(keep_prob), int(seed) & 0xFFFFFFFF, int(stream_id) & 0xFFFFFFFF,
+                  _stream())
+    return y
+
+
 def score_convert(logits, mode):
     """mode: 'SOFTMAX' | 'SIGMOID' | 'IDENTITY' (builders/post_processing_builder.py:80-108)."""
     if mode == "IDENTITY":

@@ -26,6 +26,11 @@ class BoxClassifierTower:
     def layers(self):
         return self.stack.layers()
 
+    @staticmethod
+    def out_hw(p):
+        """Spatial size of the tower's output for p x p crops (block4 runs at stride 1)."""
+        return (p, p)
+
     def forward(self, crops, save):
         x, ctxs = crops, []
         for u in self.stack.units:

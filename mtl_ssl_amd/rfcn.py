@@ -75,7 +75,15 @@ class RfcnBoxPredictor:
 
 
 class RFCNMetaArch(FasterRCNNMetaArch):
-    def _make_predictor(self, scope, num_classes, bp_cfg, class_only):
+    def __init__(self, ps, is_training, frcnn, mtl, feature_extractor, seed=0):
+        super().__init__(ps, is_training, frcnn, mtl, feature_extractor, seed=seed)
+        # the switches below are built for the Faster R-CNN second stage only (no paper configuration combines them
+        # with R-FCN: configs/test/model4?.config)
+        if self._shared_classifier or self._first_stage_only or (mtl.refine and int(mtl.refine_num_fc_layers) > 0):
+            raise ValueError("RFCNMetaArch: shared_feature 'classifier_feature_maps', first_stage_only and a refiner FC "
+                             "stack are implemented for FasterRCNNMetaArch only")
+
+    def _make_predictor(self, scope, num_classes, bp_cfg, class_only, slot0=0):
         if not bp_cfg.has("rfcn_box_predictor"):
             raise ValueError("RFCNMetaArch needs rfcn_box_predictor for %s" % scope)
         return RfcnBoxPredictor(self.ps, scope, self.tower.cout, num_classes, bp_cfg.rfcn_box_predictor,

@@ -99,6 +99,13 @@ def hash_priority(seed, n, stream=0):
     return x.astype(np.uint32)
 
 
+def dropout_mask(seed, n, keep_prob, stream=0):
+    """Bernoulli(keep_prob) mask of slim.dropout with the uniform draw replaced by the counter hash above: element i
+    is kept iff hash_priority(seed, stream)[i] < floor(keep_prob * 2^32) (csrc/glue.hip: k_dropout does the same)."""
+    thr = min(int(np.floor(float(np.float32(keep_prob)) * 4294967296.0)), 4294967296)
+    return hash_priority(seed, n, stream).astype(np.uint64) < np.uint64(thr)
+
+
 def subsample_indicator(indicator, num_samples, priority):
     """object_detection/core/minibatch_sampler.py:64-90 with the shuffle replaced by
     'keep the num_samples True entries of smallest (priority, index)'."""

@@ -193,6 +193,37 @@ class Oracle:
     def fc(self, x, scope):
         return x @ self.v[scope + "/weights"] + self.v[scope + "/biases"]
 
+    @staticmethod
+    def dropout_stream(step, slot):
+        """Stream id of a dropout layer's counter hash (restated from mtl_ssl_amd/nn.py:dropout_stream)."""
+        return (0x80000000 | ((int(step) & 0x7FFFFF) << 8) | (int(slot) & 0xFF)) & 0xFFFFFFFF
+
+    def dropout(self, x, keep_prob, seed, step, slot):
+        """slim.dropout while training: x / keep_prob where kept, the Bernoulli draw being the counter hash."""
+        from . import assign as A_
+        m = A_.dropout_mask(seed, x.numel(), keep_prob, self.dropout_stream(step, slot)).reshape(tuple(x.shape))
+        return x / F(keep_prob) * torch.as_tensor(m.astype(np.float32)).to(x.dtype)
+
+    def fc_stack(self, x, scopes, keep_prob, slot0, seed, step, training):
+        """slim.fully_connected(relu) layers, each followed by slim.dropout when keep_prob < 1 (training only)."""
+        for i, sc in enumerate(scopes):
+            x = torch.relu(self.fc(x, sc))
+            if training and keep_prob is not None and keep_prob < 1.0:
+                x = self.dropout(x, keep_prob, seed, step, slot0 + i)
+        return x
+
+    def head_input(self, feat, scope, seed=0, step=0, training=True):
+        """core/box_predictor.py:464-488, 569-594: RoI features -> spatial mean or flatten -> the optional
+        FC_i_depth layers (+ dropout). hp['predictors'][scope] = dict(spatial_average, n_extra, depth, keep_prob,
+        slot0); absent -> spatial mean, no extra layers."""
+        spec = (self.hp.get("predictors") or {}).get(scope, {})
+        net = feat.mean((1, 2)) if spec.get("spatial_average", True) else feat.reshape(feat.shape[0], -1)
+        n = int(spec.get("n_extra", 0))
+        if n:
+            scopes = ["%s/FC_%d_%d" % (scope, i, spec["depth"]) for i in range(n)]
+            net = self.fc_stack(net, scopes, spec.get("keep_prob"), int(spec.get("slot0", 0)), seed, step, training)
+        return net
+
     def conv(self, x, scope, act=None, rate=1):
         y = T.conv2d(x, self.v[scope + "/weights"], 1, rate, "SAME") + self.v[scope + "/biases"]
         return {None: y, "relu": torch.relu(y), "tanh": torch.tanh(y)}[act]
@@ -249,7 +280,10 @@ class Oracle:
             boxes_abs = np.stack([B.to_absolute(boxes_norm[b], H, W) for b in range(Bn)])
             box_ind = np.repeat(np.arange(Bn), P)
             crops = self.crop(Fm, boxes_norm.reshape(-1, 4), box_ind)
-            feat = self.tower(crops, "SecondStageFeatureExtractor").mean((1, 2))
+            shared = mtl.get("shared_feature", "proposal_feature_maps") == "classifier_feature_maps"
+            wscope = "SecondStageFeatureExtractor" if shared else "WindowBoxPredictor"
+            tfeat = self.tower(crops, "SecondStageFeatureExtractor")
+            feat = self.head_input(tfeat, "SecondStageBoxPredictor", training=False)
             box_enc = self.fc(feat, "SecondStageBoxPredictor/BoxEncodingPredictor").reshape(Bn * P, K, 4)
             cls = self.fc(feat, "SecondStageBoxPredictor/ClassPredictor")
             final = cls
@@ -265,17 +299,22 @@ class Oracle:
                                           ymax + (F(1) - ymax) / ne * F(i), xmax + (F(1) - xmax) / ne * F(i)],
                                          1).astype(F) for i in range(5)]
                         ew = np.concatenate(wins, 0)
-                        ef = self.tower(self.crop(Fm, ew, np.full(len(ew), b)), "WindowBoxPredictor").mean((1, 2))
+                        ef = self.head_input(self.tower(self.crop(Fm, ew, np.full(len(ew), b)), wscope),
+                                             "WindowBoxPredictor", training=False)
                         ep = self.fc(ef, "WindowBoxPredictor/ClassPredictor")
                         per_img.append(ep.reshape(5, P, K1).permute(1, 0, 2).reshape(P, 5 * K1))
                     src.append(torch.cat(per_img, 0))
                 if mtl["closeness"]:
-                    cf = self.tower(crops, "ClosenessBoxPredictor").mean((1, 2))
+                    cf = self.head_input(tfeat if shared else self.tower(crops, "ClosenessBoxPredictor"),
+                                         "ClosenessBoxPredictor", training=False)
                     c3 = self.fc(cf, "ClosenessBoxPredictor/ClassPredictor").reshape(Bn, P, K1)
                     if mtl["global_closeness"]:
                         c3 = c3.mean(1, keepdim=True).expand(Bn, P, K1)
                     src.append(c3.reshape(Bn * P, K1))
-                final = self.fc(torch.cat(src, 1), "MTLClassRefiner/fc1")
+                nh = int(mtl.get("refine_num_fc_layers", 0))
+                hidden = self.fc_stack(torch.cat(src, 1), ["MTLClassRefiner/fc%d" % (i + 1) for i in range(nh)],
+                                       None, 0, 0, 0, False)
+                final = self.fc(hidden, "MTLClassRefiner/fc%d" % (nh + 1))
                 if mtl["refine_residue"]:
                     final = final + cls
             ob, os_, oc, on = N.postprocess_box_classifier(
@@ -339,14 +378,24 @@ class Oracle:
         rfcn = hp.get("rfcn")
         stop_aux = mtl["stop_gradient_for_aux_tasks"]
         clo = None
-        if rfcn is None:
+        shared = mtl.get("shared_feature", "proposal_feature_maps") == "classifier_feature_maps"
+        first_only = bool(hp.get("first_stage_only", False))
+        cls = box_enc = None
+        if first_only:
+            pass
+        elif rfcn is None:
             crops = self.crop(Fm, boxes_norm.reshape(-1, 4), box_ind)
-            feat = self.tower(crops, "SecondStageFeatureExtractor").mean((1, 2))
+            tfeat = self.tower(crops, "SecondStageFeatureExtractor")
+            feat = self.head_input(tfeat, "SecondStageBoxPredictor", seed, step)
             box_enc = self.fc(feat, "SecondStageBoxPredictor/BoxEncodingPredictor").reshape(Bn * N2, K, 4)
             cls = self.fc(feat, "SecondStageBoxPredictor/ClassPredictor")
             aux_crops = crops.detach() if stop_aux else crops
             if mtl["closeness"]:
-                cf = self.tower(aux_crops, "ClosenessBoxPredictor").mean((1, 2))
+                if shared:       # faster_rcnn_meta_arch.py:701-714: the main tower's features (stopped or not)
+                    cfeat = tfeat.detach() if stop_aux else tfeat
+                else:
+                    cfeat = self.tower(aux_crops, "ClosenessBoxPredictor")
+                cf = self.head_input(cfeat, "ClosenessBoxPredictor", seed, step)
                 clo = self.fc(cf, "ClosenessBoxPredictor/ClassPredictor")
         else:
             # rfcn_meta_arch.py:208-310: block4 on the whole map, then position-sensitive pooling
@@ -365,19 +414,24 @@ class Oracle:
                                  hp["first_stage_objectness_loss_weight"]))
         # ---- detector loss
         dt = L.detector_targets(boxes_abs, gt_abs, gt_cls_bg, gt_clo)
-        losses.update(L.loss_box_classifier(box_enc, cls, num, dt,
-                                            hp["second_stage_localization_loss_weight"],
-                                            hp["second_stage_classification_loss_weight"],
-                                            clo if mtl["closeness"] else None, mtl["closeness_loss_weight"]))
+        if not first_only:
+            losses.update(L.loss_box_classifier(box_enc, cls, num, dt,
+                                                hp["second_stage_localization_loss_weight"],
+                                                hp["second_stage_classification_loss_weight"],
+                                                clo if mtl["closeness"] else None, mtl["closeness_loss_weight"]))
         win_logits = None
-        if mtl["window"]:
+        wscope = "SecondStageFeatureExtractor" if shared else "WindowBoxPredictor"     # :738-741
+        if mtl["window"] and not first_only:
             wb = np.stack([np.asarray(w, F) for w in batch["window_boxes"]])
             Wn = wb.shape[1]
             if rfcn is None:
                 wc = self.crop(Fm, wb.reshape(-1, 4), np.repeat(np.arange(Bn), Wn))
-                if stop_aux:
+                if stop_aux and not shared:
                     wc = wc.detach()
-                wf = self.tower(wc, "WindowBoxPredictor").mean((1, 2))
+                wt = self.tower(wc, wscope)
+                if stop_aux and shared:          # :746-747: the gradient stops at the shared tower's output
+                    wt = wt.detach()
+                wf = self.head_input(wt, "WindowBoxPredictor", seed, step)
                 win_logits = self.fc(wf, "WindowBoxPredictor/ClassPredictor")
             else:
                 wmap = self.tower(Fm.detach() if stop_aux else Fm, "WindowBoxPredictor")
@@ -390,7 +444,7 @@ class Oracle:
             losses.update(L.loss_edgemask(em, np.stack(batch["groundtruth_edgemask"]),
                                           mtl["edgemask_loss_weight"]))
         refined = net = None
-        if mtl["refine"]:
+        if mtl["refine"] and not first_only:
             src = [cls]
             if mtl["window"]:
                 per_img = []
@@ -407,7 +461,7 @@ class Oracle:
                     ew = np.concatenate(wins, 0)                       # [5*N2,4], window-major
                     if rfcn is None:
                         ec = self.crop(Fm.detach(), ew, np.full(len(ew), b))
-                        ef = self.tower(ec, "WindowBoxPredictor").mean((1, 2))
+                        ef = self.head_input(self.tower(ec, wscope), "WindowBoxPredictor", seed, step)
                         ep = self.fc(ef, "WindowBoxPredictor/ClassPredictor")          # [5*N2,K1]
                     else:
                         ep, _ = self.rfcn_predict(wmap.detach(), "WindowBoxPredictor", ew,
@@ -420,7 +474,10 @@ class Oracle:
                     c3 = c3.mean(1, keepdim=True).expand(Bn, N2, K1)
                 src.append(c3.reshape(Bn * N2, K1))
             net = torch.cat(src, 1).detach()                               # tf.stop_gradient :834
-            refined = self.fc(net, "MTLClassRefiner/fc1")
+            nh = int(mtl.get("refine_num_fc_layers", 0))
+            hidden = self.fc_stack(net, ["MTLClassRefiner/fc%d" % (i + 1) for i in range(nh)],
+                                   mtl.get("refine_dropout_rate", 1.0), 0, seed, step, True)   # :835-839
+            refined = self.fc(hidden, "MTLClassRefiner/fc%d" % (nh + 1))
             if mtl["refine_residue"]:
                 refined = refined + cls
             losses.update(L.loss_refined_classifier(refined, num, dt, mtl["refined_classification_loss_weight"]))
@@ -429,7 +486,8 @@ class Oracle:
         grads = {k: t.grad.numpy() for k, t in self.v.items() if t.grad is not None}
         aux = dict(proposal_boxes=boxes_abs, num_proposals=num, rpn_match=tg["match"],
                    rpn_sampled=tg["samp"], det_match=dt["match"], rpn_box_encodings=enc.detach().numpy(),
-                   rpn_objectness=obj.detach().numpy(), class_predictions=cls.detach().numpy(), features=Fm.detach().numpy(),
+                   rpn_objectness=obj.detach().numpy(),
+                   class_predictions=None if cls is None else cls.detach().numpy(), features=Fm.detach().numpy(),
                    refined=None if refined is None else refined.detach().numpy(),
                    refine_in=None if net is None else net.numpy(),
                    d_features=Fm.grad.numpy())

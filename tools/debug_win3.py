@@ -5,41 +5,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 g.build()
 from mtl_ssl_amd import ops
-from oracle import ops_torch as T
-from tests.test_gpu_model import _setup
-ops.set_winograd(0)
+from oracle.model import Oracle
+from tests.test_gpu_model import _setup, _host_batch
+ops.set_winograd(int(os.environ.get("WINO", "0")))
 model, tr, batch, hp = _setup(True, True, 14, 2)
-tr.forward_backward(batch)
-torch.cuda.synchronize()
-pd = tr._pd
-F = pd["rpn_features_to_crop"]
-B = F.shape[0]
-N2 = model.max_num_proposals
-ew = ops.expand_windows(pd["proposal_boxes_normalized"], 5)      # [B,5,N2,4]
-pbn = pd["proposal_boxes_normalized"].cpu().numpy()
-ne = np.float32(4)
-for i in range(5):
-    fi = np.float32(i)
-    w = np.stack([pbn[..., 0] - pbn[..., 0] / ne * fi, pbn[..., 1] - pbn[..., 1] / ne * fi,
-                  pbn[..., 2] + (np.float32(1) - pbn[..., 2]) / ne * fi, pbn[..., 3] + (np.float32(1) - pbn[..., 3]) / ne * fi], -1).astype(np.float32)
-    print("window", i, "boxes bit-identical:", np.array_equal(w, ew[:, i].cpu().numpy()))
-flat = ew.view(B * 5 * N2, 4).contiguous()
-bi = (torch.arange(B * 5 * N2, device="cuda", dtype=torch.int32) // (5 * N2)).contiguous()
-crops, _ = ops.roi_crop_pool_fwd(F, flat, bi, 14, 2, 2, False)
-ref = T.max_pool(T.crop_and_resize(F.cpu(), flat.cpu(), bi.cpu(), 14), 2, 2, "VALID")
-d = (crops.cpu() - ref).abs().reshape(B, 5, N2, -1).amax(-1)
-print("max abs diff per window:", d.amax((0, 2)))
-idx = torch.nonzero(d > 1e-4)
-print("rows differing:", idx[:10].tolist())
-Hf, Wf = F.shape[1], F.shape[2]
-for b, i, p in idx[:4].tolist():
-    bx = ew[b, i, p].cpu().numpy()
-    print("box", bx, [x.hex() for x in bx.astype(np.float32).tolist()] if False else "")
-    y1, x1, y2, x2 = [np.float32(v) for v in bx]
-    hs = (y2 - y1) * np.float32(Hf - 1) / np.float32(13)
-    ws = (x2 - x1) * np.float32(Wf - 1) / np.float32(13)
-    iy = y1 * np.float32(Hf - 1) + np.arange(14, dtype=np.float32) * hs
-    ix = x1 * np.float32(Wf - 1) + np.arange(14, dtype=np.float32) * ws
-    print("  in_y last", repr(iy[-1]), "H-1", Hf - 1, " in_x last", repr(ix[-1]), "W-1", Wf - 1)
-    dd = (crops.cpu() - ref).abs().reshape(B, 5, N2, 7, 7, -1)[b, i, p].amax(-1)
-    print("  cell diff map\n", dd.numpy().round(4))
+values = model.ps.state_dict()
+for slots in (8, 0):
+    type(model).DEDUP_SLOTS = slots
+    tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    pd = tr._pd
+    B, N2, K1 = 2, model.max_num_proposals, model.num_classes + 1
+    win = pd["expand_window_class_predictions"].cpu().numpy()            # [B,5,N2,K1]
+    _, _, aux = Oracle(hp, values).step(_host_batch(batch), seed=model.seed, step=0)
+    rin = aux["refine_in"].reshape(B, N2, 7, K1)
+    owin = rin[:, :, 1:6].transpose(0, 2, 1, 3)                            # [B,5,N2,K1]
+    d = np.abs(win - owin).max(-1)                                        # [B,5,N2]
+    print("DEDUP_SLOTS", slots, "max abs diff per (image, window):\n", d.max(-1).round(5))
+    b, i = np.unravel_index(d.max(-1).argmax(), d.max(-1).shape)
+    print("  worst (image %d, window %d): per-proposal diffs" % (b, i), d[b, i].round(4))
+    print("  num_proposals", pd["num_proposals"].cpu().tolist())
+    bad = np.nonzero(d[b, i] > 1e-3)[0]
+    ew = ops.expand_windows(pd["proposal_boxes_normalized"], 5).cpu().numpy()
+    for p in bad[:6]:
+        print("   proposal", p, "box", ew[b, i, p], "prop", pd["proposal_boxes_normalized"][b, p].cpu().numpy())
