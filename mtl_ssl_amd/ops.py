@@ -245,6 +245,24 @@ def force_conv_config(d, mode, cfg):
     return lib().conv2d_tile_config(ctypes.byref(d), mode)
 
 
+def reset_tuning(use_plan_db=True, autotune=True):
+    """Forget every measured / pinned plan: each (problem, mode) seen so far goes back to the library's planner, and
+    the next call decides again — from conv_plans.json when `use_plan_db`, by timing when `autotune`. Tests that force
+    one algorithm (set_winograd(0 / 2)) call reset_tuning(False, False) first: a tile pinned by an earlier test of
+    the same process would otherwise override the mode for that problem."""
+    global _plan_db, AUTOTUNE
+    import collections
+    D = collections.namedtuple("D", "N H W C K R S OH OW stride dilation pad_t pad_l")
+    from .lib import ConvDesc
+    for key in list(_tuned):
+        mode, vals = key[0], key[1:]
+        d = ConvDesc(**D(*vals)._asdict())
+        lib().conv2d_force_config(ctypes.byref(d), mode, -1)
+    _tuned.clear()
+    _plan_db = None if use_plan_db else {}
+    AUTOTUNE = bool(autotune)
+
+
 def set_winograd(mode):
     """0: direct convolution only, 1: plan registry / time model (default), 2: Winograd F(4x4,3x3) for every
     eligible 3x3 stride-1 layer. Returns the previous mode (mode=-1 only queries)."""

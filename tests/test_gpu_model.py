@@ -88,9 +88,13 @@ def conv_algorithm(request):
     import __graft_entry__ as g
     g.build()
     from mtl_ssl_amd import ops
+    # no plan table, no autotuner: a tile pinned for a problem (by conv_plans.json, or by the timing of an earlier test
+    # of this process) overrides the global mode for that problem, and the "winograd" case would quietly run direct
+    ops.reset_tuning(use_plan_db=False, autotune=False)
     ops.set_winograd(request.param)
     yield request.param
     ops.set_winograd(1)
+    ops.reset_tuning(use_plan_db=True, autotune=True)
 
 
 @pytest.mark.parametrize("conv_algorithm", [0, 2], indirect=True, ids=["direct", "winograd"])
@@ -100,6 +104,8 @@ def test_step_losses_and_gradients_match_oracle(refine, aux, crop, pk, conv_algo
     from mtl_ssl_amd import ops
     model, tr, batch, hp = _setup(refine, aux, crop, pk)
     assert ops.set_winograd(-1) == conv_algorithm
+    d33 = ops.conv_desc((2, 10, 14, 256), (3, 3, 256, 256), 1, 1, "SAME")          # a block3 conv2 of this input size
+    assert (ops.lib().conv2d_tile_config(__import__("ctypes").byref(d33), 0) >= ops.WINO_CFG0) == (conv_algorithm == 2)
     values = model.ps.state_dict()
     reports = {}
     model.ps.grad_ready_hook = lambda sp: reports.__setitem__(sp.name, reports.get(sp.name, 0) + 1)
@@ -129,12 +135,9 @@ def test_step_losses_and_gradients_match_oracle(refine, aux, crop, pk, conv_algo
     # fp32 oracle is itself up to ~1e-3 away from it on the trunk variables — a ReLU pre-activation within an ulp of
     # zero takes the other branch and one flipped element of a 286 720-element map moves a filter gradient by ~1e-3 of
     # its norm (tools/grad_error_study.py: 14 such flips in the oracle's d_features against fp64, 1 in the HIP path's).
-    # So the claim "gradients within 1e-3" is asserted against the better yardstick, per variable:
-    #   direct implicit GEMM : every variable within 1e-3 relative L2 of float64 (observed worst 1.6e-4)
-    #   Winograd F(4x4,3x3) forced on EVERY 3x3 layer: the transforms' rounding (intermediates ~100x the operands,
-    #     cancelled by the output transform) is dense, ~8e-5 per layer and adds up along the backward chain
-    #     (observed worst 1.8e-3 at this depth; the shipped plan table mixes both and measures 3e-4 at full size,
-    #     tests/test_gpu_fullsize_parity.py) — bounded at 2.5e-3 per variable, 1e-3 in the median.
+    # So the claim "gradients within 1e-3" is asserted against the better yardstick, per variable and for both
+    # algorithms: every variable within 1e-3 relative L2 of float64 (observed worst 1.6e-4 with every 3x3 layer on the
+    # direct implicit GEMM and with every 3x3 layer on Winograd F(4x4,3x3) alike, profiles/r03_grad_error_study_*.txt).
     ref64, g64, aux64 = Oracle(hp, values, np.float64).step(_host_batch(batch), seed=model.seed, step=0, forced=aux_o)
     np.testing.assert_array_equal(aux64["det_match"], aux_o["det_match"])
     gF, F_ref = pd["_gpF"].cpu().numpy(), aux64["features"]
@@ -143,7 +146,7 @@ def test_step_losses_and_gradients_match_oracle(refine, aux, crop, pk, conv_algo
     assert bad.mean() < 5e-5, bad.sum()                       # branch flips: a handful of elements, not a pattern
     grads = model.ps.grads_dict()
     rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
-    cap = 1e-3 if conv_algorithm == 0 else 2.5e-3
+    cap = 1e-3
     e_gpu, e_cpu, l2errs = [], [], []
     for name, g in grads.items():
         r = rgrads.get(name)

@@ -27,6 +27,8 @@ def main():
     from mtl_ssl_amd import ops
     from oracle.model import Oracle
     from tests.test_gpu_model import _host_batch, _setup
+    if len(sys.argv) > 2 and sys.argv[2] == "planner":     # no plan table, no autotuner: the planner's own choices
+        ops.reset_tuning(use_plan_db=False, autotune=False)
     ops.set_winograd(2 if mode == "winograd" else 0)
     model, tr, batch, hp = _setup(True, True, 14, 2)
     values = model.ps.state_dict()
@@ -76,7 +78,16 @@ def main():
     print(out)
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    open(os.path.join(d, "grad_error_study_%s.txt" % mode), "w").write(out + "\n")
+    tag = mode + ("_planner" if len(sys.argv) > 2 else "")
+    import ctypes
+    extra = []
+    for name, shape, wshape in (("block3 3x3 10x14", (2, 10, 14, 256), (3, 3, 256, 256)), ("block2 3x3 20x28", (2, 20, 28, 128), (3, 3, 128, 128)),
+                                ("tower 3x3 7x7", (32, 7, 7, 512), (3, 3, 512, 512)), ("rpn 3x3", (2, 10, 14, 1024), (3, 3, 1024, 512))):
+        dd = ops.conv_desc(shape, wshape, 1, 1, "SAME")
+        extra.append("%s: plan codes fwd/dgrad/wgrad = %s" % (name, [ops.lib().conv2d_tile_config(ctypes.byref(dd), m) for m in range(3)]))
+    out += "\n" + "\n".join(extra)
+    print("\n".join(extra))
+    open(os.path.join(d, "grad_error_study_%s.txt" % tag), "w").write(out + "\n")
 
 
 if __name__ == "__main__":

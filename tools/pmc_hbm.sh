@@ -1,6 +1,6 @@
 #!/bin/bash
 # FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) for the HBM-bound kernels: tools/hbm_kernels.py
-# under rocprofv3, summarised to gpurun_out/pmc_hbm/hbm_kernels_pmc.json (copy to profiles/r02_hbm_kernels_pmc.json).
+# under rocprofv3, summarised to gpurun_out/pmc_hbm/hbm_kernels_pmc.json (copy to profiles/r03_hbm_kernels_pmc.json).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_hbm
 rm -rf $OUT; mkdir -p $OUT

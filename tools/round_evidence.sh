@@ -1,5 +1,5 @@
 #!/bin/bash
-# One-shot evidence run on the GPU box (round 2): un-profiled default bench, rocprofv3 kernel stats + step timeline
+# One-shot evidence run on the GPU box (round 3): un-profiled default bench, rocprofv3 kernel stats + step timeline
 # of the same command, the PMC passes (roofline kernel + HBM-bound kernels), the per-kernel conv breakdown, the
 # 1-rank RCCL self-test bench and the other shipped configurations. Everything lands under gpurun_out/evidence/;
 # copy what is to be judged into profiles/.
@@ -7,24 +7,20 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 E=$R/gpurun_out/evidence
 rm -rf $E; mkdir -p $E
 cd $R
-python bench.py > $E/bench_default.json 2> $E/bench_default.err
+python bench.py --split-engine-steps 0 > $E/bench_default.json 2> $E/bench_default.err
 python bench.py --steps 20 --warmup 5 --conv-breakdown --no-cpu-baseline > $E/bench_conv_breakdown.json 2>> $E/bench_default.err
 MTLSSL_COMM_SELFTEST=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_rccl_1rank.json 2> $E/bench_rccl_1rank.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --config configs/rfcn_resnet101_voc_mtl.config > $E/bench_rfcn.json 2> $E/bench_rfcn.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --config configs/frcnn_mobilenet_v1_voc_mtl.config > $E/bench_mobilenet.json 2> $E/bench_mobilenet.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --config configs/frcnn_inception_resnet_v2_coco_mtl.config --height 800 --width 1333 > $E/bench_inception.json 2> $E/bench_inception.err
-MTLSSL_FP32_ENGINE=split python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_split_engine.json 2> $E/bench_split_engine.err
-(cd /tmp && export TMPDIR=/tmp && MTLSSL_FP32_ENGINE=split rocprofv3 --kernel-trace --stats -d $E/prof_split -o ev -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $E/bench_split_profiled.err)
-DBS=$(find $E/prof_split -name "*.db" | head -1)
-python tools/rocprof_summary.py $DBS 30 > $E/kernel_stats_split_engine.md
-rm -rf $E/prof_split
-python tools/bench_tiles.py 7 > $E/bench_tiles.txt 2>/dev/null
 python tools/phase_times.py > $E/phase_times.txt 2>/dev/null
 python tools/phase_times.py --config configs/frcnn_mobilenet_v1_voc_mtl.config --steps 30 >> $E/phase_times.txt 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $E/prof -o ev -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --split-engine-steps 0 > $E/bench_profiled.json 2> $E/bench_profiled.err)
 DB=$(find $E/prof -name "*.db" | head -1)
 python tools/rocprof_summary.py $DB 45 > $E/kernel_stats.md
 python tools/step_timeline.py $DB 1 > $E/step_timeline.txt
+python tools/kernel_sequence.py $DB 0 60 > $E/kernel_sequence.txt
+python tools/bench_roi_bwd.py > $E/roi_bwd.txt 2>/dev/null
 python tools/stream_gaps.py $DB 0.3 > $E/stream_gaps.txt
 rm -rf $E/prof
 bash tools/pmc_bench.sh > $E/pmc.log 2>&1
