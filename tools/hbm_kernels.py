@@ -20,7 +20,7 @@ cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", "frcnn_res
 model = model_builder.build(cfg.model, True, "cuda", seed=0)
 tr = trainer.Trainer(model, cfg.train_config, 1)
 batch = tr.stage_batch(synthetic.make_batch(2, 600, 1024, 90, seed=1234, device="cuda"))
-for _ in range(int(os.environ.get("HBM_KERNELS_STEPS", "60"))):      # the state bench.py measures them in: after its timed steps
+for _ in range(int(os.environ.get("HBM_KERNELS_STEPS", "12"))):      # the state bench.py measures them in: after its timed steps
     tr.step(batch)
 torch.cuda.synchronize()
 print("HBM_KERNELS_BEGIN", flush=True)
