@@ -49,8 +49,13 @@ def hyper_params_for_oracle(cfg):
     predictors = {"SecondStageBoxPredictor": predictor_spec(fr.second_stage_box_predictor, 16, tower_cout),
                   "ClosenessBoxPredictor": predictor_spec(mtl.closeness_box_predictor, 32, tower_cout),
                   "WindowBoxPredictor": predictor_spec(mtl.window_box_predictor, 48, tower_cout)}
+    miner = None
+    if fr.has("hard_example_miner"):
+        hm = fr.hard_example_miner
+        miner = dict(num_hard_examples=int(hm.num_hard_examples) or None, iou_threshold=float(hm.iou_threshold),
+                     loss_type={"BOTH": "both", "CLASSIFICATION": "cls", "LOCALIZATION": "loc"}[str(hm.loss_type)])
     return dict(
-        predictors=predictors, first_stage_only=bool(fr.first_stage_only),
+        predictors=predictors, first_stage_only=bool(fr.first_stage_only), hard_example_miner=miner,
         rfcn=rf, stride=int(fr.feature_extractor.first_stage_features_stride),
         first_stage_atrous_rate=int(fr.first_stage_atrous_rate), anchor_stride=int(g.height_stride),
         arch={"faster_rcnn_resnet50": "resnet_v1_50", "faster_rcnn_resnet101": "resnet_v1_101",

@@ -501,6 +501,21 @@ int mtlssl_expand_windows(const float* proposals_norm, int batch, int n2, int n_
  * more than `capacity` distinct last windows (then results are wrong and the caller must fail). */
 int mtlssl_dedup_windows(const float* windows, int batch, int n_expand, int n2, int capacity, float* rois_out,
                          int32_t* src_row, int32_t* overflow, mtlssl_stream_t stream);
+/* core/losses.py:418-631 HardExampleMiner as the second stage applies it (faster_rcnn_meta_arch.py:1758-1762,
+ * 1902-1946; builders/losses_builder.py:57-93): per image, tf.image.non_max_suppression over the proposal boxes scored
+ * by their per-proposal loss keeps at most num_hard_examples proposals; the loss terms are the sums over the kept
+ * ones and only they are back-propagated.
+ *   _scores: scores[B,n2] = cls + loc row losses (loss_type 0 BOTH — the row losses carry weight / normaliser),
+ *            cls only (1) or loc only (2); rows >= num_proposals[b] get -inf (not candidates). Feed each image's
+ *            row to mtlssl_nms.
+ *   _apply:  selected[B,max_selected] / num_selected[B] = the NMS output per image; zeroes the rows of d_box
+ *            [B*n2, box_ld] and d_cls [B*n2, cls_ld] that were not kept and writes the mined loss sums per image. */
+int mtlssl_hard_mining_scores(const float* loc_row_loss, const float* cls_row_loss, const int32_t* num_proposals,
+                              int batch, int n2, int loss_type, float* scores, mtlssl_stream_t stream);
+int mtlssl_hard_mining_apply(const int32_t* selected, const int32_t* num_selected, int batch, int max_selected, int n2,
+                             const float* loc_row_loss, const float* cls_row_loss, float* d_box, int box_ld,
+                             float* d_cls, int cls_ld, float* loc_loss_out, float* cls_loss_out,
+                             mtlssl_stream_t stream);
 /* slim.dropout (faster_rcnn_meta_arch.py:838-839 in the refiner's FC stack; core/box_predictor.py:484-488, 590-594 after
  * the predictors' extra FC layers): y[i] = x[i] / keep_prob if element i is kept, else 0. The Bernoulli draw is the
  * samplers' counter hash: kept iff mix32(seed, stream_id, i) < floor(keep_prob * 2^32) — reproducible and identical in

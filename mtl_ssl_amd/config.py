@@ -110,6 +110,9 @@ DEFAULTS = {
     "RfcnBoxPredictor": {"num_spatial_bins_height": 3, "num_spatial_bins_width": 3, "depth": 1024,
                          "box_code_size": 4, "crop_height": 12, "crop_width": 12,
                          "conv_hyperparams": "@Hyperparams"},
+    # protos/losses.proto:93-122
+    "HardExampleMiner": {"num_hard_examples": 64, "iou_threshold": 0.7, "loss_type": "BOTH",
+                         "max_negatives_per_positive": 0, "min_negatives_per_image": 0},
     "MaskPredictor": {"trainable": True, "kernel_size": 3, "conv_hyperparams": "@Hyperparams"},
     "BatchNonMaxSuppression": {"score_threshold": 0.0, "iou_threshold": 0.6,
                                "max_detections_per_class": 100, "max_total_detections": 100},

@@ -116,6 +116,49 @@ __global__ void __launch_bounds__(256)
   y[i] = (uint64_t)glue_mix32(seed, stream, (uint32_t)i) < thr ? x[i] / keep_prob : 0.f;
 }
 
+// core/losses.py:418-631 HardExampleMiner as the second stage uses it (faster_rcnn_meta_arch.py:1758-1762,
+// 1902-1946): per image, greedy NMS over the first num_proposals proposal boxes with the per-proposal LOSS as score
+// keeps at most num_hard_examples mutually non-overlapping "hard" proposals; the two loss terms become the sums over
+// the kept ones and only those rows receive a gradient. Stage 1: the NMS scores (padding rows = -inf, not
+// candidates). The row losses already carry weight / normaliser, so 'both' (cls * w_cls + loc * w_loc) is their sum.
+__global__ void __launch_bounds__(256)
+    k_hard_mining_scores(const float* loc_rl, const float* cls_rl, const int32_t* num_prop, int n2, int loss_type,
+                         float* scores) {
+  int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n2) return;
+  int64_t o = (int64_t)b * n2 + i;
+  float v = loss_type == 1 ? cls_rl[o] : loss_type == 2 ? loc_rl[o] : cls_rl[o] + loc_rl[o];
+  scores[o] = i < num_prop[b] ? v : -INFINITY;
+}
+// Stage 2 (one block per image): rows the NMS kept stay, every other row's gradient is zeroed; the mined losses are
+// the sums of the kept rows, accumulated in row order (fixed order: reproducible).
+__global__ void __launch_bounds__(256)
+    k_hard_mining_apply(const int32_t* sel, const int32_t* num_sel, int max_sel, int n2, const float* loc_rl,
+                        const float* cls_rl, float* d_box, int box_ld, float* d_cls, int cls_ld, float* loc_loss,
+                        float* cls_loss) {
+  extern __shared__ unsigned char hm_keep[];      // [n2]
+  __shared__ float s4[4];
+  int b = blockIdx.x;
+  for (int i = threadIdx.x; i < n2; i += 256) hm_keep[i] = 0;
+  __syncthreads();
+  int ns = min(num_sel[b], max_sel);
+  for (int j = threadIdx.x; j < ns; j += 256) {
+    int r = sel[(int64_t)b * max_sel + j];
+    if (r >= 0 && r < n2) hm_keep[r] = 1;
+  }
+  __syncthreads();
+  float al = 0.f, ac = 0.f;
+  for (int i = threadIdx.x; i < n2; i += 256)
+    if (hm_keep[i]) { al += loc_rl[(int64_t)b * n2 + i]; ac += cls_rl[(int64_t)b * n2 + i]; }
+  float sl = block_sum_256(al, s4);
+  float sc = block_sum_256(ac, s4);
+  if (threadIdx.x == 0) { loc_loss[b] = sl; cls_loss[b] = sc; }
+  for (int64_t t = threadIdx.x; t < (int64_t)n2 * box_ld; t += 256)
+    if (!hm_keep[t / box_ld]) d_box[(int64_t)b * n2 * box_ld + t] = 0.f;
+  for (int64_t t = threadIdx.x; t < (int64_t)n2 * cls_ld; t += 256)
+    if (!hm_keep[t / cls_ld]) d_cls[(int64_t)b * n2 * cls_ld + t] = 0.f;
+}
+
 // faster_rcnn_meta_arch.py:776-803: window i = proposal pushed i/4 of the way to the full image.
 __global__ void k_expand_windows(const float* prop, int n2, int n_expand, float* out) {
   int b = blockIdx.y;
@@ -299,6 +342,26 @@ int mtlssl_expand_windows(const float* proposals_norm, int batch, int n2, int n_
   hipLaunchKernelGGL(k_expand_windows, dim3(cdiv(n_expand * n2, 256), batch), dim3(256), 0, S(stream),
                      proposals_norm, n2, n_expand, out);
   return check_launch("expand_windows");
+}
+
+int mtlssl_hard_mining_scores(const float* loc_row_loss, const float* cls_row_loss, const int32_t* num_proposals,
+                              int batch, int n2, int loss_type, float* scores, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(loss_type >= 0 && loss_type <= 2, "hard_mining: loss_type 0 (both), 1 (classification) or 2 (localization)");
+  if (!batch || !n2) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_hard_mining_scores, dim3(cdiv(n2, 256), batch), dim3(256), 0, S(stream), loc_row_loss,
+                     cls_row_loss, num_proposals, n2, loss_type, scores);
+  return check_launch("hard_mining_scores");
+}
+int mtlssl_hard_mining_apply(const int32_t* selected, const int32_t* num_selected, int batch, int max_selected, int n2,
+                             const float* loc_row_loss, const float* cls_row_loss, float* d_box, int box_ld,
+                             float* d_cls, int cls_ld, float* loc_loss_out, float* cls_loss_out,
+                             mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(n2 <= 60000, "hard_mining: at most 60 000 proposals per image");
+  if (!batch || !n2) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_hard_mining_apply, dim3(batch), dim3(256), (size_t)n2, S(stream), selected, num_selected,
+                     max_selected, n2, loc_row_loss, cls_row_loss, d_box, box_ld, d_cls, cls_ld, loc_loss_out,
+                     cls_loss_out);
+  return check_launch("hard_mining_apply");
 }
 
 int mtlssl_dropout(const float* x, float* y, int64_t n, float keep_prob, uint32_t seed, uint32_t stream_id,

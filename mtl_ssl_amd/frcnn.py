@@ -136,8 +136,17 @@ class FasterRCNNMetaArch:
         ag = frcnn.first_stage_anchor_generator
         if not ag.has("grid_anchor_generator"):
             raise ValueError("first_stage_anchor_generator must be of type grid_anchor_generator.")
+        # builders/model_builder.py:334-339 -> builders/losses_builder.py:57-93: the second stage's hard example miner
+        # (num_hard_examples 0 = every NMS survivor; max_negatives_per_positive needs a match_list the meta-architecture
+        # never passes, faster_rcnn_meta_arch.py:1941-1945, so it has no effect there and none here)
+        self._hard_miner = None
         if frcnn.has("hard_example_miner"):
-            raise ValueError("hard_example_miner is not supported by this build (unused by the paper configs)")
+            hm = frcnn.hard_example_miner
+            lt = {"BOTH": "both", "CLASSIFICATION": "cls", "LOCALIZATION": "loc"}.get(str(hm.loss_type))
+            if lt is None:
+                raise ValueError("hard_example_miner.loss_type %s" % hm.loss_type)
+            self._hard_miner = dict(num_hard_examples=int(hm.num_hard_examples) or None,
+                                    iou_threshold=float(hm.iou_threshold), loss_type=lt)
         if mtl.shared_feature not in ("proposal_feature_maps", "classifier_feature_maps"):
             raise ValueError("mtl.shared_feature must be 'proposal_feature_maps' or 'classifier_feature_maps', got %r"
                              % (mtl.shared_feature,))
@@ -718,11 +727,21 @@ class FasterRCNNMetaArch:
             c.second_stage_classification_loss_weight, c.second_stage_localization_loss_weight,
             mtl.closeness_loss_weight)
         cls_targets = dt["cls_targets"].view(B * N2, K1)
-        rl, d_box = ops.box_select_smooth_l1(pd["refined_box_encodings"], cls_targets,
-                                             dt["reg_targets"].view(B * N2, 4), loc_s2.view(-1), 1.0)
-        losses["second_stage_localization_loss"] = ops.reduce_sum(rl)
-        rl, d_cls = ops.softmax_ce(pd["class_predictions_with_background"], cls_targets, cls_s.view(-1))
-        losses["second_stage_classification_loss"] = ops.reduce_sum(rl)
+        rl_loc, d_box = ops.box_select_smooth_l1(pd["refined_box_encodings"], cls_targets,
+                                                 dt["reg_targets"].view(B * N2, 4), loc_s2.view(-1), 1.0)
+        rl_cls, d_cls = ops.softmax_ce(pd["class_predictions_with_background"], cls_targets, cls_s.view(-1))
+        if self._hard_miner is not None:
+            # :1758-1762 -> _unpad_proposals_and_apply_hard_mining (:1902-1946), per image like a clone of the reference
+            # (whose loop returns after its first — only — image): NMS over the proposals scored by their loss, the
+            # terms become sums over the mined proposals, the others get no gradient
+            hm = self._hard_miner
+            lm, cm, sel, nsel = ops.hard_example_mining(rl_loc.view(B, N2), rl_cls.view(B, N2), pd["proposal_boxes"],
+                                                        pd["num_proposals"], d_box, d_cls, hm["num_hard_examples"],
+                                                        hm["iou_threshold"], hm["loss_type"])
+            rl_loc, rl_cls = lm, cm
+            pd["_mined"] = (sel, nsel)
+        losses["second_stage_localization_loss"] = ops.reduce_sum(rl_loc)
+        losses["second_stage_classification_loss"] = ops.reduce_sum(rl_cls)
         d["refined_box_encodings"], d["class_predictions"] = d_box, d_cls
         pd["_det_targets"] = dt
         if mtl.closeness:

@@ -721,6 +721,30 @@ def batch_multiclass_nms(boxes, scores, score_thresh, iou_thresh, max_per_class,
     return ob, os_, oc, on
 
 
+def hard_example_mining(loc_rl, cls_rl, boxes, num_proposals, d_box, d_cls, num_hard_examples, iou_threshold, loss_type):
+    """core/losses.py:418-631 on the second stage (see mtlssl_hard_mining_*): loc_rl / cls_rl [B,n2] per-proposal
+    losses, boxes [B,n2,4] the proposal boxes. Zeroes the gradient rows of proposals that were not mined (in place)
+    and returns (mined loc loss [B], mined cls loss [B])."""
+    B, n2 = loc_rl.shape
+    dev = loc_rl.device
+    scores = torch.empty((B, n2), dtype=f32, device=dev)
+    lib().hard_mining_scores(ptr(_chk(loc_rl)), ptr(_chk(cls_rl)), ptr(_chk(num_proposals, i32)), B, n2,
+                             {"both": 0, "cls": 1, "loc": 2}[loss_type], ptr(scores), _stream())
+    max_sel = int(num_hard_examples) if num_hard_examples else n2
+    sel = torch.empty((B, max_sel), dtype=i32, device=dev)
+    num = torch.empty((B,), dtype=i32, device=dev)
+    ws = workspace(lib().nms_workspace_bytes(max(n2, 1)), "nms", dev)
+    for b in range(B):                       # per image, like the reference's loop over the clone's images
+        lib().nms(ptr(_chk(boxes[b])), ptr(scores[b]), n2, float(iou_threshold), max_sel, ptr(sel[b]), ptr(num[b:b + 1]),
+                  ptr(ws), _stream())
+    loc_loss = torch.empty((B,), dtype=f32, device=dev)
+    cls_loss = torch.empty((B,), dtype=f32, device=dev)
+    lib().hard_mining_apply(ptr(sel), ptr(num), B, max_sel, n2, ptr(loc_rl), ptr(cls_rl), ptr(_chk(d_box)),
+                            d_box.numel() // (B * n2), ptr(_chk(d_cls)), d_cls.numel() // (B * n2), ptr(loc_loss),
+                            ptr(cls_loss), _stream())
+    return loc_loss, cls_loss, sel, num
+
+
 def dropout(x, keep_prob, seed, stream_id, out=None):
     """slim.dropout in training mode with counter-hash draws (mtlssl_dropout). Call it again on the gradient with the
     same (seed, stream_id) for the backward pass."""

@@ -99,9 +99,12 @@ def detector_targets(proposal_boxes_abs, gt_boxes_abs_list, gt_classes_with_bg_l
 
 def loss_box_classifier(refined_box_encodings, class_predictions, num_proposals, tg,
                         loc_weight, cls_weight, closeness_predictions=None,
-                        closeness_weight=0.0):
+                        closeness_weight=0.0, miner=None, proposal_boxes=None):
     """faster_rcnn_meta_arch.py:1714-1793.
-    refined_box_encodings [B*N2, K, 4]; class_predictions [B*N2, K+1]."""
+    refined_box_encodings [B*N2, K, 4]; class_predictions [B*N2, K+1].
+    miner: dict(num_hard_examples | None, iou_threshold, loss_type 'both'|'cls'|'loc') = core/losses.py:418-631
+    HardExampleMiner as :1758-1762 / :1902-1946 apply it, with proposal_boxes [B,N2,4] as the decoded boxes; mined per
+    image (each clone of the reference holds one image; its loop returns after the first)."""
     cls_t = torch.from_numpy(tg["cls_targets"])            # [B,N2,K+1]
     Bn, N2, K1 = cls_t.shape
     nump = torch.as_tensor(np.asarray(num_proposals), dtype=torch.float32)
@@ -116,6 +119,28 @@ def loss_box_classifier(refined_box_encodings, class_predictions, num_proposals,
                        torch.from_numpy(tg["cls_weights"])) / normalizer
     out = {"second_stage_localization_loss": loc_weight * (loc * pad_ind).sum(),
            "second_stage_classification_loss": cls_weight * (cls * pad_ind).sum()}
+    if miner is not None:
+        from . import nms as N_
+        loc_sum, cls_sum, mined = 0.0, 0.0, []
+        for i in range(Bn):
+            n = int(num_proposals[i])
+            lc, cc = loc[i, :n], cls[i, :n]
+            if miner["loss_type"] == "cls":
+                score = cc
+            elif miner["loss_type"] == "loc":
+                score = lc
+            else:
+                score = cc * cls_weight + lc * loc_weight
+            k = miner["num_hard_examples"] if miner["num_hard_examples"] else n
+            idx = N_.greedy_nms(np.asarray(proposal_boxes[i][:n], F), score.detach().numpy().astype(F), k,
+                                miner["iou_threshold"])
+            sel = torch.as_tensor(idx.astype(np.int64))
+            loc_sum = loc_sum + lc[sel].sum()
+            cls_sum = cls_sum + cc[sel].sum()
+            mined.append(idx)
+        out = {"second_stage_localization_loss": loc_weight * loc_sum,
+               "second_stage_classification_loss": cls_weight * cls_sum}
+        out["_mined"] = mined
     if closeness_predictions is not None:
         regw = torch.from_numpy(tg["reg_weights"])
         norm_reg = torch.clamp(regw.sum(1), min=1.0)[:, None]

@@ -415,10 +415,13 @@ class Oracle:
         # ---- detector loss
         dt = L.detector_targets(boxes_abs, gt_abs, gt_cls_bg, gt_clo)
         if not first_only:
-            losses.update(L.loss_box_classifier(box_enc, cls, num, dt,
-                                                hp["second_stage_localization_loss_weight"],
-                                                hp["second_stage_classification_loss_weight"],
-                                                clo if mtl["closeness"] else None, mtl["closeness_loss_weight"]))
+            lb = L.loss_box_classifier(box_enc, cls, num, dt,
+                                       hp["second_stage_localization_loss_weight"],
+                                       hp["second_stage_classification_loss_weight"],
+                                       clo if mtl["closeness"] else None, mtl["closeness_loss_weight"],
+                                       miner=hp.get("hard_example_miner"), proposal_boxes=boxes_abs)
+            mined = lb.pop("_mined", None)
+            losses.update(lb)
         win_logits = None
         wscope = "SecondStageFeatureExtractor" if shared else "WindowBoxPredictor"     # :738-741
         if mtl["window"] and not first_only:
@@ -489,6 +492,6 @@ class Oracle:
                    rpn_objectness=obj.detach().numpy(),
                    class_predictions=None if cls is None else cls.detach().numpy(), features=Fm.detach().numpy(),
                    refined=None if refined is None else refined.detach().numpy(),
-                   refine_in=None if net is None else net.numpy(),
+                   refine_in=None if net is None else net.numpy(), mined=locals().get("mined"),
                    d_features=Fm.grad.numpy())
         return {k: float(v.detach()) for k, v in losses.items()}, grads, aux

@@ -7,6 +7,7 @@
   * mtl.shared_feature: 'classifier_feature_maps'               faster_rcnn_meta_arch.py:701-714, 735-747
     (stop_gradient_for_aux_tasks on and off)
   * first_stage_only (RPN + edge-mask head only)                faster_rcnn_meta_arch.py:603, 1029-1039, 1549-1567
+  * hard_example_miner on the second stage                      core/losses.py:418-631, faster_rcnn_meta_arch.py:1758-1762
 Dropout draws are the samplers' counter hash in both implementations (mtlssl_dropout / oracle.assign.dropout_mask)."""
 import os
 
@@ -36,6 +37,7 @@ model {
   faster_rcnn {
     num_classes: 5
     first_stage_only: %(first_only)s
+    %(miner)s
     image_resizer { keep_aspect_ratio_resizer { min_dimension: 160 max_dimension: 224 } }
     feature_extractor { type: 'faster_rcnn_resnet50' first_stage_features_stride: 16 weight_decay: 0.0 }
     first_stage_anchor_generator { grid_anchor_generator {
@@ -60,7 +62,7 @@ train_config { batch_size: 2
 """
 
 BASE = dict(refine="true", window="true", closeness="true", refine_layers=0, refine_keep="1.0", stop="true",
-            shared="proposal_feature_maps", win_avg="true", first_only="false", main_extra="")
+            shared="proposal_feature_maps", win_avg="true", first_only="false", main_extra="", miner="")
 CASES = {
     "refiner_fc_stack_with_dropout": dict(refine_layers=2, refine_keep="0.7"),
     "predictor_extra_layers_with_dropout": dict(
@@ -70,6 +72,9 @@ CASES = {
     "shared_classifier_features_stopped": dict(shared="classifier_feature_maps", stop="true"),
     "shared_classifier_features_with_gradient": dict(shared="classifier_feature_maps", stop="false"),
     "first_stage_only": dict(first_only="true", refine="false", window="false", closeness="false"),
+    "hard_example_miner_both": dict(miner="hard_example_miner { num_hard_examples: 6 iou_threshold: 0.5 loss_type: BOTH }"),
+    "hard_example_miner_cls_all_survivors": dict(
+        miner="hard_example_miner { num_hard_examples: 0 iou_threshold: 0.3 loss_type: CLASSIFICATION }"),
 }
 
 
@@ -125,6 +130,18 @@ def test_switch_matches_the_oracle(case):
     else:
         assert set(got) == {"first_stage_localization_loss", "first_stage_objectness_loss", "edgemask_loss"}
         assert "refined_box_encodings" not in pd
+    if case.startswith("hard_example_miner"):
+        sel, nsel = pd["_mined"]
+        for b in range(2):
+            n = int(nsel[b].item())
+            assert sel[b, :n].cpu().tolist() == aux["mined"][b].tolist()          # the same proposals, in mining order
+            if case == "hard_example_miner_both":
+                assert 0 < n <= 6
+        d_cls = pd["_d"]["class_predictions"].view(2, 16, -1)
+        kept = torch.zeros(2, 16, dtype=torch.bool)
+        for b in range(2):
+            kept[b, sel[b, :int(nsel[b].item())].cpu().long()] = True
+        assert not d_cls.cpu()[~kept].any()                                        # no gradient for the rest
     assert set(got) == set(ref), (sorted(got), sorted(ref))
     for k in ref:
         assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
