@@ -137,11 +137,8 @@ def test_switch_matches_the_oracle(case):
             assert sel[b, :n].cpu().tolist() == aux["mined"][b].tolist()          # the same proposals, in mining order
             if case == "hard_example_miner_both":
                 assert 0 < n <= 6
-        d_cls = pd["_d"]["class_predictions"].view(2, 16, -1)
-        kept = torch.zeros(2, 16, dtype=torch.bool)
-        for b in range(2):
-            kept[b, sel[b, :int(nsel[b].item())].cpu().long()] = True
-        assert not d_cls.cpu()[~kept].any()                                        # no gradient for the rest
+        # (that only the mined rows are back-propagated is what the gradient comparison below checks: after backward()
+        # pd["_d"]["class_predictions"] also holds the refiner's residual gradient)
     assert set(got) == set(ref), (sorted(got), sorted(ref))
     for k in ref:
         assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
