@@ -184,23 +184,37 @@ class GradientReducer:
                 "buckets": len(self.buckets)}
 
 
+def filter_variable_names(names, filter_regex_list, invert=False):
+    """utils/variables_helper.py:27-54 on names: drops the names matching (`re.match`) any non-empty pattern of the
+    list and returns the rest; with `invert` the complement (the matching names). Empty patterns are ignored."""
+    import re
+    patterns = [str(r) for r in (filter_regex_list or []) if r]
+    kept = []
+    for n in names:
+        hit = any(re.match(r, n) for r in patterns)
+        if (not hit) != bool(invert):
+            kept.append(n)
+    return kept
+
+
 def gradient_multipliers(ps, train_config):
     """Per-variable table for the fused optimizer launch, object_detection/trainer.py:389-410:
     grad_multiplier / divide_grad_by_batch on every gradient, bias_grad_multiplier on '.*/biases'
     (utils/variables_helper.py:58-78), freeze_variables (regex list, `re.match`, :29-55,100-118) as a
     negative entry = the variable is left out of the update. None when every entry is 1."""
-    import re
     base = float(train_config.grad_multiplier) if train_config.grad_multiplier else 1.0
     if train_config.divide_grad_by_batch:
         base /= float(train_config.batch_size)
     bias = float(train_config.bias_grad_multiplier) if train_config.bias_grad_multiplier else None
-    freeze = [str(r) for r in (train_config.freeze_variables or [])]
+    names = [sp.name for sp in ps.trainable_specs]
+    biases = set(filter_variable_names(names, [".*/biases"], invert=True)) if bias is not None else ()
+    frozen = set(filter_variable_names(names, list(train_config.freeze_variables or []), invert=True))
     mult = []
-    for sp in ps.trainable_specs:
+    for n in names:
         m = base
-        if bias is not None and re.match(".*/biases", sp.name):
+        if n in biases:
             m *= bias
-        if any(re.match(r, sp.name) for r in freeze):
+        if n in frozen:
             m = -1.0
         mult.append(m)
     if all(m == 1.0 for m in mult):

@@ -42,11 +42,12 @@ def argmax_match(sim, matched_threshold, unmatched_threshold=None,
 
 def assign_targets(anchors, gt_boxes, gt_labels, unmatched_cls_target,
                    matched_threshold, unmatched_threshold=None, force_match=False,
-                   gt_closeness=None, coder=None, similarity=None):
+                   gt_closeness=None, coder=None, similarity=None, match=None):
     """object_detection/core/target_assigner.py:99-213,256-403 (effective behaviour:
     crowd/ignore passes are no-ops).
 
     anchors [N,4], gt_boxes [G,4], gt_labels [G, d] (or None -> ones [G,1]).
+    match: a precomputed int32[N] match vector (e.g. from another matcher) instead of the arg-max matcher's.
     Returns dict(cls_targets [N,d], cls_weights [N], reg_targets [N,4], reg_weights [N],
                  match int32[N], closeness_targets [N,dc] or None).
     """
@@ -57,9 +58,12 @@ def assign_targets(anchors, gt_boxes, gt_labels, unmatched_cls_target,
         gt_labels = np.ones([G, 1], F)
     gt_labels = np.asarray(gt_labels, F)
     unmatched = np.asarray(unmatched_cls_target, F)
-    sim = (similarity or B.iou)(gt_boxes, anchors)
-    match = argmax_match(sim, matched_threshold, unmatched_threshold,
-                         True, force_match)
+    if match is None:
+        sim = (similarity or B.iou)(gt_boxes, anchors)
+        match = argmax_match(sim, matched_threshold, unmatched_threshold,
+                             True, force_match)
+    else:
+        match = np.asarray(match, np.int32)
     pos = match >= 0
     enc = coder if coder is not None else B.encode
     reg_targets = np.zeros([N, 4], F)

@@ -97,6 +97,34 @@ def detector_targets(proposal_boxes_abs, gt_boxes_abs_list, gt_classes_with_bg_l
     return {k: (np.stack(v) if v[0] is not None else None) for k, v in acc.items()}
 
 
+def hard_example_miner(location_losses, cls_losses, decoded_boxes, num_hard_examples, iou_threshold, loss_type,
+                        loc_loss_weight=1.0, cls_loss_weight=1.0):
+    """core/losses.py:497-573 HardExampleMiner.__call__ without a match list (the way the second stage calls it,
+    faster_rcnn_meta_arch.py:1930-1937): per image, the selection score is the classification loss ('cls'), the
+    localization loss ('loc') or their weighted sum ('both'); greedy NMS over the image's decoded boxes keeps at most
+    num_hard_examples (None: all) of them; the mined losses are the sums over the kept indices.
+    location_losses / cls_losses: per image 1-D torch tensors (or arrays); decoded_boxes: per image [n,4].
+    Returns (loc_sum, cls_sum, [kept indices per image])."""
+    from . import nms as N_
+    loc_sum, cls_sum, mined = 0.0, 0.0, []
+    for lc, cc, bx in zip(location_losses, cls_losses, decoded_boxes):
+        lc, cc = torch.as_tensor(lc), torch.as_tensor(cc)
+        n = int(lc.shape[0])
+        if loss_type == "cls":
+            score = cc
+        elif loss_type == "loc":
+            score = lc
+        else:
+            score = cc * cls_loss_weight + lc * loc_loss_weight
+        k = num_hard_examples if num_hard_examples else n
+        idx = N_.greedy_nms(np.asarray(bx, F), score.detach().numpy().astype(F), k, iou_threshold)
+        sel = torch.as_tensor(idx.astype(np.int64))
+        loc_sum = loc_sum + lc[sel].sum()
+        cls_sum = cls_sum + cc[sel].sum()
+        mined.append(idx)
+    return loc_sum, cls_sum, mined
+
+
 def loss_box_classifier(refined_box_encodings, class_predictions, num_proposals, tg,
                         loc_weight, cls_weight, closeness_predictions=None,
                         closeness_weight=0.0, miner=None, proposal_boxes=None):
@@ -120,24 +148,10 @@ def loss_box_classifier(refined_box_encodings, class_predictions, num_proposals,
     out = {"second_stage_localization_loss": loc_weight * (loc * pad_ind).sum(),
            "second_stage_classification_loss": cls_weight * (cls * pad_ind).sum()}
     if miner is not None:
-        from . import nms as N_
-        loc_sum, cls_sum, mined = 0.0, 0.0, []
-        for i in range(Bn):
-            n = int(num_proposals[i])
-            lc, cc = loc[i, :n], cls[i, :n]
-            if miner["loss_type"] == "cls":
-                score = cc
-            elif miner["loss_type"] == "loc":
-                score = lc
-            else:
-                score = cc * cls_weight + lc * loc_weight
-            k = miner["num_hard_examples"] if miner["num_hard_examples"] else n
-            idx = N_.greedy_nms(np.asarray(proposal_boxes[i][:n], F), score.detach().numpy().astype(F), k,
-                                miner["iou_threshold"])
-            sel = torch.as_tensor(idx.astype(np.int64))
-            loc_sum = loc_sum + lc[sel].sum()
-            cls_sum = cls_sum + cc[sel].sum()
-            mined.append(idx)
+        loc_sum, cls_sum, mined = hard_example_miner(
+            [loc[i, :int(num_proposals[i])] for i in range(Bn)], [cls[i, :int(num_proposals[i])] for i in range(Bn)],
+            [np.asarray(proposal_boxes[i][:int(num_proposals[i])], F) for i in range(Bn)],
+            miner["num_hard_examples"], miner["iou_threshold"], miner["loss_type"], loc_weight, cls_weight)
         out = {"second_stage_localization_loss": loc_weight * loc_sum,
                "second_stage_classification_loss": cls_weight * cls_sum}
         out["_mined"] = mined

@@ -220,6 +220,145 @@ VEC = {
         gt_classes=[[[1, 0], [0, 1]], [[1, 0], [1, 0]]],
         expected=dict(first_stage_localization_loss=0, first_stage_objectness_loss=0,
                       second_stage_localization_loss=0, second_stage_classification_loss=0)),
+    # object_detection/utils/ops_test.py:24-40
+    "ops_helpers": {'source': 'object_detection/utils/ops_test.py:24-40 (normalized_to_image_coordinates), :45-84 (meshgrid), '
+               ':110-176 (padded_one_hot_encoding), :232-346 (indices_to_dense_vector)',
+     'normalized_to_image': {'boxes': [[[0.0, 0.0, 1.0, 1.0]], [[0.5, 0.5, 1.0, 1.0]]],
+                             'image_shape': [1, 4, 4, 3],
+                             'expected': [[[0, 0, 4, 4]], [[2, 2, 4, 4]]]},
+     'meshgrid_vectors': {'x': [0, 1, 2, 3], 'y': [0, 1, 2, 3, 4, 5]},
+     'meshgrid_multi': {'seed': 18,
+                        'x_shape': [4, 1, 2],
+                        'y_shape': [2, 3],
+                        'grid_shape': [2, 3, 4, 1, 2],
+                        'elements': [[[3, 0, 0], [1, 2]], [[2, 0, 1], [0, 0]], [[0, 0, 0], [1, 1]]]},
+     'one_hot': {'indices': [1, 2, 3, 5],
+                 'depth': 6,
+                 'pad0': [[0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 1]],
+                 'pad1': [[0, 0, 1, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 0, 1]],
+                 'pad3': [[0, 0, 0, 0, 1, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 0, 0, 1, 0, 0],
+                          [0, 0, 0, 0, 0, 0, 0, 0, 1]],
+                 'empty': {'depth': 6, 'pad': 2, 'shape': [0, 8]},
+                 'zero_depth_is_none': True},
+     'dense_vector': {'cases': [{'size': 10000, 'seed': 0, 'num': 4321}, {'size': 5000, 'seed': 1, 'num': 250},
+                                {'size': 500, 'seed': 2, 'num': 25, 'dtype': 'int64', 'value': 1},
+                                {'size': 100, 'seed': 3, 'num': 10, 'value': 0.37, 'default': 0.81},
+                                {'size': 500, 'seed': 4, 'num': 500}, {'size': 500, 'seed': 5, 'num': 0}]}},
+    # object_detection/meta_architectures/faster_rcnn_meta_arch_test_lib.py:461-521
+    "rpn_postprocess_train": {'source': 'object_detection/meta_architectures/faster_rcnn_meta_arch_test_lib.py:461-521 '
+               '(test_postprocess_first_stage_only_train_mode; model of :109-224: nms score -1 / iou 1.0, 8 proposals, '
+               'second_stage_batch_size 2, balance fraction 1.0)',
+     'anchors': [[0, 0, 16, 16], [0, 16, 16, 32], [16, 0, 32, 16], [16, 16, 32, 32]],
+     'objectness': [[[-10, 13], [-10, 12], [-10, 11], [-10, 10]], [[-10, 13], [-10, 12], [-10, 11], [-10, 10]]],
+     'image_hw': [32, 32],
+     'max_proposals': 8,
+     'iou_thresh': 1.0,
+     'score_thresh': -1.0,
+     'second_stage_batch_size': 2,
+     'balance_fraction': 1.0,
+     'gt_boxes': [[[0, 0, 0.5, 0.5], [0.5, 0.5, 1, 1]], [[0, 0.5, 0.5, 1], [0.5, 0, 1, 0.5]]],
+     'gt_classes': [[[1, 0], [0, 1]], [[1, 0], [1, 0]]],
+     'expected_boxes_normalized': [[[0, 0, 0.5, 0.5], [0.5, 0.5, 1, 1]], [[0, 0.5, 0.5, 1], [0.5, 0, 1, 0.5]]],
+     'expected_num': [2, 2]},
+    # object_detection/meta_architectures/faster_rcnn_meta_arch_test_lib.py:523-590
+    "second_stage_postprocess": {'source': 'object_detection/meta_architectures/faster_rcnn_meta_arch_test_lib.py:523-590 '
+               '(test_postprocess_second_stage_only_inference_mode; model of :109-224: identity score conversion, nms '
+               'score -20 / iou 1.0, 5 per class, 5 in total, 2 classes, 8 padded proposals)',
+     'image_hw': [36, 48],
+     'num_classes': 2,
+     'max_num_proposals': 8,
+     'proposal_boxes': [[[1, 1, 2, 3], [0, 0, 1, 1], [0.5, 0.5, 0.6, 0.6], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0],
+                         [0, 0, 0, 0], [0, 0, 0, 0]],
+                        [[2, 3, 6, 8], [1, 2, 5, 3], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0],
+                         [0, 0, 0, 0], [0, 0, 0, 0]]],
+     'num_proposals': [3, 2],
+     'score_thresh': -20.0,
+     'iou_thresh': 1.0,
+     'max_per_class': 5,
+     'max_total': 5,
+     'expected_scores': [[1, 1, 1, 1, 1], [1, 1, 1, 1, 0]],
+     'expected_classes': [[0, 0, 0, 1, 1], [0, 0, 1, 1, 0]],
+     'expected_num': [5, 4],
+     'expected_boxes_shape': [2, 5, 4]},
+    # object_detection/core/losses_test.py:377-457 (HardExampleMiner without a match list, the way the second stage
+    # calls it): per-image location / classification losses, decoded boxes, expected mined sums
+    "hard_example_miner": [
+        dict(source="losses_test.py:377-403", loc=[[100, 90, 80, 0], [0, 1, 2, 3]], cls=[[0, 10, 50, 110], [9, 6, 3, 0]],
+             boxes=4 * [[0.1, 0.1, 0.9, 0.9]], num_hard_examples=1, iou_threshold=0.0, loss_type="loc",
+             exp_loc=103, exp_cls=0),
+        dict(source="losses_test.py:405-430", loc=[[100, 90, 80, 0], [0, 1, 2, 3]], cls=[[0, 10, 50, 110], [9, 6, 3, 0]],
+             boxes=4 * [[0.1, 0.1, 0.9, 0.9]], num_hard_examples=1, iou_threshold=0.0, loss_type="both",
+             exp_loc=80, exp_cls=59),
+        dict(source="losses_test.py:432-457", loc=[[100, 90, 80, 0], [0, 1, 2, 3]], cls=[[0, 10, 50, 110], [9, 6, 3, 0]],
+             boxes=[[0.1, 0.1, 0.9, 0.9], [0.9, 0.9, 0.99, 0.99], [0.1, 0.1, 0.9, 0.9], [0.1, 0.1, 0.9, 0.9]],
+             num_hard_examples=2, iou_threshold=0.5, loss_type="cls", exp_loc=91, exp_cls=135),
+    ],
+    # object_detection/core/box_list_ops_test.py:48-62 (scale), :219-235 (ioa), :292-303 (change_coordinate_frame),
+    # :785-824 (to_normalized / to_absolute); core/region_similarity_calculator_test.py:25-36 (IoU similarity)
+    "box_ops_more": dict(
+        scale=dict(boxes=[[0, 0, 100, 200], [50, 120, 100, 140]], y=1.0 / 100, x=1.0 / 200,
+                   expected=[[0, 0, 1, 1], [0.5, 0.6, 1.0, 0.7]]),
+        c1=[[4.0, 3.0, 7.0, 5.0], [5.0, 6.0, 10.0, 7.0]],
+        c2=[[3.0, 4.0, 6.0, 8.0], [14.0, 14.0, 15.0, 15.0], [0.0, 0.0, 20.0, 20.0]],
+        ioa_12=[[2.0 / 12.0, 0, 6.0 / 400.0], [1.0 / 12.0, 0.0, 5.0 / 400.0]],
+        ioa_21=[[2.0 / 6.0, 1.0 / 5.0], [0, 0], [6.0 / 6.0, 5.0 / 5.0]],
+        iou_12=[[2.0 / 16.0, 0, 6.0 / 400.0], [1.0 / 16.0, 0.0, 5.0 / 400.0]],
+        change_frame=dict(boxes=[[0.25, 0.5, 0.75, 0.75], [0.5, 0.0, 1.0, 1.0]], window=[0.25, 0.25, 0.75, 0.75],
+                          expected=[[0, 0.5, 1.0, 1.0], [0.5, -0.5, 1.5, 1.5]]),
+        absolute=[[0, 0, 100, 100], [25, 25, 75, 75]], normalized=[[0, 0, 1, 1], [0.25, 0.25, 0.75, 0.75]],
+        image_hw=[100, 100]),
+    # object_detection/core/target_assigner_test.py:261-317 (multiclass targets), :412-465 (no groundtruth) and
+    # :595-662 (batch of two images). Those tests match with GreedyBipartiteMatcher on negated squared distances,
+    # components the Faster R-CNN path never builds; `match` is the matcher's result as the tests state it
+    # (matched_column_indices per image), the expectations pin what the assigner makes of a match: class targets with
+    # the unmatched (background) row, class weights, MeanStddev-coded regression targets, regression weights.
+    "assign_multiclass": dict(
+        priors=[[0.0, 0.0, 0.5, 0.5], [0.5, 0.5, 1.0, 0.8], [0, 0.5, .5, 1.0], [.75, 0, 1.0, .25]],
+        boxes=[[0.0, 0.0, 0.5, 0.5], [0.5, 0.5, 0.9, 0.9], [.75, 0, .95, .27]],
+        labels=[[0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1, 0], [0, 0, 0, 1, 0, 0, 0]],
+        unmatched=[1, 0, 0, 0, 0, 0, 0], match=[0, 1, -1, 2],
+        cls_targets=[[0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1, 0], [1, 0, 0, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0, 0]],
+        cls_weights=[1, 1, 1, 1], reg_targets=[[0, 0, 0, 0], [0, 0, -1, 1], [0, 0, 0, 0], [0, 0, -.5, .2]],
+        reg_weights=[1, 1, 0, 1]),
+    "assign_empty_groundtruth": dict(
+        priors=[[0.0, 0.0, 0.5, 0.5], [0.5, 0.5, 1.0, 0.8], [0, 0.5, .5, 1.0], [.75, 0, 1.0, .25]],
+        unmatched=[0, 0, 0], cls_targets=4 * [[0, 0, 0]], cls_weights=[1, 1, 1, 1], reg_targets=4 * [[0, 0, 0, 0]],
+        reg_weights=[0, 0, 0, 0]),
+    "batch_assign_multiclass": dict(
+        priors=[[0, 0, .25, .25], [0, .25, 1, 1], [0, .1, .5, .5], [.75, .75, 1, 1]],
+        boxes=[[[0., 0., 0.2, 0.2]], [[0, 0.25123152, 1, 1], [0.015789, 0.0985, 0.55789, 0.3842]]],
+        labels=[[[0, 1, 0, 0]], [[0, 0, 0, 1], [0, 0, 1, 0]]], unmatched=[1, 0, 0, 0],
+        match=[[0, -1, -1, -1], [-1, 0, 1, -1]],
+        reg_targets=[[[0, 0, -0.5, -0.5], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]],
+                     [[0, 0, 0, 0], [0, 0.01231521, 0, 0], [0.15789001, -0.01500003, 0.57889998, -1.15799987],
+                      [0, 0, 0, 0]]],
+        cls_weights=[[1, 1, 1, 1], [1, 1, 1, 1]],
+        cls_targets=[[[0, 1, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0]],
+                     [[1, 0, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0], [1, 0, 0, 0]]],
+        reg_weights=[[1, 0, 0, 0], [0, 1, 1, 0]]),
+    # object_detection/core/balanced_positive_negative_sampler_test.py:26-63 and minibatch_sampler_test.py:26-80:
+    # the reference shuffles, so its tests state counts and containment only
+    "sampler_counts": dict(
+        balanced=[dict(n=300, indicator_below=300, positives_from=201, batch=64, exp_total=64, exp_pos=32, exp_neg=32),
+                  dict(n=100, indicator_below=90, positives_from=80, batch=64, exp_total=64, exp_pos=10, exp_neg=54)],
+        indicator=[True, False, True, False, True, True, False],
+        subsample=[dict(num=3, exp=3), dict(num=5, exp=4), dict(num=0, exp=0)]),
+    # object_detection/utils/learning_schedules_test.py:42-56
+    "manual_stepping": dict(boundaries=[2, 3, 7], rates=[1.0, 2.0, 3.0, 4.0],
+                            expected=[1.0, 1.0, 2.0, 3.0, 3.0, 3.0, 3.0, 4.0, 4.0, 4.0]),
+    # object_detection/utils/variables_helper_test.py:65-126: (gradient, variable value) pairs before / after
+    "variables_helper": dict(
+        names=["FeatureExtractor/InceptionV3/weights", "FeatureExtractor/InceptionV3/biases",
+               "StackProposalGenerator/weights", "StackProposalGenerator/biases"],
+        grads=[1.0, 2.0, 3.0, 4.0],
+        multiply=[dict(regex=["FeatureExtractor/.*"], multiplier=0.0, expected=[0.0, 0.0, 3.0, 4.0]),
+                  dict(regex=[".*/biases"], multiplier=0.0, expected=[1.0, 0.0, 3.0, 0.0])],
+        freeze=dict(regex=["FeatureExtractor/.*"], kept=[2, 3]),
+        filter=[dict(regex=[""], invert=False, kept=[0, 1, 2, 3]),
+                dict(regex=["FeatureExtractor/.*"], invert=False, kept=[2, 3]),
+                dict(regex=["FeatureExtractor.*biases", "StackProposalGenerator.*biases"], invert=False, kept=[0, 2]),
+                dict(regex=[""], invert=True, kept=[]),
+                dict(regex=["FeatureExtractor.*biases", "StackProposalGenerator.*biases"], invert=True, kept=[1, 3])]),
 }
 
 

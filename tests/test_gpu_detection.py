@@ -405,3 +405,27 @@ def test_scatter_rows_is_indices_to_dense_vector(ops, vec):
         want = Hh.indices_to_dense_vector(idx, c["size"])
         got = ops.scatter_rows(torch.ones((1, len(idx), 1), device="cuda"), cu(idx), c["size"])
         np.testing.assert_array_equal(got.cpu().numpy().reshape(-1), want)
+
+
+def test_hard_example_miner_golden(ops, vec):
+    """core/losses_test.py:377-457 through mtlssl_hard_mining_scores / mtlssl_nms / mtlssl_hard_mining_apply: the mined
+    sums of the reference's three cases, the same indices as the oracle, and gradient rows of proposals that were not
+    mined set to zero."""
+    for c in vec["hard_example_miner"]:
+        loc, cls = np.array(c["loc"], np.float32), np.array(c["cls"], np.float32)
+        Bn, n2 = loc.shape
+        boxes = np.tile(np.array(c["boxes"], np.float32)[None], (Bn, 1, 1))
+        d_box = torch.ones((Bn * n2, 8), dtype=torch.float32, device="cuda")
+        d_cls = torch.ones((Bn * n2, 3), dtype=torch.float32, device="cuda")
+        ll, cl, sel, num = ops.hard_example_mining(cu(loc), cu(cls), cu(boxes), cu(np.full(Bn, n2, np.int32)), d_box, d_cls,
+                                                   c["num_hard_examples"], c["iou_threshold"], c["loss_type"])
+        assert float(ll.sum()) == c["exp_loc"] and float(cl.sum()) == c["exp_cls"], c["source"]
+        _, _, mined = L.hard_example_miner(list(loc), list(cls), list(boxes), c["num_hard_examples"], c["iou_threshold"],
+                                           c["loss_type"])
+        keep = np.zeros((Bn, n2), bool)
+        for b in range(Bn):
+            k = int(num[b])
+            assert sel[b, :k].cpu().tolist() == mined[b].tolist()
+            keep[b, mined[b]] = True
+        np.testing.assert_array_equal(d_box.cpu().numpy(), np.repeat(keep.reshape(-1, 1), 8, 1).astype(np.float32))
+        np.testing.assert_array_equal(d_cls.cpu().numpy(), np.repeat(keep.reshape(-1, 1), 3, 1).astype(np.float32))

@@ -460,3 +460,52 @@ def test_oracle_rmsprop_and_adam_known_answers():
     v, m, vv = {"w": np.array([1.0, -2.0], np.float32)}, {}, {}
     O.adam_update(v, {"w": np.array([0.5, -1.0], np.float32)}, m, vv, step=1, lr=0.1, beta1=0.9, beta2=0.999, epsilon=1e-8, clip_norm=0.0)
     np.testing.assert_allclose(v["w"], np.array([0.9, -1.9]), rtol=1e-5)      # the first Adam step moves every weight by lr
+
+
+def _reference_vectors():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")) as f:
+        return json.load(f)
+
+
+def test_manual_stepping_on_the_reference_vector():
+    """utils/learning_schedules_test.py:42-56: boundaries [2, 3, 7], rates [1, 2, 3, 4], steps 0..9."""
+    from mtl_ssl_amd import trainer
+    v = _reference_vectors()["manual_stepping"]
+    got = [trainer.manual_stepping(s, v["boundaries"], v["rates"]) for s in range(len(v["expected"]))]
+    assert got == v["expected"]
+
+
+def test_variable_filters_on_the_reference_vectors():
+    """utils/variables_helper_test.py:32-126: filter_variables with and without `invert` (empty patterns ignored),
+    multiply_gradients_matching_regex and freeze_gradients_matching_regex — as name filters and as the per-variable
+    multiplier table the fused update takes (negative = left out of the update)."""
+    from mtl_ssl_amd import config, trainer
+    from mtl_ssl_amd.params import ParamStore
+    v = _reference_vectors()["variables_helper"]
+    names = v["names"]
+    for c in v["filter"]:
+        assert trainer.filter_variable_names(names, c["regex"], invert=c["invert"]) == [names[i] for i in c["kept"]]
+    for c in v["multiply"]:
+        hit = trainer.filter_variable_names(names, c["regex"], invert=True)
+        got = [g * (c["multiplier"] if n in hit else 1.0) for g, n in zip(v["grads"], names)]
+        assert got == c["expected"]
+    ps = ParamStore()
+    for n in names:
+        ps.add(n, (2,), ("zeros",))
+    ps.finalize("cpu")
+    assert [sp.name for sp in ps.trainable_specs] == names
+    fz = v["freeze"]
+    tc = config.parse_pipeline_config("train_config { batch_size: 1 %s }" % " ".join(
+        "freeze_variables: '%s'" % r for r in fz["regex"])).train_config
+    m = trainer.gradient_multipliers(ps, tc).numpy()
+    assert [i for i in range(len(names)) if m[i] >= 0] == fz["kept"]
+    # the second multiply case is trainer.py:399-403's bias multiplier ('.*/biases'); 0.0 means "unset" there
+    # (a proto float tested for truth), so the selection is checked with another factor
+    tc = config.parse_pipeline_config("train_config { batch_size: 1 bias_grad_multiplier: 2.0 }").train_config
+    m = trainer.gradient_multipliers(ps, tc).numpy()
+    want_hit = [e == 0.0 for e in v["multiply"][1]["expected"]]
+    assert [x == 2.0 for x in m] == want_hit
+    # an empty pattern in freeze_variables freezes nothing (filter(None, ...) at variables_helper.py:45)
+    tc = config.parse_pipeline_config("train_config { batch_size: 1 freeze_variables: '' }").train_config
+    assert trainer.gradient_multipliers(ps, tc) is None

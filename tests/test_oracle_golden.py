@@ -297,3 +297,82 @@ def test_second_stage_postprocess_known_answer(vec):
     np.testing.assert_allclose(os_, v["expected_scores"])
     np.testing.assert_allclose(oc, v["expected_classes"])
     assert on.tolist() == v["expected_num"]
+
+
+def test_hard_example_miner_known_answers(vec):
+    """core/losses_test.py:377-457: the three HardExampleMiner cases that run without a match list (the second
+    stage's call, faster_rcnn_meta_arch.py:1930-1937)."""
+    for c in vec["hard_example_miner"]:
+        loc = [torch.tensor(r, dtype=torch.float32) for r in c["loc"]]
+        cls = [torch.tensor(r, dtype=torch.float32) for r in c["cls"]]
+        boxes = [np.array(c["boxes"], np.float32)] * len(loc)
+        ls, cs, mined = L.hard_example_miner(loc, cls, boxes, c["num_hard_examples"], c["iou_threshold"], c["loss_type"])
+        assert float(ls) == c["exp_loc"] and float(cs) == c["exp_cls"], (c["source"], float(ls), float(cs))
+        assert all(len(m) <= c["num_hard_examples"] for m in mined)
+
+
+def test_more_box_ops_known_answers(vec):
+    """box_list_ops_test.py:48-62, 219-235, 292-303, 785-824; region_similarity_calculator_test.py:25-36."""
+    v = vec["box_ops_more"]
+    s = v["scale"]
+    np.testing.assert_allclose(B.scale(s["boxes"], s["y"], s["x"]), s["expected"], rtol=1e-6)
+    np.testing.assert_allclose(B.ioa(v["c1"], v["c2"]), v["ioa_12"], rtol=1e-6)
+    np.testing.assert_allclose(B.ioa(v["c2"], v["c1"]), v["ioa_21"], rtol=1e-6)
+    np.testing.assert_allclose(B.iou(v["c1"], v["c2"]), v["iou_12"], rtol=1e-6)
+    cf = v["change_frame"]
+    np.testing.assert_allclose(B.change_coordinate_frame(cf["boxes"], cf["window"]), cf["expected"], rtol=1e-6)
+    H, W = v["image_hw"]
+    np.testing.assert_allclose(B.to_normalized(v["absolute"], H, W), v["normalized"], rtol=1e-6)
+    np.testing.assert_allclose(B.to_absolute(v["normalized"], H, W), v["absolute"], rtol=1e-6)
+
+
+def test_target_assigner_multiclass_and_batch_known_answers(vec):
+    """target_assigner_test.py:261-317, 412-465, 595-662: what the assigner makes of a given match (the tests'
+    bipartite matcher is not part of this path; its result is fixture data)."""
+    v = vec["assign_multiclass"]
+    r = A.assign_targets(v["priors"], v["boxes"], v["labels"], v["unmatched"], None, coder=B.mean_stddev_encode,
+                         match=v["match"])
+    np.testing.assert_allclose(r["cls_targets"], v["cls_targets"])
+    np.testing.assert_allclose(r["cls_weights"], v["cls_weights"])
+    np.testing.assert_allclose(r["reg_targets"], v["reg_targets"], atol=1e-5)
+    np.testing.assert_allclose(r["reg_weights"], v["reg_weights"])
+    for k in ("cls_targets", "cls_weights", "reg_targets", "reg_weights"):
+        assert r[k].dtype == np.float32
+    assert r["match"].dtype == np.int32
+    # no groundtruth at all: through the arg-max matcher itself (G == 0)
+    v = vec["assign_empty_groundtruth"]
+    r = A.assign_targets(v["priors"], np.zeros((0, 4), np.float32), np.zeros((0, 3), np.float32), v["unmatched"], 0.5,
+                         coder=B.mean_stddev_encode)
+    np.testing.assert_allclose(r["cls_targets"], v["cls_targets"])
+    np.testing.assert_allclose(r["cls_weights"], v["cls_weights"])
+    np.testing.assert_allclose(r["reg_targets"], v["reg_targets"])
+    np.testing.assert_allclose(r["reg_weights"], v["reg_weights"])
+    assert (r["match"] == -1).all()
+    v = vec["batch_assign_multiclass"]
+    for i in range(2):
+        r = A.assign_targets(v["priors"], v["boxes"][i], v["labels"][i], v["unmatched"], None,
+                             coder=B.mean_stddev_encode, match=v["match"][i])
+        np.testing.assert_allclose(r["cls_targets"], v["cls_targets"][i])
+        np.testing.assert_allclose(r["cls_weights"], v["cls_weights"][i])
+        np.testing.assert_allclose(r["reg_targets"], v["reg_targets"][i], atol=2e-6)
+        np.testing.assert_allclose(r["reg_weights"], v["reg_weights"][i])
+
+
+def test_sampler_counts_of_the_reference_tests(vec):
+    """balanced_positive_negative_sampler_test.py:26-63, minibatch_sampler_test.py:26-80 — the reference's own inputs
+    and count expectations (its shuffle is replaced by the counter hash: any priority must satisfy them)."""
+    v = vec["sampler_counts"]
+    for c in v["balanced"]:
+        for seed in (0, 7, 12345):
+            n = c["n"]
+            labels = np.random.RandomState(seed).permutation(n) >= c["positives_from"] if c["indicator_below"] == n \
+                else np.arange(n) >= c["positives_from"]
+            ind = np.arange(n) < c["indicator_below"]
+            s = A.balanced_subsample(ind, c["batch"], labels, 0.5, A.hash_priority(seed, n))
+            assert s.sum() == c["exp_total"] and (s & labels).sum() == c["exp_pos"] and (s & ~labels).sum() == c["exp_neg"]
+            assert not (s & ~ind).any()
+    ind = np.array(v["indicator"], bool)
+    for c in v["subsample"]:
+        s = A.subsample_indicator(ind, c["num"], A.hash_priority(3, len(ind)))
+        assert s.sum() == c["exp"] and not (s & ~ind).any()
+    assert A.subsample_indicator(np.zeros(0, bool), 4, A.hash_priority(3, 0)).size == 0
