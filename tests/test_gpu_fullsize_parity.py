@@ -5,6 +5,7 @@ finishes in seconds on the GPU box's host cores):
               (configs/frcnn_resnet101_coco_mtl.config — bench.py's workload; 14 453 anchors inside the window)
   configs[0]  Faster R-CNN MobileNet-v1, VOC07 settings, 600x800 (a 500x375 VOC image through the 600/1024 resizer)
   configs[2]  R-FCN ResNet-101 (block4 on the whole 38x64 map, PS-RoI pooling), 600x1024
+  configs[4]  Faster R-CNN Inception-ResNet-v2, 90 classes, 800x1333 (one GPU's share of the 8-GPU configuration)
 
 `Trainer.forward_backward` (HIP path through the C ABI) against `Oracle.step` (torch-CPU fp32 + numpy) on the same
 synthetic image, weights and sampler seed: every loss <= 1e-3 relative, anchor matches / sampler picks / detector
@@ -36,6 +37,8 @@ CASES = {
                                          n_all=38 * 50 * 12),
     "configs2_rfcn_resnet101_voc": dict(config="rfcn_resnet101_voc_mtl.config", H=600, W=1024, n_inside=14453,
                                         n_all=29184),
+    "configs4_frcnn_inception_resnet_v2_coco": dict(config="frcnn_inception_resnet_v2_coco_mtl.config", H=800, W=1333,
+                                                    n_inside=None, n_all=None),
 }
 
 
@@ -108,7 +111,8 @@ def test_full_size_step_matches_the_oracle(name):
     mine = pd["proposal_boxes"].cpu().numpy()
     same_rows = int((np.abs(free_boxes - mine).max(-1) <= 1e-3 * max(H, W)).sum())
     # ---- shapes of the reference's prediction_dict at this size
-    assert pd["_n_all"] == case["n_all"]
+    if case["n_all"]:
+        assert pd["_n_all"] == case["n_all"]
     if case["n_inside"]:
         assert pd["anchors"].shape[0] == case["n_inside"]
     # ---- integer work: bit-exact
