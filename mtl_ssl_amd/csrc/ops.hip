@@ -377,42 +377,121 @@ __global__ void __launch_bounds__(256)
   float inv = 1.f / (float)(nb * bs_y * bs_x);
   for (int c = threadIdx.x; c < Cc; c += blockDim.x) out[(int64_t)r * Cc + c] = s_acc[c] * inv;
 }
+// Backward as a gather: one block per score-map pixel, a thread per channel. A channel belongs to one bin of every
+// RoI; the bilinear weights a bin's bs_y x bs_x samples put on pixel (y, x) factor into (sum over the sample rows
+// touching y) * (sum over the sample columns touching x) and do not depend on the channel inside the bin. So the block
+// first evaluates, for every RoI of its image, bins_y row sums and bins_x column sums, keeps the RoIs with a non-zero
+// one of each (an ORDER-PRESERVING compaction: thread t owns a contiguous run of RoIs) in LDS, and then every channel
+// thread adds dout[r][c] * wy[r][by] * wx[r][bx] over the kept RoIs in index order. No atomics: the element's owner
+// is the only writer and the order of its sum is fixed, so two runs give the same bits.
+constexpr int kPsChunk = 1024;          // RoIs per pass through LDS
+constexpr int kPsBins = 8;             // bins per side at most
 __global__ void __launch_bounds__(256)
-    k_psroi_bwd(const float* __restrict__ dout, int H, int W, int Ctot, const float* __restrict__ boxes,
-                const int32_t* __restrict__ box_ind, int bins_y, int bins_x, int bs_y, int bs_x, int Cc,
-                float* __restrict__ dfmap) {
-  int r = blockIdx.x;
-  float4 bx = *reinterpret_cast<const float4*>(boxes + (int64_t)r * 4);
-  float* fb = dfmap + (int64_t)box_ind[r] * H * W * Ctot;
-  int nb = bins_y * bins_x;
-  float step_y = (bx.z - bx.x) / (float)bins_y, step_x = (bx.w - bx.y) / (float)bins_x;
-  float inv = 1.f / (float)(nb * bs_y * bs_x);
-  for (int t = threadIdx.x; t < nb * Cc; t += blockDim.x) {
-    int g = t / Cc, c = t % Cc;
-    int by = g / bins_x, bxi = g % bins_x;
-    float y1 = bx.x + (float)by * step_y, y2 = bx.x + (float)(by + 1) * step_y;
-    float x1 = bx.y + (float)bxi * step_x, x2 = bx.y + (float)(bxi + 1) * step_x;
-    float hs = bs_y > 1 ? (y2 - y1) * (float)(H - 1) / (float)(bs_y - 1) : 0.f;
-    float ws = bs_x > 1 ? (x2 - x1) * (float)(W - 1) / (float)(bs_x - 1) : 0.f;
-    float gr = dout[(int64_t)r * Cc + c] * inv;
-    int ch = g * Cc + c;
-    for (int iy = 0; iy < bs_y; ++iy) {
-      float in_y = bs_y > 1 ? y1 * (float)(H - 1) + (float)iy * hs : 0.5f * (y1 + y2) * (float)(H - 1);
-      if (in_y < 0.f || in_y > (float)(H - 1)) continue;
-      int ty = (int)floorf(in_y), byy = (int)ceilf(in_y);
-      float yl = in_y - (float)ty;
-      for (int ix = 0; ix < bs_x; ++ix) {
-        float in_x = bs_x > 1 ? x1 * (float)(W - 1) + (float)ix * ws : 0.5f * (x1 + x2) * (float)(W - 1);
-        if (in_x < 0.f || in_x > (float)(W - 1)) continue;
-        int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
-        float xl = in_x - (float)lx;
-        float dtop = (1.f - yl) * gr, dbot = yl * gr;
-        unsafeAtomicAdd(fb + ((int64_t)ty * W + lx) * Ctot + ch, (1.f - xl) * dtop);
-        unsafeAtomicAdd(fb + ((int64_t)ty * W + rx) * Ctot + ch, xl * dtop);
-        unsafeAtomicAdd(fb + ((int64_t)byy * W + lx) * Ctot + ch, (1.f - xl) * dbot);
-        unsafeAtomicAdd(fb + ((int64_t)byy * W + rx) * Ctot + ch, xl * dbot);
+    k_psroi_bwd_gather(const float* __restrict__ dout, int H, int W, int Ctot, const float* __restrict__ boxes,
+                       const int32_t* __restrict__ box_ind, int R, int bins_y, int bins_x, int bs_y, int bs_x, int Cc,
+                       float* __restrict__ dfmap) {
+  extern __shared__ float s_dyn[];
+  const int nw = bins_y + bins_x;
+  float* s_w = s_dyn;                                         // [kept][nw]: row sums then column sums
+  int* s_r = reinterpret_cast<int*>(s_dyn + (size_t)kPsChunk * nw);   // [kept] RoI index
+  __shared__ int s_cnt[257];
+  const int px = blockIdx.x, tid = threadIdx.x;
+  const int x = px % W, y = (px / W) % H, img = px / (W * H);
+  const float fy = (float)y, fx = (float)x, Hm = (float)(H - 1), Wm = (float)(W - 1);
+  const int nb = bins_y * bins_x;
+  const float inv = 1.f / (float)(nb * bs_y * bs_x);
+  const int nch = (Ctot + 255) / 256;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                        // channels tid, tid + 256, ... (host: Ctot <= 1024)
+  for (int r0 = 0; r0 < R; r0 += kPsChunk) {
+    const int rn = min(kPsChunk, R - r0);
+    const int per = (rn + 255) / 256;                         // thread t owns RoIs [r0 + t*per, r0 + (t+1)*per)
+    const int lo = r0 + tid * per, hi = min(lo + per, r0 + rn);
+    // pass 1: count this thread's kept RoIs; pass 2 (after the scan) recomputes and stores them in order
+    for (int pass = 0; pass < 2; ++pass) {
+      int n = 0;
+      int base = pass ? s_cnt[tid] : 0;
+      for (int r = lo; r < hi; ++r) {
+        if (box_ind[r] != img) continue;
+        float4 bx = *reinterpret_cast<const float4*>(boxes + (int64_t)r * 4);
+        {   // cheap reject on the whole box grown by a pixel
+          float ylo = fminf(bx.x, bx.z) * Hm, yhi = fmaxf(bx.x, bx.z) * Hm;
+          float xlo = fminf(bx.y, bx.w) * Wm, xhi = fmaxf(bx.y, bx.w) * Wm;
+          if (!(fy >= floorf(ylo) - 1.f && fy <= ceilf(yhi) + 1.f && fx >= floorf(xlo) - 1.f && fx <= ceilf(xhi) + 1.f))
+            continue;
+        }
+        float step_y = (bx.z - bx.x) / (float)bins_y, step_x = (bx.w - bx.y) / (float)bins_x;
+        float wsum_y = 0.f, wsum_x = 0.f;
+        float wv[2 * kPsBins];
+#pragma unroll
+        for (int b = 0; b < kPsBins; ++b) {
+          if (b >= bins_y) continue;
+          float y1 = bx.x + (float)b * step_y, y2 = bx.x + (float)(b + 1) * step_y;
+          float hs = bs_y > 1 ? (y2 - y1) * Hm / (float)(bs_y - 1) : 0.f;
+          float wy = 0.f;
+          for (int iy = 0; iy < bs_y; ++iy) {
+            float in_y = bs_y > 1 ? y1 * Hm + (float)iy * hs : 0.5f * (y1 + y2) * Hm;
+            if (in_y < 0.f || in_y > Hm) continue;
+            float ty = floorf(in_y), yl = in_y - ty;
+            if (ty == fy) wy += 1.f - yl;
+            if (ceilf(in_y) == fy) wy += yl;
+          }
+          wv[b] = wy; wsum_y += wy;
+        }
+        if (wsum_y == 0.f) continue;
+#pragma unroll
+        for (int b = 0; b < kPsBins; ++b) {
+          if (b >= bins_x) continue;
+          float x1 = bx.y + (float)b * step_x, x2 = bx.y + (float)(b + 1) * step_x;
+          float ws = bs_x > 1 ? (x2 - x1) * Wm / (float)(bs_x - 1) : 0.f;
+          float wx = 0.f;
+          for (int ix = 0; ix < bs_x; ++ix) {
+            float in_x = bs_x > 1 ? x1 * Wm + (float)ix * ws : 0.5f * (x1 + x2) * Wm;
+            if (in_x < 0.f || in_x > Wm) continue;
+            float lx = floorf(in_x), xl = in_x - lx;
+            if (lx == fx) wx += 1.f - xl;
+            if (ceilf(in_x) == fx) wx += xl;
+          }
+          wv[kPsBins + b] = wx; wsum_x += wx;
+        }
+        if (wsum_x == 0.f) continue;
+        if (pass) {
+          s_r[base + n] = r;
+#pragma unroll
+          for (int b = 0; b < kPsBins; ++b) {
+            if (b < bins_y) s_w[(size_t)(base + n) * nw + b] = wv[b];
+            if (b < bins_x) s_w[(size_t)(base + n) * nw + bins_y + b] = wv[kPsBins + b];
+          }
+        }
+        ++n;
+      }
+      if (!pass) {
+        __syncthreads();                                      // previous chunk's readers are done with s_cnt / s_w
+        s_cnt[tid + 1] = n;
+        if (tid == 0) s_cnt[0] = 0;
+        __syncthreads();
+        if (tid == 0)
+          for (int t = 1; t <= 256; ++t) s_cnt[t] += s_cnt[t - 1];   // 256 adds; the lists above dominate
+        __syncthreads();
       }
     }
+    __syncthreads();
+    const int kept = s_cnt[256];
+    for (int k = 0; k < nch; ++k) {
+      const int ch = tid + k * 256;
+      if (ch >= Ctot) break;
+      const int g = ch / Cc, c = ch % Cc;
+      const int by = g / bins_x, bxi = bins_y + g % bins_x;
+      float a = acc[k];
+      for (int h = 0; h < kept; ++h) {
+        float w = s_w[(size_t)h * nw + by] * s_w[(size_t)h * nw + bxi];
+        if (w != 0.f) a += dout[(int64_t)s_r[h] * Cc + c] * inv * w;
+      }
+      acc[k] = a;
+    }
+  }
+  for (int k = 0; k < nch; ++k) {
+    const int ch = tid + k * 256;
+    if (ch < Ctot && acc[k] != 0.f) dfmap[(int64_t)px * Ctot + ch] += acc[k];
   }
 }
 
@@ -498,8 +577,8 @@ __global__ void k_maxpool_fwd(const float* x, float* y, int H, int W, int C4, in
   }
   reinterpret_cast<float4*>(y)[i] = m;
 }
-// Gradient goes to the first maximum in window order (TF MaxPoolGrad semantics). Windows may
-// overlap (3x3/2), so accumulate with atomics into a zeroed dx.
+// Gradient goes to the first maximum in window order (TF MaxPoolGrad semantics). Non-overlapping windows
+// (k <= stride) scatter into a zeroed dx; overlapping ones (3x3/2) use the gather below.
 __global__ void k_maxpool_bwd(const float* x, const float* y, const float* dy, float* dx, int H,
                               int W, int C, int k, int stride, int pt, int pl, int OH, int OW,
                               int64_t total) {
@@ -516,11 +595,45 @@ __global__ void k_maxpool_bwd(const float* x, const float* y, const float* dy, f
     if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
     int64_t o = (((int64_t)n * H + iy) * W + ix) * C + c;
     if (x[o] == m) {
-      if (k > stride) unsafeAtomicAdd(dx + o, g);
-      else dx[o] = g;
+      dx[o] = g;
       break;
     }
   }
+}
+// Overlapping windows: one thread per INPUT element visits the (at most ceil(k/stride)^2) windows that contain it, in
+// (oy, ox) order, and takes a window's gradient when it is that window's first maximum. Every element of dx is
+// written once by its owner: no memset, no atomics, the same bits on every run.
+__global__ void k_maxpool_bwd_gather(const float* __restrict__ x, const float* __restrict__ y,
+                                     const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C, int k,
+                                     int stride, int pt, int pl, int OH, int OW, int64_t total) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = i % C;
+  int64_t t = i / C;
+  int ix = t % W; t /= W;
+  int iy = t % H;
+  int n = t / H;
+  const float v = x[i];
+  float acc = 0.f;
+  int oy0 = iy + pt - k + 1; oy0 = oy0 <= 0 ? 0 : (oy0 + stride - 1) / stride;
+  int ox0 = ix + pl - k + 1; ox0 = ox0 <= 0 ? 0 : (ox0 + stride - 1) / stride;
+  int oy1 = min((iy + pt) / stride, OH - 1), ox1 = min((ix + pl) / stride, OW - 1);
+  for (int oy = oy0; oy <= oy1; ++oy) {
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      int64_t o = (((int64_t)n * OH + oy) * OW + ox) * C + c;
+      if (v != y[o]) continue;
+      // an earlier position of this window holding the same value takes the gradient instead
+      const int dme = (iy - (oy * stride - pt)) * k + (ix - (ox * stride - pl));
+      bool first = true;
+      for (int d = 0; d < dme && first; ++d) {
+        int yy = oy * stride - pt + d / k, xx = ox * stride - pl + d % k;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        first = x[(((int64_t)n * H + yy) * W + xx) * C + c] != v;
+      }
+      if (first) acc += dy[o];
+    }
+  }
+  dx[i] = acc;
 }
 __global__ void k_spatial_mean_fwd(const float* x, float* y, int HW, int C) {
   int n = blockIdx.y;
@@ -921,8 +1034,11 @@ int mtlssl_psroi_bwd(const float* dout, int B, int H, int W, int C, const float*
                      C % (bins_y * bins_x) == 0, "psroi_bwd: bad geometry");
   if (R == 0) return MTLSSL_OK;
   int Cc = C / (bins_y * bins_x);
-  hipLaunchKernelGGL(k_psroi_bwd, dim3(R), dim3(256), 0, S(stream), dout, H, W, C, boxes, box_ind, bins_y,
-                     bins_x, crop_h / bins_y, crop_w / bins_x, Cc, dfmap);
+  MTLSSL_REQUIRE(C <= 1024 && bins_y <= kPsBins && bins_x <= kPsBins,
+                 "psroi_bwd: at most 1024 score-map channels and 8 bins per side");
+  const size_t lds = (size_t)kPsChunk * (bins_y + bins_x + 1) * 4;
+  hipLaunchKernelGGL(k_psroi_bwd_gather, dim3((unsigned)(B * H * W)), dim3(256), lds, S(stream),
+                     dout, H, W, C, boxes, box_ind, R, bins_y, bins_x, crop_h / bins_y, crop_w / bins_x, Cc, dfmap);
   return check_launch("psroi_bwd");
 }
 
@@ -957,6 +1073,12 @@ int mtlssl_maxpool_bwd(const float* x, const float* y, const float* dy, float* d
                        mtlssl_stream_t stream) {
   int64_t total = (int64_t)N * OH * OW * C;
   if (!total) return MTLSSL_OK;
+  if (k > stride) {
+    int64_t tin = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(k_maxpool_bwd_gather, dim3(cdiv(tin, 256)), dim3(256), 0, S(stream), x, y, dy, dx, H, W, C, k,
+                       stride, pt, pl, OH, OW, tin);
+    return check_launch("maxpool_bwd");
+  }
   if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, S(stream)) != hipSuccess)
     return check_launch("maxpool_bwd memset");
   hipLaunchKernelGGL(k_maxpool_bwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, dy, dx, H,

@@ -308,6 +308,25 @@ def test_maxpool(ops, k, s, pad, shape):
     ref.backward(gy)
     dx = ops.maxpool_bwd(x.cuda(), y, gy.cuda(), k, s, pads)
     assert relerr(dx, xr.grad) < 1e-6
+    assert torch.equal(dx, ops.maxpool_bwd(x.cuda(), y, gy.cuda(), k, s, pads))     # no atomics: same bits
+
+
+@pytest.mark.parametrize("pad,shape", [("VALID", (2, 35, 37, 24)), ("SAME", (1, 9, 8, 8))])
+def test_maxpool_overlapping_windows_with_ties(ops, pad, shape):
+    """3x3 / 2 windows overlap: the backward gathers per input element. Small integers make most windows hold several
+    equal maxima — the gradient goes to the FIRST one in window order, and an element can be the first maximum of up to
+    four windows."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 3, shape, generator=g).float()
+    xr = x.clone().requires_grad_()
+    ref = T.max_pool(xr, 3, 2, pad)
+    y, pads = ops.maxpool_fwd(x.cuda(), 3, 2, pad)
+    np.testing.assert_array_equal(y.cpu().numpy(), ref.detach().numpy())
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    dx = ops.maxpool_bwd(x.cuda(), y, gy.cuda(), 3, 2, pads)
+    assert relerr(dx, xr.grad) < 1e-6
+    assert abs(float(dx.sum()) - float(gy.sum())) < 1e-3 * float(gy.abs().sum())    # every window's gradient lands once
 
 
 def test_spatial_mean(ops):

@@ -62,7 +62,28 @@ def test_psroi_fwd_bwd_vs_oracle(ops, K):
     gy = torch.randn(ref.shape, generator=g)
     ref.backward(gy)
     df = ops.psroi_bwd(gy.cuda(), fmap.shape, boxes.cuda(), bi.cuda(), (18, 18), (3, 3))
-    assert float((df.cpu() - fr.grad).abs().max() / fr.grad.abs().max()) < 1e-4
+    assert float((df.cpu() - fr.grad).abs().max() / fr.grad.abs().max()) < 1e-5
+    # the backward is a gather in RoI order: the same bits on every run, and it ADDS to what dfmap holds
+    df2 = ops.psroi_bwd(gy.cuda(), fmap.shape, boxes.cuda(), bi.cuda(), (18, 18), (3, 3))
+    assert torch.equal(df, df2)
+    base = torch.randn(fmap.shape, generator=g).cuda()
+    df3 = ops.psroi_bwd(gy.cuda(), fmap.shape, boxes.cuda(), bi.cuda(), (18, 18), (3, 3), dfmap=base.clone())
+    assert float((df3 - base - df).abs().max()) < 1e-5
+
+
+def test_psroi_bwd_single_sample_bins_and_piled_boxes(ops):
+    """crop == bins (one sample per bin, taken at the bin's centre) and every RoI on the same box."""
+    g = torch.Generator().manual_seed(5)
+    fmap = torch.randn(1, 11, 13, 4 * 7, generator=g)
+    R = 33
+    boxes = torch.tensor([[0.2, 0.1, 0.8, 0.7]]).repeat(R, 1)
+    bi = torch.zeros(R, dtype=torch.int32)
+    fr = fmap.clone().requires_grad_()
+    ref = T.position_sensitive_crop_regions(fr, boxes, bi, (2, 2), (2, 2), True)[:, 0, 0, :]
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    df = ops.psroi_bwd(gy.cuda(), fmap.shape, boxes.cuda(), bi.cuda(), (2, 2), (2, 2))
+    assert float((df.cpu() - fr.grad).abs().max() / fr.grad.abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("arch", ["faster_rcnn_resnet50", "faster_rcnn_resnet101"])
