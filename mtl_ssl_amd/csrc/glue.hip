@@ -270,6 +270,23 @@ __global__ void k_bias_add_channels(const float* x, const float* bias, float* ou
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < total) out[i] = x[i] + bias[i % C];
 }
+// total % 4 == 0, total < 2^31: four elements per thread, 32-bit index arithmetic (the form above spends its time in a
+// 64-bit modulo per element: 82 us for the [2,600,1024,3] image of the step's preprocess).
+__global__ void __launch_bounds__(256)
+    k_bias_add_channels4(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out,
+                         unsigned total4, unsigned C) {
+  unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 >= total4) return;
+  unsigned c = (i4 * 4u) % C;
+  float4 v = reinterpret_cast<const float4*>(x)[i4];
+  float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] += bias[c];
+    c = c + 1 == C ? 0 : c + 1;
+  }
+  reinterpret_cast<float4*>(out)[i4] = make_float4(o[0], o[1], o[2], o[3]);
+}
 __global__ void k_relu_bwd(const float* y, const float* dy, float* dx, int64_t n) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
@@ -401,8 +418,13 @@ int mtlssl_bias_add_channels(const float* x, const float* bias, float* out, int6
                              mtlssl_stream_t stream) {
   int64_t total = rows * C;
   if (!total) return MTLSSL_OK;
-  hipLaunchKernelGGL(k_bias_add_channels, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, bias,
-                     out, total, C);
+  if (total % 4 == 0 && total < (1ll << 31) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+    hipLaunchKernelGGL(k_bias_add_channels4, dim3(cdiv(total / 4, 256)), dim3(256), 0, S(stream), x, bias, out,
+                       (unsigned)(total / 4), (unsigned)C);
+  else
+    hipLaunchKernelGGL(k_bias_add_channels, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, bias,
+                       out, total, C);
   return check_launch("bias_add_channels");
 }
 int mtlssl_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, mtlssl_stream_t stream) {

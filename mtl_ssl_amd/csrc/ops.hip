@@ -577,6 +577,37 @@ __global__ void k_maxpool_fwd(const float* x, float* y, int H, int W, int C4, in
   }
   reinterpret_cast<float4*>(y)[i] = m;
 }
+// K x K windows with every load issued before the first use (the generic kernel above waits for each tap's load
+// inside its bounds-checked loop: 197 us for the 3x3/2 stem pool of a [2,300,512,64] map = 0.9 TB/s). Out-of-range
+// taps read a clamped (valid) address and are replaced by -inf.
+template <int K>
+__global__ void __launch_bounds__(256)
+    k_maxpool_fwd_k(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C4, int stride, int pt, int pl,
+                    int OH, int OW, int64_t total) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c4 = i % C4;
+  int64_t t = i / C4;
+  int ox = t % OW; t /= OW;
+  int oy = t % OH;
+  int n = t / OH;
+  const float4* xb = reinterpret_cast<const float4*>(x) + (int64_t)n * H * W * C4 + c4;
+  float4 v[K * K];
+  bool ok[K * K];
+#pragma unroll
+  for (int d = 0; d < K * K; ++d) {
+    int iy = oy * stride - pt + d / K, ix = ox * stride - pl + d % K;
+    ok[d] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+    v[d] = xb[((int64_t)cy * W + cx) * C4];
+  }
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int d = 0; d < K * K; ++d) {
+    if (ok[d]) { m.x = fmaxf(m.x, v[d].x); m.y = fmaxf(m.y, v[d].y); m.z = fmaxf(m.z, v[d].z); m.w = fmaxf(m.w, v[d].w); }
+  }
+  reinterpret_cast<float4*>(y)[i] = m;
+}
 // Gradient goes to the first maximum in window order (TF MaxPoolGrad semantics). Non-overlapping windows
 // (k <= stride) scatter into a zeroed dx; overlapping ones (3x3/2) use the gather below.
 __global__ void k_maxpool_bwd(const float* x, const float* y, const float* dy, float* dx, int H,
@@ -1064,8 +1095,15 @@ int mtlssl_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, int
   MTLSSL_REQUIRE(C % 4 == 0, "maxpool: C must be a multiple of 4");
   int64_t total = (int64_t)N * OH * OW * (C / 4);
   if (!total) return MTLSSL_OK;
-  hipLaunchKernelGGL(k_maxpool_fwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W,
-                     C / 4, k, stride, pt, pl, OH, OW, total);
+  if (k == 3)
+    hipLaunchKernelGGL(k_maxpool_fwd_k<3>, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W, C / 4, stride, pt,
+                       pl, OH, OW, total);
+  else if (k == 2)
+    hipLaunchKernelGGL(k_maxpool_fwd_k<2>, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W, C / 4, stride, pt,
+                       pl, OH, OW, total);
+  else
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W,
+                       C / 4, k, stride, pt, pl, OH, OW, total);
   return check_launch("maxpool_fwd");
 }
 int mtlssl_maxpool_bwd(const float* x, const float* y, const float* dy, float* dx, int N, int H,

@@ -466,3 +466,14 @@ def test_rmsprop_and_adam_match_the_oracle(ops, kind):
     for i, n in enumerate(names):
         np.testing.assert_allclose(got[offs[i]:offs[i + 1]], vals[n], rtol=2e-5, atol=2e-6)
     assert np.array_equal(got[offs[2]:offs[3]], w[offs[2]:offs[3]])                         # the frozen variable
+
+
+@pytest.mark.parametrize("shape", [(2, 60, 104, 3), (1, 7, 5, 3), (3, 16, 16, 64), (2, 9, 11, 6)])
+def test_bias_add_channels(ops, shape):
+    """Channel-wise constant (the preprocess's mean subtraction): the four-at-a-time kernel (element count a multiple of
+    4) and the scalar form give x + bias[c]."""
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g) * 100
+    b = torch.randn(shape[-1], generator=g) * 50
+    y = ops.bias_add_channels(x.cuda(), b.cuda())
+    assert torch.equal(y.cpu(), x + b)
