@@ -413,6 +413,16 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              int64_t max_var_size, float lr, float momentum, float clip_norm,
                              float grad_scale, const float* var_weight_decay, const float* var_grad_mult,
                              float* norms_ws, mtlssl_stream_t stream);
+/* The same update that also refreshes the shadow weights of mtlssl_fold_scales (eff = w * scale[channel] for the
+ * variables with a registered scale vector; same tables) on the values it already holds. Only valid when no scale
+ * vector depends on a variable of this update — every BatchNorm frozen, the reference's configs for ResNet and
+ * Inception-ResNet-v2 (faster_rcnn.proto batch_norm_trainable default false). eff == NULL: plain update. */
+int mtlssl_sgd_momentum_clip_fold(float* weights, const float* grads, float* accum,
+                                  const int32_t* var_offsets, int num_vars, int64_t total,
+                                  int64_t max_var_size, float lr, float momentum, float clip_norm,
+                                  float grad_scale, const float* var_weight_decay, const float* var_grad_mult,
+                                  float* norms_ws, float* eff, const void* scale_ptrs, const int32_t* scale_len,
+                                  mtlssl_stream_t stream);
 /* The other two optimizers of builders/optimizer_builder.py:40-62 behind the same gradient pipeline (L2 term,
  * multipliers / frozen variables, per-variable clip; same tables and workspace as above). kind 1 =
  * tf.train.RMSPropOptimizer: slot0 = mean square (TensorFlow initialises it to ONE), slot1 = momentum;

@@ -822,10 +822,15 @@ __global__ void k_var_norm_fold(const float* part, int chunks, int num_vars, flo
   for (int c = 0; c < chunks; ++c) s += part[(int64_t)v * chunks + c];
   norms[v] = s;
 }
+// FOLD: also refresh the shadow weights eff = w * scale[channel] of the variables that have a scale vector registered
+// (mtlssl_fold_scales' work, on the values this thread already holds) — valid when no scale depends on a variable
+// this same launch updates, i.e. when every BatchNorm of the model is frozen.
+template <bool FOLD>
 __global__ void __launch_bounds__(256)
     k_momentum_update(float* w, const float* g, float* acc, const int32_t* off, int num_vars,
                       int64_t total4, float lr, float mom, float clip, float gscale,
-                      const float* norms, const float* var_wd, const float* var_mult) {
+                      const float* norms, const float* var_wd, const float* var_mult, float* eff,
+                      const float* const* scales, const int32_t* Ks) {
   int64_t i4 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i4 >= total4) return;
   int64_t i = i4 * 4;
@@ -852,6 +857,20 @@ __global__ void __launch_bounds__(256)
   wv.x -= lr * av.x; wv.y -= lr * av.y; wv.z -= lr * av.z; wv.w -= lr * av.w;
   *reinterpret_cast<float4*>(acc + i) = av;
   *reinterpret_cast<float4*>(w + i) = wv;
+  if constexpr (FOLD) {
+    const float* sc = scales[lo];
+    if (sc) {
+      const int K = Ks[lo];
+      int r = (int)((i - off[lo]) % K);
+      float o[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] *= sc[r];
+        r = r + 1 == K ? 0 : r + 1;
+      }
+      *reinterpret_cast<float4*>(eff + i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
 }
 
 // RMSProp (KIND 1) / Adam (KIND 2) behind the same gradient pipeline (L2 term, multipliers, per-variable clip):
@@ -1181,6 +1200,16 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              int64_t max_var_size, float lr, float momentum, float clip_norm,
                              float grad_scale, const float* var_weight_decay, const float* var_grad_mult,
                              float* norms_ws, mtlssl_stream_t stream) {
+  return mtlssl_sgd_momentum_clip_fold(weights, grads, accum, var_offsets, num_vars, total, max_var_size, lr, momentum,
+                                       clip_norm, grad_scale, var_weight_decay, var_grad_mult, norms_ws, nullptr,
+                                       nullptr, nullptr, stream);
+}
+int mtlssl_sgd_momentum_clip_fold(float* weights, const float* grads, float* accum,
+                                  const int32_t* var_offsets, int num_vars, int64_t total,
+                                  int64_t max_var_size, float lr, float momentum, float clip_norm,
+                                  float grad_scale, const float* var_weight_decay, const float* var_grad_mult,
+                                  float* norms_ws, float* eff, const void* scale_ptrs, const int32_t* scale_len,
+                                  mtlssl_stream_t stream) {
   MTLSSL_REQUIRE(total % 4 == 0, "sgd: total must be a multiple of 4");
   MTLSSL_REQUIRE(total < (1ll << 31), "sgd: flat parameter buffer must be < 2^31 floats");
   if (!total) return MTLSSL_OK;
@@ -1197,9 +1226,17 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
     hipLaunchKernelGGL(k_var_norm_fold, dim3(cdiv(num_vars, 256)), dim3(256), 0, st, (const float*)part, chunks,
                        num_vars, norms_ws);
   }
-  hipLaunchKernelGGL(k_momentum_update, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads,
-                     accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
-                     norms_ws, var_weight_decay, var_grad_mult);
+  if (eff != nullptr) {
+    MTLSSL_REQUIRE(scale_ptrs != nullptr && scale_len != nullptr, "sgd: fold tables required with a shadow buffer");
+    hipLaunchKernelGGL(k_momentum_update<true>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads,
+                       accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
+                       norms_ws, var_weight_decay, var_grad_mult, eff, (const float* const*)scale_ptrs, scale_len);
+  } else {
+    hipLaunchKernelGGL(k_momentum_update<false>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads,
+                       accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
+                       norms_ws, var_weight_decay, var_grad_mult, (float*)nullptr, (const float* const*)nullptr,
+                       (const int32_t*)nullptr);
+  }
   return check_launch("sgd_momentum_clip");
 }
 

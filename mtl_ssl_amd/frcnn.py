@@ -300,9 +300,10 @@ class FasterRCNNMetaArch:
         on = self.ps.device.type == "cuda" and os.environ.get("MTLSSL_FILTER_CACHE", "1") != "0"
         self.ps.filter_cache = ops.FilterXfCache() if on else None
 
-    def refold(self):
+    def refold(self, folded=False):
         """After an optimizer step: ONE batched refresh of the normaliser constants of the layers whose
-        BatchNorm parameters train, then ONE batched fold of every scale into the shadow weights."""
+        BatchNorm parameters train, then ONE batched fold of every scale into the shadow weights (`folded`: the
+        optimizer launch already wrote them, mtlssl_sgd_momentum_clip_fold)."""
         if self.ps.device.type == "cuda":
             if getattr(self, "_bn_table", None) is None:
                 self._bn_table = ops.BnRefreshTable([l for l in self.layers if getattr(l, "trainable", False)],
@@ -312,7 +313,8 @@ class FasterRCNNMetaArch:
             for l in self.layers:
                 if getattr(l, "trainable", False):
                     l.refold()
-        ops.fold_scales(self.ps)
+        if not folded:
+            ops.fold_scales(self.ps)
         if self.ps.filter_cache is not None:
             # all filter transforms of the coming step, off the critical path: on the auxiliary stream (idle between
             # steps), behind the fold; the first consumer on each stream waits for the event

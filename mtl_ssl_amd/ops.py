@@ -914,9 +914,18 @@ def reduce_sum(x, scale=1.0, out=None):
 
 
 def sgd_momentum_clip(weights, grads, accum, var_offsets, max_var_size, lr, momentum, clip_norm,
-                      grad_scale=1.0, var_weight_decay=None, var_grad_mult=None):
+                      grad_scale=1.0, var_weight_decay=None, var_grad_mult=None, fold=None):
+    """fold: a ParamStore whose shadow weights (ops.fold_scales) the same launch refreshes — only when no scale vector
+    depends on a variable being updated (every BatchNorm frozen)."""
     nv = var_offsets.numel() - 1
     norms = workspace(lib().sgd_workspace_bytes(max(nv, 1), int(max_var_size)), "norms", weights.device)
+    if fold is not None and fold.eff is not None:
+        lib().sgd_momentum_clip_fold(ptr(_chk(weights)), ptr(_chk(grads)), ptr(_chk(accum)),
+                                     ptr(_chk(var_offsets, i32)), nv, weights.numel(), int(max_var_size),
+                                     float(lr), float(momentum), float(clip_norm), float(grad_scale),
+                                     ptr(var_weight_decay), ptr(var_grad_mult), ptr(norms), ptr(fold.eff),
+                                     ptr(fold.fold_ptrs), ptr(fold.fold_len), _stream())
+        return
     lib().sgd_momentum_clip(ptr(_chk(weights)), ptr(_chk(grads)), ptr(_chk(accum)),
                             ptr(_chk(var_offsets, i32)), nv, weights.numel(), int(max_var_size),
                             float(lr), float(momentum), float(clip_norm), float(grad_scale),

@@ -252,6 +252,9 @@ class Trainer:
         self.var_mult = gradient_multipliers(self.ps, train_config)
         import os
         self.split_loss = os.environ.get("MTLSSL_SPLIT_LOSS", "1") != "0" and self.ps.device.type == "cuda"
+        # momentum update and shadow-weight fold in one launch: only when no scale vector trains (frozen BatchNorm)
+        self.fuse_fold = (os.environ.get("MTLSSL_FUSE_FOLD", "1") != "0"
+                          and not any(getattr(l, "bn_trainable", False) for l in model.layers))
         own = os.environ.get("MTLSSL_STEP_STREAM", "auto")
         use = (self.reducer.active if own == "auto" else own == "1") and self.ps.device.type == "cuda"
         self.step_stream = torch.cuda.Stream(device=self.ps.device) if use else None
@@ -340,9 +343,14 @@ class Trainer:
         lr = self.lr_fn(self.global_step)
         ps = self.ps
         o = self.opt
+        folded = False
         if o["kind"] == "momentum":
+            # with every BatchNorm frozen the scale vectors are constants: the update launch refreshes the shadow
+            # weights itself and the separate fold (a second pass over all 78 M parameters) is skipped
+            folded = self.fuse_fold and ps.device.type == "cuda" and ps.eff is not None
             ops.sgd_momentum_clip(ps.weights, ps.grads, ps.accum, ps.var_offsets, ps.max_var_size, lr,
-                                  self.momentum, self.clip, 1.0, self.var_wd, self.var_mult)
+                                  self.momentum, self.clip, 1.0, self.var_wd, self.var_mult,
+                                  fold=ps if folded else None)
         elif o["kind"] == "rms_prop":
             ops.adaptive_update_clip(1, ps.weights, ps.grads, ps.accum, self.slot1, ps.var_offsets, ps.max_var_size, lr,
                                      o["decay"], o["momentum"], o["epsilon"], self.clip, 1.0, self.var_wd, self.var_mult)
@@ -353,7 +361,7 @@ class Trainer:
                                      o["beta1"], o["beta2"], o["epsilon"], self.clip, 1.0, self.var_wd, self.var_mult)
         if self.ema is not None:
             ops.axpby(ps.weights, self.ema, 1.0 - self.ema_decay, self.ema_decay)
-        self.model.refold()
+        self.model.refold(folded=folded)
         ops.mark("update")
         self.global_step += 1
 

@@ -35,3 +35,46 @@ def test_step_is_bit_reproducible(cfg_name):
     torch.cuda.synchronize()
     assert l3 == l2
     assert torch.equal(model.ps.grads, g2), float((model.ps.grads - g2).norm() / g2.norm())
+
+
+@pytest.mark.parametrize("cfg_name", ["smoke_resnet50_mtl.config", "smoke_rfcn_resnet50_mtl.config"])
+def test_update_with_fused_fold_equals_update_then_fold(cfg_name, monkeypatch):
+    """mtlssl_sgd_momentum_clip_fold refreshes the shadow weights in the optimizer launch (every BatchNorm frozen, so the
+    scale vectors are constants): weights, momentum accumulators and shadow weights after two steps are bit-identical
+    to the two-launch form (mtlssl_sgd_momentum_clip, then mtlssl_fold_scales)."""
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", cfg_name)).read())
+    K = int(cfg.model.faster_rcnn.num_classes)
+    state = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MTLSSL_FUSE_FOLD", mode)
+        model = model_builder.build(cfg.model, True, "cuda", seed=5)
+        tr = trainer.Trainer(model, cfg.train_config, 1)
+        assert tr.fuse_fold == (mode == "1")
+        batch = tr.stage_batch(synthetic.make_batch(2, 160, 224, K, seed=21, device="cuda", max_gt=4, num_windows=6))
+        tr.step(batch)               # the first evaluation may autotune (another summation order): not compared
+        tr.step(batch)
+        tr.step(batch)
+        torch.cuda.synchronize()
+        state[mode] = (model.ps.weights.clone(), model.ps.accum.clone(), model.ps.eff.clone())
+        del tr, model
+    if not torch.equal(state["1"][0], state["0"][0]):
+        pytest.skip("the two runs autotuned different tiles on their first step; nothing to compare bit-wise")
+    for a, b in zip(state["1"], state["0"]):
+        assert torch.equal(a, b)
+    assert float((state["1"][2] - state["1"][0]).abs().max()) > 0     # the shadow weights do differ from the raw ones
+
+
+@pytest.mark.parametrize("cfg_name", ["smoke_mobilenet_v1_mtl.config", "smoke_inception_resnet_v2_mtl.config"])
+def test_fused_fold_is_off_when_batch_norm_parameters_train(cfg_name):
+    """MobileNet-v1 and Inception-ResNet-v2 train BatchNorm parameters: their scale vectors change with the update, so
+    the fold has to follow the refresh of the normaliser constants and stays a launch of its own."""
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import config, model_builder, trainer
+    cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", cfg_name)).read())
+    model = model_builder.build(cfg.model, True, "cuda", seed=5)
+    assert any(getattr(l, "bn_trainable", False) for l in model.layers)
+    assert not trainer.Trainer(model, cfg.train_config, 1).fuse_fold
