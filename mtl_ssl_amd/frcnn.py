@@ -7,7 +7,6 @@ Differences that are deliberate: refine runs per image (Q
 uses counter-hash priorities instead of tf.random_shuffle (Q6); target assignment treats every
 groundtruth box as a normal box (Q1, the reference's effective behaviour).
 """
-import numpy as np
 import torch
 
 from . import nn, ops

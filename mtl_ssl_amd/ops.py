@@ -7,7 +7,6 @@ Names follow the reference operators they replace (see include/mtlssl_hip.h).
 import ctypes
 import os
 
-import numpy as np
 import torch
 
 from .lib import ConvDesc, lib, ptr

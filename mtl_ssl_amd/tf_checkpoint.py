@@ -27,7 +27,7 @@ import struct
 
 import numpy as np
 
-from .input_reader import crc32c, masked_crc
+from .input_reader import masked_crc
 
 MAGIC = 0xDB4775248B80FB57
 _DT = {1: np.float32, 2: np.float64, 3: np.int32, 4: np.uint8, 6: np.int8, 9: np.int64, 10: np.bool_,

@@ -8,7 +8,6 @@ import numpy as np
 import torch
 
 from . import assign as A
-from . import boxes as B
 from . import ops_torch as T
 
 F = np.float32

@@ -4,9 +4,7 @@ These follow TensorFlow 1.7 kernel semantics (TF is a third-party dependency of 
 reference, pinned at tensorflow==1.7.0 in /root/reference/requirements.txt:26 and absent
 here). All tensors are NHWC like the reference; autograd provides the backward oracle.
 """
-import math
 
-import numpy as np
 import torch
 import torch.nn.functional as Fnn
 

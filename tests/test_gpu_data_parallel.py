@@ -5,7 +5,6 @@ needs one device per rank: its single-rank run through the same reducer is tests
 8-GPU path is only run by the round driver."""
 import os
 
-import numpy as np
 import pytest
 import torch
 

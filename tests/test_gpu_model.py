@@ -227,7 +227,7 @@ def test_trainer_train_entry_point_resumes_and_fine_tunes(tmp_path):
     `fine_tune_checkpoint` through restore_map (feature extractors only by default)."""
     import __graft_entry__ as g
     g.build()
-    from mtl_ssl_amd import checkpoint, config, model_builder, synthetic, trainer
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
     cfg = config.parse_pipeline_config(TINY_CONFIG % dict(refine="false", aux="false", K=5, H=160, W=224, crop=7, pk=1))
     make = lambda: model_builder.build(cfg.model, True, "cuda", seed=3)
     data = lambda: synthetic.make_batch(2, 160, 224, 5, seed=11, device="cuda", max_gt=4, num_windows=6)

@@ -9,7 +9,6 @@
   * first_stage_only (RPN + edge-mask head only)                faster_rcnn_meta_arch.py:603, 1029-1039, 1549-1567
   * hard_example_miner on the second stage                      core/losses.py:418-631, faster_rcnn_meta_arch.py:1758-1762
 Dropout draws are the samplers' counter hash in both implementations (mtlssl_dropout / oracle.assign.dropout_mask)."""
-import os
 
 import numpy as np
 import pytest

@@ -2,7 +2,6 @@
 mtlssl_conv2d_{fwd,dgrad,wgrad}: each GEMM tile of the transformed-domain product, forced through the
 plan registry, against the torch-CPU fp32 oracle and against the direct implicit-GEMM path.
 Tolerance 1e-3 relative fp32 (BASELINE.json north_star); asserted at 1e-4, in practice ~1e-5."""
-import ctypes
 
 import numpy as np
 import pytest

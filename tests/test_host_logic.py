@@ -2,7 +2,6 @@
 layout, learning-rate schedule, label generators, and the data-parallel gradient reduction
 (world_size 2 over gloo)."""
 import os
-import sys
 
 import numpy as np
 import pytest

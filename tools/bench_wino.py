@@ -1,6 +1,5 @@
 """Direct implicit-GEMM vs Winograd F(4x4,3x3) on the 3x3/stride-1 layer shapes of the shipped configs.
 Usage: python tools/bench_wino.py"""
-import ctypes
 import os
 import sys
 

@@ -1,6 +1,5 @@
 """Per-shape conv timing of one training step of a config (which layers cost what).
 Usage: python tools/conv_shapes.py <config> <H> <W> [top]"""
-import collections
 import ctypes
 import os
 import sys

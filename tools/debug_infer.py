@@ -1,5 +1,5 @@
 import os, sys
-import numpy as np, torch
+import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g

@@ -1,6 +1,6 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from oracle import ops_torch as T
 from mtl_ssl_amd import ops
 crop,pk,ps=14,2,2

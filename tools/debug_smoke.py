@@ -1,4 +1,4 @@
-import os, sys, ctypes
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mode = sys.argv[1]

@@ -1,5 +1,5 @@
 """Would running the two images of a batch as two concurrent chains shorten the trunk forward? (un-profiled HIP-event timing)"""
-import os, sys, time
+import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
