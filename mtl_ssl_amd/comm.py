@@ -54,11 +54,19 @@ class RcclComm:
         assert self.device.type == "cuda", "RCCL communicators live on a GPU"
         self._lib = lib()
         uid = ctypes.create_string_buffer(ID_BYTES)
+        err = None
         if rank == 0:
-            self._lib.comm_unique_id(uid)
+            try:
+                self._lib.comm_unique_id(uid)
+            except Exception as e:        # e.g. librccl.so cannot be loaded: the other ranks must not wait for an id
+                err = e
         if world > 1:
-            raw = (exchange or _dist_exchange)(uid.raw if rank == 0 else None)
+            raw = (exchange or _dist_exchange)((b"" if err is not None else uid.raw) if rank == 0 else None)
+            if not raw:
+                raise RuntimeError("rank 0 could not create an RCCL unique id%s" % (": %r" % err if err else ""))
             uid = ctypes.create_string_buffer(raw, ID_BYTES)
+        elif err is not None:
+            raise err
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device), _stdout_to_stderr():
             self._lib.comm_init(ctypes.byref(handle), uid, world, rank)
@@ -90,14 +98,18 @@ class RcclComm:
 
 
 class GlooComm:
-    """torch.distributed stand-in with the same interface (tests only; not a performance path)."""
+    """torch.distributed behind the same interface: the stand-in transport of the tests (default group, gloo), and —
+    with a process group of backend 'nccl', i.e. RCCL through torch's binding — the fallback `default_comm` takes
+    when the library's own wrappers cannot be initialised."""
     backend = "gloo"
 
-    def __init__(self):
+    def __init__(self, group=None, label=None):
         import torch.distributed as dist
         assert dist.is_initialized()
         self._dist = dist
-        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self._group = group
+        self._label = label
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
 
     def _on(self, stream, fn):
         if stream is None:
@@ -107,13 +119,13 @@ class GlooComm:
 
     def allreduce(self, t, op="sum", stream=None):
         ops = {"sum": self._dist.ReduceOp.SUM, "max": self._dist.ReduceOp.MAX, "min": self._dist.ReduceOp.MIN}
-        self._on(stream, lambda: self._dist.all_reduce(t, op=ops[op]))
+        self._on(stream, lambda: self._dist.all_reduce(t, op=ops[op], group=self._group))
 
     def broadcast(self, t, root=0, stream=None):
-        self._on(stream, lambda: self._dist.broadcast(t, root))
+        self._on(stream, lambda: self._dist.broadcast(t, root, group=self._group))
 
     def info(self):
-        return {"backend": self._dist.get_backend(), "ranks": self.world, "rank": self.rank}
+        return {"backend": self._label or self._dist.get_backend(self._group), "ranks": self.world, "rank": self.rank}
 
     def close(self):
         pass
@@ -136,5 +148,22 @@ def default_comm(device):
         return None
     dev = torch.device(device)
     if dev.type == "cuda" and os.environ.get("MTLSSL_DIST_BACKEND", "rccl") != "gloo":
-        return RcclComm(dev, dist.get_rank(), dist.get_world_size())
+        comm, err = None, None
+        try:
+            comm = RcclComm(dev, dist.get_rank(), dist.get_world_size())
+        except Exception as e:
+            err = e
+        # every rank has to take the same branch: agree over the host channel
+        failed = torch.tensor([0 if comm is not None else 1], dtype=torch.int32)
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed.item()) == 0:
+            return comm
+        if comm is not None:
+            comm.close()
+        sys.stderr.write("mtl_ssl_amd.comm: mtlssl_comm_init failed on at least one rank (%r here); falling back to "
+                         "torch.distributed's nccl backend (RCCL through torch's binding)\n" % (err,))
+        return GlooComm(group=dist.new_group(backend=_FALLBACK_BACKEND), label="torch-%s (fallback)" % _FALLBACK_BACKEND)
     return GlooComm()
+
+
+_FALLBACK_BACKEND = "nccl"      # tests replace it with "gloo" to walk the fallback without a second GPU

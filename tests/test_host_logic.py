@@ -326,6 +326,26 @@ def _dp_worker(rank, world, port, out):
     # the step loop's collective failure verdict: rank 1 alone sees a problem, both ranks learn of it
     res["verdict"] = trainer.collective_verdict(GlooComm(), 2 if rank == 1 else 0, "cpu")
     res["verdict_ok"] = trainer.collective_verdict(GlooComm(), 0, "cpu")
+    # default_comm's fallback: the library's RCCL wrapper fails on ONE rank -> both ranks agree over the host channel,
+    # the rank that did get a communicator closes it, and both continue on a torch.distributed group
+    from mtl_ssl_amd import comm as C
+
+    class _Fake:
+        closed = False
+
+        def __init__(self, device, r, w):
+            if r == 1:
+                raise RuntimeError("simulated: librccl.so cannot be loaded")
+            _Fake.last = self
+
+        def close(self):
+            _Fake.closed = True
+    real, C.RcclComm, C._FALLBACK_BACKEND = C.RcclComm, _Fake, "gloo"
+    fb = C.default_comm(torch.device("cuda", 0))
+    C.RcclComm = real
+    t = torch.full((5,), float(rank + 1))
+    fb.allreduce(t)
+    res["fallback"] = (type(fb).__name__, fb.info()["backend"], t.tolist(), _Fake.closed if rank == 0 else None)
     res["overlap"] = ps.grads.clone().numpy()
     res["early"] = early
     res["order"] = list(red.launch_order)
@@ -353,6 +373,9 @@ def test_data_parallel_gradient_sum_gloo_world2():
     assert sorted(out[0]["order"]) == list(range(out[0]["nb"]))
     # trainer.collective_verdict: a failure seen by one rank stops every rank (none is left waiting in an all-reduce)
     assert out[0]["verdict"] == 2 and out[1]["verdict"] == 2 and out[0]["verdict_ok"] == 0 and out[1]["verdict_ok"] == 0
+    # comm.default_comm: one rank's RCCL init failure moves BOTH ranks to the torch.distributed fallback
+    assert out[0]["fallback"] == ("GlooComm", "torch-gloo (fallback)", [3.0] * 5, True)
+    assert out[1]["fallback"] == ("GlooComm", "torch-gloo (fallback)", [3.0] * 5, None)
 
 
 def test_random_horizontal_flip_known_answers_and_fork_extras():
