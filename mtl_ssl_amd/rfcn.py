@@ -183,35 +183,29 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         g_F = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True)
         ops.axpby(g_F, dF, 1.0, 1.0)
         stop = bool(mtl.stop_gradient_for_aux_tasks)
-        if mtl.closeness:
-            cfeat = pd["_cfeat"]
-            g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat)
-            g_F = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop)
-            if not stop:
-                ops.axpby(g_F, dF, 1.0, 1.0)
-        if mtl.window:
-            wfeat = pd["_wfeat"]
-            g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat)
-            g_F = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop)
-            if not stop:
-                ops.axpby(g_F, dF, 1.0, 1.0)
-        if mtl.edgemask:
-            em_pred = pd["edgemask_predictions"]
-            g = ops.resize_bilinear_bwd(d["edgemask_resized"], em_pred.shape)
-            g = ops.tanh_bwd(em_pred, g)
-            self.edgemask_conv.wgrad(F, g)
-            self.edgemask_conv.dgrad(F.shape, g, out=dF, accum=True)
-        rpn_feat = pd["rpn_box_predictor_features"]
-        n_all = pd["_n_all"]
-        g_enc = ops.scatter_rows(d["rpn_box_encodings"], pd["_keep"], n_all).view(B, F.shape[1], F.shape[2], -1)
-        g_obj = ops.scatter_rows(d["rpn_objectness"], pd["_keep"], n_all).view(B, F.shape[1], F.shape[2], -1)
-        self.rpn_box.wgrad(rpn_feat, g_enc)
-        self.rpn_cls.wgrad(rpn_feat, g_obj)
-        g_rf = self.rpn_box.dgrad(rpn_feat.shape, g_enc)
-        relu = self.rpn_conv.activation == "relu"
-        self.rpn_cls.dgrad(rpn_feat.shape, g_obj, out=g_rf, accum=True, mask_ref=rpn_feat if relu else None)
-        self.rpn_conv.wgrad(F, g_rf)
-        gpF = self.rpn_conv.dgrad(F.shape, g_rf, out=dF, accum=True, mask_ref=F,
-                                  mask6=getattr(self._feature_extractor, "output_relu6", False))
-        pd["_gpF"] = gpF
-        self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"])
+
+        def aux_backward():
+            if mtl.closeness:
+                cfeat = pd["_cfeat"]
+                g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat)
+                g_c = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop)
+                if not stop:
+                    ops.axpby(g_c, dF, 1.0, 1.0)
+            if mtl.window:
+                wfeat = pd["_wfeat"]
+                g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat)
+                g_w = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop)
+                if not stop:
+                    ops.axpby(g_w, dF, 1.0, 1.0)
+
+        # as in FasterRCNNMetaArch.backward: with stop_gradient_for_aux_tasks the auxiliary towers' backward (block4 on
+        # the whole map, twice) touches nothing of the main path and runs on the second stream next to the RPN / trunk
+        # backward, whose filter gradients go to the third (`_backward_first_stage` joins both)
+        side = self._aux_stream() if (stop and (mtl.closeness or mtl.window)) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                aux_backward()
+        else:
+            aux_backward()
+        return self._backward_first_stage(pd, d, F, dF, B, side)
