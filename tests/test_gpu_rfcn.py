@@ -88,7 +88,7 @@ def test_psroi_bwd_single_sample_bins_and_piled_boxes(ops):
 
 @pytest.mark.parametrize("arch", ["faster_rcnn_resnet50", "faster_rcnn_resnet101"])
 def test_rfcn_step_matches_oracle(arch):
-    """configs[2]'s architecture (R-FCN on a ResNet-101 trunk, atrous block4 on the whole map) and its
+    """configs[2]'s architecture (R-FCN on a ResNet-101 trunk, block4 on the whole map) and its
     ResNet-50 sibling at an oracle-sized input."""
     import bench
     from mtl_ssl_amd import config, model_builder, rfcn, synthetic, trainer
