@@ -71,6 +71,25 @@ def test_psroi_fwd_bwd_vs_oracle(ops, K):
     assert float((df3 - base - df).abs().max()) < 1e-5
 
 
+def test_psroi_bwd_more_rois_than_one_lds_pass(ops):
+    """2 500 RoIs over three images: the gather keeps 1 024 RoIs' weights in LDS per pass, so this takes three passes per
+    pixel block, and the order of the sum (RoI index) must survive the pass boundaries."""
+    g = torch.Generator().manual_seed(9)
+    fmap = torch.randn(3, 10, 12, 9 * 4, generator=g)
+    R = 2500
+    yx = torch.rand(R, 2, generator=g) * 0.8
+    hw = torch.rand(R, 2, generator=g) * 0.5 + 0.05
+    boxes = torch.cat([yx, yx + hw], 1)
+    bi = torch.randint(0, 3, (R,), generator=g).int()
+    fr = fmap.clone().requires_grad_()
+    ref = T.position_sensitive_crop_regions(fr, boxes, bi, (6, 6), (3, 3), True)[:, 0, 0, :]
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    df = ops.psroi_bwd(gy.cuda(), fmap.shape, boxes.cuda(), bi.cuda(), (6, 6), (3, 3))
+    assert float((df.cpu() - fr.grad).abs().max() / fr.grad.abs().max()) < 2e-5
+    assert torch.equal(df, ops.psroi_bwd(gy.cuda(), fmap.shape, boxes.cuda(), bi.cuda(), (6, 6), (3, 3)))
+
+
 def test_psroi_bwd_single_sample_bins_and_piled_boxes(ops):
     """crop == bins (one sample per bin, taken at the bin's centre) and every RoI on the same box."""
     g = torch.Generator().manual_seed(5)
