@@ -79,9 +79,9 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         super().__init__(ps, is_training, frcnn, mtl, feature_extractor, seed=seed)
         # the switches below are built for the Faster R-CNN second stage only (no paper configuration combines them
         # with R-FCN: configs/test/model4?.config)
-        if self._shared_classifier or self._first_stage_only or (mtl.refine and int(mtl.refine_num_fc_layers) > 0):
-            raise ValueError("RFCNMetaArch: shared_feature 'classifier_feature_maps', first_stage_only and a refiner FC "
-                             "stack are implemented for FasterRCNNMetaArch only")
+        if self._shared_classifier or (mtl.refine and int(mtl.refine_num_fc_layers) > 0):
+            raise ValueError("RFCNMetaArch: shared_feature 'classifier_feature_maps' and a refiner FC stack are "
+                             "implemented for FasterRCNNMetaArch only")
 
     def _make_predictor(self, scope, num_classes, bp_cfg, class_only, slot0=0):
         if not bp_cfg.has("rfcn_box_predictor"):
@@ -171,6 +171,8 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         F = pd["rpn_features_to_crop"]
         B = F.shape[0]
         dF = torch.zeros_like(F)
+        if self._first_stage_only:             # faster_rcnn_meta_arch.py:603: the RPN (+ edge-mask head) is the model
+            return self._backward_first_stage(pd, d, F, dF, B)
         d_cls = d["class_predictions"]
         if mtl.refine:
             d_ref = d["refined_class_predictions"]

@@ -156,3 +156,39 @@ def test_rfcn_step_matches_oracle(arch):
     # aux gradients are NOT stopped in the R-FCN configs: the trunk sees them
     tr.apply_gradients()
     assert np.isfinite(model.ps.weights.sum().item())
+
+
+def test_rfcn_first_stage_only_matches_oracle():
+    """first_stage_only under RFCNMetaArch (faster_rcnn_meta_arch.py:603, 1029-1039 are inherited by rfcn_meta_arch.py):
+    RPN + edge-mask head only; no second-stage variable receives a gradient."""
+    import bench
+    from mtl_ssl_amd import config, model_builder, rfcn, synthetic, trainer
+    from oracle.model import Oracle
+    text = open(os.path.join(ROOT, "configs", "smoke_rfcn_resnet50_mtl.config")).read()
+    text = text.replace("refine: true  window: true  closeness: true  edgemask: true",
+                        "refine: false  window: false  closeness: false  edgemask: true")
+    text = text.replace("    num_classes: 5\n", "    num_classes: 5\n    first_stage_only: true\n", 1)
+    cfg = config.parse_pipeline_config(text)
+    model = model_builder.build(cfg.model, True, "cuda", seed=3)
+    assert isinstance(model, rfcn.RFCNMetaArch) and model._first_stage_only
+    tr = trainer.Trainer(model, cfg.train_config, 1)
+    batch = synthetic.make_batch(2, 160, 224, 5, seed=11, device="cuda", max_gt=4, num_windows=6)
+    values = model.ps.state_dict()
+    losses = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    got = {k: float(v.item()) for k, v in losses.items()}
+    hb = dict(batch)
+    hb["images"] = batch["images"].cpu().numpy()
+    ref, rgrads, _ = Oracle(bench.hyper_params_for_oracle(cfg), values).step(hb, seed=model.seed, step=0)
+    assert set(got) == set(ref) == {"first_stage_localization_loss", "first_stage_objectness_loss", "edgemask_loss"}
+    for k in ref:
+        assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
+    grads = model.ps.grads_dict()
+    for n, gv in grads.items():
+        if n.startswith(("SecondStage", "ClosenessBoxPredictor", "WindowBoxPredictor", "MTLClassRefiner")):
+            assert not np.any(gv), n
+    common = [n for n in grads if n in rgrads and np.any(rgrads[n])]
+    assert len(common) > 20
+    for n in common:
+        a, b = grads[n].ravel(), np.asarray(rgrads[n]).ravel()
+        assert np.linalg.norm(a - b) <= 5e-3 * max(np.linalg.norm(b), 1e-12), n
