@@ -79,9 +79,9 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         super().__init__(ps, is_training, frcnn, mtl, feature_extractor, seed=seed)
         # the switches below are built for the Faster R-CNN second stage only (no paper configuration combines them
         # with R-FCN: configs/test/model4?.config)
-        if self._shared_classifier or (mtl.refine and int(mtl.refine_num_fc_layers) > 0):
-            raise ValueError("RFCNMetaArch: shared_feature 'classifier_feature_maps' and a refiner FC stack are "
-                             "implemented for FasterRCNNMetaArch only")
+        if self._shared_classifier:
+            raise ValueError("RFCNMetaArch: shared_feature 'classifier_feature_maps' is implemented for "
+                             "FasterRCNNMetaArch only")
 
     def _make_predictor(self, scope, num_classes, bp_cfg, class_only, slot0=0):
         if not bp_cfg.has("rfcn_box_predictor"):
@@ -157,7 +157,11 @@ class RFCNMetaArch(FasterRCNNMetaArch):
             pd["expand_window_class_predictions"] = win.view(B, self.N_EXPAND, N2, K1)
         clo = pd["closeness_predictions"] if mtl.closeness else None
         net = ops.refine_concat(cls, win, clo, B, N2, self.N_EXPAND, bool(mtl.global_closeness))
-        refined = self.refine_fc.forward(net)
+        hidden, sctx = net, None
+        if self.refine_stack is not None:          # faster_rcnn_meta_arch.py:833-840: FC stack + dropout before the refiner
+            hidden, sctx = self.refine_stack.forward(net, self._is_training, self.seed, self.step)
+        refined = self.refine_fc.forward(hidden)
+        pd["_refine_hidden"], pd["_refine_ctx"] = hidden, sctx
         if mtl.refine_residue:
             ops.axpby(cls, refined, 1.0, 1.0)
         pd["mtl_refined_class_predictions_with_background"] = refined
@@ -176,7 +180,10 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         d_cls = d["class_predictions"]
         if mtl.refine:
             d_ref = d["refined_class_predictions"]
-            self.refine_fc.wgrad(pd["_refine_in"], d_ref)
+            self.refine_fc.wgrad(pd["_refine_hidden"], d_ref)
+            if self.refine_stack is not None:
+                g_h = self.refine_fc.dgrad(pd["_refine_hidden"].shape, d_ref)
+                self.refine_stack.backward(pd["_refine_ctx"], g_h, need_input_grad=False)
             if mtl.refine_residue and not mtl.stop_gradient_for_prediction_org:
                 ops.axpby(d_ref, d_cls, 1.0, 1.0)
         feat = pd["_feat"]

@@ -58,7 +58,7 @@ def test_psroi_fwd_bwd_vs_oracle(ops, K):
     fr = fmap.clone().requires_grad_()
     ref = T.position_sensitive_crop_regions(fr, boxes, bi, (18, 18), (3, 3), True)[:, 0, 0, :]
     out = ops.psroi_fwd(fmap.cuda(), boxes.cuda(), bi.cuda(), (18, 18), (3, 3))
-    assert float((out.cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
+    assert float((out.cpu() - ref.detach()).abs().max() / ref.detach().abs().max()) < 1e-5
     gy = torch.randn(ref.shape, generator=g)
     ref.backward(gy)
     df = ops.psroi_bwd(gy.cuda(), fmap.shape, boxes.cuda(), bi.cuda(), (18, 18), (3, 3))
@@ -192,3 +192,35 @@ def test_rfcn_first_stage_only_matches_oracle():
     for n in common:
         a, b = grads[n].ravel(), np.asarray(rgrads[n]).ravel()
         assert np.linalg.norm(a - b) <= 5e-3 * max(np.linalg.norm(b), 1e-12), n
+
+
+def test_rfcn_refiner_fc_stack_with_dropout_matches_oracle():
+    """mtl.refine_num_fc_layers > 0 with dropout (faster_rcnn_meta_arch.py:832-841) under RFCNMetaArch."""
+    import bench
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    from oracle.model import Oracle
+    text = open(os.path.join(ROOT, "configs", "smoke_rfcn_resnet50_mtl.config")).read()
+    text = text.replace("refine_num_fc_layers: 0", "refine_num_fc_layers: 2  refine_dropout_rate: 0.7")
+    cfg = config.parse_pipeline_config(text)
+    model = model_builder.build(cfg.model, True, "cuda", seed=3)
+    names = set(model.ps.state_dict())
+    assert {"MTLClassRefiner/fc1/weights", "MTLClassRefiner/fc2/weights", "MTLClassRefiner/fc3/weights"} <= names
+    tr = trainer.Trainer(model, cfg.train_config, 1)
+    batch = synthetic.make_batch(2, 160, 224, 5, seed=11, device="cuda", max_gt=4, num_windows=6)
+    values = model.ps.state_dict()
+    losses = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    got = {k: float(v.item()) for k, v in losses.items()}
+    pd = tr._pd
+    hb = dict(batch)
+    hb["images"] = batch["images"].cpu().numpy()
+    ref, rgrads, _ = Oracle(bench.hyper_params_for_oracle(cfg), values).step(
+        hb, seed=model.seed, step=0, forced=dict(proposal_boxes=pd["proposal_boxes"].cpu().numpy(),
+                                                 num_proposals=pd["num_proposals"].cpu().numpy()))
+    assert set(got) == set(ref)
+    for k in ref:
+        assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
+    grads = model.ps.grads_dict()
+    for n in ("MTLClassRefiner/fc1/weights", "MTLClassRefiner/fc2/weights", "MTLClassRefiner/fc3/weights"):
+        a, b = grads[n].ravel(), np.asarray(rgrads[n]).ravel()
+        assert np.any(b) and np.linalg.norm(a - b) <= 5e-3 * np.linalg.norm(b), (n, np.linalg.norm(a - b) / np.linalg.norm(b))
