@@ -186,12 +186,8 @@ class RFCNMetaArch(FasterRCNNMetaArch):
                 self.refine_stack.backward(pd["_refine_ctx"], g_h, need_input_grad=False)
             if mtl.refine_residue and not mtl.stop_gradient_for_prediction_org:
                 ops.axpby(d_ref, d_cls, 1.0, 1.0)
-        feat = pd["_feat"]
-        g_feat = self.box_predictor.backward(pd["_bp"], d_cls,
-                                             d["refined_box_encodings"].view(d_cls.shape[0], -1), feat)
-        g_F = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True)
-        ops.axpby(g_F, dF, 1.0, 1.0)
         stop = bool(mtl.stop_gradient_for_aux_tasks)
+        held = []          # the aux towers' input gradients (only without stop_gradient_for_aux_tasks)
 
         def aux_backward():
             if mtl.closeness:
@@ -199,22 +195,35 @@ class RFCNMetaArch(FasterRCNNMetaArch):
                 g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat)
                 g_c = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop)
                 if not stop:
-                    ops.axpby(g_c, dF, 1.0, 1.0)
+                    held.append(g_c)
             if mtl.window:
                 wfeat = pd["_wfeat"]
                 g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat)
                 g_w = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop)
                 if not stop:
-                    ops.axpby(g_w, dF, 1.0, 1.0)
+                    held.append(g_w)
 
-        # as in FasterRCNNMetaArch.backward: with stop_gradient_for_aux_tasks the auxiliary towers' backward (block4 on
-        # the whole map, twice) touches nothing of the main path and runs on the second stream next to the RPN / trunk
-        # backward, whose filter gradients go to the third (`_backward_first_stage` joins both)
-        side = self._aux_stream() if (stop and (mtl.closeness or mtl.window)) else None
+        # The three towers' backward passes (block4 on the whole 38 x 64 map each: 9 728-row GEMMs at B = 4, none of
+        # which fills the chip) are independent of one another: the two auxiliary ones run on the second stream next
+        # to the main tower's. With stop_gradient_for_aux_tasks they feed nothing on the main path and are joined at
+        # the end of backward (`_backward_first_stage`); without it their input gradients are added to dF on this
+        # stream once the second one has been joined — before the RPN / trunk backward, which needs the sum.
+        cur = torch.cuda.current_stream()
+        side = self._aux_stream() if (mtl.closeness or mtl.window) else None
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
+            side.wait_stream(cur)
             with torch.cuda.stream(side):
                 aux_backward()
-        else:
+        feat = pd["_feat"]
+        g_feat = self.box_predictor.backward(pd["_bp"], d_cls,
+                                             d["refined_box_encodings"].view(d_cls.shape[0], -1), feat)
+        g_F = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True)
+        ops.axpby(g_F, dF, 1.0, 1.0)
+        if side is None:
             aux_backward()
-        return self._backward_first_stage(pd, d, F, dF, B, side)
+        elif not stop:
+            cur.wait_stream(side)
+        for g in held:
+            g.record_stream(cur)            # produced on the second stream, consumed (and then released) on this one
+            ops.axpby(g, dF, 1.0, 1.0)
+        return self._backward_first_stage(pd, d, F, dF, B, side if stop else None)
