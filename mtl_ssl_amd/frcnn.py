@@ -835,39 +835,60 @@ class FasterRCNNMetaArch:
                 hook, self.ps.grad_ready_hook = self.ps.grad_ready_hook, None
                 gw_shared = self.tower.backward(g, wfeat, pd["_wctx"], need_input_grad=True, masked=True)
                 self.ps.grad_ready_hook = hook
-        g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True, masked=True)
-        ops.roi_crop_pool_bwd(g_crops, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
-                              pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
-                              int(c.maxpool_stride), dfeat=dF, accumulate=False)
-        if gw_shared is not None:
-            ops.roi_crop_pool_bwd(gw_shared, pd["_wargmax"], F.shape, pd["_wboxes"], pd["_wbox_ind"],
-                                  int(c.initial_crop_size), int(c.maxpool_kernel_size), int(c.maxpool_stride), dfeat=dF)
+        crop_args = (int(c.initial_crop_size), int(c.maxpool_kernel_size), int(c.maxpool_stride))
 
-        def aux_backward():
+        def aux_backward(collect=None):
+            """collect: a list that receives (crop gradient, arg-max, boxes, box indices) instead of the RoI-crop
+            backward being issued here (the caller adds them to dF later, on the stream that owns dF)."""
             if shared:
                 if mtl.window and stop:          # the gradient stops at the shared tower's output: predictor only
                     wfeat = pd["_wfeat"]
                     self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat.shape,
                                                    need_feat_grad=False)
                 return
+            todo = []
             if mtl.closeness:
                 cfeat = pd["_cfeat"]
                 g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat.shape,
                                                       mask_ref=cfeat, mask6=m6)
                 gc = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop, masked=True)
                 if not stop:
-                    ops.roi_crop_pool_bwd(gc, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
-                                          pd["_box_ind"], int(c.initial_crop_size), int(c.maxpool_kernel_size),
-                                          int(c.maxpool_stride), dfeat=dF)
+                    todo.append((gc, pd["_argmax"], pd["proposal_boxes_normalized"].view(-1, 4), pd["_box_ind"]))
             if mtl.window:
                 wfeat = pd["_wfeat"]
                 g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat.shape,
                                                    mask_ref=wfeat, mask6=m6)
                 gw = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop, masked=True)
                 if not stop:
-                    ops.roi_crop_pool_bwd(gw, pd["_wargmax"], F.shape, pd["_wboxes"], pd["_wbox_ind"],
-                                          int(c.initial_crop_size), int(c.maxpool_kernel_size),
-                                          int(c.maxpool_stride), dfeat=dF)
+                    todo.append((gw, pd["_wargmax"], pd["_wboxes"], pd["_wbox_ind"]))
+            if collect is not None:
+                collect.extend(todo)
+            else:
+                for gx, am, bx, bi in todo:
+                    ops.roi_crop_pool_bwd(gx, am, F.shape, bx, bi, *crop_args, dfeat=dF)
+
+        # WITHOUT stop_gradient_for_aux_tasks (MobileNet's and R-FCN's paper settings) the aux towers' crop gradients
+        # join dF, but the tower passes themselves are still independent of the main tower's: they run on the second
+        # stream next to it, and their RoI-crop backward is issued on this stream, after the main head's (which
+        # writes dF in full), in the order the single-stream form used — the same sums, bit for bit.
+        cur = torch.cuda.current_stream()
+        early, pending = None, []
+        if not stop and not shared and (mtl.closeness or mtl.window):
+            early = self._aux_stream()
+        if early is not None:
+            early.wait_stream(cur)
+            with torch.cuda.stream(early):
+                aux_backward(collect=pending)
+        g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True, masked=True)
+        ops.roi_crop_pool_bwd(g_crops, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
+                              pd["_box_ind"], *crop_args, dfeat=dF, accumulate=False)
+        if gw_shared is not None:
+            ops.roi_crop_pool_bwd(gw_shared, pd["_wargmax"], F.shape, pd["_wboxes"], pd["_wbox_ind"], *crop_args, dfeat=dF)
+        if early is not None:
+            cur.wait_stream(early)
+            for gx, am, bx, bi in pending:
+                gx.record_stream(cur)         # made on the second stream, consumed and released on this one
+                ops.roi_crop_pool_bwd(gx, am, F.shape, bx, bi, *crop_args, dfeat=dF)
 
         # With stop_gradient_for_aux_tasks the aux towers' backward touches neither dF nor any
         # tensor of the main path, so it runs on a second HIP stream, concurrently with the RPN /
@@ -880,7 +901,7 @@ class FasterRCNNMetaArch:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 aux_backward()
-        else:
+        elif early is None:
             aux_backward()
         return self._backward_first_stage(pd, d, F, dF, B, side)
 
