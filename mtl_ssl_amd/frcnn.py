@@ -515,6 +515,17 @@ class FasterRCNNMetaArch:
         box_ind = self._box_ind(B, N2, F.device)
         flat = boxes_norm.view(B * N2, 4)
         crops, argmax = self._crop(F, flat, box_ind, True)
+        import os
+        cside = None
+        if (mtl.closeness and not self._shared_classifier and self._is_training
+                and os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "1") == "1"):
+            cside = self._aux_stream()
+        if cside is not None:
+            cur = torch.cuda.current_stream()
+            cside.wait_stream(cur)
+            with torch.cuda.stream(cside):
+                cfeat_s, cctx_s = self.closeness_tower.forward(crops, self._is_training)
+                cp_s = self.closeness_predictor.predict(cfeat_s, self.seed, self.step)
         feat, tower_ctx = self.tower.forward(crops, self._is_training)
         bp = self.box_predictor.predict(feat, self.seed, self.step)
         out = {
@@ -527,10 +538,13 @@ class FasterRCNNMetaArch:
         if mtl.closeness:
             if self._shared_classifier:          # :701-706, 713-714: the predictor reads the main tower's features
                 cfeat, cctx = feat, None
+            elif cside is not None:
+                torch.cuda.current_stream().wait_stream(cside)
+                cfeat, cctx = cfeat_s, cctx_s
             else:
                 # stop_gradient_for_aux_tasks only decides whether d(crops) is propagated (:668-673)
                 cfeat, cctx = self.closeness_tower.forward(crops, self._is_training)
-            cp = self.closeness_predictor.predict(cfeat, self.seed, self.step)
+            cp = cp_s if cside is not None else self.closeness_predictor.predict(cfeat, self.seed, self.step)
             out.update({"closeness_predictions": cp["class"], "_cfeat": cfeat, "_cctx": cctx, "_cp": cp})
         return out
 
