@@ -516,6 +516,16 @@ class FasterRCNNMetaArch:
         flat = boxes_norm.view(B * N2, 4)
         crops, argmax = self._crop(F, flat, box_ind, True)
         import os
+        early_win = None
+        if (self._is_training and mtl.refine and mtl.window and self._shared_classifier is False
+                and self._refine_stream() is not None):
+            # the refiner's window pass (4 x the RoIs of the main head, forward only) depends on the sampled proposals
+            # alone: issued now, on a third stream, it runs next to the main and closeness towers' forward instead of
+            # after them; predict_with_mtl_results joins it
+            third = self._refine_stream()
+            third.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(third):
+                early_win = self._refine_window_predictions(F, boxes_norm)
         cside = None
         if (mtl.closeness and not self._shared_classifier and self._is_training
                 and os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "1") == "1"):
@@ -535,6 +545,8 @@ class FasterRCNNMetaArch:
             "_crops": crops, "_argmax": argmax, "_box_ind": box_ind, "_feat": feat,
             "_tower_ctx": tower_ctx, "_bp": bp,
         }
+        if early_win is not None:
+            out["_refine_win"] = early_win
         if mtl.closeness:
             if self._shared_classifier:          # :701-706, 713-714: the predictor reads the main tower's features
                 cfeat, cctx = feat, None
@@ -583,6 +595,40 @@ class FasterRCNNMetaArch:
             raise RuntimeError("refiner window de-duplication overflowed its %d slots per image (non-finite or "
                                "out-of-range proposal boxes?)" % self.DEDUP_SLOTS)
 
+    def _refine_window_predictions(self, F, boxes_norm):
+        """faster_rcnn_meta_arch.py:774-812: window-class predictions of the N_EXPAND windows of every proposal
+        -> [B*N_EXPAND*N2 (or 1, ...), K+1] rows in [B, N_EXPAND, N2] order."""
+        B = F.shape[0]
+        N2 = self.max_num_proposals
+        K1 = self.num_classes + 1
+        ew = ops.expand_windows(boxes_norm, self.N_EXPAND)    # [B,5,N2,4]
+        if self.DEDUP_SLOTS > 0:
+            # The last window of every proposal is the whole image (up to the last bit of z + (1 - z)): crop
+            # and run the tower once per DISTINCT box instead of once per proposal, then expand the predictions
+            # back — bit-identical outputs, 4*N2 + 8 ROIs per image through the tower instead of 5*N2.
+            if getattr(self, "_dedup_overflow", None) is None:
+                self._dedup_overflow = torch.zeros((1,), dtype=torch.int32, device=F.device)
+            rois, src_row = ops.dedup_windows(ew, self.DEDUP_SLOTS, self._dedup_overflow)
+            R = rois.shape[1]
+            crops, _ = self._crop(F, rois.view(B * R, 4), self._box_ind(B, R, F.device), False)
+            feat, _ = self.window_tower.forward(crops, False)               # forward only (:834)
+            compact = self.window_predictor.predict(feat, self.seed, self.step)["class"]         # [B*R, K1]
+            return ops.gather_rows(compact.view(1, B * R, K1), src_row)      # [1, B*5*N2, K1]
+        flat = ew.view(B * self.N_EXPAND * N2, 4)
+        crops, _ = self._crop(F, flat, self._box_ind(B, self.N_EXPAND * N2, F.device), False)
+        feat, _ = self.window_tower.forward(crops, False)
+        return self.window_predictor.predict(feat, self.seed, self.step)["class"]             # [B*5*N2, K1]
+
+    def _refine_stream(self):
+        """Third forward stream: the refiner's window pass next to the second stage's own towers (None on CPU, without
+        the auxiliary stream, or with MTLSSL_REFINE_EARLY=0)."""
+        import os
+        if self._aux_stream() is None or os.environ.get("MTLSSL_REFINE_EARLY", "1") == "0":
+            return None
+        if getattr(self, "_refine_stream_obj", None) is None:
+            self._refine_stream_obj = torch.cuda.Stream(device=self.ps.device)
+        return self._refine_stream_obj
+
     def predict_with_mtl_results(self, pd):
         """faster_rcnn_meta_arch.py:764-846, executed per image."""
         mtl = self._mtl
@@ -593,24 +639,12 @@ class FasterRCNNMetaArch:
         cls = pd["class_predictions_with_background"]
         win = None
         if mtl.window:
-            ew = ops.expand_windows(pd["proposal_boxes_normalized"], self.N_EXPAND)    # [B,5,N2,4]
-            if self.DEDUP_SLOTS > 0:
-                # The last window of every proposal is the whole image (up to the last bit of z + (1 - z)): crop
-                # and run the tower once per DISTINCT box instead of once per proposal, then expand the predictions
-                # back — bit-identical outputs, 4*N2 + 8 ROIs per image through the tower instead of 5*N2.
-                if getattr(self, "_dedup_overflow", None) is None:
-                    self._dedup_overflow = torch.zeros((1,), dtype=torch.int32, device=F.device)
-                rois, src_row = ops.dedup_windows(ew, self.DEDUP_SLOTS, self._dedup_overflow)
-                R = rois.shape[1]
-                crops, _ = self._crop(F, rois.view(B * R, 4), self._box_ind(B, R, F.device), False)
-                feat, _ = self.window_tower.forward(crops, False)               # forward only (:834)
-                compact = self.window_predictor.predict(feat, self.seed, self.step)["class"]         # [B*R, K1]
-                win = ops.gather_rows(compact.view(1, B * R, K1), src_row)      # [1, B*5*N2, K1]
+            if "_refine_win" in pd:               # issued early on the third stream (_predict_second_stage)
+                torch.cuda.current_stream().wait_stream(self._refine_stream())
+                win = pd.pop("_refine_win")
+                win.record_stream(torch.cuda.current_stream())
             else:
-                flat = ew.view(B * self.N_EXPAND * N2, 4)
-                crops, _ = self._crop(F, flat, self._box_ind(B, self.N_EXPAND * N2, F.device), False)
-                feat, _ = self.window_tower.forward(crops, False)
-                win = self.window_predictor.predict(feat, self.seed, self.step)["class"]             # [B*5*N2, K1]
+                win = self._refine_window_predictions(F, pd["proposal_boxes_normalized"])
             pd["expand_window_class_predictions"] = win.view(B, self.N_EXPAND, N2, K1)
         clo = pd["closeness_predictions"] if mtl.closeness else None
         net = ops.refine_concat(cls, win, clo, B, N2, self.N_EXPAND, bool(mtl.global_closeness))
