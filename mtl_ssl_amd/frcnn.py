@@ -927,7 +927,15 @@ class FasterRCNNMetaArch:
             early.wait_stream(cur)
             with torch.cuda.stream(early):
                 aux_backward(collect=pending)
-        g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True, masked=True)
+        import os
+        if (getattr(self.tower, "supports_wgrad_stream", False) and not shared
+                and os.environ.get("MTLSSL_TOWER_WGRAD_STREAM", "1") == "1"):
+            # the main tower's filter gradients feed nothing but the optimizer: on the third stream (joined at the end
+            # of backward) they leave this stream the dgrad chain that the trunk's backward is waiting for
+            g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True, masked=True,
+                                          wgrad=self._wgrad_exec())
+        else:
+            g_crops = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True, masked=True)
         ops.roi_crop_pool_bwd(g_crops, pd["_argmax"], F.shape, pd["proposal_boxes_normalized"].view(-1, 4),
                               pd["_box_ind"], *crop_args, dfeat=dF, accumulate=False)
         if gw_shared is not None:

@@ -38,15 +38,18 @@ class BoxClassifierTower:
             ctxs.append(c)
         return x, (ctxs if save else None)
 
-    def backward(self, g_out, out, ctxs, need_input_grad, masked=False):
+    supports_wgrad_stream = True
+
+    def backward(self, g_out, out, ctxs, need_input_grad, masked=False, wgrad=nn.INLINE_WGRAD):
         """g_out: dL/d(out) (post-ReLU), or dL/d(pre-activation) when `masked`. Returns
-        dL/d(crops) or None."""
+        dL/d(crops) or None. `wgrad`: where the filter gradients run (inline, or an nn.WgradStream the caller joins)."""
         gp = g_out if masked else ops.relu_bwd(out, g_out)
         units = self.stack.units
         for i in range(len(units) - 1, -1, -1):
             first = i == 0
             gp = units[i].backward(gp, ctxs[i], need_input_grad=(need_input_grad or not first),
-                                   mask_input=not first)
+                                   mask_input=not first, wgrad=wgrad)
+        wgrad.flush()
         return gp
 
 
