@@ -928,6 +928,14 @@ class FasterRCNNMetaArch:
             with torch.cuda.stream(early):
                 aux_backward(collect=pending)
         import os
+        side0 = None
+        if (stop and not shared and (mtl.closeness or mtl.window)
+                and os.environ.get("MTLSSL_AUX_RELEASE", "start") == "start"):
+            side0 = self._aux_stream()
+            if side0 is not None:
+                side0.wait_stream(cur)
+                with torch.cuda.stream(side0):
+                    aux_backward()
         if (getattr(self.tower, "supports_wgrad_stream", False) and not shared
                 and os.environ.get("MTLSSL_TOWER_WGRAD_STREAM", "1") == "1"):
             # the main tower's filter gradients feed nothing but the optimizer: on the third stream (joined at the end
@@ -946,14 +954,16 @@ class FasterRCNNMetaArch:
                 gx.record_stream(cur)         # made on the second stream, consumed and released on this one
                 ops.roi_crop_pool_bwd(gx, am, F.shape, bx, bi, *crop_args, dfeat=dF)
 
-        # With stop_gradient_for_aux_tasks the aux towers' backward touches neither dF nor any
-        # tensor of the main path, so it runs on a second HIP stream, concurrently with the RPN /
-        # trunk backward below: those are small GEMMs (4 864 pixels at B=2) that cannot fill 256
-        # CUs on their own, and the aux towers' large wgrad/dgrad tiles take the idle ones. It is
-        # released only after the main tower's backward (two streams of large tiles would just
-        # time-slice), i.e. exactly when the small-GEMM phase of the main path begins.
+        # With stop_gradient_for_aux_tasks the aux towers' backward touches neither dF nor any tensor of the main path:
+        # it runs on the second HIP stream. Released at the START of backward (above): with the main tower's filter
+        # gradients on the third stream, this stream carries only the dgrad chain towards dF, and the aux towers' large
+        # tiles fill what that chain and, later, the small GEMMs of the RPN / trunk backward (4 864 pixels at B=2)
+        # leave idle (55.6 -> 55.3 ms against releasing it after the main tower's backward, MTLSSL_AUX_RELEASE=late,
+        # which was the better choice while the main tower's filter gradients still ran on this stream).
         side = self._aux_stream() if (stop and (mtl.closeness or mtl.window)) else None
-        if side is not None:
+        if side0 is not None:
+            side = side0
+        elif side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 aux_backward()
