@@ -104,6 +104,15 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         boxes_abs, boxes_norm, num = self._second_stage_proposals(props, nprop, gt, H, W)
         box_ind = self._box_ind(B, N2, F.device)
         flat = boxes_norm.view(B * N2, 4)
+        import os
+        cside = None
+        if mtl.closeness and self._is_training and os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "1") == "1":
+            cside = self._aux_stream()
+        if cside is not None:          # the closeness tower (block4 on the whole map) next to the main tower's forward
+            cside.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cside):
+                cfeat_s, cctx_s = self.closeness_tower.forward(F, self._is_training)
+                cp_s = self.closeness_predictor.predict(cfeat_s, flat, box_ind)
         feat, tower_ctx = self.tower.forward(F, self._is_training)
         bp = self.box_predictor.predict(feat, flat, box_ind)
         out = {
@@ -113,8 +122,12 @@ class RFCNMetaArch(FasterRCNNMetaArch):
             "_box_ind": box_ind, "_feat": feat, "_tower_ctx": tower_ctx, "_bp": bp,
         }
         if mtl.closeness:
-            cfeat, cctx = self.closeness_tower.forward(F, self._is_training)
-            cp = self.closeness_predictor.predict(cfeat, flat, box_ind)
+            if cside is not None:
+                torch.cuda.current_stream().wait_stream(cside)
+                cfeat, cctx, cp = cfeat_s, cctx_s, cp_s
+            else:
+                cfeat, cctx = self.closeness_tower.forward(F, self._is_training)
+                cp = self.closeness_predictor.predict(cfeat, flat, box_ind)
             out.update({"closeness_predictions": cp["class"], "_cfeat": cfeat, "_cctx": cctx, "_cp": cp})
         return out
 
