@@ -9,8 +9,10 @@ config[3] = the same step on 8 ranks, weak scaling).
 Prints ONE JSON line on rank 0. `value` = global_batch * K / max-over-ranks time of K steps
 (slim/learning.py:489-518: instances/sec = batch / step wall-time). Inputs are resident in HBM
 before the timed region. `roofline` is the dominant kernel (fp32-MFMA implicit-GEMM conv forward,
-128x128 tile) timed with HIP events on the launch stream inside the timed region; `cpu_baseline`
-is the CPU oracle of the identical step timed on the host cores on a bounded sample.
+128x128 tile) timed with HIP events on the launch stream inside the timed region — where its launches
+share the chip with two other streams' large-tile launches — plus `roofline.isolated`, the same launches with those
+overlaps switched off for a few extra steps; `cpu_baseline` is the CPU oracle of the identical step timed on the host
+cores on a bounded sample.
 """
 import argparse
 import json
@@ -318,6 +320,8 @@ def main():
     ap.add_argument("--split-engine-steps", type=int, default=10,
                     help="after the timed region, time this many steps on the opt-in split-bf16 fp32 engine (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-isolated-steps", type=int, default=4,
+                    help="extra steps with the forward streams serialised, for roofline.isolated (0 = skip)")
     ap.add_argument("--conv-breakdown", action="store_true",
                     help="time every conv launch (adds ~2%% to the step) and report the per-kernel table")
     a = ap.parse_args()
@@ -496,6 +500,48 @@ def main():
                 "avg_launch_us": 1e6 * dom["seconds"] / dom["dispatches"],
                 "algorithmic_flop_per_launch_avg": dom["flops"] / dom["dispatches"],
             }
+    if prof is not None and "roofline" in out and world == 1 and comm is None and a.roofline_isolated_steps > 0:
+        # In the timed region this kernel's launches share the chip: the closeness tower's forward runs next to the main
+        # tower's and the refiner's window pass next to both (three streams) — that is what makes the
+        # step faster, and it makes "flops / launch duration" the rate of a launch that owns a PART of the chip. The
+        # same launches with those two overlaps switched off (each launch alone on the chip, as in rounds 1-2) give the
+        # kernel's own rate against its roofline.
+        saved = {k: os.environ.get(k) for k in ("MTLSSL_CLOSENESS_FWD_SIDE", "MTLSSL_REFINE_EARLY")}
+        try:
+            os.environ["MTLSSL_CLOSENESS_FWD_SIDE"] = "0"
+            os.environ["MTLSSL_REFINE_EARLY"] = "0"
+            tr.step(next_batch())                      # plans of the serialised schedule are the same; one settling step
+            torch.cuda.synchronize()
+            ops.PROFILER = ops.ConvProfiler((0, 0))
+            t1 = time.perf_counter()
+            for _ in range(a.roofline_isolated_steps):
+                tr.step(next_batch())
+            torch.cuda.synchronize()
+            iso_ms = 1e3 * (time.perf_counter() - t1) / a.roofline_isolated_steps
+            iso = ops.PROFILER.summary().get(("fwd", 0))
+            ops.PROFILER = None
+            if iso and iso["seconds"] > 0:
+                out["roofline"]["overlap"] = (
+                    "in the timed region the launches of this kernel run next to other streams' large-tile launches "
+                    "(closeness tower beside the main tower, refiner window pass beside both): achieved / frac / "
+                    "avg_launch_us above are per launch WHILE SHARING the chip; `isolated` is the same kernel on the same "
+                    "problems with those two overlaps off")
+                out["roofline"]["frac_isolated"] = iso["flops"] / iso["seconds"] / FP32_MFMA_PEAK
+                out["roofline"]["isolated"] = {
+                    "achieved": iso["flops"] / iso["seconds"] / 1e12, "frac": iso["flops"] / iso["seconds"] / FP32_MFMA_PEAK,
+                    "avg_launch_us": 1e6 * iso["seconds"] / iso["dispatches"], "launches": iso["dispatches"],
+                    "steps": a.roofline_isolated_steps, "ms_per_step_of_that_schedule": iso_ms,
+                    "how": "MTLSSL_CLOSENESS_FWD_SIDE=0 MTLSSL_REFINE_EARLY=0 for these steps, after the timed region; "
+                           "rocprofv3 of a whole run in that mode: profiles/r03_kernel_stats_bench_forward_serialised.md"}
+        except Exception as e:
+            ops.PROFILER = None
+            out["roofline"]["isolated"] = {"error": repr(e)}
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     if prof is not None and a.conv_breakdown:
         fam_f = sum(v["flops"] for k, v in s.items() if k[1] >= 0)
         fam_t = sum(v["seconds"] for k, v in s.items() if k[1] >= 0)
