@@ -625,6 +625,13 @@ class FasterRCNNMetaArch:
         import os
         if self._aux_stream() is None or os.environ.get("MTLSSL_REFINE_EARLY", "1") == "0":
             return None
+        # the filter-gradient stream is idle during the forward pass: reuse it rather than create a fourth compute
+        # stream — HIP multiplexes streams onto a few hardware queues (4 by default), and with the data-parallel
+        # trainer's own step and communication streams a further one ended up sharing a queue with another compute
+        # stream (measured with a 1-rank communicator: 60.2 ms/step against 55.5)
+        w = self._wgrad_exec()
+        if getattr(w, "stream", None) is not None and os.environ.get("MTLSSL_REFINE_OWN_STREAM", "0") != "1":
+            return w.stream
         if getattr(self, "_refine_stream_obj", None) is None:
             self._refine_stream_obj = torch.cuda.Stream(device=self.ps.device)
         return self._refine_stream_obj

@@ -9,7 +9,7 @@ rm -rf $E; mkdir -p $E
 cd $R
 python bench.py --split-engine-steps 0 > $E/bench_default.json 2> $E/bench_default.err
 python bench.py --steps 20 --warmup 5 --conv-breakdown --no-cpu-baseline > $E/bench_conv_breakdown.json 2>> $E/bench_default.err
-MTLSSL_COMM_SELFTEST=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_rccl_1rank.json 2> $E/bench_rccl_1rank.err
+MTLSSL_COMM_SELFTEST=1 python bench.py --steps 30 --warmup 10 --no-cpu-baseline > $E/bench_rccl_1rank.json 2> $E/bench_rccl_1rank.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --config configs/rfcn_resnet101_voc_mtl.config > $E/bench_rfcn.json 2> $E/bench_rfcn.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --config configs/frcnn_mobilenet_v1_voc_mtl.config > $E/bench_mobilenet.json 2> $E/bench_mobilenet.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --config configs/frcnn_inception_resnet_v2_coco_mtl.config --height 800 --width 1333 > $E/bench_inception.json 2> $E/bench_inception.err
