@@ -601,7 +601,10 @@ def main():
                 "note": "per step; main_ms / side_ms = wall time of the calls issued to the step's main stream / to the "
                         "auxiliary and filter-gradient streams (a Winograd call = its transforms + its GEMM stack); "
                         "non_conv_main_stream_ms = step time minus the main stream's conv calls (RoI crop, proposal "
-                        "chain, losses, optimizer, waits on side streams); kernel-level rows: profiles/r03_kernel_stats_bench.md",
+                        "chain, losses, optimizer, waits on side streams). Calls on different streams overlap (forward: main "
+                        "tower / closeness tower / refiner pass side by side; backward: dgrad chain / aux towers / filter "
+                        "gradients), so rows do not add up to the step and a row's TFLOP/s is the rate of calls that share "
+                        "the chip; kernel-level rows: profiles/r03_kernel_stats_bench.md",
             }
         except Exception as e:
             ops.PROFILER = None
