@@ -320,6 +320,8 @@ def main():
     ap.add_argument("--split-engine-steps", type=int, default=10,
                     help="after the timed region, time this many steps on the opt-in split-bf16 fp32 engine (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-hbm-kernels", action="store_true",
+                    help="skip the stand-alone timing of the HBM-bound kernels (keeps a rocprofv3 trace to the steps)")
     ap.add_argument("--roofline-isolated-steps", type=int, default=4,
                     help="extra steps with the forward streams serialised, for roofline.isolated (0 = skip)")
     ap.add_argument("--conv-breakdown", action="store_true",
@@ -375,7 +377,7 @@ def main():
     hbm_first = None
     for i in range(a.warmup):
         tr.step(next_batch())
-        if i == 0 and world == 1 and not a.no_roofline:
+        if i == 0 and world == 1 and not a.no_roofline and not a.no_hbm_kernels:
             # the proposal chain and the ROI scatter are data dependent (how many candidates a suppression round
             # needs, how many atomics collide): time them once on the freshly initialised detector too — the entry
             # after the timed steps sees a detector over-fitted to one batch, whose proposals pile onto the groundtruth
@@ -610,7 +612,7 @@ def main():
             ops.PROFILER = None
             out["step_breakdown"] = {"error": repr(e)}
     # the secondary blocks below never take the headline line down: a failure is reported in place of the block
-    if world == 1 and not a.no_roofline:
+    if world == 1 and not a.no_roofline and not a.no_hbm_kernels:
         try:
             out["hbm_kernels"] = hbm_kernels(tr)
             for r in out["hbm_kernels"]:
