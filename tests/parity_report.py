@@ -34,3 +34,27 @@ def gradients(tag, grads, ref, losses=None, ref_losses=None):
         line += "; loss rel err worst %.2e" % worst
     add(line)
     return l2
+
+
+def against_float64(tag, Oracle, hp, values, host_batch, seed, step, aux, grads, rgrads, cap=1e-3):
+    """The gradient claim against the better yardstick: the same graph evaluated by the oracle in float64 on the SAME
+    sampled boxes (`aux["proposal_boxes"]`, `aux["num_proposals"]` forced). Asserts every variable of `grads` (HIP path)
+    within `cap` relative L2 of float64; returns {name: (hip_vs_f64, fp32_oracle_vs_f64)} and records worst / median of
+    both (the torch-CPU fp32 oracle is itself up to ~1e-3 from float64 on variables behind ReLU / max-pool branch
+    flips; an fp32-vs-fp32 figure above 1e-3 therefore says nothing about which side is off)."""
+    _, g64, _ = Oracle(hp, values, np.float64).step(host_batch, seed=seed, step=step,
+                                                     forced=dict(proposal_boxes=aux["proposal_boxes"],
+                                                                 num_proposals=aux["num_proposals"]))
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+    out = {}
+    for name, g in grads.items():
+        if name in g64 and name in rgrads:
+            out[name] = (rel(g, g64[name]), rel(rgrads[name], g64[name]))
+    worst = max(out, key=lambda n: out[n][0])
+    worst_cpu = max(out, key=lambda n: out[n][1])
+    add("    vs float64 (%s): HIP path worst %.2e (%s) median %.2e; torch-CPU fp32 oracle worst %.2e (%s) median %.2e" % (
+        tag, out[worst][0], worst.split("/", 1)[-1], np.median([v[0] for v in out.values()]),
+        out[worst_cpu][1], worst_cpu.split("/", 1)[-1], np.median([v[1] for v in out.values()])))
+    for name, (e, _) in out.items():
+        assert e < cap, (tag, name, e)
+    return out

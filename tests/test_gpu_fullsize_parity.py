@@ -1,5 +1,6 @@
-"""Whole-step oracle parity at the FULL sizes the benchmark quotes, one image per case (what the CPU oracle
-finishes in seconds on the GPU box's host cores):
+"""Whole-step oracle parity at the FULL sizes the benchmark quotes (one image per case where the CPU oracle is slow,
+and the benchmark's own per-GPU batch of 2 for configs[1] / configs[2] — per-image refine, the batch-mean closeness
+tile, the 1/(max(1,n_i)*B) detector normalisation and the two-image proposal chain are where B matters):
 
   configs[1]  Faster R-CNN ResNet-101, 90 classes, crop 14 -> pool 2, three aux heads + refine, 600x1024
               (configs/frcnn_resnet101_coco_mtl.config — bench.py's workload; 14 453 anchors inside the window)
@@ -30,20 +31,27 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# worst: cap on the per-variable relative L2 between the HIP path and the torch-CPU fp32 oracle (two fp32 evaluations:
+# two sets of ReLU / max-pool branch flips), set from what is observed (profiles/r0*_parity_report.txt) with ~3x room;
+# f64: additionally judge every variable against a float64 evaluation of the same graph (<= 1e-3, the claim proper).
 CASES = {
     "configs1_frcnn_resnet101_coco": dict(config="frcnn_resnet101_coco_mtl.config", H=600, W=1024, n_inside=14453,
-                                          n_all=29184),
+                                          n_all=29184, B=1, worst=1.5e-3, f64=False),
+    "configs1_frcnn_resnet101_coco_batch2": dict(config="frcnn_resnet101_coco_mtl.config", H=600, W=1024, n_inside=14453,
+                                                 n_all=29184, B=2, worst=1.5e-3, f64=False),
     "configs0_frcnn_mobilenet_voc": dict(config="frcnn_mobilenet_v1_voc_mtl.config", H=600, W=800, n_inside=None,
-                                         n_all=38 * 50 * 12),
+                                         n_all=38 * 50 * 12, B=1, worst=5e-3, f64=True),
     "configs2_rfcn_resnet101_voc": dict(config="rfcn_resnet101_voc_mtl.config", H=600, W=1024, n_inside=14453,
-                                        n_all=29184),
+                                        n_all=29184, B=1, worst=2e-3, f64=False),
+    "configs2_rfcn_resnet101_voc_batch2": dict(config="rfcn_resnet101_voc_mtl.config", H=600, W=1024, n_inside=14453,
+                                               n_all=29184, B=2, worst=2e-3, f64=False),
     "configs4_frcnn_inception_resnet_v2_coco": dict(config="frcnn_inception_resnet_v2_coco_mtl.config", H=800, W=1333,
-                                                    n_inside=None, n_all=None),
+                                                    n_inside=None, n_all=None, B=1, worst=2.5e-3, f64=False),
 }
 
 
-def oracle_rerun(Oracle, hp, values, hb, seed, boxes, num):
-    return Oracle(hp, values).step(hb, seed=seed, step=0, forced=dict(proposal_boxes=boxes, num_proposals=num))
+def oracle_rerun(Oracle, hp, values, hb, seed, boxes, num, step=0):
+    return Oracle(hp, values).step(hb, seed=seed, step=step, forced=dict(proposal_boxes=boxes, num_proposals=num))
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -61,7 +69,7 @@ def test_full_size_step_matches_the_oracle(name):
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     model = model_builder.build(cfg.model, True, "cuda", seed=0)
     tr = trainer.Trainer(model, cfg.train_config, 1)
-    batch = synthetic.make_batch(1, H, W, K, seed=1234, device="cuda")
+    batch = synthetic.make_batch(case["B"], H, W, K, seed=1234, device="cuda")
     values = model.ps.state_dict()
     losses = tr.forward_backward(batch)
     torch.cuda.synchronize()
@@ -137,14 +145,101 @@ def test_full_size_step_matches_the_oracle(name):
     for n, gval in grads.items():
         if n not in rgrads:
             assert not np.any(gval), n
-    l2 = parity_report.gradients("%s FULL SIZE %dx%d batch 1, K=%d (anchors %d, proposals %s)" % (
-        name, W, H, K, pd["anchors"].shape[0], aux["num_proposals"].tolist()), grads, rgrads, got, ref)
+    l2 = parity_report.gradients("%s FULL SIZE %dx%d batch %d, K=%d (anchors %d, proposals %s)" % (
+        name, W, H, case["B"], K, pd["anchors"].shape[0], aux["num_proposals"].tolist()), grads, rgrads, got, ref)
     parity_report.add("    %s: feature map rel err %.2e, RPN objectness rel err %.2e, proposal boxes err %.2e of the image "
                       "side, worst loss rel err %.2e; rpn_match / rpn_sampled bit-exact; %s; free-running oracle: %d of %d "
                       "sampled boxes in the same slot" % (name, feat_err, rpn_err, box_err, worst_loss, chain, same_rows,
                                                           mine.shape[0] * mine.shape[1]))
     assert len(l2) == len(set(grads) & set(rgrads)) > 50
     assert np.median(l2) < 1e-3, np.median(l2)
-    assert l2[-1] < 5e-3, l2[-1]
+    assert l2[-1] < case["worst"], l2[-1]
+    if case["f64"]:
+        # the outlier of round 3 (MobileNet's first filter, 3.5e-3 fp32-vs-fp32) judged against float64 on the device's
+        # boxes: the HIP path must be within 1e-3 of it on EVERY variable
+        parity_report.against_float64("%s FULL SIZE batch %d" % (name, case["B"]), Oracle, hp, values, hb, model.seed, 0,
+                                      aux, grads, rgrads, cap=1e-3)
     del model, tr, batch
+    torch.cuda.empty_cache()
+
+
+def test_trained_state_step_matches_the_free_running_oracle():
+    """The state the benchmark spends its time in: a detector whose RPN scores are spread out (not the ~0.5 plateau of
+    a fresh initialisation). configs[1] at the benchmark's batch (2 x 600x1024) is trained for 30 steps on a ring of
+    four batches at a learning rate that moves the RPN (the COCO schedule's 1e-5 would not in 30 steps), then ONE
+    step is compared with the oracle FREE-RUNNING — its own trunk, its own RPN floats, its own decode -> sort -> NMS ->
+    sampling — with nothing forced. Asserted: the RPN scores are in fact spread; proposal counts equal; the sampled
+    boxes slot by slot with at most a handful of slots differing (a greedy NMS over thousands of candidate pairs has
+    O(1) IoU comparisons within 1e-6 of the 0.7 threshold, and the two fp32 trunks differ by ~1e-6); detector matches
+    bit-exact on the agreeing slots; anchor targets / sampler bit-exact (they do not depend on the RPN floats); losses
+    1e-3 free-running when every slot agrees, else on the device's boxes. faster_rcnn_meta_arch.py:1055-1216, 1670-1793."""
+    import __graft_entry__ as g
+    g.build()
+    import bench
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    from oracle.model import Oracle
+    from tests import parity_report
+    text = open(os.path.join(ROOT, "configs", "frcnn_resnet101_coco_mtl.config")).read()
+    assert text.count("learning_rate: .00001") == 3
+    cfg = config.parse_pipeline_config(text.replace("learning_rate: .00001", "learning_rate: .0003"))
+    K = int(cfg.model.faster_rcnn.num_classes)
+    H, W, Bn = 600, 1024, 2
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    model = model_builder.build(cfg.model, True, "cuda", seed=0)
+    tr = trainer.Trainer(model, cfg.train_config, 1)
+    ring = [synthetic.make_batch(Bn, H, W, K, seed=1234 + 1000 * i, device="cuda") for i in range(4)]
+    for i in range(30):
+        tr.step(ring[i % 4])
+    torch.cuda.synchronize()
+    model.check_device_flags()
+    batch = ring[30 % 4]
+    values = model.ps.state_dict()
+    step_no = tr.global_step
+    losses = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    model.check_device_flags()
+    got = {k: float(v.item()) for k, v in losses.items()}
+    pd = tr._pd
+    hb = {k: v for k, v in batch.items() if k != "_staged"}
+    hb["images"] = batch["images"].cpu().numpy()
+    hp = bench.hyper_params_for_oracle(cfg)
+    ref, rgrads, aux = Oracle(hp, values).step(hb, seed=model.seed, step=step_no)       # nothing forced
+    # the RPN is no longer on the initialisation plateau: foreground probabilities spread over a wide range
+    obj = pd["rpn_objectness_predictions_with_background"].cpu().numpy()
+    fg = 1.0 / (1.0 + np.exp(obj[..., 0] - obj[..., 1]))
+    spread = float(np.percentile(fg, 99.5) - np.percentile(fg, 0.5))
+    assert spread > 0.2, spread
+    rpn_err = float(np.abs(obj - aux["rpn_objectness"]).max() / np.abs(aux["rpn_objectness"]).max())
+    assert rpn_err < 1e-3, rpn_err
+    # anchor targets do not see the RPN floats: bit-exact
+    np.testing.assert_array_equal(pd["_rpn_targets"]["match"].cpu().numpy(), aux["rpn_match"])
+    np.testing.assert_array_equal(pd["_rpn_targets"]["sampled"].cpu().numpy(), aux["rpn_sampled"])
+    np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
+    mine = pd["proposal_boxes"].cpu().numpy()
+    same = np.abs(mine - aux["proposal_boxes"]).max(-1) <= 1e-3 * max(H, W)           # [B, N2]
+    differing = int((~same).sum())
+    a, b = aux["proposal_boxes"].reshape(-1, 4), mine.reshape(-1, 4)
+    in_set = int((np.abs(a[:, None, :] - b[None, :, :]).max(-1) <= 1e-3 * max(H, W)).any(1).sum())
+    assert differing <= 4, (differing, in_set)
+    dm, rm = pd["_det_targets"]["match"].cpu().numpy().reshape(same.shape), aux["det_match"].reshape(same.shape)
+    np.testing.assert_array_equal(dm[same], rm[same])
+    chain = "every slot agrees, det_match bit-exact, losses compared free-running"
+    if differing:
+        chain = ("%d of %d slots differ (%d of the oracle's boxes found in the device's set): near-threshold NMS / "
+                 "near-tied scores; losses and gradients compared on the device's boxes" % (differing, same.size, in_set))
+        ref, rgrads, aux = oracle_rerun(Oracle, hp, values, hb, model.seed, mine, pd["num_proposals"].cpu().numpy(),
+                                        step=step_no)
+    worst_loss = 0.0
+    for k in ref:
+        err = abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-3)
+        worst_loss = max(worst_loss, err)
+        assert err <= 1e-3, (k, got[k], ref[k])
+    grads = model.ps.grads_dict()
+    tag = "configs1 TRAINED STATE (30 steps, lr 3e-4) %dx%d batch %d" % (W, H, Bn)
+    l2 = parity_report.gradients(tag, grads, rgrads, got, ref)
+    assert np.median(l2) < 1e-3 and l2[-1] < 5e-3, (np.median(l2), l2[-1])
+    parity_report.add("    %s: RPN foreground-probability spread (p99.5 - p0.5) %.3f, RPN objectness rel err %.2e, proposals %s; "
+                      "FREE-RUNNING oracle: %s; worst loss rel err %.2e" % (
+                          tag, spread, rpn_err, aux["num_proposals"].tolist(), chain, worst_loss))
+    del model, tr, ring
     torch.cuda.empty_cache()

@@ -153,6 +153,10 @@ def test_rfcn_step_matches_oracle(arch):
     assert len(l2errs) > 60 and np.median(l2errs) < 1e-3
     from tests import parity_report
     parity_report.gradients("R-FCN %s 160x224" % arch, grads, rgrads, got, ref)
+    # round 3's two fp32-vs-fp32 outliers live here (ClosenessBoxPredictor/.../conv1 2.5e-3, MTLClassRefiner/fc1
+    # 1.3e-3): judged against float64 on the same boxes, the HIP path is held to 1e-3 on every variable
+    parity_report.against_float64("R-FCN %s 160x224" % arch, Oracle, bench.hyper_params_for_oracle(cfg), values, hb,
+                                  model.seed, 0, aux, grads, rgrads, cap=1e-3)
     # aux gradients are NOT stopped in the R-FCN configs: the trunk sees them
     tr.apply_gradients()
     assert np.isfinite(model.ps.weights.sum().item())
