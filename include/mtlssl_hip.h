@@ -518,14 +518,17 @@ int mtlssl_dedup_windows(const float* windows, int batch, int n_expand, int n2, 
  *   _scores: scores[B,n2] = cls + loc row losses (loss_type 0 BOTH — the row losses carry weight / normaliser),
  *            cls only (1) or loc only (2); rows >= num_proposals[b] get -inf (not candidates). Feed each image's
  *            row to mtlssl_nms.
- *   _apply:  selected[B,max_selected] / num_selected[B] = the NMS output per image; zeroes the rows of d_box
- *            [B*n2, box_ld] and d_cls [B*n2, cls_ld] that were not kept and writes the mined loss sums per image. */
+ *   _apply:  selected[B,max_selected] / num_selected[B] = the NMS output per image; selected indices >=
+ *            num_proposals[b] (padding rows the NMS appended after every real candidate; nullable = none) are
+ *            dropped — the reference unpads BEFORE mining (:1921-1929); zeroes the rows of d_box [B*n2, box_ld]
+ *            and d_cls [B*n2, cls_ld] that were not kept, writes the mined loss sums per image and, if given,
+ *            num_kept_out[b] = how many of selected[b, :] were kept (they lead the row, in mining order). */
 int mtlssl_hard_mining_scores(const float* loc_row_loss, const float* cls_row_loss, const int32_t* num_proposals,
                               int batch, int n2, int loss_type, float* scores, mtlssl_stream_t stream);
-int mtlssl_hard_mining_apply(const int32_t* selected, const int32_t* num_selected, int batch, int max_selected, int n2,
-                             const float* loc_row_loss, const float* cls_row_loss, float* d_box, int box_ld,
-                             float* d_cls, int cls_ld, float* loc_loss_out, float* cls_loss_out,
-                             mtlssl_stream_t stream);
+int mtlssl_hard_mining_apply(const int32_t* selected, const int32_t* num_selected, const int32_t* num_proposals,
+                             int batch, int max_selected, int n2, const float* loc_row_loss, const float* cls_row_loss,
+                             float* d_box, int box_ld, float* d_cls, int cls_ld, float* loc_loss_out,
+                             float* cls_loss_out, int32_t* num_kept_out, mtlssl_stream_t stream);
 /* slim.dropout (faster_rcnn_meta_arch.py:838-839 in the refiner's FC stack; core/box_predictor.py:484-488, 590-594 after
  * the predictors' extra FC layers): y[i] = x[i] / keep_prob if element i is kept, else 0. The Bernoulli draw is the
  * samplers' counter hash: kept iff mix32(seed, stream_id, i) < floor(keep_prob * 2^32) — reproducible and identical in
@@ -559,6 +562,11 @@ typedef struct mtlssl_comm* mtlssl_comm_t;
 #define MTLSSL_COMM_SUM 0
 #define MTLSSL_COMM_MAX 1
 #define MTLSSL_COMM_MIN 2
+/* Non-collective probe of the preconditions of mtlssl_comm_init on THIS rank: RCCL can be loaded and every entry
+ * point is bound (rccl_version_out, nullable) and a HIP device is current and usable (device_out, nullable).
+ * MTLSSL_ECOMM with the reason in mtlssl_last_error otherwise. Ranks agree on the result over their host channel
+ * BEFORE any of them enters the collective mtlssl_comm_init (a rank that fails alone would leave the others blocked). */
+int mtlssl_comm_available(int* rccl_version_out, int* device_out);
 int mtlssl_comm_unique_id(void* id_out);
 int mtlssl_comm_init(mtlssl_comm_t* comm_out, const void* id, int nranks, int rank);
 /* What RCCL itself reports for the communicator (ncclCommCount / UserRank / CuDevice / ncclGetVersion);

@@ -43,16 +43,60 @@ def _stdout_to_stderr():
         os.close(saved)
 
 
+def _apply_rccl_knobs():
+    """Knobs for sharing the chip between the step's compute streams and RCCL's own kernels (each RCCL channel is a
+    persistent workgroup that holds a CU for the duration of a collective): MTLSSL_COMM_MAX_CHANNELS /
+    MTLSSL_COMM_MIN_CHANNELS are handed to RCCL as NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS (read by RCCL when the
+    communicator is created; an explicit NCCL_* setting in the environment wins). tools/cu_thief_probe.py sizes what a
+    given channel count costs the step on one GPU."""
+    for mine, theirs in (("MTLSSL_COMM_MAX_CHANNELS", "NCCL_MAX_NCHANNELS"), ("MTLSSL_COMM_MIN_CHANNELS", "NCCL_MIN_NCHANNELS")):
+        v = os.environ.get(mine)
+        if v and theirs not in os.environ:
+            os.environ[theirs] = str(int(v))
+
+
+def comm_stream_priority():
+    """Priority of the gradient all-reduce stream (MTLSSL_COMM_STREAM_PRIORITY: 0 default, -1 high). The collectives
+    are few, large and off the critical path until the optimizer waits for them; high priority lets their channels
+    claim CUs at kernel boundaries instead of queueing behind three saturated compute streams."""
+    return int(os.environ.get("MTLSSL_COMM_STREAM_PRIORITY", "0"))
+
+
+def _dist_agree(failed):
+    """True on every rank iff `failed` is False on every rank (host channel: the initialised torch.distributed group)."""
+    import torch.distributed as dist
+    t = torch.tensor([1 if failed else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item()) == 0
+
+
 class RcclComm:
     """One RCCL communicator rank bound to `device` (mtlssl_comm_init). `exchange(id_or_None)` must
     return rank 0's unique id on every rank; the default uses the initialised torch.distributed
-    group (any backend) as the host channel. world == 1 needs no channel at all."""
+    group (any backend) as the host channel. world == 1 needs no channel at all. `agree(failed) -> bool` is the
+    all-ranks AND of "my preconditions hold" over the same channel: the ranks settle it BEFORE the collective
+    mtlssl_comm_init, so a rank that cannot load RCCL or see its device makes every rank raise instead of leaving the
+    healthy ones blocked inside ncclCommInitRank."""
     backend = "rccl"
 
-    def __init__(self, device, rank=0, world=1, exchange=None):
+    def __init__(self, device, rank=0, world=1, exchange=None, agree=None):
         self.device = torch.device(device)
         assert self.device.type == "cuda", "RCCL communicators live on a GPU"
         self._lib = lib()
+        _apply_rccl_knobs()
+        pre = None
+        try:
+            if self.device.index is not None and self.device.index >= torch.cuda.device_count():
+                raise RuntimeError("device %s is not visible (%d devices)" % (self.device, torch.cuda.device_count()))
+            with torch.cuda.device(self.device):
+                self._lib.comm_available(None, None)
+        except Exception as e:
+            pre = e
+        if world > 1:
+            if not (agree or _dist_agree)(pre is not None):
+                raise RuntimeError("RCCL preconditions failed on at least one rank%s" % (": %r" % pre if pre else ""))
+        elif pre is not None:
+            raise pre
         uid = ctypes.create_string_buffer(ID_BYTES)
         err = None
         if rank == 0:
@@ -109,6 +153,7 @@ class GlooComm:
         self._dist = dist
         self._group = group
         self._label = label
+        self.backend = str(dist.get_backend(group))          # the group's actual backend (nccl for the fallback)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
 
     def _on(self, stream, fn):

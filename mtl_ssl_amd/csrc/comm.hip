@@ -100,6 +100,23 @@ using namespace mtlssl;
 
 extern "C" {
 
+int mtlssl_comm_available(int* rccl_version_out, int* device_out) {
+  const Rccl* r = rccl();
+  if (!r) return MTLSSL_ECOMM;
+  int v = 0;
+  ncclResult_t e = r->GetVersion(&v);
+  if (e != ncclSuccess) return nccl_fail(r, "ncclGetVersion", e);
+  int dev = -1;
+  hipError_t he = hipGetDevice(&dev);
+  if (he != hipSuccess || dev < 0) {
+    set_error("comm: no usable HIP device is current (%s)", hipGetErrorString(he));
+    return MTLSSL_ECOMM;
+  }
+  if (rccl_version_out) *rccl_version_out = v;
+  if (device_out) *device_out = dev;
+  return MTLSSL_OK;
+}
+
 int mtlssl_comm_unique_id(void* id_out) {
   MTLSSL_REQUIRE(id_out != nullptr, "comm_unique_id: null output");
   const Rccl* r = rccl();

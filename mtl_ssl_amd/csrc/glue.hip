@@ -133,20 +133,25 @@ __global__ void __launch_bounds__(256)
 // Stage 2 (one block per image): rows the NMS kept stay, every other row's gradient is zeroed; the mined losses are
 // the sums of the kept rows, accumulated in row order (fixed order: reproducible).
 __global__ void __launch_bounds__(256)
-    k_hard_mining_apply(const int32_t* sel, const int32_t* num_sel, int max_sel, int n2, const float* loc_rl,
-                        const float* cls_rl, float* d_box, int box_ld, float* d_cls, int cls_ld, float* loc_loss,
-                        float* cls_loss) {
+    k_hard_mining_apply(const int32_t* sel, const int32_t* num_sel, const int32_t* num_prop, int max_sel, int n2,
+                        const float* loc_rl, const float* cls_rl, float* d_box, int box_ld, float* d_cls, int cls_ld,
+                        float* loc_loss, float* cls_loss, int32_t* num_kept) {
   extern __shared__ unsigned char hm_keep[];      // [n2]
   __shared__ float s4[4];
+  __shared__ int s_kept;
   int b = blockIdx.x;
   for (int i = threadIdx.x; i < n2; i += 256) hm_keep[i] = 0;
+  if (threadIdx.x == 0) s_kept = 0;
   __syncthreads();
   int ns = min(num_sel[b], max_sel);
+  // padding rows (index >= num_proposals, score -inf) come last in the NMS order: selected ones are not mined
+  int nvalid = num_prop ? min(num_prop[b], n2) : n2;
   for (int j = threadIdx.x; j < ns; j += 256) {
     int r = sel[(int64_t)b * max_sel + j];
-    if (r >= 0 && r < n2) hm_keep[r] = 1;
+    if (r >= 0 && r < nvalid) { hm_keep[r] = 1; atomicAdd(&s_kept, 1); }
   }
   __syncthreads();
+  if (threadIdx.x == 0 && num_kept) num_kept[b] = s_kept;
   float al = 0.f, ac = 0.f;
   for (int i = threadIdx.x; i < n2; i += 256)
     if (hm_keep[i]) { al += loc_rl[(int64_t)b * n2 + i]; ac += cls_rl[(int64_t)b * n2 + i]; }
@@ -369,15 +374,15 @@ int mtlssl_hard_mining_scores(const float* loc_row_loss, const float* cls_row_lo
                      cls_row_loss, num_proposals, n2, loss_type, scores);
   return check_launch("hard_mining_scores");
 }
-int mtlssl_hard_mining_apply(const int32_t* selected, const int32_t* num_selected, int batch, int max_selected, int n2,
-                             const float* loc_row_loss, const float* cls_row_loss, float* d_box, int box_ld,
-                             float* d_cls, int cls_ld, float* loc_loss_out, float* cls_loss_out,
-                             mtlssl_stream_t stream) {
+int mtlssl_hard_mining_apply(const int32_t* selected, const int32_t* num_selected, const int32_t* num_proposals,
+                             int batch, int max_selected, int n2, const float* loc_row_loss, const float* cls_row_loss,
+                             float* d_box, int box_ld, float* d_cls, int cls_ld, float* loc_loss_out,
+                             float* cls_loss_out, int32_t* num_kept_out, mtlssl_stream_t stream) {
   MTLSSL_REQUIRE(n2 <= 60000, "hard_mining: at most 60 000 proposals per image");
   if (!batch || !n2) return MTLSSL_OK;
   hipLaunchKernelGGL(k_hard_mining_apply, dim3(batch), dim3(256), (size_t)n2, S(stream), selected, num_selected,
-                     max_selected, n2, loc_row_loss, cls_row_loss, d_box, box_ld, d_cls, cls_ld, loc_loss_out,
-                     cls_loss_out);
+                     num_proposals, max_selected, n2, loc_row_loss, cls_row_loss, d_box, box_ld, d_cls, cls_ld,
+                     loc_loss_out, cls_loss_out, num_kept_out);
   return check_launch("hard_mining_apply");
 }
 

@@ -146,6 +146,12 @@ class FasterRCNNMetaArch:
                 raise ValueError("hard_example_miner.loss_type %s" % hm.loss_type)
             self._hard_miner = dict(num_hard_examples=int(hm.num_hard_examples) or None,
                                     iou_threshold=float(hm.iou_threshold), loss_type=lt)
+            if is_training and mtl.refine and not frcnn.first_stage_only:
+                # faster_rcnn_meta_arch.py:1828-1832 unpacks THREE values from _unpad_proposals_and_apply_hard_mining,
+                # which returns the miner's two (core/losses.py:571): the reference cannot build a training graph with a
+                # miner and the refiner together. Same failure here, at the same point of a run (before the first step).
+                raise ValueError("hard_example_miner with mtl.refine: need more than 2 values to unpack "
+                                 "(faster_rcnn_meta_arch.py:1828-1832; set mtl.refine: false to mine)")
         if mtl.shared_feature not in ("proposal_feature_maps", "classifier_feature_maps"):
             raise ValueError("mtl.shared_feature must be 'proposal_feature_maps' or 'classifier_feature_maps', got %r"
                              % (mtl.shared_feature,))
@@ -248,8 +254,9 @@ class FasterRCNNMetaArch:
     # ------------------------------------------------------------------ properties / plumbing
     @property
     def max_num_proposals(self):
-        """faster_rcnn_meta_arch.py:463-477."""
-        if self._is_training:
+        """faster_rcnn_meta_arch.py:463-477: second_stage_batch_size while training WITHOUT a hard example miner; with
+        one (and at inference) every NMS survivor is kept, padded to first_stage_max_proposals."""
+        if self._is_training and self._hard_miner is None:
             return int(self.cfg.second_stage_batch_size)
         return int(self.cfg.first_stage_max_proposals)
 
@@ -488,7 +495,7 @@ class FasterRCNNMetaArch:
         proposals against the groundtruth; inference keeps all of them. Returns absolute boxes,
         normalised boxes (to_normalized_coordinates = multiply by 1/H, 1/W) and the valid count."""
         c = self.cfg
-        if self._is_training:
+        if self._is_training and self._hard_miner is None:      # :1118: a configured miner replaces the balanced sample
             stream0 = (2 * self.step * 65536 + 1) & 0xFFFFFFFF
             return ops.sample_proposals(props, nprop, gt["boxes_abs"], gt["num"], gt["classes_bg"],
                                         self.max_num_proposals, c.second_stage_balance_fraction, self.seed,
@@ -787,9 +794,11 @@ class FasterRCNNMetaArch:
                                                  dt["reg_targets"].view(B * N2, 4), loc_s2.view(-1), 1.0)
         rl_cls, d_cls = ops.softmax_ce(pd["class_predictions_with_background"], cls_targets, cls_s.view(-1))
         if self._hard_miner is not None:
-            # :1758-1762 -> _unpad_proposals_and_apply_hard_mining (:1902-1946), per image like a clone of the reference
-            # (whose loop returns after its first — only — image): NMS over the proposals scored by their loss, the
-            # terms become sums over the mined proposals, the others get no gradient
+            # :1758-1762 -> _unpad_proposals_and_apply_hard_mining (:1902-1946) over ALL the NMS survivors of the RPN (no
+            # balanced sample when a miner is configured, :475, :1118): greedy NMS over the first num_proposals boxes
+            # scored by their loss, the terms become sums over the mined proposals, the others get no gradient. Mined
+            # per image and summed; the reference's loop `return`s inside its first iteration (:1930), i.e. a clone
+            # with more than one image would silently drop the others' second-stage loss — not reproduced.
             hm = self._hard_miner
             lm, cm, sel, nsel = ops.hard_example_mining(rl_loc.view(B, N2), rl_cls.view(B, N2), pd["proposal_boxes"],
                                                         pd["num_proposals"], d_box, d_cls, hm["num_hard_examples"],

@@ -313,10 +313,15 @@ class Conv:
         return dx.view(x_shape) if self.fc else dx
 
 
+DROPOUT_SEED_SALT = 0x6D2B79F5
+
+
 def dropout_stream(step, slot):
-    """Counter-hash stream id of a dropout layer: top bit set (the samplers use the streams below it), 23 bits of
-    step, 8 bits of layer slot. oracle/model.py restates the same formula."""
-    return (0x80000000 | ((int(step) & 0x7FFFFF) << 8) | (int(slot) & 0xFF)) & 0xFFFFFFFF
+    """Counter-hash (seed salt, stream id) of a dropout layer. Dropout draws live in a hash domain of their own: the
+    model seed is XOR-ed with DROPOUT_SEED_SALT (the samplers hash the plain seed with stream 2 * step * 65536 + k, which
+    covers every 32-bit stream id over a long run — a bit partition of the stream id cannot keep the two apart); the
+    stream id is 24 bits of step and 8 bits of layer slot. oracle/model.py restates the same formula."""
+    return (((int(step) & 0xFFFFFF) << 8) | (int(slot) & 0xFF)) & 0xFFFFFFFF
 
 
 class FCStack:
@@ -342,8 +347,9 @@ class FCStack:
         for i, l in enumerate(self.layers):
             a = l.forward(x)
             drop = training and self.keep_prob is not None
-            y = ops.dropout(a, self.keep_prob, seed, dropout_stream(step, self.slot0 + i)) if drop else a
-            ctx.append((x, a, (seed, dropout_stream(step, self.slot0 + i)) if drop else None))
+            dseed = (int(seed) ^ DROPOUT_SEED_SALT) & 0xFFFFFFFF
+            y = ops.dropout(a, self.keep_prob, dseed, dropout_stream(step, self.slot0 + i)) if drop else a
+            ctx.append((x, a, (dseed, dropout_stream(step, self.slot0 + i)) if drop else None))
             x = y
         return x, ctx
 

@@ -723,7 +723,9 @@ def batch_multiclass_nms(boxes, scores, score_thresh, iou_thresh, max_per_class,
 def hard_example_mining(loc_rl, cls_rl, boxes, num_proposals, d_box, d_cls, num_hard_examples, iou_threshold, loss_type):
     """core/losses.py:418-631 on the second stage (see mtlssl_hard_mining_*): loc_rl / cls_rl [B,n2] per-proposal
     losses, boxes [B,n2,4] the proposal boxes. Zeroes the gradient rows of proposals that were not mined (in place)
-    and returns (mined loc loss [B], mined cls loss [B])."""
+    and returns (mined loc loss [B], mined cls loss [B], selected [B,max_sel], number kept [B]). The NMS sees padding
+    rows (score -inf) LAST, so they never suppress a proposal; the ones it may append are dropped by _apply, which also
+    returns the count without them (= NMS over the first num_proposals rows, the reference's unpad step)."""
     B, n2 = loc_rl.shape
     dev = loc_rl.device
     scores = torch.empty((B, n2), dtype=f32, device=dev)
@@ -738,10 +740,11 @@ def hard_example_mining(loc_rl, cls_rl, boxes, num_proposals, d_box, d_cls, num_
                   ptr(ws), _stream())
     loc_loss = torch.empty((B,), dtype=f32, device=dev)
     cls_loss = torch.empty((B,), dtype=f32, device=dev)
-    lib().hard_mining_apply(ptr(sel), ptr(num), B, max_sel, n2, ptr(loc_rl), ptr(cls_rl), ptr(_chk(d_box)),
-                            d_box.numel() // (B * n2), ptr(_chk(d_cls)), d_cls.numel() // (B * n2), ptr(loc_loss),
-                            ptr(cls_loss), _stream())
-    return loc_loss, cls_loss, sel, num
+    kept = torch.empty((B,), dtype=i32, device=dev)
+    lib().hard_mining_apply(ptr(sel), ptr(num), ptr(_chk(num_proposals, i32)), B, max_sel, n2, ptr(loc_rl), ptr(cls_rl),
+                            ptr(_chk(d_box)), d_box.numel() // (B * n2), ptr(_chk(d_cls)), d_cls.numel() // (B * n2),
+                            ptr(loc_loss), ptr(cls_loss), ptr(kept), _stream())
+    return loc_loss, cls_loss, sel, kept
 
 
 def dropout(x, keep_prob, seed, stream_id, out=None):

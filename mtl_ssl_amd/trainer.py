@@ -95,7 +95,10 @@ class GradientReducer:
             self.buckets.append((start, ps.n_train)); self.nvars.append(count)
         if self.buckets:
             self.buckets[-1] = (self.buckets[-1][0], ps.n_train)
-        self.stream = torch.cuda.Stream() if (self.active and ps.device.type == "cuda") else None
+        self.stream = None
+        if self.active and ps.device.type == "cuda":
+            from .comm import comm_stream_priority
+            self.stream = torch.cuda.Stream(priority=comm_stream_priority())
         self.compute_streams = []          # extra compute streams whose work a bucket may depend on
         self.compute_streams_fn = None     # asked at every bucket launch (a model may create streams lazily)
         self.main_stream = None

@@ -196,12 +196,14 @@ class Oracle:
     @staticmethod
     def dropout_stream(step, slot):
         """Stream id of a dropout layer's counter hash (restated from mtl_ssl_amd/nn.py:dropout_stream)."""
-        return (0x80000000 | ((int(step) & 0x7FFFFF) << 8) | (int(slot) & 0xFF)) & 0xFFFFFFFF
+        return (((int(step) & 0xFFFFFF) << 8) | (int(slot) & 0xFF)) & 0xFFFFFFFF
 
     def dropout(self, x, keep_prob, seed, step, slot):
         """slim.dropout while training: x / keep_prob where kept, the Bernoulli draw being the counter hash."""
         from . import assign as A_
-        m = A_.dropout_mask(seed, x.numel(), keep_prob, self.dropout_stream(step, slot)).reshape(tuple(x.shape))
+        # a hash domain of its own: the seed is salted (mtl_ssl_amd/nn.py: DROPOUT_SEED_SALT), the samplers use it plain
+        m = A_.dropout_mask((int(seed) ^ 0x6D2B79F5) & 0xFFFFFFFF, x.numel(), keep_prob,
+                            self.dropout_stream(step, slot)).reshape(tuple(x.shape))
         return x / F(keep_prob) * torch.as_tensor(m.astype(np.float32)).to(x.dtype)
 
     def fc_stack(self, x, scopes, keep_prob, slot0, seed, step, training):
@@ -362,6 +364,14 @@ class Oracle:
         gt_clo = [np.asarray(c, F) for c in batch["groundtruth_closeness"]] if mtl["closeness"] else None
         # proposals (no gradient: tf.stop_gradient, faster_rcnn_meta_arch.py:1117)
         N2 = hp["second_stage_batch_size"]
+        miner_on = hp.get("hard_example_miner") is not None and not hp.get("first_stage_only", False)
+        if miner_on:
+            # faster_rcnn_meta_arch.py:463-477, :1118: with a hard example miner configured there is no balanced sample;
+            # every NMS survivor goes through the second stage, padded to first_stage_max_proposals
+            N2 = hp["max_proposals"]
+            if mtl["refine"]:
+                raise ValueError("hard_example_miner with mtl.refine: need more than 2 values to unpack "
+                                 "(faster_rcnn_meta_arch.py:1828-1832)")
         if forced is not None and "proposal_boxes" in forced:
             boxes_abs = np.asarray(forced["proposal_boxes"], F)
             num = np.asarray(forced["num_proposals"], np.int32)
@@ -371,8 +381,11 @@ class Oracle:
                 e_np, o_np = np.asarray(forced["rpn_box_encodings"], F), np.asarray(forced["rpn_objectness"], F)
             pb, _, _, pn = N.rpn_proposals(e_np, o_np, anchors, (H, W), hp["nms_score_threshold"],
                                            hp["nms_iou_threshold"], hp["max_proposals"])
-            boxes_abs, num, _ = L.sample_box_classifier_batch(pb, pn, gt_abs, gt_cls_bg, N2,
-                                                              hp["second_stage_balance_fraction"], seed, step)
+            if miner_on:
+                boxes_abs, num = np.asarray(pb, F), np.asarray(pn, np.int32)
+            else:
+                boxes_abs, num, _ = L.sample_box_classifier_batch(pb, pn, gt_abs, gt_cls_bg, N2,
+                                                                  hp["second_stage_balance_fraction"], seed, step)
         boxes_norm = np.stack([B.to_normalized(boxes_abs[b], H, W) for b in range(Bn)])
         box_ind = np.repeat(np.arange(Bn), N2)
         rfcn = hp.get("rfcn")

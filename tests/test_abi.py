@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_abi_version_and_error_string(built):
     L = built.lib()
-    assert L.abi_version() == 3
+    assert L.abi_version() == 4
     assert isinstance(L.last_error(), bytes)
 
 
