@@ -559,6 +559,21 @@ static int tuned_cfg(const mtlssl_conv_desc* d, int mode) {
   auto it = tuned_map().find(make_key(d, mode));
   return it == tuned_map().end() ? -1 : it->second;
 }
+// Plan-registry codes: code = 4 * algorithm + tile shape (0..3) for the register-staged engine, 12 + the same for the
+// LDS-DMA engine; algorithm 0 = direct implicit GEMM, 1 = Winograd F(4x4,3x3), 2 = whole-7-span Winograd.
+// Internally a tile index is shape + 4 * engine (conv_mfma.h).
+constexpr int CODE_ENGINE1 = 12, CODE_END = 24;
+static inline int code_alg(int code) { return code < 0 ? -1 : (code % CODE_ENGINE1) / 4; }
+static inline int code_tile(int code) { return code < 0 ? -1 : (code % 4) + (code >= CODE_ENGINE1 ? 4 : 0); }
+static inline int make_code(int alg, int tile) { return 4 * alg + (tile & 3) + (tile >= 4 ? CODE_ENGINE1 : 0); }
+// tile (0..NTILE-1) the registry pins for the DIRECT path of (d, mode), or -1
+static int tuned_direct_tile(const mtlssl_conv_desc* d, int mode) {
+  const int code = tuned_cfg(d, mode);
+  return code_alg(code) == 0 ? code_tile(code) : -1;
+}
+// The LDS-DMA engine moves 16-byte pieces global -> LDS with no fix-up in between: every operand row it reads must be
+// 16-byte aligned, i.e. the GEMM width a multiple of 4 floats (the K = 91 / 364 heads stay on the register engine).
+static inline bool glds_ok(int64_t NG) { return (NG & 3) == 0; }
 
 static bool tail_split_enabled() {
   static int v = -1;
@@ -576,10 +591,11 @@ static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double
   static int env_force = -2;
   if (env_force == -2) { const char* e = getenv("MTLSSL_FORCE_CFG"); env_force = e ? atoi(e) : -1; }
   int force = env_force >= 0 ? env_force : tuned;
-  if (force >= NCFG || (force >= 0 && !cfg_allowed(force, kc))) force = -1;
-  for (int c = 0; c < NCFG; ++c) {
+  if (force >= NTILE || (force >= 0 && !cfg_allowed(force, kc))) force = -1;
+  if (force >= NCFG && !glds_ok(NG)) force -= NCFG;            // same shape on the register engine
+  for (int c = 0; c < NTILE; ++c) {
     if (!cfg_allowed(c, kc)) continue;
-    if (force >= 0 && c != force) continue;
+    if (force >= 0 ? c != force : c >= NCFG) continue;          // LDS-DMA tiles only when pinned
     int ksteps = taps * (kc / CFG_BK[c]);
     const int64_t tiles_m = cdiv(M, CFG_BM[c]), tiles_n = cdiv(NG, CFG_BN[c]);
     int64_t tiles = tiles_m * tiles_n;
@@ -650,7 +666,7 @@ static Plan plan_dir(const mtlssl_conv_desc* d, int mode, double* t_out = nullpt
   const int64_t M = mode == MODE_FWD ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W;
   PlanMemo pm;
   pm.plan = plan_gemm(M, mode == MODE_FWD ? d->K : d->C, d->R * d->S, mode == MODE_FWD ? d->C : d->K,
-                      tuned_cfg(d, mode), &pm.t);
+                      tuned_direct_tile(d, mode), &pm.t);
   {
     std::lock_guard<std::mutex> g(memo_mutex());
     plan_map()[k] = pm;
@@ -777,11 +793,16 @@ static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st, int ti
   p.tiles_m = tile_rows >= 0 ? tile_rows : (int)cdiv(p.M, CFG_BM[cfg]);
   p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
+  if (cfg >= NCFG && (p.a_tab || !glds_ok(p.NG) || (MODE == MODE_WGRAD && !glds_ok(p.M)))) cfg -= NCFG;
   switch (cfg) {
     case 0: hipLaunchKernelGGL((k_conv_mfma<128, 128, MODE, 16>), grid, dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((k_conv_mfma<128, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
     case 2: hipLaunchKernelGGL((k_conv_mfma<64, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((k_conv_mfma<256, 128, MODE, 16>), grid, dim3(512), 0, st, p); break;
+    case 3: hipLaunchKernelGGL((k_conv_mfma<256, 128, MODE, 16>), grid, dim3(512), 0, st, p); break;
+    case 4: hipLaunchKernelGGL((k_conv_glds<128, 128, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+    case 5: hipLaunchKernelGGL((k_conv_glds<128, 64, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+    case 6: hipLaunchKernelGGL((k_conv_glds<64, 64, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_conv_glds<256, 128, MODE, 16, GLDS_STAGES>), grid, dim3(512), 0, st, p); break;
   }
 }
 
@@ -829,9 +850,9 @@ static void wgrad_plan_uncached(const mtlssl_conv_desc* d, int* cfg, int* nsplit
   int RS = d->R * d->S;
   double best_t = 1e30;
   *cfg = 2; *nsplit = 1; *pps = (int)align_up(P, 16);
-  const int force = tuned_cfg(d, MODE_WGRAD);
-  for (int c = 0; c < NCFG; ++c) {
-    if (force >= 0 && force < NCFG && c != force) continue;
+  const int force = tuned_direct_tile(d, MODE_WGRAD);
+  for (int c = 0; c < NTILE; ++c) {
+    if (force >= 0 ? c != force : c >= NCFG) continue;
     int bk = CFG_BK[c];
     int ksteps = (int)cdiv(P, bk);
     int64_t tiles = cdiv(d->C, CFG_BM[c]) * cdiv(d->K, CFG_BN[c]) * RS;
@@ -910,9 +931,9 @@ static bool choose_wino_uncached(const mtlssl_conv_desc* d, int mode, WinoChoice
   if (env == 0 || !wino_eligible(d, WINO_F43)) return false;     // F43's domain contains M7's
   if (mode == MODE_FWD ? !mfma_fwd_ok(d) : (mode == MODE_DGRAD ? !mfma_dgrad_ok(d) : !mfma_wgrad_ok(d))) return false;
   const int force = tuned_cfg(d, mode);
-  if (force >= WINO_CFG0) {
-    const int variant = (force - WINO_CFG0) / 4, tile = (force - WINO_CFG0) % 4;
-    if (variant < WINO_VARIANTS && tile < NCFG && wino_eligible(d, variant)) { *wc = WinoChoice{variant, tile}; return true; }
+  if (code_alg(force) >= 1) {
+    const int variant = code_alg(force) - 1, tile = code_tile(force);
+    if (variant < WINO_VARIANTS && wino_eligible(d, variant)) { *wc = WinoChoice{variant, tile}; return true; }
   }
   double tw = 1e30;
   for (int v = 0; v < WINO_VARIANTS; ++v) {
@@ -922,7 +943,7 @@ static bool choose_wino_uncached(const mtlssl_conv_desc* d, int mode, WinoChoice
     if (t < tw) { tw = t; *wc = WinoChoice{v, tile}; }
   }
   if (env == 2) return true;
-  if (force >= 0 && force < NCFG) return false;
+  if (code_alg(force) == 0) return false;
   double td;
   if (mode == MODE_WGRAD) { int c, ns, pps; wgrad_plan(d, &c, &ns, &pps, &td); }
   else plan_dir(d, mode, &td);
@@ -1021,8 +1042,7 @@ __global__ void k_parity_scatter(const float* tmp, float* dx, const float* resid
   reinterpret_cast<floatx4*>(dx)[o] = val;
 }
 static Plan parity_plan(const mtlssl_conv_desc* d, const ParityProblem& q) {
-  int forced = tuned_cfg(d, MODE_DGRAD);
-  return plan_gemm((int64_t)d->N * q.Hs * q.Ws, d->C, q.Rs * q.Ss, d->K, forced >= 0 && forced < NCFG ? forced : -1);
+  return plan_gemm((int64_t)d->N * q.Hs * q.Ws, d->C, q.Rs * q.Ss, d->K, tuned_direct_tile(d, MODE_DGRAD));
 }
 static int64_t parity_split_bytes(const mtlssl_conv_desc* d, const ParityProblem& q) {
   if (q.Rs == 0 || q.Ss == 0) return 0;
@@ -1285,13 +1305,13 @@ int mtlssl_conv2d_tile_config(const mtlssl_conv_desc* d, int mode) {
   if (!d || mode < MODE_FWD || mode > MODE_WGRAD) return -1;
   if (!(mode == MODE_FWD ? mfma_fwd_ok(d) : (mode == MODE_DGRAD ? mfma_dgrad_ok(d) : mfma_wgrad_ok(d)))) return -1;
   WinoChoice wc;
-  if (choose_wino(d, mode, &wc)) return WINO_CFG0 + 4 * wc.variant + wc.tile;
+  if (choose_wino(d, mode, &wc)) return make_code(1 + wc.variant, wc.tile);
   if (mode == MODE_WGRAD) {
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);
-    return cfg;
+    return make_code(0, cfg);
   }
-  return plan_dir(d, mode).cfg;
+  return make_code(0, plan_dir(d, mode).cfg);
 }
 
 // Multiply-accumulates the launch plan of (d, mode) executes, on the matrix cores (on_mfma = 1) or in a VALU
@@ -1330,8 +1350,7 @@ int64_t mtlssl_conv2d_executed_macs(const mtlssl_conv_desc* d, int mode, int on_
 
 int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg) {
   MTLSSL_REQUIRE(d != nullptr && mode >= MODE_FWD && mode <= MODE_WGRAD, "force_config: bad arguments");
-  MTLSSL_REQUIRE(cfg < WINO_CFG0 + 4 * WINO_VARIANTS && (cfg < 0 || cfg % 4 < NCFG),
-                 "force_config: tile configuration out of range");
+  MTLSSL_REQUIRE(cfg < CODE_END, "force_config: plan code out of range (0..%d)", CODE_END - 1);
   TunedKey k = make_key(d, mode);
   {
     std::lock_guard<std::mutex> g(tuned_mutex());

@@ -876,12 +876,20 @@ k_wino_gemm(ConvArgs p) {
 // quarter less operand staging per MAC. It wins on the pixel-reduction (wgrad) GEMMs (+3 %: 133 -> 137
 // TFLOP/s) and on the short-K wide-N forward layers (1x1 512->2048 on 2560 ROIs: 113 -> 123.5), loses
 // elsewhere (tools/bench_tiles.py) — a candidate for the measured plan table, not a default.
+// Tile index t = shape (t & 3: 128x128, 128x64, 64x64, 256x128) + 4 * engine (t >> 2: 0 = operands staged through
+// registers, k_conv_mfma / k_wino_gemm; 1 = operands staged by LDS-DMA, k_conv_glds / k_wino_glds, two stages). The time
+// models only rank the NCFG register-staged tiles; an LDS-DMA tile is chosen by the measured plan table alone
+// (mtlssl_conv2d_force_config codes 12..23): it wins on grids of >= ~4 blocks per CU of the 64x64 / 128x64 tiles
+// (+5 ... +20 % on the 9 728-row R-FCN and the narrow-channel Inception GEMMs, profiles/r04_mid_gemm_lab.txt) and loses
+// on under-filled grids, which no model of this size predicts well.
 constexpr int NCFG = 4;
-static const int CFG_BM[NCFG] = {128, 128, 64, 256};
-static const int CFG_BN[NCFG] = {128, 64, 64, 128};
-static const int CFG_BK[NCFG] = {16, 16, 16, 16};
-static const int CFG_THREADS[NCFG] = {256, 256, 256, 512};
-static const int CFG_RESIDENT[NCFG] = {3, 6, 8, 2};      // blocks a CU holds
+constexpr int NTILE = 8;
+static const int CFG_BM[NTILE] = {128, 128, 64, 256, 128, 128, 64, 256};
+static const int CFG_BN[NTILE] = {128, 64, 64, 128, 128, 64, 64, 128};
+static const int CFG_BK[NTILE] = {16, 16, 16, 16, 16, 16, 16, 16};
+static const int CFG_THREADS[NTILE] = {256, 256, 256, 512, 256, 256, 256, 512};
+static const int CFG_RESIDENT[NTILE] = {3, 6, 8, 2, 3, 6, 8, 2};      // blocks a CU holds
+constexpr int GLDS_STAGES = 2;
 
 // Time model shared by the planners (microseconds). A CU retires one 16-deep K-step of a
 // bm x bn tile in bm*bn*32 FLOP / 614 GFLOP/s (fp32 MFMA peak per CU); blocks beyond what is
@@ -891,9 +899,9 @@ static inline double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block
   const double base_eff[NCFG] = {0.80, 0.76, 0.72, 0.78};
   int64_t per_cu = cdiv(nblocks, 256);
   int64_t occ = per_cu < CFG_RESIDENT[cfg] ? per_cu : CFG_RESIDENT[cfg];
-  if (cfg == 3) occ *= 2;                                  // 8 waves per block
+  if ((cfg & 3) == 3) occ *= 2;                            // 8 waves per block
   double occ_eff = occ <= 1 ? 0.55 : (occ == 2 ? 0.80 : 1.0);
-  double step_us = CFG_BM[cfg] * CFG_BN[cfg] * 2.0 * CFG_BK[cfg] / 614e9 * 1e6 / (base_eff[cfg] * occ_eff);
+  double step_us = CFG_BM[cfg] * CFG_BN[cfg] * 2.0 * CFG_BK[cfg] / 614e9 * 1e6 / (base_eff[cfg & 3] * occ_eff);
   return (double)per_cu * (ksteps_per_block + 96 / CFG_BK[cfg]) * step_us;
 }
 

@@ -436,11 +436,16 @@ void launch_gemm(int cfg, ConvArgs& p, int planes, int nz, hipStream_t st) {
   p.tiles_m = (int)cdiv(p.M, CFG_BM[cfg]);
   p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
   dim3 grid(p.tiles_m * p.tiles_n, planes, nz);
+  if (cfg >= NCFG && ((p.NG & 3) || (MODE == MODE_WGRAD && (p.M & 3)))) cfg -= NCFG;   // LDS-DMA needs 16-byte rows
   switch (cfg) {
     case 0: hipLaunchKernelGGL((k_wino_gemm<128, 128, MODE>), grid, dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((k_wino_gemm<128, 64, MODE>), grid, dim3(256), 0, st, p); break;
     case 2: hipLaunchKernelGGL((k_wino_gemm<64, 64, MODE>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((k_wino_gemm<256, 128, MODE>), grid, dim3(512), 0, st, p); break;
+    case 3: hipLaunchKernelGGL((k_wino_gemm<256, 128, MODE>), grid, dim3(512), 0, st, p); break;
+    case 4: hipLaunchKernelGGL((k_wino_glds<128, 128, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+    case 5: hipLaunchKernelGGL((k_wino_glds<128, 64, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+    case 6: hipLaunchKernelGGL((k_wino_glds<64, 64, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_wino_glds<256, 128, MODE, 16, GLDS_STAGES>), grid, dim3(512), 0, st, p); break;
   }
 }
 

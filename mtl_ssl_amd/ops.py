@@ -149,11 +149,26 @@ def conv_class(cfg, mfma_macs):
     """Launch class of a conv-family call from its plan code (mtlssl_conv2d_tile_config)."""
     if cfg < 0:
         return "mfma_padded_or_space_to_depth" if mfma_macs else "valu_fallback"
-    if cfg >= 8:
+    alg, shape = plan_code_algorithm(cfg), cfg % 4
+    if alg == 2:
         return "winograd_M7"
-    if cfg >= 4:
+    if alg == 1:
         return "winograd_F43"
-    return "direct_128x128_256x128" if cfg in (0, 3) else "direct_small_tiles"
+    return "direct_128x128_256x128" if shape in (0, 3) else "direct_small_tiles"
+
+
+ENGINE1_CFG0 = 12      # plan codes 12..23: the same algorithms / tile shapes as 0..11 on the LDS-DMA tile engine
+PLAN_CODES = tuple(range(24))
+
+
+def plan_code_algorithm(cfg):
+    """0: direct implicit GEMM, 1: Winograd F(4x4,3x3), 2: whole-7-span Winograd (either tile engine)."""
+    return (cfg % ENGINE1_CFG0) // 4
+
+
+def plan_code_engine(cfg):
+    """0: operands staged through registers (k_conv_mfma / k_wino_gemm), 1: LDS-DMA (k_conv_glds / k_wino_glds)."""
+    return 1 if cfg >= ENGINE1_CFG0 else 0
 
 
 class FlopAccount:
@@ -198,6 +213,7 @@ def mark(name):
 AUTOTUNE = os.environ.get("MTLSSL_AUTOTUNE", "1") != "0"
 TUNE_RUNS = int(os.environ.get("MTLSSL_TUNE_RUNS", "4"))
 TUNE_MARGIN = float(os.environ.get("MTLSSL_TUNE_MARGIN", "0.05"))   # a candidate must beat the planner's choice by this much
+TUNE_ENGINES = os.environ.get("MTLSSL_TUNE_ENGINES", "1") != "0"     # 0: the autotuner leaves the LDS-DMA tile engine out
 _PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_plans.json")
 _tuned = {}
 _plan_db = None
@@ -222,7 +238,7 @@ def save_plans(path=_PLAN_FILE):
             plans[",".join(str(v) for v in key)] = val[1] if val[1] != val[0] else -1
     json.dump({"comment": "mode,N,H,W,C,K,R,S,OH,OW,stride,dilation,pad_t,pad_l -> forced tile "
                           "(0: 128x128, 1: 128x64, 2: 64x64, 3: 256x128; 4-7: Winograd F(4x4,3x3) with GEMM tile 0-3; 8-11: whole-7-span Winograd with GEMM "
-                          "tile 0-3; "
+                          "tile 0-3; 12-23: the same twelve on the LDS-DMA tile engine; "
                           "-1: keep the planner's choice); "
                           "measured on MI355X",
                "plans": dict(sorted(plans.items()))}, open(path, "w"), indent=0)
@@ -291,7 +307,7 @@ def _autotune(d, mode, run):
     if not AUTOTUNE:
         return
     times = {}
-    for cfg in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+    for cfg in (PLAN_CODES if TUNE_ENGINES else PLAN_CODES[:ENGINE1_CFG0]):
         L.conv2d_force_config(ref, mode, cfg)
         if L.conv2d_tile_config(ref, mode) != cfg:    # this tile is not available for the problem
             continue

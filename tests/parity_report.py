@@ -36,25 +36,54 @@ def gradients(tag, grads, ref, losses=None, ref_losses=None):
     return l2
 
 
-def against_float64(tag, Oracle, hp, values, host_batch, seed, step, aux, grads, rgrads, cap=1e-3):
-    """The gradient claim against the better yardstick: the same graph evaluated by the oracle in float64 on the SAME
-    sampled boxes (`aux["proposal_boxes"]`, `aux["num_proposals"]` forced). Asserts every variable of `grads` (HIP path)
-    within `cap` relative L2 of float64; returns {name: (hip_vs_f64, fp32_oracle_vs_f64)} and records worst / median of
-    both (the torch-CPU fp32 oracle is itself up to ~1e-3 from float64 on variables behind ReLU / max-pool branch
-    flips; an fp32-vs-fp32 figure above 1e-3 therefore says nothing about which side is off)."""
-    _, g64, _ = Oracle(hp, values, np.float64).step(host_batch, seed=seed, step=step,
-                                                     forced=dict(proposal_boxes=aux["proposal_boxes"],
-                                                                 num_proposals=aux["num_proposals"]))
+def against_float64(tag, Oracle, hp, values, host_batch, seed, step, boxes, num, grads, cap=1e-3, outliers=12, worst=5e-3,
+                    feat=None, d_feat=None):
+    """The gradient claim against the better yardstick: the same graph evaluated by the oracle in float64 AND in
+    float32 on the DEVICE'S sampled boxes (`boxes` [B,N2,4] absolute, `num` [B]; forcing them takes the proposal chain
+    and the crop knife edge at the image border — a sample at in_y = H-1 up to the last bit of a decoded box — out of
+    the comparison). Asserted for the HIP path against float64:
+      * every variable within `cap` (1e-3) relative L2, except at most `outliers` variables, none beyond `worst`;
+      * those exceptions are what a single activation branch flip does: a pre-activation within an ulp of 0 (or 6)
+        takes the other branch in one fp32 implementation, and one flipped element of a map moves every filter
+        gradient behind it by ~1e-3 of its norm. The torch-CPU fp32 oracle shows the same class of outliers against
+        float64 (reported next to the HIP path's). When the trunk's output map and its gradient are given (`feat`,
+        `d_feat` = gradient masked by the last activation), the flips at that map are located and it is asserted that
+        without those (at most 3) elements the map's gradient agrees with float64 to 1e-4.
+    Returns {name: (hip_vs_f64, fp32_oracle_vs_f64)}."""
+    forced = dict(proposal_boxes=np.asarray(boxes), num_proposals=np.asarray(num))
+    _, g32, a32 = Oracle(hp, values).step(host_batch, seed=seed, step=step, forced=forced)
+    _, g64, a64 = Oracle(hp, values, np.float64).step(host_batch, seed=seed, step=step, forced=forced)
     rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
     out = {}
     for name, g in grads.items():
-        if name in g64 and name in rgrads:
-            out[name] = (rel(g, g64[name]), rel(rgrads[name], g64[name]))
-    worst = max(out, key=lambda n: out[n][0])
-    worst_cpu = max(out, key=lambda n: out[n][1])
-    add("    vs float64 (%s): HIP path worst %.2e (%s) median %.2e; torch-CPU fp32 oracle worst %.2e (%s) median %.2e" % (
-        tag, out[worst][0], worst.split("/", 1)[-1], np.median([v[0] for v in out.values()]),
-        out[worst_cpu][1], worst_cpu.split("/", 1)[-1], np.median([v[1] for v in out.values()])))
-    for name, (e, _) in out.items():
-        assert e < cap, (tag, name, e)
+        if name in g64 and name in g32:
+            out[name] = (rel(g, g64[name]), rel(g32[name], g64[name]))
+    e_gpu = np.array([v[0] for v in out.values()])
+    e_cpu = np.array([v[1] for v in out.values()])
+    w_gpu = max(out, key=lambda n: out[n][0])
+    w_cpu = max(out, key=lambda n: out[n][1])
+    line = ("    vs float64 on the device's boxes (%s): HIP path worst %.2e (%s) median %.2e, %d of %d variables beyond %.0e; "
+            "torch-CPU fp32 oracle worst %.2e (%s) median %.2e, %d beyond" % (
+                tag, out[w_gpu][0], w_gpu.split("/", 1)[-1], np.median(e_gpu), int((e_gpu >= cap).sum()), len(e_gpu), cap,
+                out[w_cpu][1], w_cpu.split("/", 1)[-1], np.median(e_cpu), int((e_cpu >= cap).sum())))
+    if feat is not None and d_feat is not None:
+        act6 = hp["arch"] == "mobilenet_v1"
+        on = lambda F: (F > 0) & ((F < 6) if act6 else True)
+        F64 = a64["features"]
+        ref = a64["d_features"] * on(F64)
+        flips = np.argwhere(on(np.asarray(feat)) != on(F64))
+        keep = np.ones(ref.shape, bool)
+        for f in flips:
+            keep[tuple(f)] = False
+        near = [float(min(abs(F64[tuple(f)]), abs(F64[tuple(f)] - 6.0) if act6 else np.inf)) for f in flips]
+        e_all, e_wo = rel(np.asarray(d_feat), ref), rel(np.asarray(d_feat) * keep, ref * keep)
+        line += ("; trunk output: %d activation flip(s) vs float64 (|pre-activation - threshold| <= %.1e of range %.1e), map "
+                 "gradient rel err %.2e with them, %.2e without" % (len(flips), max(near) if near else 0.0, np.abs(F64).max(),
+                                                                    e_all, e_wo))
+        assert len(flips) <= 3 and all(v <= 1e-5 * np.abs(F64).max() for v in near), (tag, flips[:5], near[:5])
+        assert e_wo < 1e-4, (tag, e_wo)
+    add(line)
+    assert np.median(e_gpu) < 3e-4, (tag, np.median(e_gpu))
+    assert int((e_gpu >= cap).sum()) <= outliers, (tag, sorted(((v[0], n) for n, v in out.items()), reverse=True)[:outliers + 2])
+    assert e_gpu.max() < worst, (tag, w_gpu, e_gpu.max())
     return out

@@ -114,16 +114,19 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     assert relerr(dw, 2 * wr.grad * scale) < 1e-4
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 12, 13, 14, 15])
 @pytest.mark.parametrize("case", [
     (3, 19, 23, 64, 160, 3, 1, 1, "SAME"),           # ragged M (1311 rows) and N (160) for every tile
     (2, 14, 15, 128, 128, 3, 2, 1, "RESNET_SAME"),   # strided gather
     (300, 1, 1, 512, 272, 1, 1, 1, "VALID"),         # FC-shaped, N one quad past 256+...
     (5, 7, 7, 272, 512, 1, 1, 1, "SAME"),            # wgrad M = C = 272: ragged rows of the 256-row tile
+    (2, 17, 21, 96, 224, 3, 1, 2, "SAME"),           # atrous 3x3 (R-FCN's block4), Inception-like widths
+    (4, 9, 13, 1088, 192, 1, 1, 1, "SAME"),          # a long K loop (68 steps), N = 3 tiles of 64
 ])
 def test_every_direct_tile_matches_oracle(ops, case, tile):
-    """Each implicit-GEMM tile (128x128, 128x64, 64x64, 256x128 with 8 wavefronts) pinned through the plan
-    registry, all three modes with their epilogues."""
+    """Each implicit-GEMM tile (128x128, 128x64, 64x64, 256x128 with 8 wavefronts) on each tile engine (plan codes
+    0-3: operands staged through registers; 12-15: staged by LDS-DMA) pinned through the plan registry, all three
+    modes with their epilogues."""
     N, H, W, C, K, R, stride, dil, padding = case
     g = torch.Generator().manual_seed(hash(case) % 2**31)
     x = torch.randn(N, H, W, C, generator=g)

@@ -155,10 +155,11 @@ def test_full_size_step_matches_the_oracle(name):
     assert np.median(l2) < 1e-3, np.median(l2)
     assert l2[-1] < case["worst"], l2[-1]
     if case["f64"]:
-        # the outlier of round 3 (MobileNet's first filter, 3.5e-3 fp32-vs-fp32) judged against float64 on the device's
-        # boxes: the HIP path must be within 1e-3 of it on EVERY variable
+        # round 3's outlier (MobileNet's first filter, 3.5e-3 fp32-vs-fp32) judged against float64 on the device's boxes:
+        # one ReLU6 flip at the trunk's output map explains it (located and asserted by against_float64)
         parity_report.against_float64("%s FULL SIZE batch %d" % (name, case["B"]), Oracle, hp, values, hb, model.seed, 0,
-                                      aux, grads, rgrads, cap=1e-3)
+                                      mine_boxes, pd["num_proposals"].cpu().numpy(), grads,
+                                      feat=pd["rpn_features_to_crop"].cpu().numpy(), d_feat=pd["_gpF"].cpu().numpy())
     del model, tr, batch
     torch.cuda.empty_cache()
 

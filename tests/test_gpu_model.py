@@ -105,7 +105,7 @@ def test_step_losses_and_gradients_match_oracle(refine, aux, crop, pk, conv_algo
     model, tr, batch, hp = _setup(refine, aux, crop, pk)
     assert ops.set_winograd(-1) == conv_algorithm
     d33 = ops.conv_desc((2, 10, 14, 256), (3, 3, 256, 256), 1, 1, "SAME")          # a block3 conv2 of this input size
-    assert (ops.lib().conv2d_tile_config(__import__("ctypes").byref(d33), 0) >= ops.WINO_CFG0) == (conv_algorithm == 2)
+    assert (ops.plan_code_algorithm(ops.lib().conv2d_tile_config(__import__("ctypes").byref(d33), 0)) > 0) == (conv_algorithm == 2)
     values = model.ps.state_dict()
     reports = {}
     model.ps.grad_ready_hook = lambda sp: reports.__setitem__(sp.name, reports.get(sp.name, 0) + 1)

@@ -47,10 +47,11 @@ CASES_M7 = [
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 12, 13, 14, 15], ids=lambda t: "tile%d%s" % (t % 4, "-glds" if t >= 12 else ""))
 @pytest.mark.parametrize("case", [(c, "f43") for c in CASES] + [(c, "m7") for c in CASES_M7],
                          ids=lambda cv: "%s-%s" % (cv[1], "x".join(map(str, cv[0]))))
 def test_winograd_matches_oracle_and_direct(ops, case, tile):
+    """tile 0-3: the GEMM stack on the register-staged engine; 12-15: the same tile shapes on the LDS-DMA engine."""
     (N, H, W, C, K), variant = case
     wino_cfg = (ops.WINO_CFG0 if variant == "f43" else ops.WINO7_CFG0) + tile
     g = torch.Generator().manual_seed(hash(case[0]) % 2**31)
@@ -102,13 +103,14 @@ def test_winograd_not_offered_outside_its_domain(ops):
                                             ((2, 9, 9, 16), (3, 3, 16, 64), 1, 1, "SAME")]:
         d = ops.conv_desc(shape, wshape, stride, dil, pad)
         for mode in (0, 1, 2):
-            assert ops.force_conv_config(d, mode, ops.WINO_CFG0) < ops.WINO_CFG0
-            assert ops.force_conv_config(d, mode, ops.WINO7_CFG0) < ops.WINO_CFG0
+            assert ops.plan_code_algorithm(ops.force_conv_config(d, mode, ops.WINO_CFG0)) == 0
+            assert ops.plan_code_algorithm(ops.force_conv_config(d, mode, ops.WINO7_CFG0)) == 0
+            assert ops.plan_code_algorithm(ops.force_conv_config(d, mode, ops.ENGINE1_CFG0 + ops.WINO_CFG0)) == 0
             ops.force_conv_config(d, mode, -1)
     # the whole-7-span specification needs map sides that are multiples of 7; F(4x4,3x3) takes the rest
     d = ops.conv_desc((2, 38, 64, 64), (3, 3, 64, 64), 1, 1, "SAME")
     for mode in (0, 1, 2):
-        assert ops.force_conv_config(d, mode, ops.WINO7_CFG0 + 1) < ops.WINO7_CFG0
+        assert ops.plan_code_algorithm(ops.force_conv_config(d, mode, ops.WINO7_CFG0 + 1)) < 2
         ops.force_conv_config(d, mode, -1)
 
 
@@ -165,7 +167,7 @@ def test_kept_input_transform_gives_the_same_filter_gradient(ops, case):
         for ws in ops._ws_cache.values():        # nothing left over from the calls above may stand in for a skipped transform
             ws.fill_(255)                        # 0xFFFFFFFF = NaN
         y1 = ops.conv2d_fwd(d, x, w, keep_input_xf=kept)
-        assert list(kept) == [x.data_ptr()] and kept[x.data_ptr()][1] == (1 if cfg >= 8 else 0)
+        assert list(kept) == [x.data_ptr()] and kept[x.data_ptr()][1] == (1 if ops.plan_code_algorithm(cfg) == 2 else 0)
         dw1 = torch.zeros_like(w)
         for ws in ops._ws_cache.values():
             ws.fill_(255)
