@@ -7,6 +7,8 @@
 // as oracle/boxes.py so that integer outputs (matches, keep lists, NMS selections) are
 // bit-exact against the CPU oracle.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -411,6 +413,8 @@ struct NmsWs {
   unsigned long long* mask;
   unsigned long long* remv;    // [batch][nchunks] removed-set of the greedy scan between rounds
   int32_t* state;              // [batch][2] {selected so far, done}
+  float4* selbox;              // [batch][max_out] boxes selected so far (k_nms_greedy head -> prune -> tail)
+  unsigned long long* alive;   // [batch][nchunks] candidates still in play after the prune
   int nchunks;
 };
 static int64_t nms_ws_layout(int batch, int n, int max_out, char* base, NmsWs* ws) {
@@ -434,13 +438,216 @@ static int64_t nms_ws_layout(int batch, int n, int max_out, char* base, NmsWs* w
   const int64_t round_rows = (int64_t)(nchunks < NMS_ROUND_CHUNKS ? nchunks : NMS_ROUND_CHUNKS) * 64;
   w.mask = (unsigned long long*)take((int64_t)batch * round_rows * nchunks * 8);
   w.remv = (unsigned long long*)take((int64_t)batch * nchunks * 8);
-  w.state = (int32_t*)take((int64_t)batch * 2 * 4);
+  w.state = (int32_t*)take((int64_t)batch * 4 * 4);
+  w.selbox = (float4*)take((int64_t)batch * max_out * 16);
+  w.alive = (unsigned long long*)take((int64_t)batch * nchunks * 8);
   if (ws) *ws = w;
   return off;
 }
 
+// Greedy NMS without the n x n bit matrix (round 4). The rounds above materialise suppression rows for every
+// candidate although the scan only ever uses the rows of the <= max_out candidates it selects; here the test is turned
+// around. Candidates are visited in score order in groups of up to 128; each is tested against the boxes selected SO
+// FAR (in LDS: <= max_out x 16 B) and against the earlier candidates of its own group (a 128 x 128 bit matrix in LDS),
+// then one wavefront resolves the group serially in registers (k_nms_greedy, one block per image). One CU retires
+// ~64 lane-operations per clock: 128 candidates against 300 selected boxes are ~5 us of VALU time, and a trained
+// detector visits thousands of candidates — so the single CU only ever tests against RECENT selections, and the whole
+// chip prunes in between:
+//   head   k_nms_greedy over the first 256 candidates                                  -> S0 (<= 256 selected boxes)
+//   prune  k_nms_prune, the whole chip: every unresolved candidate against the boxes selected since the last prune
+//          -> `alive` bit set
+//   tail   k_nms_greedy over the ALIVE candidates from its cursor on, testing against the boxes selected since that
+//          prune only; it returns after ~96 new selections (state: {selected, done, first unpruned box, cursor})
+// and (prune, tail) repeats; the last tail runs to the end. A launch whose image is done returns at once. Every
+// candidate a prune drops overlaps a higher-scored SELECTED box — exactly the greedy rule — and the survivors are
+// resolved in the same order with the same predicate (nms_iou_gt) as k_nms_mask + k_nms_scan: bit-identical selections
+// (tests/test_gpu_detection.py runs both).
+constexpr int GN_THREADS = 1024, GN_GROUP = 128, GN_HEAD = 256, GN_BUDGET = 96, GN_STATE = 4;
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// Candidates [cursor, last) of each image (cursor = state[3], 0 at the head); `alive` (nullable): bit set of candidates
+// still in play — when given, they have already been tested against every box selected before this launch. The launch
+// returns after a group that brought its new selections to `budget`. state[b] = {selected so far, done, first box the
+// next prune has to test against, cursor}; selbox [b][max_out] carries the selected boxes from launch to launch.
+__global__ void __launch_bounds__(GN_THREADS) k_nms_greedy(const float* sboxes, const int32_t* nvalid, int n, float thr,
+                                                           int max_out, int last, int budget,
+                                                           const unsigned long long* alive, int nwords, float4* selbox,
+                                                           int32_t* state, int32_t* sel_rank, int32_t* num_out) {
+  extern __shared__ float4 gn_sel[];                       // [max_out] boxes selected so far, in order
+  __shared__ float4 s_cand[GN_GROUP];
+  __shared__ int s_idx[GN_GROUP];
+  __shared__ unsigned long long s_rows[GN_GROUP][2];       // bit c of row r: candidate c > r of the group overlaps r
+  __shared__ unsigned long long s_rem[2];                  // group candidates suppressed by earlier selections
+  __shared__ int s_wcnt[GN_THREADS / 64];
+  __shared__ int s_nsel, s_cursor;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int32_t* stt = state + b * GN_STATE;
+  if (stt[1]) return;
+  const int nv = nvalid ? min(nvalid[b], n) : n;
+  const int lim = min(nv, last);
+  const float* bx = sboxes + (int64_t)b * n * 4;
+  const unsigned long long* al = alive ? alive + (int64_t)b * nwords : nullptr;
+  float4* sb = selbox + (int64_t)b * max_out;
+  const int nsel0 = stt[0];
+  const int ktest = al ? nsel0 : 0;                        // alive candidates were tested against boxes [0, nsel0)
+  for (int k = ktest + tid; k < nsel0; k += GN_THREADS) gn_sel[k] = sb[k];
+  const int cand = tid >> 3, part = tid & 7;               // 8 adjacent lanes share a candidate
+  int nsel = nsel0, cursor = stt[3];
+  __syncthreads();
+  while (cursor < lim && nsel < max_out && nsel - nsel0 < budget) {
+    // ---- the next (up to) GN_GROUP alive candidates among the 1024 slots from the cursor on, in order
+    const int idx = cursor + tid;
+    bool live = idx < lim;
+    if (live && al) live = (al[idx >> 6] >> (idx & 63)) & 1ull;
+    const unsigned long long lm = __ballot(live);
+    if (lane == 0) s_wcnt[wave] = __popcll(lm);
+    if (tid < GN_GROUP) { s_rows[tid][0] = 0ull; s_rows[tid][1] = 0ull; }
+    if (tid < 2) s_rem[tid] = 0ull;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < GN_THREADS / 64; ++w) { const int c = s_wcnt[w]; before += w < wave ? c : 0; total += c; }
+    const int r = before + __popcll(lm & ((1ull << lane) - 1ull));
+    const int cnt = min(total, GN_GROUP);
+    if (live && r < GN_GROUP) {
+      s_idx[r] = idx;
+      s_cand[r] = *reinterpret_cast<const float4*>(bx + (int64_t)idx * 4);
+      if (r == GN_GROUP - 1) s_cursor = idx + 1;           // more alive candidates may follow in this window
+    }
+    if (tid == 0 && total < GN_GROUP) s_cursor = min(cursor + GN_THREADS, lim);
+    __syncthreads();
+    cursor = s_cursor;
+    if (cnt == 0) continue;
+    // ---- against the boxes selected so far
+    const float4 cv = cand < cnt ? s_cand[cand] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const Box cb{cv.x, cv.y, cv.z, cv.w};
+    bool hit = false;
+    if (cand < cnt)
+      for (int k = ktest + part; k < nsel; k += 8) {
+        const float4 v = gn_sel[k];
+        if (nms_iou_gt(Box{v.x, v.y, v.z, v.w}, cb, thr)) { hit = true; break; }
+      }
+    const unsigned long long m = __ballot(hit);
+    const bool rem = ((m >> ((lane >> 3) * 8)) & 0xFFull) != 0ull;
+    if (part == 0 && rem) atomicOr(&s_rem[cand >> 6], 1ull << (cand & 63));
+    // ---- against the earlier candidates of the group
+    unsigned piece = 0;
+    if (cand < cnt && !rem) {
+#pragma unroll 4
+      for (int j = 0; j < 16; ++j) {
+        const int c = part * 16 + j;
+        if (c > cand && c < cnt) {
+          const float4 v = s_cand[c];
+          if (nms_iou_gt(cb, Box{v.x, v.y, v.z, v.w}, thr)) piece |= 1u << j;
+        }
+      }
+    }
+    if (piece) atomicOr(&s_rows[cand][part >> 2], (unsigned long long)piece << ((part & 3) * 16));
+    __syncthreads();
+    if (tid < 64) {
+      // lane l keeps rows l and l + 64 (a row's bits for columns < 64 are zero once the row is >= 64)
+      const unsigned long long r0a = s_rows[lane][0], r0b = s_rows[lane][1], r1b = s_rows[lane + 64][1];
+      unsigned long long rem0 = s_rem[0], rem1 = s_rem[1], sel0 = 0ull, sel1 = 0ull;
+      int ns = nsel;
+      const int c0 = min(cnt, 64);
+      for (int j = 0; j < c0 && ns < max_out; ++j) {
+        if (!((rem0 >> j) & 1ull)) {
+          sel0 |= 1ull << j; ++ns;
+          rem0 |= readlane64(r0a, j); rem1 |= readlane64(r0b, j);
+        }
+      }
+      for (int j = 64; j < cnt && ns < max_out; ++j) {
+        if (!((rem1 >> (j - 64)) & 1ull)) {
+          sel1 |= 1ull << (j - 64); ++ns;
+          rem1 |= readlane64(r1b, j - 64);
+        }
+      }
+      const int n0 = __popcll(sel0);
+      if ((sel0 >> lane) & 1ull) {
+        const int pos = nsel + __popcll(sel0 & ((1ull << lane) - 1ull));
+        gn_sel[pos] = s_cand[lane];
+        sb[pos] = s_cand[lane];
+        sel_rank[(int64_t)b * max_out + pos] = s_idx[lane];
+      }
+      if ((sel1 >> lane) & 1ull) {
+        const int pos = nsel + n0 + __popcll(sel1 & ((1ull << lane) - 1ull));
+        gn_sel[pos] = s_cand[lane + 64];
+        sb[pos] = s_cand[lane + 64];
+        sel_rank[(int64_t)b * max_out + pos] = s_idx[lane + 64];
+      }
+      if (lane == 0) s_nsel = ns;
+    }
+    __syncthreads();
+    nsel = s_nsel;
+  }
+  if (tid == 0) {
+    const bool done = nsel >= max_out || cursor >= nv;
+    stt[0] = nsel;
+    stt[1] = done;
+    stt[2] = nsel0;
+    stt[3] = cursor;
+    if (done) num_out[b] = nsel;
+  }
+}
+// Whole-chip prune between two launches of k_nms_greedy: an unresolved candidate (>= the cursor, still alive) stays
+// alive unless it overlaps one of the boxes selected since the last prune (state[2] .. state[0]).
+__global__ void __launch_bounds__(256) k_nms_prune(const float* sboxes, const int32_t* nvalid, int n, float thr, int max_out,
+                                                   const float4* selbox, const int32_t* state, int have_alive,
+                                                   unsigned long long* alive, int nwords) {
+  __shared__ float4 s_sel[GN_HEAD];
+  const int b = blockIdx.y;
+  const int32_t* stt = state + b * GN_STATE;
+  if (stt[1]) return;
+  const int nv = nvalid ? min(nvalid[b], n) : n;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int cursor = stt[3];
+  if ((int)blockIdx.x * 256 >= nv || (int)blockIdx.x * 256 + 256 <= (cursor & ~63)) return;
+  const int lo = stt[2], ns = min(stt[0] - lo, GN_HEAD);
+  if ((int)threadIdx.x < ns) s_sel[threadIdx.x] = selbox[(int64_t)b * max_out + lo + threadIdx.x];
+  __syncthreads();
+  bool live = i < nv && i >= cursor;
+  if (live && have_alive) live = (alive[(int64_t)b * nwords + (i >> 6)] >> (i & 63)) & 1ull;
+  if (live) {
+    const float4 cv = *reinterpret_cast<const float4*>(sboxes + ((int64_t)b * n + i) * 4);
+    const Box cb{cv.x, cv.y, cv.z, cv.w};
+    for (int k = 0; k < ns; ++k) {
+      const float4 v = s_sel[k];
+      if (nms_iou_gt(Box{v.x, v.y, v.z, v.w}, cb, thr)) { live = false; break; }
+    }
+  }
+  const unsigned long long m = __ballot(live);
+  if ((threadIdx.x & 63) == 0 && i < nwords * 64) alive[(int64_t)b * nwords + (i >> 6)] = m;
+}
+static bool nms_greedy_enabled() {          // MTLSSL_NMS_ALGO=rounds: the bit-matrix rounds of rounds 1-3 (read per call:
+  const char* e = getenv("MTLSSL_NMS_ALGO");    // an A/B inside one process needs no rebuild)
+  return !(e && !strcmp(e, "rounds"));
+}
+
 static int run_nms_sorted(const NmsWs& w, const int32_t* nvalid, int batch, int n, float thr,
                           int max_out, int32_t* num_out, hipStream_t st) {
+  if (nms_greedy_enabled() && max_out <= 3072) {       // selected boxes in LDS: 16 B each, within the 64 KB default
+    float4* selbox = w.selbox;
+    unsigned long long* alive = w.alive;
+    const size_t lds = sizeof(float4) * (size_t)max_out;
+    (void)hipMemsetAsync(w.state, 0, sizeof(int32_t) * GN_STATE * batch, st);
+    hipLaunchKernelGGL(k_nms_greedy, dim3(batch), dim3(GN_THREADS), lds, st, w.sboxes, nvalid, n, thr, max_out, GN_HEAD,
+                       0x7fffffff, (const unsigned long long*)nullptr, w.nchunks, selbox, w.state, w.sel_rank, num_out);
+    if (n > GN_HEAD) {
+      // enough (prune, tail) stages to reach max_out at GN_BUDGET selections each; the last tail has no budget
+      int stages = (int)cdiv(max_out, GN_BUDGET);
+      stages = stages > 5 ? 5 : (stages < 1 ? 1 : stages);
+      for (int sgi = 0; sgi < stages; ++sgi) {
+        hipLaunchKernelGGL(k_nms_prune, dim3(cdiv(n, 256), batch), dim3(256), 0, st, w.sboxes, nvalid, n, thr, max_out,
+                           selbox, w.state, sgi > 0 ? 1 : 0, alive, w.nchunks);
+        hipLaunchKernelGGL(k_nms_greedy, dim3(batch), dim3(GN_THREADS), lds, st, w.sboxes, nvalid, n, thr, max_out, n,
+                           sgi + 1 < stages ? GN_BUDGET : 0x7fffffff, alive, w.nchunks, selbox, w.state, w.sel_rank, num_out);
+      }
+    }
+    return check_launch("nms");
+  }
   // Rounds of row chunks: 2 048 rows, then 4 096, then 8 192 at a time. Every round is launched; an image whose scan
   // has its max_out survivors (or ran out of candidates) makes the later rounds' blocks return at once. The matrix
   // buffer holds one round (<= 8 192 rows x n/64 words per image: 7.8 GB -> 256 MB for the 250 000 clipped anchors

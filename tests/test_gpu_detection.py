@@ -346,6 +346,46 @@ def test_nms_many_rounds_heavy_suppression(ops):
     np.testing.assert_array_equal(sel.cpu().numpy()[:kk], ref)
 
 
+@pytest.mark.parametrize("regime", ["scattered", "piled", "few_candidates", "group_boundaries"])
+def test_greedy_nms_kernel_matches_the_rounds_and_the_oracle(ops, regime, monkeypatch):
+    """The one-launch greedy NMS (k_nms_greedy: candidates against the boxes selected so far, 128 at a time) and the
+    bit-matrix rounds of rounds 1-3 (MTLSSL_NMS_ALGO=rounds) on the same inputs: identical selections, both equal to
+    the oracle's greedy NMS — scattered boxes (300 survivors after a few groups), boxes piled onto a handful of
+    objects (every group visited, ~40 survivors), fewer candidates than max_out, and sizes around the 64 / 128
+    group boundaries."""
+    rng = np.random.RandomState({"scattered": 1, "piled": 2, "few_candidates": 3, "group_boundaries": 4}[regime])
+
+    def boxes(n, clusters=None):
+        if clusters is None:
+            cy, cx = rng.uniform(0, 600, n), rng.uniform(0, 1000, n)
+            h, w = rng.uniform(10, 200, n), rng.uniform(10, 200, n)
+        else:
+            k = rng.randint(0, clusters, n)
+            cy, cx = rng.uniform(50, 550, clusters)[k], rng.uniform(50, 950, clusters)[k]
+            h, w = rng.uniform(30, 150, clusters)[k], rng.uniform(30, 150, clusters)[k]
+            cy, cx = cy + rng.normal(0, 3, n), cx + rng.normal(0, 3, n)
+        return np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], 1).astype(np.float32)
+
+    cases = {"scattered": [(14453, None, 300, 0.7)], "piled": [(14453, 25, 300, 0.7), (5000, 3, 300, 0.5)],
+             "few_candidates": [(37, None, 300, 0.7), (1, None, 5, 0.5), (200, 4, 300, 0.3)],
+             "group_boundaries": [(n, c, 300, 0.6) for n in (63, 64, 65, 127, 128, 129, 191, 192, 193, 256, 257)
+                                  for c in (None, 6)]}[regime]
+    for n, clusters, max_out, thr in cases:
+        bx = boxes(n, clusters)
+        sc = (rng.permutation(n).astype(np.float32) + 1) / n
+        if n > 100:
+            sc[rng.randint(0, n, n // 10)] = sc[0]                  # ties: index-ascending among equal scores
+        ref = N.greedy_nms(bx, sc, max_out, thr)
+        got = {}
+        for algo in ("greedy", "rounds"):
+            monkeypatch.setenv("MTLSSL_NMS_ALGO", algo)
+            sel, num = ops.nms(cu(bx), cu(sc), thr, max_out)
+            got[algo] = sel.cpu().numpy()[:int(num.item())]
+        monkeypatch.delenv("MTLSSL_NMS_ALGO")
+        np.testing.assert_array_equal(got["greedy"], got["rounds"])
+        np.testing.assert_array_equal(got["greedy"], ref)
+
+
 def test_rpn_postprocess_train_mode_golden(ops, vec):
     """faster_rcnn_meta_arch_test_lib.py:461-521 through the HIP path: mtlssl_rpn_proposals ->
     mtlssl_sample_proposals (detector assigner + balanced sampler + boolean_mask order + padding)."""
