@@ -52,11 +52,14 @@ __device__ __forceinline__ bool nms_iou_gt(Box a, Box b, float thr) {
         ax1 = fmaxf(a.x0, a.x1);
   float by0 = fminf(b.y0, b.y1), by1 = fmaxf(b.y0, b.y1), bx0 = fminf(b.x0, b.x1),
         bx1 = fmaxf(b.x0, b.x1);
+  float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
+  float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.f);
+  // disjoint boxes: inter = 0 -> iou = 0 (or an area test that fails) -> false for every thr >= 0; decided before the
+  // areas and the division are computed (most pairs of a suppression test are disjoint). Same value as below otherwise.
+  if (!(ih > 0.f && iw > 0.f) && thr >= 0.f) return false;
   float area_a = (ay1 - ay0) * (ax1 - ax0);
   float area_b = (by1 - by0) * (bx1 - bx0);
   if (area_a <= 0.f || area_b <= 0.f) return false;
-  float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
-  float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.f);
   float inter = ih * iw;
   float iou = inter / ((area_a + area_b) - inter);
   return iou > thr;
@@ -553,17 +556,19 @@ __global__ void __launch_bounds__(GN_THREADS) k_nms_greedy(const float* sboxes, 
       unsigned long long rem0 = s_rem[0], rem1 = s_rem[1], sel0 = 0ull, sel1 = 0ull;
       int ns = nsel;
       const int c0 = min(cnt, 64);
-      for (int j = 0; j < c0 && ns < max_out; ++j) {
-        if (!((rem0 >> j) & 1ull)) {
-          sel0 |= 1ull << j; ++ns;
-          rem0 |= readlane64(r0a, j); rem1 |= readlane64(r0b, j);
-        }
+      // visit only candidates that are still free: the next one is the lowest clear bit of the removed set
+      const unsigned long long m0 = c0 >= 64 ? ~0ull : ((1ull << c0) - 1ull);
+      const unsigned long long m1 = cnt > 64 ? (cnt >= 128 ? ~0ull : ((1ull << (cnt - 64)) - 1ull)) : 0ull;
+      rem0 |= ~m0; rem1 |= ~m1;
+      while (~rem0 != 0ull && ns < max_out) {
+        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)~rem0) - 1);
+        sel0 |= 1ull << j; ++ns;
+        rem0 |= (1ull << j) | readlane64(r0a, j); rem1 |= readlane64(r0b, j);
       }
-      for (int j = 64; j < cnt && ns < max_out; ++j) {
-        if (!((rem1 >> (j - 64)) & 1ull)) {
-          sel1 |= 1ull << (j - 64); ++ns;
-          rem1 |= readlane64(r1b, j - 64);
-        }
+      while (~rem1 != 0ull && ns < max_out) {
+        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)~rem1) - 1);
+        sel1 |= 1ull << j; ++ns;
+        rem1 |= (1ull << j) | readlane64(r1b, j);
       }
       const int n0 = __popcll(sel0);
       if ((sel0 >> lane) & 1ull) {
@@ -602,24 +607,42 @@ __global__ void __launch_bounds__(256) k_nms_prune(const float* sboxes, const in
   const int32_t* stt = state + b * GN_STATE;
   if (stt[1]) return;
   const int nv = nvalid ? min(nvalid[b], n) : n;
-  const int i = blockIdx.x * 256 + threadIdx.x;
   const int cursor = stt[3];
-  if ((int)blockIdx.x * 256 >= nv || (int)blockIdx.x * 256 + 256 <= (cursor & ~63)) return;
+  // 8 adjacent lanes share a candidate (each tests every 8th box): 32 candidates per block, half a word of the bit set
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+  if ((int)blockIdx.x * 32 >= nv || (int)blockIdx.x * 32 + 32 <= (cursor & ~63)) return;
   const int lo = stt[2], ns = min(stt[0] - lo, GN_HEAD);
   if ((int)threadIdx.x < ns) s_sel[threadIdx.x] = selbox[(int64_t)b * max_out + lo + threadIdx.x];
   __syncthreads();
   bool live = i < nv && i >= cursor;
   if (live && have_alive) live = (alive[(int64_t)b * nwords + (i >> 6)] >> (i & 63)) & 1ull;
+  bool hit = false;
   if (live) {
     const float4 cv = *reinterpret_cast<const float4*>(sboxes + ((int64_t)b * n + i) * 4);
     const Box cb{cv.x, cv.y, cv.z, cv.w};
-    for (int k = 0; k < ns; ++k) {
+    for (int k = part; k < ns; k += 8) {
       const float4 v = s_sel[k];
-      if (nms_iou_gt(Box{v.x, v.y, v.z, v.w}, cb, thr)) { live = false; break; }
+      if (nms_iou_gt(Box{v.x, v.y, v.z, v.w}, cb, thr)) { hit = true; break; }
     }
   }
-  const unsigned long long m = __ballot(live);
-  if ((threadIdx.x & 63) == 0 && i < nwords * 64) alive[(int64_t)b * nwords + (i >> 6)] = m;
+  // wave w of the block holds candidates 8w .. 8w+7: a byte of the 32-bit piece this block owns
+  const unsigned long long hm = __ballot(hit);
+  unsigned byte = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) byte |= (((hm >> (c * 8)) & 0xFFull) == 0ull ? 1u : 0u) << c;
+  const unsigned long long lm = __ballot(live);
+  unsigned lbyte = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) lbyte |= (((lm >> (c * 8)) & 1ull) ? 1u : 0u) << c;
+  __shared__ unsigned s_piece[4];
+  if ((threadIdx.x & 63) == 0) s_piece[threadIdx.x >> 6] = byte & lbyte;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned piece = s_piece[0] | (s_piece[1] << 8) | (s_piece[2] << 16) | (s_piece[3] << 24);
+    const int i0 = blockIdx.x * 32;
+    if (i0 < nwords * 64)
+      reinterpret_cast<unsigned*>(alive + (int64_t)b * nwords)[i0 >> 5] = piece;
+  }
 }
 static bool nms_greedy_enabled() {          // MTLSSL_NMS_ALGO=rounds: the bit-matrix rounds of rounds 1-3 (read per call:
   const char* e = getenv("MTLSSL_NMS_ALGO");    // an A/B inside one process needs no rebuild)
@@ -640,7 +663,7 @@ static int run_nms_sorted(const NmsWs& w, const int32_t* nvalid, int batch, int 
       int stages = (int)cdiv(max_out, GN_BUDGET);
       stages = stages > 5 ? 5 : (stages < 1 ? 1 : stages);
       for (int sgi = 0; sgi < stages; ++sgi) {
-        hipLaunchKernelGGL(k_nms_prune, dim3(cdiv(n, 256), batch), dim3(256), 0, st, w.sboxes, nvalid, n, thr, max_out,
+        hipLaunchKernelGGL(k_nms_prune, dim3(cdiv(n, 32), batch), dim3(256), 0, st, w.sboxes, nvalid, n, thr, max_out,
                            selbox, w.state, sgi > 0 ? 1 : 0, alive, w.nchunks);
         hipLaunchKernelGGL(k_nms_greedy, dim3(batch), dim3(GN_THREADS), lds, st, w.sboxes, nvalid, n, thr, max_out, n,
                            sgi + 1 < stages ? GN_BUDGET : 0x7fffffff, alive, w.nchunks, selbox, w.state, w.sel_rank, num_out);
