@@ -84,6 +84,88 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same with the channel axis cut into 8 slices, one per XCD (round 4). The dispatcher places workgroup i on XCD
+// i % 8; with blockIdx.x = cell group * 8 + slice and a grid width that is a multiple of 8, every workgroup of slice s
+// runs on XCD s, so an XCD's L2 only ever sees C/8 channels of the feature map: 2.5 MB for the two 38x64x1024 maps of
+// config[1] instead of 40 MB — the map stays L2-resident across the RoIs that re-sample it (the block-per-cell kernel
+// above spreads every channel of every RoI over all eight L2s: 2.5x the compulsory HBM traffic). A workgroup handles
+// CB output cells x L = C/32 lanes (one float4 of channels per lane); arithmetic and operation order are unchanged
+// (bit-identical outputs and arg-max bytes).
+template <int PK>
+__global__ void __launch_bounds__(256)
+    k_roi_crop_pool_fwd_xcd(const float* __restrict__ feat, int H, int W, int C, const float* __restrict__ boxes,
+                            const int32_t* __restrict__ box_ind, int crop, int ps, int PH, int PW, int L, int CB,
+                            int rep, float* __restrict__ out, uint8_t* __restrict__ argmax) {
+  const int r = blockIdx.y;
+  // 8 / rep slices; the `rep` XCDs that share a slice take alternate cell groups
+  const int slice = (blockIdx.x & 7) / rep, cg = (blockIdx.x >> 3) * rep + (blockIdx.x & 7) % rep;
+  const int cell = cg * CB + (int)threadIdx.x / L, lane = (int)threadIdx.x % L;
+  if ((int)threadIdx.x >= CB * L || cell >= PH * PW) return;
+  const int py = cell / PW, px = cell % PW;
+  const int c4 = slice * L + lane;                   // float4 index along the channel axis
+  CropGeom g = crop_geom(boxes, box_ind, r, H, W, crop);
+  const float* fb = feat + (int64_t)g.b * H * W * C + c4 * 4;
+  // Every corner of every sample of the pooling window is requested before the first one is used: the block-per-cell
+  // kernel interleaves (branch, 4 loads, blend) per sample, i.e. PK*PK dependent L2 round trips per workgroup. Invalid
+  // samples (TF's extrapolation value 0) load a clamped address and are zeroed afterwards.
+  float4 tl[PK * PK], tr[PK * PK], bl[PK * PK], br[PK * PK];
+  float yl[PK], xl[PK];
+  bool vy[PK], vx[PK];
+  int ty[PK], by[PK], lx[PK], rx[PK];
+#pragma unroll
+  for (int d = 0; d < PK; ++d) {
+    float in_y = g.y1 + (float)(py * ps + d) * g.hs;
+    vy[d] = !(in_y < 0.f || in_y > (float)(H - 1));
+    ty[d] = (int)floorf(in_y); by[d] = (int)ceilf(in_y);
+    yl[d] = in_y - (float)ty[d];
+    ty[d] = min(max(ty[d], 0), H - 1); by[d] = min(max(by[d], 0), H - 1);
+    float in_x = g.x1 + (float)(px * ps + d) * g.ws;
+    vx[d] = !(in_x < 0.f || in_x > (float)(W - 1));
+    lx[d] = (int)floorf(in_x); rx[d] = (int)ceilf(in_x);
+    xl[d] = in_x - (float)lx[d];
+    lx[d] = min(max(lx[d], 0), W - 1); rx[d] = min(max(rx[d], 0), W - 1);
+  }
+#pragma unroll
+  for (int dy = 0; dy < PK; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < PK; ++dx) {
+      const int s = dy * PK + dx;
+      tl[s] = *reinterpret_cast<const float4*>(fb + ((int64_t)ty[dy] * W + lx[dx]) * C);
+      tr[s] = *reinterpret_cast<const float4*>(fb + ((int64_t)ty[dy] * W + rx[dx]) * C);
+      bl[s] = *reinterpret_cast<const float4*>(fb + ((int64_t)by[dy] * W + lx[dx]) * C);
+      br[s] = *reinterpret_cast<const float4*>(fb + ((int64_t)by[dy] * W + rx[dx]) * C);
+    }
+  // The kernel is VALU-bound (one wave64 fp32 instruction = 4 issue cycles; ~350 scalar operations per lane in the
+  // block-per-cell form): the blends run on channel PAIRS so that hipcc selects v_pk_add_f32 / v_pk_mul_f32 (same
+  // operations in the same order per channel — contraction is off for this file — so the values are unchanged).
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f best_lo = {-INFINITY, -INFINITY}, best_hi = {-INFINITY, -INFINITY};
+  uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll
+  for (int dy = 0; dy < PK; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < PK; ++dx) {
+      const int si = dy * PK + dx;
+      const bool ok = vy[dy] && vx[dx];
+      const v2f tl_lo = {tl[si].x, tl[si].y}, tl_hi = {tl[si].z, tl[si].w}, tr_lo = {tr[si].x, tr[si].y}, tr_hi = {tr[si].z, tr[si].w};
+      const v2f bl_lo = {bl[si].x, bl[si].y}, bl_hi = {bl[si].z, bl[si].w}, br_lo = {br[si].x, br[si].y}, br_hi = {br[si].z, br[si].w};
+      const v2f top_lo = tl_lo + (tr_lo - tl_lo) * xl[dx], top_hi = tl_hi + (tr_hi - tl_hi) * xl[dx];
+      const v2f bot_lo = bl_lo + (br_lo - bl_lo) * xl[dx], bot_hi = bl_hi + (br_hi - bl_hi) * xl[dx];
+      v2f v_lo = top_lo + (bot_lo - top_lo) * yl[dy], v_hi = top_hi + (bot_hi - top_hi) * yl[dy];
+      if (!ok) { v_lo = v2f{0.f, 0.f}; v_hi = v2f{0.f, 0.f}; }
+      const uint32_t sv = (uint32_t)si;
+      if (v_lo.x > best_lo.x) { best_lo.x = v_lo.x; b0 = sv; }
+      if (v_lo.y > best_lo.y) { best_lo.y = v_lo.y; b1 = sv; }
+      if (v_hi.x > best_hi.x) { best_hi.x = v_hi.x; b2 = sv; }
+      if (v_hi.y > best_hi.y) { best_hi.y = v_hi.y; b3 = sv; }
+    }
+  const float4 best = make_float4(best_lo.x, best_lo.y, best_hi.x, best_hi.y);
+  const uint32_t bi = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+  int64_t o = (((int64_t)r * PH + py) * PW + px) * C + c4 * 4;
+  *reinterpret_cast<float4*>(out + o) = best;
+  if (argmax) *reinterpret_cast<uint32_t*>(argmax + o) = bi;
+}
+
 __global__ void __launch_bounds__(256)
     k_roi_crop_pool_bwd(const float* __restrict__ dout, const uint8_t* __restrict__ argmax, int H,
                         int W, int C, const float* __restrict__ boxes,
@@ -992,6 +1074,28 @@ int mtlssl_roi_crop_pool_fwd(const float* feat, int B, int H, int W, int C, cons
   MTLSSL_REQUIRE(pk >= 1 && ps >= 1 && crop >= pk && pk * pk <= 255, "roi_crop: bad pool geometry");
   if (R == 0) return MTLSSL_OK;
   int PH = (crop - pk) / ps + 1;
+  // MTLSSL_ROI_FWD=xcd selects the channel-sliced kernel (compulsory-only HBM traffic: 148 MB instead of 375 MB per
+  // 512-RoI call, PMC in profiles/r04_pmc_hbm_kernels.md). It is NOT the default because it is not faster: either form
+  // moves 540 MB of bilinear corners from L2 into the CUs at the ~6.7 TB/s the part sustains there (74-82 us measured,
+  // 80 us predicted), whatever the HBM side does — the lever left is staging a RoI's pixel footprint in LDS once.
+  const char* algo = getenv("MTLSSL_ROI_FWD");
+  if (C % 32 == 0 && C / 32 <= 256 && pk <= 2 && algo && !strcmp(algo, "xcd")) {
+    const char* se = getenv("MTLSSL_ROI_SLICES");
+    int nsl = se ? atoi(se) : 8;
+    if (nsl != 8 && nsl != 4 && nsl != 2 && nsl != 1) nsl = 8;
+    while (nsl < 8 && C / (4 * nsl) > 256) nsl *= 2;
+    const int rep = 8 / nsl;
+    const int L = C / (4 * nsl), CB = 256 / L;
+    const int groups = (int)cdiv(cdiv(PH * PH, CB), rep);
+    const dim3 grid(groups * 8, R), block((unsigned)align_up(CB * L, 64));
+    if (pk == 1)
+      hipLaunchKernelGGL(k_roi_crop_pool_fwd_xcd<1>, grid, block, 0, S(stream), feat, H, W, C, boxes, box_ind, crop, ps, PH, PH,
+                         L, CB, rep, out, argmax);
+    else
+      hipLaunchKernelGGL(k_roi_crop_pool_fwd_xcd<2>, grid, block, 0, S(stream), feat, H, W, C, boxes, box_ind, crop, ps, PH, PH,
+                         L, CB, rep, out, argmax);
+    return check_launch("roi_crop_pool_fwd");
+  }
   int threads = (int)align_up(C / 4 < 256 ? C / 4 : 256, 64);
   hipLaunchKernelGGL(k_roi_crop_pool_fwd, dim3(PH * PH, R), dim3(threads), 0, S(stream), feat, H, W,
                      C, boxes, box_ind, crop, pk, ps, PH, PH, out, argmax);

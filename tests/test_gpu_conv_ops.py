@@ -236,6 +236,24 @@ def test_roi_crop_pool(ops, crop, pk, ps):
         assert relerr(over, fr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("H,W,C,R,crop,pk", [(38, 64, 1024, 512, 14, 2), (50, 84, 1088, 300, 17, 1), (38, 50, 512, 256, 14, 2),
+                                             (9, 11, 32, 40, 7, 1), (10, 12, 96, 33, 3, 2)])
+def test_roi_crop_fwd_channel_sliced_kernel_is_bit_identical_to_the_cell_kernel(ops, H, W, C, R, crop, pk, monkeypatch):
+    """k_roi_crop_pool_fwd_xcd (one eighth of the channels per XCD, several cells per workgroup; MTLSSL_ROI_FWD=xcd,
+    for C % 32 == 0) against the default block-per-cell kernel: same values, same arg-max bytes."""
+    g = torch.Generator().manual_seed(C + R)
+    feat = torch.randn(2, H, W, C, generator=g).cuda()
+    yx = torch.rand(R, 2, generator=g) * 0.9 - 0.05
+    hw = torch.rand(R, 2, generator=g) * 0.6 + 0.02
+    boxes = torch.cat([yx, yx + hw], 1).cuda()
+    bi = (torch.arange(R) * 2 // R).int().cuda()
+    out0, am0 = ops.roi_crop_pool_fwd(feat, boxes, bi, crop, pk, pk)
+    monkeypatch.setenv("MTLSSL_ROI_FWD", "xcd")
+    out, am = ops.roi_crop_pool_fwd(feat, boxes, bi, crop, pk, pk)
+    assert torch.equal(out, out0)
+    assert (am is None and am0 is None) or torch.equal(am, am0)
+
+
 @pytest.mark.parametrize("H,W,C,R,crop,pk", [(38, 64, 1024, 512, 14, 2), (50, 84, 1088, 300, 7, 1), (19, 25, 48, 2300, 7, 1)])
 def test_roi_crop_bwd_lds_kernel_is_bit_reproducible_and_matches_the_atomic_kernel(ops, H, W, C, R, crop, pk):
     """The LDS-resident scatter (no HBM atomics): at configs[1]'s full shape (two images, 38x64x1024, 512 RoIs of
