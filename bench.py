@@ -91,8 +91,8 @@ def pmc_traffic(default_cfg):
     """HBM bytes per launch of the roofline kernel. PMC counters cannot be read from inside the
     process being timed, so this is the committed result of the separate `rocprofv3 --pmc FETCH_SIZE`
     / `--pmc WRITE_SIZE` passes over this same command (tools/pmc_bench.sh -> tools/pmc_summary.py ->
-    profiles/r03_pmc_traffic.json); null when that file is absent or the config is not the default."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    profiles/r04_pmc_traffic.json); null when that file is absent or the config is not the default."""
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     if not default_cfg or not os.path.exists(path):
         return None
     d = json.load(open(path))
@@ -102,25 +102,71 @@ def pmc_traffic(default_cfg):
 def pmc_traffic_provenance(default_cfg):
     """Where `roofline.traffic` comes from and whether the counters were taken from the kernel sources being timed
     (tools/pmc_summary.py stores a digest of the tile engine, conv_mfma.h, with them)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     if not default_cfg or not os.path.exists(path):
         return None
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from pmc_summary import kernel_source_sha16
     d = json.load(open(path))
-    return {"file": "profiles/r03_pmc_traffic.json", "counters_from_sources": d.get("kernel_source_sha16"),
+    return {"file": "profiles/r04_pmc_traffic.json", "counters_from_sources": d.get("kernel_source_sha16"),
             "current_sources": kernel_source_sha16(), "matches_current_kernel": d.get("kernel_source_sha16") == kernel_source_sha16()}
 
 
 HBM_PEAK = 8.0e12   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def plan_kernel_name(key):
+    """Kernel a (mode, plan code) pair launches (mtlssl_conv2d_tile_config codes, include/mtlssl_hip.h)."""
+    mode, code = key
+    shape = ("128,128", "128,64", "64,64", "256,128")[code % 4]
+    alg, eng = (code % 12) // 4, code >= 12
+    what = ("implicit-GEMM conv forward", "implicit-GEMM conv input gradient", "implicit-GEMM conv filter gradient")[mode]
+    if alg == 0:
+        return "mtlssl::%s<%s,%d> (%s)" % ("k_conv_glds" if eng else "k_conv_mfma", shape, mode, what)
+    return "mtlssl::%s<%s,%d> (Winograd %s GEMM stack, %s)" % ("k_wino_glds" if eng else "k_wino_gemm", shape, mode,
+                                                             "F(4x4,3x3)" if alg == 1 else "whole-7-span", what.split(" conv ")[1])
+
+
 def pmc_hbm_counters():
     """{kernel name fragment: {"fetch_bytes", "write_bytes"} per launch} from the separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes over tools/hbm_kernels.py (tools/pmc_hbm.sh -> profiles/r03_hbm_kernels_pmc.json);
+    FETCH_SIZE / WRITE_SIZE passes over tools/hbm_kernels.py (tools/pmc_hbm.sh -> profiles/r04_hbm_kernels_pmc.json);
     empty when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r03_hbm_kernels_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r04_hbm_kernels_pmc.json")
     return json.load(open(path))["kernels"] if os.path.exists(path) else {}
+
+
+def common_tail(tr, pd, c, B, timed, add):
+    """Entries every configuration has: the RPN proposal chain and the optimizer."""
+    import torch
+    from mtl_ssl_amd import ops
+    model = tr.model
+    H, W = pd["image_shape"][1], pd["image_shape"][2]
+    enc, obj, anc = pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"]
+    Nv = anc.shape[0]
+    sec = timed(lambda: ops.rpn_proposals(enc, obj, anc, H, W, c.first_stage_nms_score_threshold,
+                                          c.first_stage_nms_iou_threshold, int(c.first_stage_max_proposals)))
+    algo = B * (Nv * (16 + 8 + 16) + Nv * 20 + 2 * (Nv * Nv // 8))
+    comp = B * (Nv * (16 + 8) + Nv * 16 + int(c.first_stage_max_proposals) * 20)
+    add("rpn_proposals (k_rpn_decode_score + k_rank_sort + k_nms_greedy + k_nms_prune + k_emit_proposals)",
+        ["k_rpn_decode_score", "k_rank_sort", "k_nms_mask", "k_nms_scan", "k_emit_proposals"], algo, comp, sec,
+        "%d images x %d anchors -> %d proposals; latency-bound (round 4: greedy NMS as head / chip-wide prune / budgeted "
+        "tails instead of the n x n bit matrix: k_nms_greedy + k_nms_prune; algorithmic bytes still price the matrix)" % (
+            B, Nv, int(c.first_stage_max_proposals)))
+    ps = model.ps
+    n = ps.weights.numel()
+    g0 = ps.grads.clone()
+
+    def opt():
+        ps.grads.copy_(g0)
+        ops.sgd_momentum_clip(ps.weights, ps.grads, ps.accum, ps.var_offsets, ps.max_var_size, 0.0,
+                              tr.momentum, tr.clip, 1.0, tr.var_wd, tr.var_mult)
+    w0, a0 = ps.weights.clone(), ps.accum.clone()
+    t_copy = timed(lambda: ps.grads.copy_(g0))
+    sec = timed(opt) - t_copy
+    ps.weights.copy_(w0)
+    ps.accum.copy_(a0)
+    add("k_var_sumsq + k_momentum_update (per-variable clip + momentum + L2)", ["k_var_sumsq", "k_momentum_update"],
+        n * 24, n * 24, sec, "%d parameters: norm pass reads g (+w), update reads w,g,acc and writes w,acc" % n)
 
 
 def hbm_kernels(tr, iters=10):
@@ -163,7 +209,56 @@ def hbm_kernels(tr, iters=10):
 
     F = pd["rpn_features_to_crop"]
     B, Hf, Wf, C = F.shape
-    if not c.has("initial_crop_size"):        # R-FCN: no crop_and_resize stage (position-sensitive pooling)
+    common_tail(tr, pd, c, B, timed, add)
+    from mtl_ssl_amd import nn as nn_mod
+    dws = [l for l in model.layers if isinstance(l, nn_mod.DepthwiseBN)]
+    if dws:
+        # MobileNet-v1's depthwise stage (slim/nets/mobilenet_v1.py:229-262): every layer / input shape the step ran,
+        # forward, input gradient and filter gradient, each timed stand-alone; one aggregated row per kernel + the
+        # single largest layer. Compulsory bytes: x + y (fwd), dy + dx + the activation mask (dgrad), x + dy (wgrad).
+        rows = {"k_dw_fwd": [0, 0.0, None], "k_dw_dgrad": [0, 0.0, None], "k_dw_wgrad_partial + k_dw_wgrad_fold": [0, 0.0, None]}
+        for l in dws:
+            for shape, d in l._desc.items():
+                x = torch.randn(shape, device=F.device)
+                y = ops.depthwise_fwd(d, x, l.w_eff, l.shift, 0)
+                gy = torch.randn_like(y)
+                dw = torch.zeros((l.k, l.k, l.c), device=F.device)
+                for name, fn, nb in (("k_dw_fwd", lambda: ops.depthwise_fwd(d, x, l.w_eff, l.shift, 0), 4 * (x.numel() + y.numel())),
+                                     ("k_dw_dgrad", lambda: ops.depthwise_dgrad(d, gy, l.w_eff, x, ops.EPI_MASK), 4 * (gy.numel() + 2 * x.numel())),
+                                     ("k_dw_wgrad_partial + k_dw_wgrad_fold", lambda: ops.depthwise_wgrad(d, x, gy, dw), 4 * (x.numel() + gy.numel()))):
+                    sec = timed(fn)
+                    r = rows[name]
+                    r[0] += nb; r[1] += sec
+                    if r[2] is None or sec > r[2][1]:
+                        r[2] = (nb, sec, "%s on %s" % (l.w.name.split("/")[-2], "x".join(map(str, shape))))
+        for name, (nb, sec, big) in rows.items():
+            add(name + " (every depthwise layer of the step, summed)", [name.split(" ")[0]], nb, nb, sec,
+                "%d depthwise layer shapes; largest: %s, %.1f MB in %.1f us = %.0f GB/s" % (
+                    sum(len(l._desc) for l in dws), big[2], big[0] / 1e6, big[1] * 1e6, big[0] / big[1] / 1e9))
+    if not c.has("initial_crop_size"):
+        # R-FCN (rfcn_meta_arch.py:208-381, utils/ops.py:462-609): position-sensitive RoI pooling of the class and box
+        # score maps. Compulsory: the map once + the pooled output once (fwd); dout once + the gradient map once (bwd).
+        bp = pd.get("_bp")
+        if bp is not None:
+            pred_l = model.box_predictor
+            boxes, bi = bp["boxes"], bp["box_ind"]
+            for tag, layer in (("class map", pred_l.cls), ("box map", pred_l.loc)):
+                if layer is None:
+                    continue
+                fmap = layer.forward(bp["net"])
+                R = boxes.shape[0]
+                nb = pred_l.bins[0] * pred_l.bins[1]
+                outn = R * (fmap.shape[-1] // nb)
+                samples = R * pred_l.crop[0] * pred_l.crop[1] * 4 * (fmap.shape[-1] // nb) * 4
+                sec = timed(lambda: ops.psroi_fwd(fmap, boxes, bi, pred_l.crop, pred_l.bins))
+                add("k_psroi_fwd (%s)" % tag, ["k_psroi_fwd"], samples + outn * 4, fmap.numel() * 4 + outn * 4, sec,
+                    "%d RoIs, crop %dx%d over %dx%d bins, map %s (%.1f MB)" % (R, pred_l.crop[0], pred_l.crop[1], pred_l.bins[0],
+                                                                             pred_l.bins[1], "x".join(map(str, fmap.shape)), fmap.numel() * 4 / 1e6))
+                g = torch.randn((R, fmap.shape[-1] // nb), device=F.device)
+                dmap = torch.empty_like(fmap)
+                sec = timed(lambda: ops.psroi_bwd(g, tuple(fmap.shape), boxes, bi, pred_l.crop, pred_l.bins, dfmap=dmap))
+                add("k_psroi_bwd_gather (%s)" % tag, ["k_psroi_bwd_gather"], samples + outn * 4, fmap.numel() * 4 + outn * 4, sec,
+                    "gather form (one block per map pixel, RoIs of the image in order): no float atomics, bit-reproducible")
         return res
     crop = int(c.initial_crop_size)
     pk, pst = int(c.maxpool_kernel_size), int(c.maxpool_stride)
@@ -188,32 +283,6 @@ def hbm_kernels(tr, iters=10):
             R * P * P * C * (4 + 4 + 1) + fmap, R * P * P * C * (4 + 4 + 1) + fmap, sec,
             "%d RoIs scattered into the %.1f MB gradient map held in LDS as 64-bit fixed point (no HBM atomics, "
             "bit-reproducible; the map is written once, no pre-zero)" % (R, fmap / 1e6))
-    H, W = pd["image_shape"][1], pd["image_shape"][2]
-    enc, obj, anc = pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"]
-    Nv = anc.shape[0]
-    sec = timed(lambda: ops.rpn_proposals(enc, obj, anc, H, W, c.first_stage_nms_score_threshold,
-                                          c.first_stage_nms_iou_threshold, int(c.first_stage_max_proposals)))
-    algo = B * (Nv * (16 + 8 + 16) + Nv * 20 + 2 * (Nv * Nv // 8))
-    comp = B * (Nv * (16 + 8) + Nv * 16 + int(c.first_stage_max_proposals) * 20)
-    add("rpn_proposals (k_rpn_decode_score + k_rank_sort + k_nms_mask + k_nms_scan + k_emit_proposals)",
-        ["k_rpn_decode_score", "k_rank_sort", "k_nms_mask", "k_nms_scan", "k_emit_proposals"], algo, comp, sec,
-        "%d images x %d anchors -> %d proposals; latency-bound (a greedy scan ends the chain)" % (
-            B, Nv, int(c.first_stage_max_proposals)))
-    ps = model.ps
-    n = ps.weights.numel()
-    g0 = ps.grads.clone()
-
-    def opt():
-        ps.grads.copy_(g0)
-        ops.sgd_momentum_clip(ps.weights, ps.grads, ps.accum, ps.var_offsets, ps.max_var_size, 0.0,
-                              tr.momentum, tr.clip, 1.0, tr.var_wd, tr.var_mult)
-    w0, a0 = ps.weights.clone(), ps.accum.clone()
-    t_copy = timed(lambda: ps.grads.copy_(g0))
-    sec = timed(opt) - t_copy
-    ps.weights.copy_(w0)
-    ps.accum.copy_(a0)
-    add("k_var_sumsq + k_momentum_update (per-variable clip + momentum + L2)", ["k_var_sumsq", "k_momentum_update"],
-        n * 24, n * 24, sec, "%d parameters: norm pass reads g (+w), update reads w,g,acc and writes w,acc" % n)
     return res
 
 
@@ -387,9 +456,24 @@ def main():
                 hbm_first = None
     if comm is not None:
         tr.reducer.timing = True
+    default_cfg = os.path.basename(a.config) == "frcnn_resnet101_coco_mtl.config"
+    dom_key = (0, 0)              # config[1]: the 128x128 implicit-GEMM forward tile
+    if not a.no_roofline and not default_cfg:
+        # another configuration: its dominant conv kernel = the (mode, plan code) with the largest summed launch time
+        # over two extra warm-up steps timed launch by launch
+        ops.PROFILER = ops.ConvProfiler(None)
+        for _ in range(2):
+            tr.step(next_batch())
+        torch.cuda.synchronize()
+        cand = {k: v["seconds"] for k, v in ops.PROFILER.summary().items() if k[1] >= 0}
+        ops.PROFILER = None
+        if cand:
+            best = max(cand, key=cand.get)
+            dom_key = (ops.ConvProfiler.MODES.index(best[0]), best[1])
     if not a.no_roofline:
-        # live HIP-event timing of the roofline kernel (forward, 128x128 tile) inside the timed region
-        ops.PROFILER = ops.ConvProfiler(None if a.conv_breakdown else (0, 0))
+        # live HIP-event timing of the roofline kernel inside the timed region
+        ops.PROFILER = ops.ConvProfiler(None if a.conv_breakdown else dom_key)
+        ops.HBM_PROFILER = ops.HbmProfiler()        # depthwise / PS-RoI / RoI-crop launches of the timed steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -408,6 +492,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILER = ops.PROFILER, None
+    hbm_prof, ops.HBM_PROFILER = ops.HBM_PROFILER, None
     account, ops.ACCOUNT = ops.ACCOUNT, None
     dp = None
     if comm is not None:
@@ -443,7 +528,6 @@ def main():
             dist.destroy_process_group()
         return
     value = B * world * a.steps / dt
-    default_cfg = os.path.basename(a.config) == "frcnn_resnet101_coco_mtl.config"
     fe_type = cfg.model.faster_rcnn.feature_extractor.type
     if cfg.model.faster_rcnn.second_stage_box_predictor.has("rfcn_box_predictor"):
         fe_type = "R-FCN " + fe_type
@@ -487,14 +571,14 @@ def main():
     }
     if prof is not None:
         s = prof.summary()
-        dom = s.get(("fwd", 0))
+        dom = s.get((ops.ConvProfiler.MODES[dom_key[0]], dom_key[1]))
         if dom and dom["seconds"] > 0:
             out["roofline"] = {
                 "bound": "mfma", "achieved": dom["flops"] / dom["seconds"] / 1e12,
                 "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": dom["flops"] / dom["seconds"] / FP32_MFMA_PEAK, "traffic": pmc_traffic(default_cfg),
                 "traffic_provenance": pmc_traffic_provenance(default_cfg),
-                "kernel": "mtlssl::k_conv_mfma<128,128,0> (implicit-GEMM conv forward)",
+                "kernel": plan_kernel_name(dom_key),
                 # calls of mtlssl_conv2d_fwd that ran this kernel; some make two launches of it (whole
                 # waves + a K-split tail), so the per-launch average divides by the dispatch count —
                 # that is the number rocprofv3's per-kernel average reports
@@ -502,7 +586,7 @@ def main():
                 "avg_launch_us": 1e6 * dom["seconds"] / dom["dispatches"],
                 "algorithmic_flop_per_launch_avg": dom["flops"] / dom["dispatches"],
             }
-    if prof is not None and "roofline" in out and world == 1 and comm is None and a.roofline_isolated_steps > 0:
+    if prof is not None and "roofline" in out and world == 1 and comm is None and a.roofline_isolated_steps > 0 and default_cfg:
         # In the timed region this kernel's launches share the chip: the closeness tower's forward runs next to the main
         # tower's and the refiner's window pass next to both (three streams) — that is what makes the
         # step faster, and it makes "flops / launch duration" the rate of a launch that owns a PART of the chip. The
@@ -534,7 +618,7 @@ def main():
                     "avg_launch_us": 1e6 * iso["seconds"] / iso["dispatches"], "launches": iso["dispatches"],
                     "steps": a.roofline_isolated_steps, "ms_per_step_of_that_schedule": iso_ms,
                     "how": "MTLSSL_CLOSENESS_FWD_SIDE=0 MTLSSL_REFINE_EARLY=0 for these steps, after the timed region; "
-                           "rocprofv3 of a whole run in that mode: profiles/r03_kernel_stats_bench_forward_serialised.md"}
+                           "rocprofv3 of a whole run in that mode: profiles/r04_resnet101_kernel_stats_serialised.md"}
         except Exception as e:
             ops.PROFILER = None
             out["roofline"]["isolated"] = {"error": repr(e)}
@@ -554,6 +638,32 @@ def main():
                                             "ms_per_step": 1e3 * v["seconds"] / a.steps}
                           for k, v in sorted(s.items()) if v["seconds"] > 0},
         }
+    if hbm_prof is not None and hbm_prof.rows:
+        # the HBM-bound families as they ran INSIDE the timed region (HIP events on their own streams; they share the
+        # chip with whatever the other streams run): compulsory bytes (inputs once + outputs once) over launch time
+        live = {}
+        for fam, r in sorted(hbm_prof.summary().items()):
+            if r["seconds"] > 0:
+                live[fam] = {"launches_per_step": r["launches"] / a.steps, "ms_per_step": 1e3 * r["seconds"] / a.steps,
+                             "compulsory_GB_per_step": r["bytes"] / a.steps / 1e9,
+                             "achieved_GBps": r["bytes"] / r["seconds"] / 1e9,
+                             "frac_of_hbm_peak": r["bytes"] / r["seconds"] / HBM_PEAK}
+        out["hbm_kernels_in_step"] = live
+        dw = live.get("depthwise_fwd")
+        if dw is not None and "mobilenet" in fe_type:
+            # MobileNet-v1: the kernel family that bounds the architecture is the depthwise stage (9 MACs per element,
+            # 8 B per element: HBM-bound); the pointwise convolutions' MFMA figure moves to `roofline_mfma`
+            if "roofline" in out:
+                out["roofline_mfma"] = out.pop("roofline")
+            out["roofline"] = {"bound": "hbm", "achieved": dw["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": dw["frac_of_hbm_peak"], "traffic": None,
+                               "kernel": "mtlssl::k_dw_fwd (depthwise 3x3 + folded BN + ReLU6, every layer of the timed steps)",
+                               "launches": int(dw["launches_per_step"] * a.steps),
+                               "avg_launch_us": 1e3 * dw["ms_per_step"] / max(dw["launches_per_step"], 1e-9),
+                               "algorithmic_bytes_per_launch_avg": 1e9 * dw["compulsory_GB_per_step"] / max(dw["launches_per_step"], 1e-9),
+                               "note": "compulsory bytes (x read once + y written once) over the launches' own durations; "
+                                       "B=1 maps are a few MB each: launch latency, not bandwidth, bounds most layers "
+                                       "(hbm_kernels has every layer stand-alone)"}
     out["fp32_engine"] = "split-bf16x3" if ops.set_fp32_engine(-1) == 1 else "native fp32 MFMA"
     if world == 1 and comm is None and a.split_engine_steps > 0 and ops.set_fp32_engine(-1) == 0:
         # NOT part of `value`: the same step with the large GEMMs on the opt-in engine (exact three-way bf16 split of
@@ -606,7 +716,7 @@ def main():
                         "chain, losses, optimizer, waits on side streams). Calls on different streams overlap (forward: main "
                         "tower / closeness tower / refiner pass side by side; backward: dgrad chain / aux towers / filter "
                         "gradients), so rows do not add up to the step and a row's TFLOP/s is the rate of calls that share "
-                        "the chip; kernel-level rows: profiles/r03_kernel_stats_bench.md",
+                        "the chip; kernel-level rows: profiles/r04_resnet101_kernel_stats.md",
             }
         except Exception as e:
             ops.PROFILER = None

@@ -416,13 +416,15 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
 /* The same update that also refreshes the shadow weights of mtlssl_fold_scales (eff = w * scale[channel] for the
  * variables with a registered scale vector; same tables) on the values it already holds. Only valid when no scale
  * vector depends on a variable of this update — every BatchNorm frozen, the reference's configs for ResNet and
- * Inception-ResNet-v2 (faster_rcnn.proto batch_norm_trainable default false). eff == NULL: plain update. */
-int mtlssl_sgd_momentum_clip_fold(float* weights, const float* grads, float* accum,
+ * Inception-ResNet-v2 (faster_rcnn.proto batch_norm_trainable default false). eff == NULL: plain update.
+ * zero_grads != 0: the launch leaves zeros in `grads` (every element, frozen variables included) — the update is the
+ * gradient buffer's last reader of a step, so the next step's accumulation needs no separate memset. */
+int mtlssl_sgd_momentum_clip_fold(float* weights, float* grads, float* accum,
                                   const int32_t* var_offsets, int num_vars, int64_t total,
                                   int64_t max_var_size, float lr, float momentum, float clip_norm,
                                   float grad_scale, const float* var_weight_decay, const float* var_grad_mult,
                                   float* norms_ws, float* eff, const void* scale_ptrs, const int32_t* scale_len,
-                                  mtlssl_stream_t stream);
+                                  int zero_grads, mtlssl_stream_t stream);
 /* The other two optimizers of builders/optimizer_builder.py:40-62 behind the same gradient pipeline (L2 term,
  * multipliers / frozen variables, per-variable clip; same tables and workspace as above). kind 1 =
  * tf.train.RMSPropOptimizer: slot0 = mean square (TensorFlow initialises it to ONE), slot1 = momentum;
@@ -578,6 +580,12 @@ int mtlssl_comm_allreduce(mtlssl_comm_t comm, void* buf, int64_t count, int dtyp
 /* bytes of buf on every rank = rank root's. */
 int mtlssl_comm_broadcast(mtlssl_comm_t comm, void* buf, int64_t bytes, int root, mtlssl_stream_t stream);
 int mtlssl_comm_destroy(mtlssl_comm_t comm);
+/* Diagnostic (no reference counterpart): `workgroups` workgroups of `threads` threads and `lds_bytes` of LDS that stay
+ * resident and issuing for `microseconds` of wall time on `stream` — a stand-in for the CU share a collective's
+ * channels take from the compute streams while gradients are reduced under backward (model_deploy.py:414-444 has the
+ * clones' gradients summed on the CPU; here RCCL's kernels share the GPU with the step). tools/cu_thief_probe.py. */
+int mtlssl_debug_cu_thief(int workgroups, int threads, int lds_bytes, int64_t microseconds, float* sink,
+                          mtlssl_stream_t stream);
 
 /* CRC-32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start): the checksum of the reference's
  * data containers — TFRecord framing (tensorflow/core/lib/io/record_writer.cc; the create_records scripts write them,

@@ -1208,7 +1208,7 @@ using namespace mtlssl;
 extern "C" {
 
 const char* mtlssl_last_error(void) { return g_err; }
-int mtlssl_abi_version(void) { return 4; }
+int mtlssl_abi_version(void) { return 5; }
 
 int mtlssl_anchors_generate(float* out, int gh, int gw, const float* scales, int ns,
                             const float* ars, int nr, float base_h, float base_w, float sy,

@@ -386,6 +386,33 @@ int mtlssl_hard_mining_apply(const int32_t* selected, const int32_t* num_selecte
   return check_launch("hard_mining_apply");
 }
 
+// Diagnostic: workgroups that sit on the chip for a fixed wall time, the way a collective's channels do (each RCCL
+// channel is a persistent workgroup that holds wave slots — and, with its staging buffers, LDS — of one CU for the
+// duration of the all-reduce). tools/cu_thief_probe.py launches it on a side stream during backward to size what a
+// given channel count costs the three compute streams of the step on ONE GPU, where RCCL itself moves no bytes.
+__global__ void k_cu_thief(long long ticks_100mhz, float* sink) {
+  extern __shared__ float thief_lds[];
+  const long long t0 = wall_clock64();
+  float x = (float)threadIdx.x;
+  while (wall_clock64() - t0 < ticks_100mhz) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) x = x * 1.0000001f + 1e-7f;     // keep the wave issuing (a polling loop does too)
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (x == 1.2345e-30f) { thief_lds[threadIdx.x % 32] = x; sink[0] = thief_lds[0]; }
+}
+int mtlssl_debug_cu_thief(int workgroups, int threads, int lds_bytes, int64_t microseconds, float* sink,
+                          mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(workgroups >= 0 && workgroups <= 4096 && threads >= 64 && threads <= 1024 && threads % 64 == 0,
+                 "cu_thief: workgroups 0..4096, threads a multiple of 64 up to 1024");
+  MTLSSL_REQUIRE(lds_bytes >= 0 && lds_bytes <= 65536 && microseconds >= 0 && microseconds <= 1000000 && sink != nullptr,
+                 "cu_thief: lds_bytes <= 64 KiB, at most one second, a sink pointer");
+  if (!workgroups || !microseconds) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_cu_thief, dim3(workgroups), dim3(threads), (size_t)lds_bytes, S(stream), (long long)microseconds * 100,
+                     sink);
+  return check_launch("cu_thief");
+}
+
 int mtlssl_dropout(const float* x, float* y, int64_t n, float keep_prob, uint32_t seed, uint32_t stream_id,
                    mtlssl_stream_t stream) {
   MTLSSL_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "dropout: keep_prob must be in (0, 1], got %g", (double)keep_prob);

@@ -909,10 +909,10 @@ __global__ void k_var_norm_fold(const float* part, int chunks, int num_vars, flo
 // this same launch updates, i.e. when every BatchNorm of the model is frozen.
 template <bool FOLD>
 __global__ void __launch_bounds__(256)
-    k_momentum_update(float* w, const float* g, float* acc, const int32_t* off, int num_vars,
+    k_momentum_update(float* w, float* g, float* acc, const int32_t* off, int num_vars,
                       int64_t total4, float lr, float mom, float clip, float gscale,
                       const float* norms, const float* var_wd, const float* var_mult, float* eff,
-                      const float* const* scales, const int32_t* Ks) {
+                      const float* const* scales, const int32_t* Ks, int zero_g) {
   int64_t i4 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i4 >= total4) return;
   int64_t i = i4 * 4;
@@ -922,7 +922,10 @@ __global__ void __launch_bounds__(256)
     if ((int64_t)off[mid] <= i) lo = mid; else hi = mid;
   }
   const float mult = var_mult ? var_mult[lo] : 1.f;
-  if (mult < 0.f) return;                  // frozen variable: left out of apply_gradients (trainer.py:408-410)
+  if (mult < 0.f) {                        // frozen variable: left out of apply_gradients (trainer.py:408-410)
+    if (zero_g) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   float f = 1.f;
   if (clip > 0.f) {
     float nrm = sqrtf(norms[lo]);
@@ -930,6 +933,8 @@ __global__ void __launch_bounds__(256)
   }
   const float wd = var_wd ? var_wd[lo] : 0.f;
   float4 gv = *reinterpret_cast<const float4*>(g + i);
+  // the gradient buffer is consumed here: leaving zeros behind saves the next step's 4 B/parameter memset launch
+  if (zero_g) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 av = *reinterpret_cast<float4*>(acc + i);
   float4 wv = *reinterpret_cast<float4*>(w + i);
   gv.x = (gv.x * gscale + wd * wv.x) * mult; gv.y = (gv.y * gscale + wd * wv.y) * mult;
@@ -1304,16 +1309,16 @@ int mtlssl_sgd_momentum_clip(float* weights, const float* grads, float* accum,
                              int64_t max_var_size, float lr, float momentum, float clip_norm,
                              float grad_scale, const float* var_weight_decay, const float* var_grad_mult,
                              float* norms_ws, mtlssl_stream_t stream) {
-  return mtlssl_sgd_momentum_clip_fold(weights, grads, accum, var_offsets, num_vars, total, max_var_size, lr, momentum,
-                                       clip_norm, grad_scale, var_weight_decay, var_grad_mult, norms_ws, nullptr,
-                                       nullptr, nullptr, stream);
+  return mtlssl_sgd_momentum_clip_fold(weights, const_cast<float*>(grads), accum, var_offsets, num_vars, total, max_var_size,
+                                       lr, momentum, clip_norm, grad_scale, var_weight_decay, var_grad_mult, norms_ws,
+                                       nullptr, nullptr, nullptr, 0, stream);
 }
-int mtlssl_sgd_momentum_clip_fold(float* weights, const float* grads, float* accum,
+int mtlssl_sgd_momentum_clip_fold(float* weights, float* grads, float* accum,
                                   const int32_t* var_offsets, int num_vars, int64_t total,
                                   int64_t max_var_size, float lr, float momentum, float clip_norm,
                                   float grad_scale, const float* var_weight_decay, const float* var_grad_mult,
                                   float* norms_ws, float* eff, const void* scale_ptrs, const int32_t* scale_len,
-                                  mtlssl_stream_t stream) {
+                                  int zero_grads, mtlssl_stream_t stream) {
   MTLSSL_REQUIRE(total % 4 == 0, "sgd: total must be a multiple of 4");
   MTLSSL_REQUIRE(total < (1ll << 31), "sgd: flat parameter buffer must be < 2^31 floats");
   if (!total) return MTLSSL_OK;
@@ -1334,12 +1339,12 @@ int mtlssl_sgd_momentum_clip_fold(float* weights, const float* grads, float* acc
     MTLSSL_REQUIRE(scale_ptrs != nullptr && scale_len != nullptr, "sgd: fold tables required with a shadow buffer");
     hipLaunchKernelGGL(k_momentum_update<true>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads,
                        accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
-                       norms_ws, var_weight_decay, var_grad_mult, eff, (const float* const*)scale_ptrs, scale_len);
+                       norms_ws, var_weight_decay, var_grad_mult, eff, (const float* const*)scale_ptrs, scale_len, zero_grads);
   } else {
     hipLaunchKernelGGL(k_momentum_update<false>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, weights, grads,
                        accum, var_offsets, num_vars, total / 4, lr, momentum, clip_norm, grad_scale,
                        norms_ws, var_weight_decay, var_grad_mult, (float*)nullptr, (const float* const*)nullptr,
-                       (const int32_t*)nullptr);
+                       (const int32_t*)nullptr, zero_grads);
   }
   return check_launch("sgd_momentum_clip");
 }

@@ -145,6 +145,46 @@ PROFILER = None
 PHASE_HOOK = None      # tools/phase_times.py: callable(name) invoked at the step's phase boundaries
 
 
+class HbmProfiler:
+    """Live HIP-event timing of the HBM-bound kernel families inside a timed region (bench.py: `roofline` of a
+    configuration whose dominant kernel is HBM-bound, and the in-step rows of `hbm_kernels`): per family the compulsory
+    bytes (inputs once + outputs once) and the launch durations on the stream they were issued to."""
+
+    def __init__(self, families=("depthwise_fwd", "depthwise_dgrad", "depthwise_wgrad", "psroi_fwd", "psroi_bwd",
+                                 "roi_crop_pool_fwd")):
+        self.families = set(families)
+        self.rows = []           # (family, bytes, start_event, end_event)
+
+    def begin(self, family):
+        if family not in self.families:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, family, nbytes, start):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.rows.append((family, int(nbytes), start, e))
+
+    def summary(self):
+        """{family: {"launches", "seconds", "bytes"}} — after torch.cuda.synchronize()."""
+        out = {}
+        for fam, nb, s, e in self.rows:
+            r = out.setdefault(fam, {"launches": 0, "seconds": 0.0, "bytes": 0})
+            r["launches"] += 1
+            r["seconds"] += s.elapsed_time(e) * 1e-3
+            r["bytes"] += nb
+        return out
+
+
+HBM_PROFILER = None
+
+
+def _hbm_begin(family):
+    return HBM_PROFILER.begin(family) if HBM_PROFILER is not None else None
+
+
 def conv_class(cfg, mfma_macs):
     """Launch class of a conv-family call from its plan code (mtlssl_conv2d_tile_config)."""
     if cfg < 0:
@@ -517,21 +557,30 @@ def conv2d_wgrad_grouped(d, xs, dys, dws, scales=None, beta=0.0):
 
 def depthwise_fwd(d, x, w, bias=None, epilogue=0):
     y = torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
+    t0 = _hbm_begin("depthwise_fwd")
     lib().depthwise_fwd(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(w)), ptr(bias), ptr(y), epilogue, _stream())
+    if t0 is not None:
+        HBM_PROFILER.end("depthwise_fwd", 4 * (x.numel() + y.numel()), t0)
     return y
 
 
 def depthwise_dgrad(d, dy, w, mask_ref=None, epilogue=0):
     dx = torch.empty((d.N, d.H, d.W, d.C), dtype=f32, device=dy.device)
+    t0 = _hbm_begin("depthwise_dgrad")
     lib().depthwise_dgrad(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(mask_ref), ptr(dx), epilogue,
                           _stream())
+    if t0 is not None:
+        HBM_PROFILER.end("depthwise_dgrad", 4 * (dy.numel() + dx.numel() + (dx.numel() if mask_ref is not None else 0)), t0)
     return dx
 
 
 def depthwise_wgrad(d, x, dy, dw, out_scale=None, beta=0.0):
     ws = workspace(lib().depthwise_wgrad_workspace_bytes(ctypes.byref(d)), "dwgrad", x.device)
+    t0 = _hbm_begin("depthwise_wgrad")
     lib().depthwise_wgrad(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(dy)), ptr(out_scale), ptr(dw), float(beta),
                           ptr(ws), _stream())
+    if t0 is not None:
+        HBM_PROFILER.end("depthwise_wgrad", 4 * (x.numel() + dy.numel()), t0)
     return dw
 
 
@@ -847,8 +896,11 @@ def roi_crop_pool_fwd(feat, boxes, box_ind, crop, pool_k=1, pool_stride=1, want_
     out = torch.empty((R, P, P, C), dtype=f32, device=feat.device)
     am = (torch.empty((R, P, P, C), dtype=torch.uint8, device=feat.device)
           if (want_argmax and pool_k > 1) else None)
+    t0 = _hbm_begin("roi_crop_pool_fwd")
     lib().roi_crop_pool_fwd(ptr(_chk(feat)), B, H, W, C, ptr(_chk(boxes)), ptr(_chk(box_ind, i32)),
                             R, crop, pool_k, pool_stride, ptr(out), ptr(am), _stream())
+    if t0 is not None:
+        HBM_PROFILER.end("roi_crop_pool_fwd", 4 * (feat.numel() + out.numel()) + (am.numel() if am is not None else 0), t0)
     return out, am
 
 
@@ -875,8 +927,11 @@ def psroi_fwd(fmap, boxes, box_ind, crop, bins):
     R = boxes.shape[0]
     Cc = C // max(bins[0] * bins[1], 1)     # invalid geometry is rejected by the C ABI below
     out = torch.empty((R, Cc), dtype=f32, device=fmap.device)
+    t0 = _hbm_begin("psroi_fwd")
     lib().psroi_fwd(ptr(_chk(fmap)), B, H, W, C, ptr(_chk(boxes)), ptr(_chk(box_ind, i32)), R, crop[0],
                     crop[1], bins[0], bins[1], ptr(out), _stream())
+    if t0 is not None:
+        HBM_PROFILER.end("psroi_fwd", 4 * (fmap.numel() + out.numel()), t0)
     return out
 
 
@@ -884,8 +939,11 @@ def psroi_bwd(dout, fmap_shape, boxes, box_ind, crop, bins, dfmap=None):
     B, H, W, C = fmap_shape
     if dfmap is None:
         dfmap = torch.zeros(fmap_shape, dtype=f32, device=dout.device)
+    t0 = _hbm_begin("psroi_bwd")
     lib().psroi_bwd(ptr(_chk(dout)), B, H, W, C, ptr(_chk(boxes)), ptr(_chk(box_ind, i32)), boxes.shape[0],
                     crop[0], crop[1], bins[0], bins[1], ptr(dfmap), _stream())
+    if t0 is not None:
+        HBM_PROFILER.end("psroi_bwd", 4 * (dout.numel() + dfmap.numel()), t0)
     return dfmap
 
 
@@ -932,17 +990,19 @@ def reduce_sum(x, scale=1.0, out=None):
 
 
 def sgd_momentum_clip(weights, grads, accum, var_offsets, max_var_size, lr, momentum, clip_norm,
-                      grad_scale=1.0, var_weight_decay=None, var_grad_mult=None, fold=None):
+                      grad_scale=1.0, var_weight_decay=None, var_grad_mult=None, fold=None, zero_grads=False):
     """fold: a ParamStore whose shadow weights (ops.fold_scales) the same launch refreshes — only when no scale vector
-    depends on a variable being updated (every BatchNorm frozen)."""
+    depends on a variable being updated (every BatchNorm frozen). zero_grads: the launch leaves zeros in `grads`."""
     nv = var_offsets.numel() - 1
     norms = workspace(lib().sgd_workspace_bytes(max(nv, 1), int(max_var_size)), "norms", weights.device)
-    if fold is not None and fold.eff is not None:
+    has_fold = fold is not None and fold.eff is not None
+    if has_fold or zero_grads:
         lib().sgd_momentum_clip_fold(ptr(_chk(weights)), ptr(_chk(grads)), ptr(_chk(accum)),
                                      ptr(_chk(var_offsets, i32)), nv, weights.numel(), int(max_var_size),
                                      float(lr), float(momentum), float(clip_norm), float(grad_scale),
-                                     ptr(var_weight_decay), ptr(var_grad_mult), ptr(norms), ptr(fold.eff),
-                                     ptr(fold.fold_ptrs), ptr(fold.fold_len), _stream())
+                                     ptr(var_weight_decay), ptr(var_grad_mult), ptr(norms),
+                                     ptr(fold.eff) if has_fold else None, ptr(fold.fold_ptrs) if has_fold else None,
+                                     ptr(fold.fold_len) if has_fold else None, 1 if zero_grads else 0, _stream())
         return
     lib().sgd_momentum_clip(ptr(_chk(weights)), ptr(_chk(grads)), ptr(_chk(accum)),
                             ptr(_chk(var_offsets, i32)), nv, weights.numel(), int(max_var_size),

@@ -255,6 +255,10 @@ class Trainer:
         self.var_mult = gradient_multipliers(self.ps, train_config)
         import os
         self.split_loss = os.environ.get("MTLSSL_SPLIT_LOSS", "1") != "0" and self.ps.device.type == "cuda"
+        # the momentum update is the gradient buffer's last reader of a step: it leaves zeros behind, which saves the
+        # next step's memset launch over every parameter (the first step starts from ParamStore's zero-initialised buffer)
+        self.zero_in_update = os.environ.get("MTLSSL_ZERO_IN_UPDATE", "1") != "0" and self.ps.device.type == "cuda"
+        self._grads_clean = False
         # momentum update and shadow-weight fold in one launch: only when no scale vector trains (frozen BatchNorm)
         self.fuse_fold = (os.environ.get("MTLSSL_FUSE_FOLD", "1") != "0"
                           and not any(getattr(l, "bn_trainable", False) for l in model.layers))
@@ -308,7 +312,9 @@ class Trainer:
         m = self.model
         m.step = self.global_step
         self.provide(batch)
-        self.ps.grads.zero_()
+        if not self._grads_clean:            # the momentum update leaves zeros behind (MTLSSL_ZERO_IN_UPDATE, default on)
+            self.ps.grads.zero_()
+        self._grads_clean = False
         self.reducer.compute_streams = m.compute_streams()
         self.reducer.compute_streams_fn = m.compute_streams
         self.reducer.begin_step()
@@ -353,7 +359,8 @@ class Trainer:
             folded = self.fuse_fold and ps.device.type == "cuda" and ps.eff is not None
             ops.sgd_momentum_clip(ps.weights, ps.grads, ps.accum, ps.var_offsets, ps.max_var_size, lr,
                                   self.momentum, self.clip, 1.0, self.var_wd, self.var_mult,
-                                  fold=ps if folded else None)
+                                  fold=ps if folded else None, zero_grads=self.zero_in_update)
+            self._grads_clean = self.zero_in_update
         elif o["kind"] == "rms_prop":
             ops.adaptive_update_clip(1, ps.weights, ps.grads, ps.accum, self.slot1, ps.var_offsets, ps.max_var_size, lr,
                                      o["decay"], o["momentum"], o["epsilon"], self.clip, 1.0, self.var_wd, self.var_mult)

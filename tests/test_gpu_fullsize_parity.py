@@ -217,10 +217,13 @@ def test_trained_state_step_matches_the_free_running_oracle():
     np.testing.assert_array_equal(pd["_rpn_targets"]["sampled"].cpu().numpy(), aux["rpn_sampled"])
     np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
     mine = pd["proposal_boxes"].cpu().numpy()
-    same = np.abs(mine - aux["proposal_boxes"]).max(-1) <= 1e-3 * max(H, W)           # [B, N2]
+    # "the same box" = within 0.02 px: two decodes of RPN floats that agree to ~4e-6 differ by ~1e-3 px, while two
+    # DIFFERENT anchors' decodes that survive NMS against each other are pixels apart
+    tol = 0.02
+    same = np.abs(mine - aux["proposal_boxes"]).max(-1) <= tol           # [B, N2]
     differing = int((~same).sum())
     a, b = aux["proposal_boxes"].reshape(-1, 4), mine.reshape(-1, 4)
-    in_set = int((np.abs(a[:, None, :] - b[None, :, :]).max(-1) <= 1e-3 * max(H, W)).any(1).sum())
+    in_set = int((np.abs(a[:, None, :] - b[None, :, :]).max(-1) <= tol).any(1).sum())
     assert differing <= 4, (differing, in_set)
     dm, rm = pd["_det_targets"]["match"].cpu().numpy().reshape(same.shape), aux["det_match"].reshape(same.shape)
     np.testing.assert_array_equal(dm[same], rm[same])

@@ -14,13 +14,14 @@ CFG[resnet101]="--config $R/configs/frcnn_resnet101_coco_mtl.config"
 CFG[rfcn]="--config $R/configs/rfcn_resnet101_voc_mtl.config"
 CFG[mobilenet]="--config $R/configs/frcnn_mobilenet_v1_voc_mtl.config"
 CFG[inception]="--config $R/configs/frcnn_inception_resnet_v2_coco_mtl.config --height 800 --width 1333"
-COMMON="--steps 6 --warmup 3 --no-cpu-baseline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 --no-roofline"
+COMMON="--steps 8 --warmup 4 --no-cpu-baseline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 --no-roofline"
 for name in ${CFGS:-resnet101 rfcn mobilenet inception}; do
   args="${CFG[$name]}"
   (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $E/prof_$name -o ev -- python $R/bench.py $COMMON $args > $E/${TAG}_${name}_bench_profiled.json 2> $E/${name}.err)
   DB=$(find $E/prof_$name -name "*.db" | head -1)
   python tools/rocprof_summary.py $DB 60 > $E/${TAG}_${name}_kernel_stats.md
   python tools/step_timeline.py $DB 1 > $E/${TAG}_${name}_step_timeline.txt 2>/dev/null
+  python tools/non_conv_breakdown.py $DB 10 > $E/${TAG}_${name}_non_conv_breakdown.md 2>/dev/null
   rm -rf $E/prof_$name
   (cd /tmp && export TMPDIR=/tmp && MTLSSL_AUX_STREAM=0 MTLSSL_WGRAD_STREAM=0 MTLSSL_SPLIT_LOSS=0 timeout 600 rocprofv3 --kernel-trace --stats -d $E/profs_$name -o ev -- python $R/bench.py $COMMON $args > $E/${TAG}_${name}_bench_profiled_serialised.json 2>> $E/${name}.err)
   DB=$(find $E/profs_$name -name "*.db" | head -1)

@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-WANT = ["k_roi_crop_pool_fwd", "k_roi_crop_pool_bwd_lds", "k_absmax_bits", "k_rpn_decode_score", "k_rank_sort", "k_nms_mask", "k_nms_scan",
+WANT = ["k_roi_crop_pool_fwd", "k_roi_crop_pool_bwd_lds", "k_absmax_bits", "k_rpn_decode_score", "k_rank_partial", "k_rank_scatter", "k_nms_greedy", "k_nms_prune", "k_nms_mask", "k_nms_scan",
         "k_emit_proposals", "k_var_sumsq", "k_momentum_update"]
 TAIL = {"k_var_sumsq": 5, "k_momentum_update": 5}     # launches of the stand-alone loop to average (default 5)
 
