@@ -227,12 +227,20 @@ def test_trained_state_step_matches_the_free_running_oracle():
     assert differing <= 4, (differing, in_set)
     dm, rm = pd["_det_targets"]["match"].cpu().numpy().reshape(same.shape), aux["det_match"].reshape(same.shape)
     np.testing.assert_array_equal(dm[same], rm[same])
-    chain = "every slot agrees, det_match bit-exact, losses compared free-running"
-    if differing:
+    # free-running losses: 1e-3 (the two runs crop at boxes that differ in the last bits; a sample at the image border
+    # is the crop knife edge of DESIGN.md section 4)
+    free_loss = 0.0
+    if not differing:
+        for k in ref:
+            free_loss = max(free_loss, abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-3))
+        assert free_loss <= 1e-3, free_loss
+        chain = "every one of the %d slots agrees, det_match bit-exact, losses free-running within %.1e" % (same.size, free_loss)
+    else:
         chain = ("%d of %d slots differ (%d of the oracle's boxes found in the device's set): near-threshold NMS / "
-                 "near-tied scores; losses and gradients compared on the device's boxes" % (differing, same.size, in_set))
-        ref, rgrads, aux = oracle_rerun(Oracle, hp, values, hb, model.seed, mine, pd["num_proposals"].cpu().numpy(),
-                                        step=step_no)
+                 "near-tied scores" % (differing, same.size, in_set))
+    # the float comparison proper (losses 1e-3, gradients) on the device's own boxes
+    ref, rgrads, aux = oracle_rerun(Oracle, hp, values, hb, model.seed, mine, pd["num_proposals"].cpu().numpy(),
+                                    step=step_no)
     worst_loss = 0.0
     for k in ref:
         err = abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-3)
@@ -243,7 +251,7 @@ def test_trained_state_step_matches_the_free_running_oracle():
     l2 = parity_report.gradients(tag, grads, rgrads, got, ref)
     assert np.median(l2) < 1e-3 and l2[-1] < 5e-3, (np.median(l2), l2[-1])
     parity_report.add("    %s: RPN foreground-probability spread (p99.5 - p0.5) %.3f, RPN objectness rel err %.2e, proposals %s; "
-                      "FREE-RUNNING oracle: %s; worst loss rel err %.2e" % (
+                      "FREE-RUNNING oracle: %s; on the device's boxes: worst loss rel err %.2e" % (
                           tag, spread, rpn_err, aux["num_proposals"].tolist(), chain, worst_loss))
     del model, tr, ring
     torch.cuda.empty_cache()
