@@ -148,7 +148,7 @@ def common_tail(tr, pd, c, B, timed, add):
     algo = B * (Nv * (16 + 8 + 16) + Nv * 20 + 2 * (Nv * Nv // 8))
     comp = B * (Nv * (16 + 8) + Nv * 16 + int(c.first_stage_max_proposals) * 20)
     add("rpn_proposals (k_rpn_decode_score + k_rank_sort + k_nms_greedy + k_nms_prune + k_emit_proposals)",
-        ["k_rpn_decode_score", "k_rank_sort", "k_nms_mask", "k_nms_scan", "k_emit_proposals"], algo, comp, sec,
+        ["k_rpn_decode_score", "k_rank_partial", "k_rank_scatter", "k_nms_greedy", "k_nms_prune", "k_emit_proposals"], algo, comp, sec,
         "%d images x %d anchors -> %d proposals; latency-bound (round 4: greedy NMS as head / chip-wide prune / budgeted "
         "tails instead of the n x n bit matrix: k_nms_greedy + k_nms_prune; algorithmic bytes still price the matrix)" % (
             B, Nv, int(c.first_stage_max_proposals)))

@@ -346,6 +346,9 @@ def _dp_worker(rank, world, port, out):
     t = torch.full((5,), float(rank + 1))
     fb.allreduce(t)
     res["fallback"] = (type(fb).__name__, fb.info()["backend"], t.tolist(), _Fake.closed if rank == 0 else None)
+    # RcclComm's precondition agreement (before the collective mtlssl_comm_init): one rank that cannot load RCCL or see
+    # its device makes EVERY rank raise, nobody is left inside ncclCommInitRank; and the wrapper reports its group's backend
+    res["agree"] = (C._dist_agree(rank == 1), C._dist_agree(False), fb.backend, GlooComm().backend)
     res["overlap"] = ps.grads.clone().numpy()
     res["early"] = early
     res["order"] = list(red.launch_order)
@@ -376,6 +379,27 @@ def test_data_parallel_gradient_sum_gloo_world2():
     # comm.default_comm: one rank's RCCL init failure moves BOTH ranks to the torch.distributed fallback
     assert out[0]["fallback"] == ("GlooComm", "torch-gloo (fallback)", [3.0] * 5, True)
     assert out[1]["fallback"] == ("GlooComm", "torch-gloo (fallback)", [3.0] * 5, None)
+    assert out[0]["agree"] == (False, True, "gloo", "gloo") and out[1]["agree"] == (False, True, "gloo", "gloo")
+
+
+def test_rccl_channel_and_priority_knobs(monkeypatch):
+    """MTLSSL_COMM_MAX_CHANNELS / _MIN_CHANNELS reach RCCL as NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS unless those are set
+    explicitly; MTLSSL_COMM_STREAM_PRIORITY picks the all-reduce stream's priority (default 0: tools/cu_thief_probe.py
+    measured a resident kernel on a HIGH-priority stream starving the three compute streams, 55 -> 75 ms/step)."""
+    from mtl_ssl_amd import comm as C
+    for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "MTLSSL_COMM_MAX_CHANNELS", "MTLSSL_COMM_MIN_CHANNELS",
+              "MTLSSL_COMM_STREAM_PRIORITY"):
+        monkeypatch.delenv(k, raising=False)
+    C._apply_rccl_knobs()
+    assert "NCCL_MAX_NCHANNELS" not in os.environ and C.comm_stream_priority() == 0
+    monkeypatch.setenv("MTLSSL_COMM_MAX_CHANNELS", "8")
+    monkeypatch.setenv("NCCL_MIN_NCHANNELS", "2")
+    monkeypatch.setenv("MTLSSL_COMM_MIN_CHANNELS", "4")
+    monkeypatch.setenv("MTLSSL_COMM_STREAM_PRIORITY", "-1")
+    C._apply_rccl_knobs()
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "8" and os.environ["NCCL_MIN_NCHANNELS"] == "2"     # explicit NCCL_* wins
+    assert C.comm_stream_priority() == -1
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
 
 
 def test_random_horizontal_flip_known_answers_and_fork_extras():
