@@ -461,115 +461,136 @@ __global__ void __launch_bounds__(256)
 }
 // Backward as a gather: one block per score-map pixel, a thread per channel. A channel belongs to one bin of every
 // RoI; the bilinear weights a bin's bs_y x bs_x samples put on pixel (y, x) factor into (sum over the sample rows
-// touching y) * (sum over the sample columns touching x) and do not depend on the channel inside the bin. So the block
-// first evaluates, for every RoI of its image, bins_y row sums and bins_x column sums, keeps the RoIs with a non-zero
-// one of each (an ORDER-PRESERVING compaction: thread t owns a contiguous run of RoIs) in LDS, and then every channel
-// thread adds dout[r][c] * wy[r][by] * wx[r][bx] over the kept RoIs in index order. No atomics: the element's owner
-// is the only writer and the order of its sum is fixed, so two runs give the same bits.
-constexpr int kPsChunk = 1024;          // RoIs per pass through LDS
+// touching y) * (sum over the sample columns touching x) and do not depend on the channel inside the bin. Per chunk
+// of kPsChunk RoIs the block
+//   1. evaluates, for every RoI of its image, bins_y row sums and bins_x column sums and keeps the RoIs with a
+//      non-zero one of each — RoI r0 + it*256 + tid in iteration `it`, compacted with ballots in (iteration, lane)
+//      order = RoI order (round 4: a thread used to own a contiguous RUN of RoIs, which put all 256 RoIs of an image
+//      on ONE wavefront, twice — count pass and store pass — while the other three waited at the barrier: 81 % of the
+//      kernel's wave cycles were waits);
+//   2. builds, per bin, the ordered list of kept RoIs whose weight product for that bin is non-zero (a pixel lies in
+//      one or two bins per axis of a RoI, so a bin's list is ~1/6 of the kept RoIs);
+//   3. has every channel thread add dout[r][c] * inv * wy * wx over ITS bin's list — no per-RoI branch, loads that
+//      the compiler can keep in flight, a sixth of the iterations.
+// No atomics: the element's owner is the only writer and its sum runs over the same RoIs in the same (index) order
+// as before, so the bits are those of the previous kernel and two runs give the same bits.
+constexpr int kPsChunk = 512;           // RoIs per pass through LDS
 constexpr int kPsBins = 8;             // bins per side at most
 __global__ void __launch_bounds__(256)
     k_psroi_bwd_gather(const float* __restrict__ dout, int H, int W, int Ctot, const float* __restrict__ boxes,
                        const int32_t* __restrict__ box_ind, int R, int bins_y, int bins_x, int bs_y, int bs_x, int Cc,
                        float* __restrict__ dfmap) {
   extern __shared__ float s_dyn[];
-  const int nw = bins_y + bins_x;
-  float* s_w = s_dyn;                                         // [kept][nw]: row sums then column sums
-  int* s_r = reinterpret_cast<int*>(s_dyn + (size_t)kPsChunk * nw);   // [kept] RoI index
-  __shared__ int s_cnt[257];
-  const int px = blockIdx.x, tid = threadIdx.x;
+  const int nw = bins_y + bins_x, nb = bins_y * bins_x;
+  float* s_w = s_dyn;                                                      // [kept][nw]: row sums then column sums
+  int* s_r = reinterpret_cast<int*>(s_dyn + (size_t)kPsChunk * nw);        // [kept] RoI index
+  unsigned short* s_list = reinterpret_cast<unsigned short*>(s_r + kPsChunk);   // [nb][kPsChunk] kept-list positions
+  __shared__ int s_wave[4];
+  __shared__ int s_len[kPsBins * kPsBins];
+  const int px = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x = px % W, y = (px / W) % H, img = px / (W * H);
   const float fy = (float)y, fx = (float)x, Hm = (float)(H - 1), Wm = (float)(W - 1);
-  const int nb = bins_y * bins_x;
   const float inv = 1.f / (float)(nb * bs_y * bs_x);
   const int nch = (Ctot + 255) / 256;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};                        // channels tid, tid + 256, ... (host: Ctot <= 1024)
   for (int r0 = 0; r0 < R; r0 += kPsChunk) {
     const int rn = min(kPsChunk, R - r0);
-    const int per = (rn + 255) / 256;                         // thread t owns RoIs [r0 + t*per, r0 + (t+1)*per)
-    const int lo = r0 + tid * per, hi = min(lo + per, r0 + rn);
-    // pass 1: count this thread's kept RoIs; pass 2 (after the scan) recomputes and stores them in order
-    for (int pass = 0; pass < 2; ++pass) {
-      int n = 0;
-      int base = pass ? s_cnt[tid] : 0;
-      for (int r = lo; r < hi; ++r) {
-        if (box_ind[r] != img) continue;
+    int kept = 0;
+    for (int it = 0; it * 256 < rn; ++it) {
+      const int r = r0 + it * 256 + tid;
+      bool keep = false;
+      float wv[2 * kPsBins];
+      if (r < r0 + rn && box_ind[r] == img) {
         float4 bx = *reinterpret_cast<const float4*>(boxes + (int64_t)r * 4);
-        {   // cheap reject on the whole box grown by a pixel
-          float ylo = fminf(bx.x, bx.z) * Hm, yhi = fmaxf(bx.x, bx.z) * Hm;
-          float xlo = fminf(bx.y, bx.w) * Wm, xhi = fmaxf(bx.y, bx.w) * Wm;
-          if (!(fy >= floorf(ylo) - 1.f && fy <= ceilf(yhi) + 1.f && fx >= floorf(xlo) - 1.f && fx <= ceilf(xhi) + 1.f))
-            continue;
-        }
-        float step_y = (bx.z - bx.x) / (float)bins_y, step_x = (bx.w - bx.y) / (float)bins_x;
-        float wsum_y = 0.f, wsum_x = 0.f;
-        float wv[2 * kPsBins];
-#pragma unroll
-        for (int b = 0; b < kPsBins; ++b) {
-          if (b >= bins_y) continue;
-          float y1 = bx.x + (float)b * step_y, y2 = bx.x + (float)(b + 1) * step_y;
-          float hs = bs_y > 1 ? (y2 - y1) * Hm / (float)(bs_y - 1) : 0.f;
-          float wy = 0.f;
-          for (int iy = 0; iy < bs_y; ++iy) {
-            float in_y = bs_y > 1 ? y1 * Hm + (float)iy * hs : 0.5f * (y1 + y2) * Hm;
-            if (in_y < 0.f || in_y > Hm) continue;
-            float ty = floorf(in_y), yl = in_y - ty;
-            if (ty == fy) wy += 1.f - yl;
-            if (ceilf(in_y) == fy) wy += yl;
-          }
-          wv[b] = wy; wsum_y += wy;
-        }
-        if (wsum_y == 0.f) continue;
-#pragma unroll
-        for (int b = 0; b < kPsBins; ++b) {
-          if (b >= bins_x) continue;
-          float x1 = bx.y + (float)b * step_x, x2 = bx.y + (float)(b + 1) * step_x;
-          float ws = bs_x > 1 ? (x2 - x1) * Wm / (float)(bs_x - 1) : 0.f;
-          float wx = 0.f;
-          for (int ix = 0; ix < bs_x; ++ix) {
-            float in_x = bs_x > 1 ? x1 * Wm + (float)ix * ws : 0.5f * (x1 + x2) * Wm;
-            if (in_x < 0.f || in_x > Wm) continue;
-            float lx = floorf(in_x), xl = in_x - lx;
-            if (lx == fx) wx += 1.f - xl;
-            if (ceilf(in_x) == fx) wx += xl;
-          }
-          wv[kPsBins + b] = wx; wsum_x += wx;
-        }
-        if (wsum_x == 0.f) continue;
-        if (pass) {
-          s_r[base + n] = r;
+        // cheap reject on the whole box grown by a pixel
+        float ylo = fminf(bx.x, bx.z) * Hm, yhi = fmaxf(bx.x, bx.z) * Hm;
+        float xlo = fminf(bx.y, bx.w) * Wm, xhi = fmaxf(bx.y, bx.w) * Wm;
+        if (fy >= floorf(ylo) - 1.f && fy <= ceilf(yhi) + 1.f && fx >= floorf(xlo) - 1.f && fx <= ceilf(xhi) + 1.f) {
+          float step_y = (bx.z - bx.x) / (float)bins_y, step_x = (bx.w - bx.y) / (float)bins_x;
+          float wsum_y = 0.f, wsum_x = 0.f;
 #pragma unroll
           for (int b = 0; b < kPsBins; ++b) {
-            if (b < bins_y) s_w[(size_t)(base + n) * nw + b] = wv[b];
-            if (b < bins_x) s_w[(size_t)(base + n) * nw + bins_y + b] = wv[kPsBins + b];
+            if (b >= bins_y) continue;
+            float y1 = bx.x + (float)b * step_y, y2 = bx.x + (float)(b + 1) * step_y;
+            float hs = bs_y > 1 ? (y2 - y1) * Hm / (float)(bs_y - 1) : 0.f;
+            float wy = 0.f;
+            for (int iy = 0; iy < bs_y; ++iy) {
+              float in_y = bs_y > 1 ? y1 * Hm + (float)iy * hs : 0.5f * (y1 + y2) * Hm;
+              if (in_y < 0.f || in_y > Hm) continue;
+              float ty = floorf(in_y), yl = in_y - ty;
+              if (ty == fy) wy += 1.f - yl;
+              if (ceilf(in_y) == fy) wy += yl;
+            }
+            wv[b] = wy; wsum_y += wy;
+          }
+          if (wsum_y != 0.f) {
+#pragma unroll
+            for (int b = 0; b < kPsBins; ++b) {
+              if (b >= bins_x) continue;
+              float x1 = bx.y + (float)b * step_x, x2 = bx.y + (float)(b + 1) * step_x;
+              float ws = bs_x > 1 ? (x2 - x1) * Wm / (float)(bs_x - 1) : 0.f;
+              float wx = 0.f;
+              for (int ix = 0; ix < bs_x; ++ix) {
+                float in_x = bs_x > 1 ? x1 * Wm + (float)ix * ws : 0.5f * (x1 + x2) * Wm;
+                if (in_x < 0.f || in_x > Wm) continue;
+                float lx = floorf(in_x), xl = in_x - lx;
+                if (lx == fx) wx += 1.f - xl;
+                if (ceilf(in_x) == fx) wx += xl;
+              }
+              wv[kPsBins + b] = wx; wsum_x += wx;
+            }
+            keep = wsum_x != 0.f;
           }
         }
-        ++n;
       }
-      if (!pass) {
-        __syncthreads();                                      // previous chunk's readers are done with s_cnt / s_w
-        s_cnt[tid + 1] = n;
-        if (tid == 0) s_cnt[0] = 0;
-        __syncthreads();
-        if (tid == 0)
-          for (int t = 1; t <= 256; ++t) s_cnt[t] += s_cnt[t - 1];   // 256 adds; the lists above dominate
-        __syncthreads();
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) s_wave[wave] = __popcll(m);
+      __syncthreads();
+      int before = kept, total = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { const int c = s_wave[w]; before += w < wave ? c : 0; total += c; }
+      if (keep) {
+        const int pos = before + __popcll(m & lt);
+        s_r[pos] = r;
+#pragma unroll
+        for (int b = 0; b < kPsBins; ++b) {
+          if (b < bins_y) s_w[(size_t)pos * nw + b] = wv[b];
+          if (b < bins_x) s_w[(size_t)pos * nw + bins_y + b] = wv[kPsBins + b];
+        }
       }
+      kept += total;
+      __syncthreads();
+    }
+    for (int g = wave; g < nb; g += 4) {
+      const int by = g / bins_x, bxi = bins_y + g % bins_x;
+      int len = 0;
+      for (int k0 = 0; k0 < kept; k0 += 64) {
+        const int k = k0 + lane;
+        const bool nz = k < kept && (s_w[(size_t)k * nw + by] * s_w[(size_t)k * nw + bxi]) != 0.f;
+        const unsigned long long m = __ballot(nz);
+        if (nz) s_list[(size_t)g * kPsChunk + len + __popcll(m & lt)] = (unsigned short)k;
+        len += __popcll(m);
+      }
+      if (lane == 0) s_len[g] = len;
     }
     __syncthreads();
-    const int kept = s_cnt[256];
     for (int k = 0; k < nch; ++k) {
       const int ch = tid + k * 256;
       if (ch >= Ctot) break;
       const int g = ch / Cc, c = ch % Cc;
       const int by = g / bins_x, bxi = bins_y + g % bins_x;
+      const unsigned short* L = s_list + (size_t)g * kPsChunk;
+      const int len = s_len[g];
       float a = acc[k];
-      for (int h = 0; h < kept; ++h) {
-        float w = s_w[(size_t)h * nw + by] * s_w[(size_t)h * nw + bxi];
-        if (w != 0.f) a += dout[(int64_t)s_r[h] * Cc + c] * inv * w;
+      for (int h = 0; h < len; ++h) {
+        const int kk = L[h];
+        const float w = s_w[(size_t)kk * nw + by] * s_w[(size_t)kk * nw + bxi];
+        a += dout[(int64_t)s_r[kk] * Cc + c] * inv * w;
       }
       acc[k] = a;
     }
+    __syncthreads();
   }
   for (int k = 0; k < nch; ++k) {
     const int ch = tid + k * 256;
@@ -1195,7 +1216,12 @@ int mtlssl_psroi_bwd(const float* dout, int B, int H, int W, int C, const float*
   int Cc = C / (bins_y * bins_x);
   MTLSSL_REQUIRE(C <= 1024 && bins_y <= kPsBins && bins_x <= kPsBins,
                  "psroi_bwd: at most 1024 score-map channels and 8 bins per side");
-  const size_t lds = (size_t)kPsChunk * (bins_y + bins_x + 1) * 4;
+  const size_t lds = (size_t)kPsChunk * (bins_y + bins_x + 1) * 4 + (size_t)kPsChunk * bins_y * bins_x * 2;
+  static bool attr_set = false;
+  if (!attr_set) {            // up to 8 x 8 bins: 34 KB of lists + 64 KB of per-bin lists
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_psroi_bwd_gather), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(k_psroi_bwd_gather, dim3((unsigned)(B * H * W)), dim3(256), lds, S(stream),
                      dout, H, W, C, boxes, box_ind, R, bins_y, bins_x, crop_h / bins_y, crop_w / bins_x, Cc, dfmap);
   return check_launch("psroi_bwd");
