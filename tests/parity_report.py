@@ -36,7 +36,7 @@ def gradients(tag, grads, ref, losses=None, ref_losses=None):
     return l2
 
 
-def against_float64(tag, Oracle, hp, values, host_batch, seed, step, boxes, num, grads, cap=1e-3, outliers=12, worst=5e-3,
+def against_float64(tag, Oracle, hp, values, host_batch, seed, step, boxes, num, grads, cap=1e-3, outliers=12, worst=1e-2,
                     feat=None, d_feat=None):
     """The gradient claim against the better yardstick: the same graph evaluated by the oracle in float64 AND in
     float32 on the DEVICE'S sampled boxes (`boxes` [B,N2,4] absolute, `num` [B]; forcing them takes the proposal chain
@@ -48,7 +48,7 @@ def against_float64(tag, Oracle, hp, values, host_batch, seed, step, boxes, num,
         gradient behind it by ~1e-3 of its norm. The torch-CPU fp32 oracle shows the same class of outliers against
         float64 (reported next to the HIP path's). When the trunk's output map and its gradient are given (`feat`,
         `d_feat` = gradient masked by the last activation), the flips at that map are located and it is asserted that
-        without those (at most 3) elements the map's gradient agrees with float64 to 1e-4.
+        without those (at most 6; observed 1) elements the map's gradient agrees with float64 to 1e-4.
     Returns {name: (hip_vs_f64, fp32_oracle_vs_f64)}."""
     forced = dict(proposal_boxes=np.asarray(boxes), num_proposals=np.asarray(num))
     _, g32, a32 = Oracle(hp, values).step(host_batch, seed=seed, step=step, forced=forced)
@@ -80,7 +80,7 @@ def against_float64(tag, Oracle, hp, values, host_batch, seed, step, boxes, num,
         line += ("; trunk output: %d activation flip(s) vs float64 (|pre-activation - threshold| <= %.1e of range %.1e), map "
                  "gradient rel err %.2e with them, %.2e without" % (len(flips), max(near) if near else 0.0, np.abs(F64).max(),
                                                                     e_all, e_wo))
-        assert len(flips) <= 3 and all(v <= 1e-5 * np.abs(F64).max() for v in near), (tag, flips[:5], near[:5])
+        assert len(flips) <= 6 and all(v <= 1e-5 * np.abs(F64).max() for v in near), (tag, flips[:8], near[:8])
         assert e_wo < 1e-4, (tag, e_wo)
     add(line)
     assert np.median(e_gpu) < 3e-4, (tag, np.median(e_gpu))

@@ -32,7 +32,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # worst: cap on the per-variable relative L2 between the HIP path and the torch-CPU fp32 oracle (two fp32 evaluations:
-# two sets of ReLU / max-pool branch flips), set from what is observed (profiles/r0*_parity_report.txt) with ~3x room;
+# two sets of ReLU / max-pool branch flips; which elements flip depends on the plans the on-line tuner picks on a given
+# box), set from the largest value observed over the round's runs (profiles/r0*_parity_report.txt: 3.1e-4, 2.2e-4,
+# 3.5e-3, 7.1e-4, 9.1e-4, 1.0e-3 in the order below) with ~3x room;
 # f64: additionally judge every variable against a float64 evaluation of the same graph (<= 1e-3, the claim proper).
 CASES = {
     "configs1_frcnn_resnet101_coco": dict(config="frcnn_resnet101_coco_mtl.config", H=600, W=1024, n_inside=14453,
@@ -40,13 +42,13 @@ CASES = {
     "configs1_frcnn_resnet101_coco_batch2": dict(config="frcnn_resnet101_coco_mtl.config", H=600, W=1024, n_inside=14453,
                                                  n_all=29184, B=2, worst=1.5e-3, f64=False),
     "configs0_frcnn_mobilenet_voc": dict(config="frcnn_mobilenet_v1_voc_mtl.config", H=600, W=800, n_inside=None,
-                                         n_all=38 * 50 * 12, B=1, worst=5e-3, f64=True),
+                                         n_all=38 * 50 * 12, B=1, worst=1e-2, f64=True),
     "configs2_rfcn_resnet101_voc": dict(config="rfcn_resnet101_voc_mtl.config", H=600, W=1024, n_inside=14453,
-                                        n_all=29184, B=1, worst=2e-3, f64=False),
+                                        n_all=29184, B=1, worst=3e-3, f64=False),
     "configs2_rfcn_resnet101_voc_batch2": dict(config="rfcn_resnet101_voc_mtl.config", H=600, W=1024, n_inside=14453,
-                                               n_all=29184, B=2, worst=2e-3, f64=False),
+                                               n_all=29184, B=2, worst=3e-3, f64=False),
     "configs4_frcnn_inception_resnet_v2_coco": dict(config="frcnn_inception_resnet_v2_coco_mtl.config", H=800, W=1333,
-                                                    n_inside=None, n_all=None, B=1, worst=2.5e-3, f64=False),
+                                                    n_inside=None, n_all=None, B=1, worst=3e-3, f64=False),
 }
 
 
