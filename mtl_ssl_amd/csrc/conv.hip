@@ -27,8 +27,22 @@ namespace mtlssl {
 // wgrad split-K fold: dw = beta*dw + scale[k] * sum_split ws[split]; float4 over k. Four lanes share one
 // output quad and stride over the splits (the sum of 8-64 partials is a latency chain, not bandwidth), then
 // combine with two shuffles: a fixed order, deterministic.
+// `cs_part` != nullptr: the blocks past `main_blocks` fold the bias-gradient column sums of the same layer
+// ([cs_chunks][K] partials of k_colsum_partial -> dbias; the k_colsum_fold launch rides along: Inception-ResNet-v2 has a
+// trainable BatchNorm beta on every one of its ~370 convolutions, i.e. one launch less per layer and step).
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* ws, int nsplit, int64_t total4, int K,
-                                                      const float* scale, float* dw, float beta) {
+                                                      const float* scale, float* dw, float beta, int main_blocks,
+                                                      const float* cs_part, int cs_chunks, float* dbias) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int lane = threadIdx.x & 63;
+    const int k = ((int)blockIdx.x - main_blocks) * 4 + (threadIdx.x >> 6);
+    if (k >= K) return;
+    float s = 0.f;
+    for (int c = lane; c < cs_chunks; c += 64) s += cs_part[(int64_t)c * K + k];
+    s = wave_sum(s);
+    if (lane == 0) dbias[k] = beta != 0.f ? beta * dbias[k] + s : s;
+    return;
+  }
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t i = t >> 2;
   const int sl = (int)(t & 3);
@@ -1467,11 +1481,26 @@ int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const floa
   int64_t P = (int64_t)d->N * d->OH * d->OW;
   MTLSSL_REQUIRE(workspace != nullptr, "conv_wgrad: workspace required");
   float* ws_main = (float*)((char*)workspace + align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256));
+  // bias gradient = column sums of dy: the partial pass runs first (its region of the workspace is its own); on the
+  // MFMA path the fold rides on the filter gradient's reduce kernel, elsewhere k_colsum_fold closes it below
+  ColsumPlan cp = colsum_plan(P, d->K);
+  bool colsum_folded = false;
+  auto colsum_partial = [&]() {
+    const int kg = (int)cdiv(d->K, (d->K & 3) ? 1 : 4);
+    dim3 grid(cdiv(kg, cp.CQ), cp.chunks);
+    if (d->K & 3)
+      hipLaunchKernelGGL(k_colsum_partial<float>, grid, dim3(256), 0, st, dy, (int)P, d->K, cp.per_chunk, cp.CQ,
+                         (float*)workspace);
+    else
+      hipLaunchKernelGGL(k_colsum_partial<floatx4>, grid, dim3(256), 0, st, dy, (int)P, d->K, cp.per_chunk, cp.CQ,
+                         (float*)workspace);
+  };
   WinoChoice wc;
   if (choose_wino(d, MODE_WGRAD, &wc)) {
     wino_wgrad(d, wc.variant, wc.tile, x, dy, out_scale, dw, beta, ws_main, st,
                (input_xf && input_variant == wc.variant) ? input_xf : nullptr);
   } else if (mfma_wgrad_ok(d)) {
+    if (dbias) colsum_partial();
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);
     const bool split = fp32_engine() == 1 && (cfg == 0 || cfg == 3) &&
@@ -1481,8 +1510,11 @@ int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const floa
     if (split) launch_split<MODE_WGRAD, false>(p, dim3(1, d->R * d->S, ns), st);
     else launch_mfma<MODE_WGRAD>(cfg, p, dim3(1, d->R * d->S, ns), st);
     int64_t total4 = (int64_t)d->R * d->S * d->C * d->K / 4;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(total4 * 4, 256)), dim3(256), 0, st,
-                       (const float*)ws_main, ns, total4, d->K, out_scale, dw, beta);
+    const int main_blocks = (int)cdiv(total4 * 4, 256);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(main_blocks + (dbias ? (int)cdiv(d->K, 4) : 0)), dim3(256), 0, st,
+                       (const float*)ws_main, ns, total4, d->K, out_scale, dw, beta, main_blocks,
+                       (const float*)workspace, cp.chunks, dbias);
+    colsum_folded = dbias != nullptr;
   } else if (is_pointwise(d)) {
     int ns, kps;
     small_wgrad_plan(d, &ns, &kps);
@@ -1502,16 +1534,8 @@ int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const floa
     hipLaunchKernelGGL(k_conv_direct_wgrad, dim3(d->C, d->R * d->S), dim3(64), 0, st, p, out_scale,
                        dw, beta);
   }
-  if (dbias) {
-    ColsumPlan cp = colsum_plan(P, d->K);
-    const int kg = (int)cdiv(d->K, (d->K & 3) ? 1 : 4);
-    dim3 grid(cdiv(kg, cp.CQ), cp.chunks);
-    if (d->K & 3)
-      hipLaunchKernelGGL(k_colsum_partial<float>, grid, dim3(256), 0, st, dy, (int)P, d->K, cp.per_chunk, cp.CQ,
-                         (float*)workspace);
-    else
-      hipLaunchKernelGGL(k_colsum_partial<floatx4>, grid, dim3(256), 0, st, dy, (int)P, d->K, cp.per_chunk, cp.CQ,
-                         (float*)workspace);
+  if (dbias && !colsum_folded) {
+    colsum_partial();
     hipLaunchKernelGGL(k_colsum_fold, dim3(cdiv(d->K, 4)), dim3(256), 0, st, (const float*)workspace, cp.chunks, d->K,
                        dbias, beta);
   }
