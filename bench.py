@@ -10,8 +10,8 @@ Prints ONE JSON line on rank 0. `value` = global_batch * K / max-over-ranks time
 (slim/learning.py:489-518: instances/sec = batch / step wall-time). Inputs are resident in HBM
 before the timed region. `roofline` is the dominant kernel (fp32-MFMA implicit-GEMM conv forward,
 128x128 tile) timed with HIP events on the launch stream inside the timed region — where its launches
-share the chip with two other streams' large-tile launches — plus `roofline.isolated`, the same launches with those
-overlaps switched off for a few extra steps; `cpu_baseline` is the CPU oracle of the identical step timed on the host
+share the chip with two other streams' large-tile launches — plus `roofline.isolated`, the same launches with every side
+stream switched off for a few extra steps; `cpu_baseline` is the CPU oracle of the identical step timed on the host
 cores on a bounded sample.
 """
 import argparse
@@ -593,12 +593,12 @@ def main():
         # In the timed region this kernel's launches share the chip: the closeness tower's forward runs next to the main
         # tower's and the refiner's window pass next to both (three streams) — that is what makes the
         # step faster, and it makes "flops / launch duration" the rate of a launch that owns a PART of the chip. The
-        # same launches with those two overlaps switched off (each launch alone on the chip, as in rounds 1-2) give the
+        # same launches with every side stream switched off (each launch alone on the chip, as in rounds 1-2) give the
         # kernel's own rate against its roofline.
-        saved = {k: os.environ.get(k) for k in ("MTLSSL_CLOSENESS_FWD_SIDE", "MTLSSL_REFINE_EARLY")}
+        saved = {k: os.environ.get(k) for k in ("MTLSSL_AUX_STREAM", "MTLSSL_WGRAD_STREAM")}
         try:
-            os.environ["MTLSSL_CLOSENESS_FWD_SIDE"] = "0"
-            os.environ["MTLSSL_REFINE_EARLY"] = "0"
+            os.environ["MTLSSL_AUX_STREAM"] = "0"       # every side stream off: each launch has the chip to itself
+            os.environ["MTLSSL_WGRAD_STREAM"] = "0"
             tr.step(next_batch())                      # plans of the serialised schedule are the same; one settling step
             torch.cuda.synchronize()
             ops.PROFILER = ops.ConvProfiler((0, 0))
@@ -614,14 +614,14 @@ def main():
                     "in the timed region the launches of this kernel run next to other streams' large-tile launches "
                     "(closeness tower beside the main tower, refiner window pass beside both): achieved / frac / "
                     "avg_launch_us above are per launch WHILE SHARING the chip; `isolated` is the same kernel on the same "
-                    "problems with those two overlaps off")
+                    "problems with every side stream off")
                 out["roofline"]["frac_isolated"] = iso["flops"] / iso["seconds"] / FP32_MFMA_PEAK
                 out["roofline"]["isolated"] = {
                     "achieved": iso["flops"] / iso["seconds"] / 1e12, "frac": iso["flops"] / iso["seconds"] / FP32_MFMA_PEAK,
                     "avg_launch_us": 1e6 * iso["seconds"] / iso["dispatches"], "launches": iso["dispatches"],
                     "steps": a.roofline_isolated_steps, "ms_per_step_of_that_schedule": iso_ms,
-                    "how": "MTLSSL_CLOSENESS_FWD_SIDE=0 MTLSSL_REFINE_EARLY=0 for these steps, after the timed region; "
-                           "rocprofv3 of a whole run in that mode: profiles/r04_resnet101_kernel_stats_serialised.md"}
+                    "how": "MTLSSL_AUX_STREAM=0 MTLSSL_WGRAD_STREAM=0 (the fully serialised schedule) for these steps, after the "
+                           "timed region; rocprofv3 of a whole run in that mode: profiles/r04_resnet101_kernel_stats_serialised.md"}
         except Exception as e:
             ops.PROFILER = None
             out["roofline"]["isolated"] = {"error": repr(e)}
