@@ -588,6 +588,10 @@ static int tuned_direct_tile(const mtlssl_conv_desc* d, int mode) {
 // The LDS-DMA engine moves 16-byte pieces global -> LDS with no fix-up in between: every operand row it reads must be
 // 16-byte aligned, i.e. the GEMM width a multiple of 4 floats (the K = 91 / 364 heads stay on the register engine).
 static inline bool glds_ok(int64_t NG) { return (NG & 3) == 0; }
+// the layer runs on the tile engine's pointwise instantiation (conv_is_pointwise on its ConvArgs)
+static inline bool desc_is_pointwise(const mtlssl_conv_desc* d) {
+  return d->R == 1 && d->S == 1 && d->stride == 1 && d->dilation == 1 && d->pad_t == 0 && d->pad_l == 0 && d->OH == d->H && d->OW == d->W;
+}
 
 static bool tail_split_enabled() {
   static int v = -1;
@@ -598,7 +602,7 @@ static bool tail_split_enabled() {
   return v != 0;
 }
 // kc = reduction channels per filter tap (C for fwd, K for dgrad), taps = R*S.
-static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double* t_out = nullptr) {
+static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double* t_out = nullptr, bool pw = false) {
   const int* resident = CFG_RESIDENT;
   Plan best{2, 1, taps * (kc / 16), 0, 1, 0};
   double best_t = 1e30;
@@ -618,7 +622,7 @@ static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double
       int per = (int)cdiv(ksteps, s);
       int ns = (int)cdiv(ksteps, per);
       if (ns != s) continue;
-      double t = tile_time_us(c, tiles * ns, per);
+      double t = tile_time_us(c, tiles * ns, per, pw);
       if (ns > 1) t += 3.0 + (double)M * NG * 4.0 * (ns + 2) / 3.0e6;    // fold kernel: launch + traffic
       if (t < best_t) { best_t = t; best = Plan{c, ns, per, 0, 1, 0}; }
     }
@@ -634,7 +638,7 @@ static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double
       if (ns >= 2 && rows < tiles_m) {
         int per = (int)cdiv(ksteps, ns);
         ns = (int)cdiv(ksteps, per);
-        double t = tile_time_us(c, tiles - tail_tiles, ksteps) + tile_time_us(c, tail_tiles * ns, per) +
+        double t = tile_time_us(c, tiles - tail_tiles, ksteps, pw) + tile_time_us(c, tail_tiles * ns, per, pw) +
                    8.0 + (double)rows * CFG_BM[c] * NG * 4.0 * (ns + 2) / 3.0e6;   // 2 more launches + fold traffic
         if (t < best_t) { best_t = t; best = Plan{c, 1, ksteps, (int)rows, ns, per}; }
       }
@@ -680,7 +684,7 @@ static Plan plan_dir(const mtlssl_conv_desc* d, int mode, double* t_out = nullpt
   const int64_t M = mode == MODE_FWD ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W;
   PlanMemo pm;
   pm.plan = plan_gemm(M, mode == MODE_FWD ? d->K : d->C, d->R * d->S, mode == MODE_FWD ? d->C : d->K,
-                      tuned_direct_tile(d, mode), &pm.t);
+                      tuned_direct_tile(d, mode), &pm.t, desc_is_pointwise(d));
   {
     std::lock_guard<std::mutex> g(memo_mutex());
     plan_map()[k] = pm;
@@ -808,6 +812,24 @@ static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st, int ti
   p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
   if (cfg >= NCFG && (p.a_tab || !glds_ok(p.NG) || (MODE == MODE_WGRAD && !glds_ok(p.M)))) cfg -= NCFG;
+  if (cfg < NCFG && conv_is_pointwise(p)) {     // 1x1 stride-1 layers: the engine's pointwise instantiation
+    switch (cfg) {
+      case 0: hipLaunchKernelGGL((k_conv_mfma_pw<128, 128, MODE>), grid, dim3(256), 0, st, p); break;
+      case 1: hipLaunchKernelGGL((k_conv_mfma_pw<128, 64, MODE>), grid, dim3(256), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((k_conv_mfma_pw<64, 64, MODE>), grid, dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL((k_conv_mfma_pw<256, 128, MODE>), grid, dim3(512), 0, st, p); break;
+    }
+    return;
+  }
+  if (conv_is_pointwise(p)) {
+    switch (cfg) {
+      case 4: hipLaunchKernelGGL((k_conv_glds_pw<128, 128, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+      case 5: hipLaunchKernelGGL((k_conv_glds_pw<128, 64, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+      case 6: hipLaunchKernelGGL((k_conv_glds_pw<64, 64, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL((k_conv_glds_pw<256, 128, MODE, 16, GLDS_STAGES>), grid, dim3(512), 0, st, p); break;
+    }
+    return;
+  }
   switch (cfg) {
     case 0: hipLaunchKernelGGL((k_conv_mfma<128, 128, MODE, 16>), grid, dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((k_conv_mfma<128, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
@@ -876,7 +898,7 @@ static void wgrad_plan_uncached(const mtlssl_conv_desc* d, int* cfg, int* nsplit
       int ns = (int)cdiv(ksteps, per);
       if (ns != s) continue;
       // partial tiles written + read once by the fold kernel
-      double t = tile_time_us(c, tiles * ns, per) +
+      double t = tile_time_us(c, tiles * ns, per, desc_is_pointwise(d)) +
                  2.0 + (double)RS * d->C * d->K * 4.0 * (ns + 1) / 3.0e6;
       if (t < best_t) { best_t = t; *cfg = c; *nsplit = ns; *pps = per * bk; }
     }
@@ -1426,7 +1448,7 @@ static void wgrad_group_plan(const mtlssl_conv_desc* d, int n, int* cfg, int* ns
       if (s > 1 && ksteps * CFG_BK[c] / s < 128) break;
       const int per = (int)cdiv(ksteps, s), ns = (int)cdiv(ksteps, per);
       if (ns != s) continue;
-      const double t = tile_time_us(c, tiles * ns, per) + 2.0 + (double)n * RS * d->C * d->K * 4.0 * (ns + 1) / 3.0e6;
+      const double t = tile_time_us(c, tiles * ns, per, desc_is_pointwise(d)) + 2.0 + (double)n * RS * d->C * d->K * 4.0 * (ns + 1) / 3.0e6;
       if (t < best_t) { best_t = t; *cfg = c; *nsplit = ns; *pps = per * CFG_BK[c]; }
     }
   }

@@ -204,7 +204,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
 
 // BATCH: the launch is a stack of gridDim.y independent GEMMs (the Winograd-domain products);
 // blockIdx.y selects the operand / output planes `a_bs` / `b_bs` / `o_bs` elements apart.
-template <int BM, int BN, int MODE, int BKT, bool BATCH>
+// PW: pointwise problem (1x1 filter, stride 1, no padding, output map = input map): a lane's operand address is a
+// constant plus the K-step's offset — the buffer load's SCALAR offset in forward / dgrad, one saturating add in wgrad —
+// so the K loop carries no tap / bounds / division arithmetic at all (two thirds of the executed FLOPs of config[1] are
+// 1x1 layers and Winograd-domain GEMM stacks, which are pointwise by construction).
+template <int BM, int BN, int MODE, int BKT, bool BATCH, bool PW = false>
 __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
   // 4 wavefronts (2x2) per block; the 256-row tile has 8 (4x2) so that a wave's tile stays 64x64
   constexpr int NW = BM > 128 ? 8 : 4, NT = 64 * NW, WR = NW / 2;
@@ -249,11 +253,6 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
       p.b = p.b_tab[grp];
     }
   }
-  const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_b =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
-
   // ---- K-loop extent
   int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps, ks_begin = 0;
   if constexpr (MODE == MODE_FWD) {
@@ -268,6 +267,15 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     pix1 = min(P, pix0 + p.pix_per_split);
     ksteps = (max(pix1 - pix0, 0) + BKT - 1) / BKT;
   }
+  // Pointwise wgrad: both operands are pixel-major ([pixel][C], [pixel][K]), so cutting the buffers off at this block's
+  // last pixel makes the hardware range check supply the zeros of the ragged last K-step.
+  unsigned a_rec = p.a_bytes, b_rec = p.b_bytes;
+  if constexpr (PW && MODE == MODE_WGRAD) {
+    a_rec = min(a_rec, (unsigned)(max(pix1, 0) * p.C) * 4u);
+    b_rec = min(b_rec, (unsigned)(max(pix1, 0) * p.K) * 4u);
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, a_rec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, b_rec, 0x00020000);
   if constexpr (MODE != MODE_WGRAD) {
     if (p.nsplit > 1) {          // split-K: this block covers K-steps [ks_begin, ksteps)
       ks_begin = blockIdx.z * p.ks_per_split;
@@ -280,8 +288,23 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
   // MC loaders: thread -> float4 unit u = tid + 256*i of the [16][B?/4] tile
   int a_base[A_LD], a_y[A_LD], a_x[A_LD], a_n[A_LD];
   bool a_ok[A_LD];
+  unsigned a_voff[A_LD];
   unsigned b_base[B_LD];
-  if constexpr (A_KC) {
+  if constexpr (PW && MODE == MODE_WGRAD) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int u = tid + NT * i;
+      const int col = m0 + (u % (BM / 4)) * 4;
+      a_voff[i] = col < p.M ? (unsigned)((pix0 + u / (BM / 4)) * p.C + col) * 4u : OOB;
+    }
+  } else if constexpr (PW) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int m = m0 + (tid / KQ) + RP * i;
+      const int ld = MODE == MODE_FWD ? p.C : p.K;
+      a_voff[i] = m < p.M ? (unsigned)(m * ld + kq4) * 4u : OOB;
+    }
+  } else if constexpr (A_KC) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       int m = m0 + (tid / KQ) + RP * i;
@@ -316,7 +339,40 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     } else {
       int u = tid + NT * i;
       int col = n0 + (u % (BN / 4)) * 4;
-      b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
+      if constexpr (PW)
+        b_base[i] = col < p.NG ? (unsigned)((pix0 + u / (BN / 4)) * p.K + col) * 4u : OOB;
+      else
+        b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
+    }
+  }
+
+  // Tap state of the next K-step to be loaded: load_tile is only ever called for consecutive K-steps, so the filter tap
+  // (r, s) and the channel offset advance by carry instead of two integer divisions per K-step; the wgrad gather keeps
+  // each A row's output pixel (n, oh, ow) the same way.
+  int t_r = 0, t_s = 0, t_c = 0;
+  if constexpr (!PW && MODE != MODE_WGRAD) {
+    const int cpk = (MODE == MODE_FWD ? p.C : p.K) / BKT;
+    const int rs = ks_begin / cpk;
+    t_c = (ks_begin - rs * cpk) * BKT;
+    t_r = rs / p.S;
+    t_s = rs - t_r * p.S;
+  }
+  auto next_tap = [&]() {
+    t_c += BKT;
+    if (t_c >= (MODE == MODE_FWD ? p.C : p.K)) {
+      t_c = 0;
+      if (++t_s == p.S) { t_s = 0; ++t_r; }
+    }
+  };
+  int w_n[A_LD], w_oh[A_LD], w_ow[A_LD];
+  if constexpr (!PW && MODE == MODE_WGRAD) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int pix = pix0 + (tid + NT * i) / (BM / 4);
+      w_ow[i] = pix % p.OW;
+      const int t = pix / p.OW;
+      w_oh[i] = t % p.OH;
+      w_n[i] = t / p.OH;
     }
   }
 
@@ -330,12 +386,33 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
   auto load_tile = [&](int ks, auto SET) {
     floatx4 (&ra)[A_LD] = rA[decltype(SET)::value];
     floatx4 (&rb)[B_LD] = rB[decltype(SET)::value];
-    if constexpr (MODE == MODE_FWD) {
-      int cpk = p.C / BKT;
-      int rs = ks / cpk, c0 = (ks - rs * cpk) * BKT;
-      int r = rs / p.S, s = rs - r * p.S;
-      int dy = r * p.dil, dx = s * p.dil;
-      int tapoff = (dy * p.W + dx) * p.C + c0;
+    if constexpr (PW && MODE == MODE_WGRAD) {
+      // the K-step's rows start ks*BKT pixels further on; a saturating add keeps the out-of-range marker out of range
+      const unsigned sa = (unsigned)(ks * BKT * p.C) * 4u, sb = (unsigned)(ks * BKT * p.K) * 4u;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) ra[i] = bufload4(rsrc_a, __builtin_elementwise_add_sat(a_voff[i], sa), 0);
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, __builtin_elementwise_add_sat(b_base[i], sb), 0);
+    } else if constexpr (PW) {
+      const unsigned ka = (unsigned)(ks * BKT) * 4u;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) ra[i] = bufload4(rsrc_a, a_voff[i], ka);
+      const unsigned so = MODE == MODE_FWD ? (unsigned)(ks * BKT * p.K) * 4u : ka;
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, b_base[i], so);
+      if constexpr (MODE == MODE_FWD)
+        if (p.NG & 3) {
+#pragma unroll
+          for (int i = 0; i < B_LD; ++i) {
+            int left = p.NG - (n0 + ((tid + NT * i) % (BN / 4)) * 4);
+#pragma unroll
+            for (int e = 1; e < 4; ++e) rb[i][e] = e < left ? rb[i][e] : 0.f;
+          }
+        }
+    } else if constexpr (MODE == MODE_FWD) {
+      const int dy = t_r * p.dil, dx = t_s * p.dil;
+      const int tapoff = (dy * p.W + dx) * p.C + t_c;
+      next_tap();
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) {
         int ih = a_y[i] + dy, iw = a_x[i] + dx;
@@ -354,10 +431,9 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
         }
       }
     } else if constexpr (MODE == MODE_DGRAD) {
-      int kpk = p.K / BKT;
-      int rs = ks / kpk, k0 = (ks - rs * kpk) * BKT;
-      int r = rs / p.S, s = rs - r * p.S;
-      int dy = r * p.dil, dx = s * p.dil;
+      const int rs = t_r * p.S + t_s, k0 = t_c;
+      const int dy = t_r * p.dil, dx = t_s * p.dil;
+      next_tap();
       if (p.stride == 1) {
         int tapoff = k0 - (dy * p.OW + dx) * p.K;
 #pragma unroll
@@ -388,18 +464,15 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
         int kr = u / (BM / 4), m4 = u % (BM / 4);
         int pix = pix0 + ks * BKT + kr;
         bool ok = pix < pix1;
-        int off = 0;
-        if (p.R == 1 && p.S == 1 && p.stride == 1) {
-          off = pix * p.C;
-        } else {
-          int ow = pix % p.OW, t = pix / p.OW;
-          int oh = t % p.OH, n = t / p.OH;
-          int ih = oh * p.stride - p.pt + r * p.dil, iw = ow * p.stride - p.pl + s * p.dil;
-          ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-          off = ((n * p.H + ih) * p.W + iw) * p.C;
-        }
-        ok = ok && (m0 + m4 * 4) < p.M;
+        const int ih = w_oh[i] * p.stride - p.pt + r * p.dil, iw = w_ow[i] * p.stride - p.pl + s * p.dil;
+        ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && (m0 + m4 * 4) < p.M;
+        const int off = ((w_n[i] * p.H + ih) * p.W + iw) * p.C;
         ra[i] = bufload4(rsrc_a, ok ? (unsigned)(off + m0 + m4 * 4) * 4u : OOB, 0);
+        w_ow[i] += BKT;                      // the next K-step's pixel of this row: BKT further on, by carry
+        while (w_ow[i] >= p.OW) {
+          w_ow[i] -= p.OW;
+          if (++w_oh[i] == p.OH) { w_oh[i] = 0; ++w_n[i]; }
+        }
       }
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) {
@@ -522,7 +595,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
 // k in a different order — same fp32 products, not bit-identical to the register-staged engine.
 // NSTAGE LDS stages of BKT x (BM + BN) floats; tile it+NSTAGE-1 is in flight while tile it is multiplied;
 // one raw s_barrier per K-step behind a counted s_waitcnt vmcnt (never a drain while a tile is in flight).
-template <int BM, int BN, int MODE, int BKT, int NSTAGE, bool BATCH>
+template <int BM, int BN, int MODE, int BKT, int NSTAGE, bool BATCH, bool PWISE = false>
 __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
   constexpr int NW = BM > 128 ? 8 : 4, WR = NW / 2;
   constexpr int TM = BM / (32 * WR), TN = BN / 64;   // 32x32 MFMA tiles per wave in m / n
@@ -561,11 +634,6 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
     p.b += (int64_t)blockIdx.y * p.b_bs;
     if constexpr (MODE != MODE_WGRAD) p.out += (int64_t)blockIdx.y * p.o_bs;
   }
-  const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_b =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
-
   int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps, ks_begin = 0;
   if constexpr (MODE == MODE_FWD) {
     ksteps = p.R * p.S * (p.C / BKT);
@@ -586,11 +654,34 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
     }
   }
 
+  unsigned a_rec = p.a_bytes, b_rec = p.b_bytes;     // pointwise wgrad: see conv_mfma_body
+  if constexpr (PWISE && MODE == MODE_WGRAD) {
+    a_rec = min(a_rec, (unsigned)(max(pix1, 0) * p.C) * 4u);
+    b_rec = min(b_rec, (unsigned)(max(pix1, 0) * p.K) * 4u);
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, a_rec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, b_rec, 0x00020000);
+
   // ---- per-lane gather state. Piece i of wave w is piece w*P? + i of the operand's stage image.
   int a_base[PA], a_y[PA], a_x[PA], a_n[PA], a_q4[PA];
   bool a_ok[PA];
+  unsigned a_voff[PA];
   unsigned b_base[PB];
-  if constexpr (A_KC) {
+  if constexpr (PWISE && MODE == MODE_WGRAD) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int pos = (wid * PA + i) * 64 + lane;
+      const int col = m0 + (pos % (BM / 4)) * 4;
+      a_voff[i] = col < p.M ? (unsigned)((pix0 + pos / (BM / 4)) * p.C + col) * 4u : OOB;
+    }
+  } else if constexpr (PWISE) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int row = kc_row(wid * PA + i);
+      const int m = m0 + row;
+      a_voff[i] = m < p.M ? (unsigned)(m * (MODE == MODE_FWD ? p.C : p.K) + kc_quad4(row)) * 4u : OOB;
+    }
+  } else if constexpr (A_KC) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int row = kc_row(wid * PA + i);
@@ -624,7 +715,10 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
       b_base[i] = n0 + row < p.NG ? (unsigned)((n0 + row) * p.K + kc_quad4(row)) * 4u : OOB;
     } else {
       int col = n0 + (pos % (BN / 4)) * 4;
-      b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
+      if constexpr (PWISE)
+        b_base[i] = col < p.NG ? (unsigned)((pix0 + pos / (BN / 4)) * p.K + col) * 4u : OOB;
+      else
+        b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
     }
   }
 
@@ -633,7 +727,24 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
     if constexpr (LAB & 32) ks = ks_begin;          // lab: every K-step re-reads the first tile (cache-resident)
     float* sa = smem + st * STAGE + wid * (PA * 256);
     float* sb = smem + st * STAGE + A_FL + wid * (PB * 256);
-    if constexpr (MODE == MODE_FWD) {
+    if constexpr (PWISE && MODE == MODE_WGRAD) {
+      const unsigned sa_off = (unsigned)(ks * BKT * p.C) * 4u, sb_off = (unsigned)(ks * BKT * p.K) * 4u;
+#pragma unroll
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + i * 256), 16, __builtin_elementwise_add_sat(a_voff[i], sa_off), 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < PB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(sb + i * 256), 16, __builtin_elementwise_add_sat(b_base[i], sb_off), 0, 0, 0);
+    } else if constexpr (PWISE) {
+      const unsigned ka = (unsigned)(ks * BKT) * 4u;
+      const unsigned so = MODE == MODE_FWD ? (unsigned)(ks * BKT * p.K) * 4u : ka;
+#pragma unroll
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + i * 256), 16, a_voff[i], ka, 0, 0);
+#pragma unroll
+      for (int i = 0; i < PB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(sb + i * 256), 16, b_base[i], so, 0, 0);
+    } else if constexpr (MODE == MODE_FWD) {
       int cpk = p.C / BKT;
       int rs = ks / cpk, c0 = (ks - rs * cpk) * BKT;
       int r = rs / p.S, s = rs - r * p.S;
@@ -740,12 +851,12 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
   }
 
   const int nk = ksteps - ks_begin;
-  constexpr int PW = ((LAB & 64) ? 0 : PA) + ((LAB & 128) ? 0 : PB);   // LDS-DMA instructions per wave per tile
+  constexpr int NDMA = ((LAB & 64) ? 0 : PA) + ((LAB & 128) ? 0 : PB);   // LDS-DMA instructions per wave per tile
   // ---- prologue: NSTAGE-1 tiles in flight, the first one landed
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue_tile(ks_begin + s, s);
-  if (NSTAGE == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+  if (NSTAGE == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -822,7 +933,7 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
     // the next tile (issued NSTAGE-1 K-steps ago by this wave) must have landed before anyone reads it;
     // the tile issued this K-step (NSTAGE == 3) stays in flight across the barrier
     if constexpr (!(LAB & 4)) {
-      if (NSTAGE == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+      if (NSTAGE == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -849,8 +960,13 @@ k_conv_glds(ConvArgs p) {
 }
 template <int BM, int BN, int MODE, int BKT, int NSTAGE>
 __global__ void __launch_bounds__(BM > 128 ? 512 : 256, (glds_waves<BM, BN, BKT, NSTAGE>()))
+k_conv_glds_pw(ConvArgs p) {
+  conv_glds_body<BM, BN, MODE, BKT, NSTAGE, false, true>(p);
+}
+template <int BM, int BN, int MODE, int BKT, int NSTAGE>
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (glds_waves<BM, BN, BKT, NSTAGE>()))
 k_wino_glds(ConvArgs p) {
-  conv_glds_body<BM, BN, MODE, BKT, NSTAGE, true>(p);
+  conv_glds_body<BM, BN, MODE, BKT, NSTAGE, true, true>(p);
 }
 
 template <int BM, int BN, int MODE, int BKT>
@@ -858,12 +974,22 @@ __global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN 
 k_conv_mfma(ConvArgs p) {
   conv_mfma_body<BM, BN, MODE, BKT, false>(p);
 }
+// the pointwise instantiation (1x1 stride-1 layers, all three passes)
+template <int BM, int BN, int MODE>
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN >= 128 * 128 ? 3 : 4))
+k_conv_mfma_pw(ConvArgs p) {
+  conv_mfma_body<BM, BN, MODE, 16, false, true>(p);
+}
+// a problem the pointwise kernels take: 1x1, stride 1, dilation 1, no padding, same map in and out
+inline bool conv_is_pointwise(const ConvArgs& p) {
+  return p.R == 1 && p.S == 1 && p.stride == 1 && p.dil == 1 && p.pt == 0 && p.pl == 0 && p.OH == p.H && p.OW == p.W;
+}
 // The same tile engine over a stack of plain GEMMs (1x1 "convolutions"): the 36 Winograd-domain
 // products of F(4x4,3x3). A kernel of its own so that profiles tell the two apart.
 template <int BM, int BN, int MODE>
 __global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN >= 128 * 128 ? 3 : 4))
 k_wino_gemm(ConvArgs p) {
-  conv_mfma_body<BM, BN, MODE, 16, true>(p);
+  conv_mfma_body<BM, BN, MODE, 16, true, true>(p);
 }
 
 // Tile configurations (bm x bn, 16-deep K-step) shared by the planners. The kernel template takes the
@@ -895,8 +1021,11 @@ constexpr int GLDS_STAGES = 2;
 // bm x bn tile in bm*bn*32 FLOP / 614 GFLOP/s (fp32 MFMA peak per CU); blocks beyond what is
 // resident queue up. A CU holding a single block (one wave per SIMD) cannot hide its own LDS /
 // barrier latencies, hence the occupancy factor. Constants fitted to tools/bench_conv.py.
-static inline double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block) {
-  const double base_eff[NCFG] = {0.80, 0.76, 0.72, 0.78};
+// `pointwise`: the problem runs on the pointwise instantiation (1x1 stride-1 layers, Winograd-domain GEMM stacks), whose
+// K loop has no gather arithmetic: 126-141 TFLOP/s where the general one reaches 108-124 (profiles/r04_pointwise_lab.txt).
+static inline double tile_time_us(int cfg, int64_t nblocks, int ksteps_per_block, bool pointwise = false) {
+  const double eff_general[NCFG] = {0.80, 0.76, 0.72, 0.78}, eff_pointwise[NCFG] = {0.90, 0.88, 0.87, 0.90};
+  const double* base_eff = pointwise ? eff_pointwise : eff_general;
   int64_t per_cu = cdiv(nblocks, 256);
   int64_t occ = per_cu < CFG_RESIDENT[cfg] ? per_cu : CFG_RESIDENT[cfg];
   if ((cfg & 3) == 3) occ *= 2;                            // 8 waves per block

@@ -470,7 +470,7 @@ void wgrad_split(int64_t T, int planes, int C, int K, int cfg, int* nsplit, int*
     int64_t per = cdiv(ksteps, s);
     int64_t ns = cdiv(ksteps, per);
     if (ns != s) continue;
-    double t = tile_time_us(cfg, tiles * ns, (int)per) + (double)planes * C * K * 4.0 * ns / 3.0e6;
+    double t = tile_time_us(cfg, tiles * ns, (int)per, true) + (double)planes * C * K * 4.0 * ns / 3.0e6;
     if (t < best) { best = t; *nsplit = (int)ns; *pps = (int)(per * 16); }
   }
 }
@@ -479,7 +479,7 @@ int best_tile(int64_t rows, int64_t cols, int planes, int ksteps, double* t_out)
   int best = 2;
   double bt = 1e30;
   for (int c = 0; c < NCFG; ++c) {
-    double t = tile_time_us(c, cdiv(rows, CFG_BM[c]) * cdiv(cols, CFG_BN[c]) * planes, ksteps);
+    double t = tile_time_us(c, cdiv(rows, CFG_BM[c]) * cdiv(cols, CFG_BN[c]) * planes, ksteps, true);
     if (t < bt) { bt = t; best = c; }
   }
   if (t_out) *t_out = bt;
@@ -512,7 +512,7 @@ double time_us(const mtlssl_conv_desc* d, int mode, int* tile) {
     cfg = best_tile(d->C, d->K, PL, (int)cdiv(g.T, 16), &tg);
     int ns, pps;
     wgrad_split(g.T, PL, d->C, d->K, cfg, &ns, &pps);
-    tg = tile_time_us(cfg, cdiv(d->C, CFG_BM[cfg]) * cdiv(d->K, CFG_BN[cfg]) * PL * ns, pps / 16);
+    tg = tile_time_us(cfg, cdiv(d->C, CFG_BM[cfg]) * cdiv(d->K, CFG_BN[cfg]) * PL * ns, pps / 16, true);
     bytes = 4.0 * (px * (d->C + d->K) + 2.0 * PL * g.T * (d->C + d->K) + (double)PL * d->C * d->K * (ns + 1));
   } else {
     int cin = mode == MODE_FWD ? d->C : d->K, cout = mode == MODE_FWD ? d->K : d->C;

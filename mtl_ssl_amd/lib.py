@@ -10,7 +10,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "mtlssl_hip.h")
-LIB_PATH = os.path.join(HERE, "libmtlssl_hip.so")
+LIB_PATH = os.environ.get("MTLSSL_LIB_PATH") or os.path.join(HERE, "libmtlssl_hip.so")   # the override is for A/B measurements of two builds
 
 
 class ConvDesc(ctypes.Structure):

@@ -78,14 +78,21 @@ def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding="SAME"):
     return ConvDesc(N, H, W, C, K, R, S, OH, OW, stride, dilation, pt, pl)
 
 
+def desc_is_pointwise(d):
+    """The layer runs on the tile engine's pointwise instantiation (k_conv_mfma_pw / k_conv_glds_pw): 1x1, stride 1,
+    no padding, output map = input map (conv_is_pointwise in csrc/conv_mfma.h)."""
+    return (d.R == 1 and d.S == 1 and d.stride == 1 and d.dilation == 1 and d.pad_t == 0 and d.pad_l == 0
+            and d.OH == d.H and d.OW == d.W)
+
+
 class ConvProfiler:
-    """Per-launch HIP-event timing of the conv family, keyed by (mode, tile config). Events are
+    """Per-launch HIP-event timing of the conv family, keyed by (mode, tile config, pointwise). Events are
     recorded on the stream the kernels are launched on (torch's current stream). Used by bench.py
     for the `roofline` object; off by default (PROFILER is None)."""
     MODES = ("fwd", "dgrad", "wgrad")
 
     def __init__(self, only=None):
-        """only: optional (mode, tile config) — time just that kernel (two events per launch cost
+        """only: optional (mode, tile config, pointwise) — time just that kernel (two events per launch cost
         ~1 us of stream time each; timing every conv of the step costs ~2 % of the step)."""
         self.pending = []          # (key, flops, start_event, end_event)
         self.calls = []            # (launch class, stream handle, executed MFMA flops, start_event, end_event)
@@ -93,7 +100,8 @@ class ConvProfiler:
 
     def begin(self, d=None, mode=None):
         if self.only is not None and (mode != self.only[0]
-                                      or lib().conv2d_tile_config(ctypes.byref(d), mode) != self.only[1]):
+                                      or lib().conv2d_tile_config(ctypes.byref(d), mode) != self.only[1]
+                                      or desc_is_pointwise(d) != self.only[2]):
             return None
         e = torch.cuda.Event(enable_timing=True)
         e.record()
@@ -104,13 +112,13 @@ class ConvProfiler:
         e.record()
         cfg = lib().conv2d_tile_config(ctypes.byref(d), mode)
         flops = 2.0 * d.N * d.OH * d.OW * d.K * d.C * d.R * d.S
-        self.pending.append(((self.MODES[mode], cfg), flops, start, e,
+        self.pending.append(((self.MODES[mode], cfg, desc_is_pointwise(d)), flops, start, e,
                              lib().conv2d_num_dispatches(ctypes.byref(d), mode)))
         mf = int(lib().conv2d_executed_macs(ctypes.byref(d), mode, 1))
         self.calls.append((conv_class(cfg, mf), torch.cuda.current_stream().cuda_stream, 2.0 * mf, start, e))
 
     def summary(self):
-        """{(mode, cfg): dict(launches, dispatches, seconds, flops)} — call after
+        """{(mode, cfg, pointwise): dict(launches, dispatches, seconds, flops)} — call after
         torch.cuda.synchronize(). launches = calls; dispatches = launches of the MFMA kernel."""
         out = {}
         for key, flops, s, e, nd in self.pending:
@@ -254,7 +262,7 @@ AUTOTUNE = os.environ.get("MTLSSL_AUTOTUNE", "1") != "0"
 TUNE_RUNS = int(os.environ.get("MTLSSL_TUNE_RUNS", "4"))
 TUNE_MARGIN = float(os.environ.get("MTLSSL_TUNE_MARGIN", "0.05"))   # a candidate must beat the planner's choice by this much
 TUNE_ENGINES = os.environ.get("MTLSSL_TUNE_ENGINES", "1") != "0"     # 0: the autotuner leaves the LDS-DMA tile engine out
-_PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_plans.json")
+_PLAN_FILE = os.environ.get("MTLSSL_PLAN_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_plans.json")
 _tuned = {}
 _plan_db = None
 

@@ -67,7 +67,7 @@ def kernel_source_sha16():
 if __name__ == "__main__":
     rows = main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 14)
     if len(sys.argv) > 3:
-        dom = next(r for r in rows if "k_conv_mfma<128, 128, 0" in r["kernel"])
+        dom = next(r for r in rows if "k_conv_mfma_pw<128, 128, 0" in r["kernel"])
         json.dump({"kernel": dom["kernel"], "launches": dom["launches"],
                    "hbm_read_bytes_per_launch": dom["fetch_bytes"], "hbm_write_bytes_per_launch": dom["write_bytes"],
                    "mfma_util": dom["mfma_util"], "l2_hit": dom["l2_hit"], "kernel_source_sha16": kernel_source_sha16(),
