@@ -601,6 +601,9 @@ static bool tail_split_enabled() {
   }
   return v != 0;
 }
+// The split-K fold kernel: a launch plus its traffic. Partials of a few tens of MB are still in the L2 / MALL when the
+// fold reads them (measured 5-6 us for 4 x 5 MB, tools/lab/mid_lab.hip); larger ones stream at the HBM rate the fold reaches.
+static inline double fold_time_us(double bytes) { return 3.0 + bytes / (bytes < 48.0e6 ? 7.0e6 : 3.0e6); }
 // kc = reduction channels per filter tap (C for fwd, K for dgrad), taps = R*S.
 static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double* t_out = nullptr, bool pw = false) {
   const int* resident = CFG_RESIDENT;
@@ -623,7 +626,7 @@ static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double
       int ns = (int)cdiv(ksteps, per);
       if (ns != s) continue;
       double t = tile_time_us(c, tiles * ns, per, pw);
-      if (ns > 1) t += 3.0 + (double)M * NG * 4.0 * (ns + 2) / 3.0e6;    // fold kernel: launch + traffic
+      if (ns > 1) t += fold_time_us((double)M * NG * 4.0 * (ns + 2));    // fold kernel: launch + traffic
       if (t < best_t) { best_t = t; best = Plan{c, ns, per, 0, 1, 0}; }
     }
     // Un-split main launch on a whole number of waves + K-split launch of the remaining tile rows.
@@ -639,7 +642,7 @@ static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double
         int per = (int)cdiv(ksteps, ns);
         ns = (int)cdiv(ksteps, per);
         double t = tile_time_us(c, tiles - tail_tiles, ksteps, pw) + tile_time_us(c, tail_tiles * ns, per, pw) +
-                   8.0 + (double)rows * CFG_BM[c] * NG * 4.0 * (ns + 2) / 3.0e6;   // 2 more launches + fold traffic
+                   5.0 + fold_time_us((double)rows * CFG_BM[c] * NG * 4.0 * (ns + 2));   // 2 more launches + fold traffic
         if (t < best_t) { best_t = t; best = Plan{c, 1, ksteps, (int)rows, ns, per}; }
       }
     }

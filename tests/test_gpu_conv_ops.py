@@ -151,8 +151,10 @@ def test_every_direct_tile_matches_oracle(ops, case, tile):
         assert relerr(dx, (xr.grad + addend + prev) * (mref > 0)) < 1e-4
         scale = torch.rand(K, generator=g) + 0.5
         dw = torch.ones(w.shape).cuda()
-        ops.conv2d_wgrad(d, xd, gyd, dw, out_scale=scale.cuda(), beta=1.0)
+        db = torch.full((K,), 3.0).cuda()        # the bias gradient rides on the register engine's wgrad blocks
+        ops.conv2d_wgrad(d, xd, gyd, dw, out_scale=scale.cuda(), dbias=db, beta=1.0)
         assert relerr(dw, 1 + wr.grad * scale) < 1e-4
+        assert relerr(db, 3 + gy.sum((0, 1, 2))) < 1e-4
     finally:
         ops.set_winograd(1)
         for mode in (0, 1, 2):

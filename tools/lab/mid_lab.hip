@@ -1,4 +1,4 @@
-// Mid-size GEMM lab (round 4): the product's tile engine (conv_mfma.h) on the 4 000 - 17 000-row problems that carry
+// Mid-size GEMM lab (round 4): the product's tile engine (conv_mfma.h, pointwise instantiation) on the 4 000 - 17 000-row problems that carry
 // R-FCN (B=4: 9 728 rows), the B=2 ResNet trunk (4 864 rows) and Inception-ResNet-v2 (4 200 / 16 700 rows), with the
 // ablation switches of gemm_lab.hip compiled in (-DMTLSSL_LAB_FLAGS=n) and every split-K count, so that what bounds the
 // 64x64 / 128x64 tiles on these shapes can be read off. Stand-alone (no torch):
@@ -51,10 +51,10 @@ static void launch(int cfg, ConvArgs p, hipStream_t st) {
   p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
   dim3 grid(p.tiles_m * p.tiles_n, 1, p.nsplit);
   switch (cfg) {
-    case 0: hipLaunchKernelGGL((k_conv_mfma<128, 128, MODE, 16>), grid, dim3(256), 0, st, p); break;
-    case 1: hipLaunchKernelGGL((k_conv_mfma<128, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((k_conv_mfma<64, 64, MODE, 16>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((k_conv_mfma<256, 128, MODE, 16>), grid, dim3(512), 0, st, p); break;
+    case 0: hipLaunchKernelGGL((k_conv_mfma_pw<128, 128, MODE>), grid, dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((k_conv_mfma_pw<128, 64, MODE>), grid, dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((k_conv_mfma_pw<64, 64, MODE>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_conv_mfma_pw<256, 128, MODE>), grid, dim3(512), 0, st, p); break;
   }
 }
 template <int MODE, int NSTAGE>
@@ -63,9 +63,9 @@ static void launch_glds(int cfg, ConvArgs p, hipStream_t st) {
   p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
   dim3 grid(p.tiles_m * p.tiles_n, 1, p.nsplit);
   switch (cfg) {
-    case 0: hipLaunchKernelGGL((k_conv_glds<128, 128, MODE, 16, NSTAGE>), grid, dim3(256), 0, st, p); break;
-    case 1: hipLaunchKernelGGL((k_conv_glds<128, 64, MODE, 16, NSTAGE>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((k_conv_glds<64, 64, MODE, 16, NSTAGE>), grid, dim3(256), 0, st, p); break;
+    case 0: hipLaunchKernelGGL((k_conv_glds_pw<128, 128, MODE, 16, NSTAGE>), grid, dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((k_conv_glds_pw<128, 64, MODE, 16, NSTAGE>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_conv_glds_pw<64, 64, MODE, 16, NSTAGE>), grid, dim3(256), 0, st, p); break;
   }
 }
 
@@ -74,6 +74,8 @@ int main(int argc, char** argv) {
   printf("LAB_FLAGS=%d (1 no global loads, 2 no LDS stores, 4 no barrier, 8 no fragment reads, 16 no epilogue)\n", MTLSSL_LAB_FLAGS);
   struct Shape { int64_t M, N, K; const char* what; };
   std::vector<Shape> shapes = {
+      {101136, 2048, 512, "config[1] refine pass (2 064 RoIs) block4 1x1 512->2048"},
+      {25088, 512, 2048, "config[1] second stage (512 RoIs) block4 1x1 2048->512"},
       {9728, 512, 1024, "R-FCN B=4 block4 1x1 1024->512"},   {9728, 2048, 512, "R-FCN block4 1x1 512->2048"},
       {9728, 512, 2048, "R-FCN block4 1x1 2048->512"},       {9728, 512, 4608, "R-FCN block4 3x3 rate 2 (as a K=9*512 GEMM)"},
       {9728, 256, 1024, "R-FCN block3 1x1 1024->256"},       {9728, 1024, 256, "R-FCN block3 1x1 256->1024"},
@@ -81,11 +83,11 @@ int main(int argc, char** argv) {
       {4200, 192, 1088, "Inception block17 1x1 1088->192"},  {4200, 1088, 384, "Inception block17 up 384->1088"},
       {4200, 192, 1120, "Inception block17 1x7 160->192 (K=7*160)"},
       {16700, 320, 128, "Inception block35 up 128->320"},    {16700, 32, 320, "Inception block35 1x1 320->32"}};
-  if (MTLSSL_LAB_FLAGS != 0) shapes.resize(7);
+  if (MTLSSL_LAB_FLAGS != 0) shapes.resize(9);
   for (auto s : shapes) {
     float *A, *B, *C, *bias, *ws;
     CK(hipMalloc(&A, s.M * s.K * 4)); CK(hipMalloc(&B, s.K * s.N * 4)); CK(hipMalloc(&C, s.M * s.N * 4));
-    CK(hipMalloc(&bias, s.N * 4)); CK(hipMalloc(&ws, s.M * s.N * 4 * 8));
+    CK(hipMalloc(&bias, s.N * 4)); CK(hipMalloc(&ws, s.M * s.N * 4 * (s.M > 50000 ? 1 : 8)));
     std::vector<float> h((size_t)std::max(s.M * s.K, s.K * s.N));
     unsigned r = 12345;
     for (auto& v : h) { r = r * 1664525u + 1013904223u; v = ((r >> 8) & 0xffff) / 32768.f - 1.f; }
@@ -96,6 +98,11 @@ int main(int argc, char** argv) {
     p.N = 1; p.H = 1; p.W = (int)s.M; p.C = (int)s.K; p.K = (int)s.N; p.R = p.S = 1; p.OH = 1; p.OW = (int)s.M;
     p.stride = 1; p.dil = 1; p.M = (int)s.M; p.NG = (int)s.N; p.nsplit = 1;
     p.epi = MTLSSL_EPI_BIAS | MTLSSL_EPI_RELU; p.bias = bias;
+    float* resid = nullptr;
+    if (getenv("LAB_RESIDUAL")) {            // the shortcut add of a bottleneck's last 1x1 (M x N more bytes in)
+      CK(hipMalloc(&resid, s.M * s.N * 4)); CK(hipMemset(resid, 0, s.M * s.N * 4));
+      p.epi |= MTLSSL_EPI_RESIDUAL; p.residual = resid;
+    }
     p.a = A; p.b = B; p.out = C; p.a_bytes = (unsigned)(s.M * s.K * 4); p.b_bytes = (unsigned)(s.K * s.N * 4);
     p.splitk_ws = ws;
     const double fl = 2.0 * s.M * s.N * s.K;
@@ -104,7 +111,7 @@ int main(int argc, char** argv) {
     for (int cfg : {2, 1, 0}) {
       int64_t tiles = cdiv(s.M, CFG_BM[cfg]) * cdiv(s.N, CFG_BN[cfg]);
       for (int ns : {1, 2, 3, 4, 6, 8}) {
-        if (ns > 1 && (ksteps / ns < 8 || tiles * ns > 256 * 16)) continue;
+        if (ns > 1 && (ksteps / ns < 8 || tiles * ns > 256 * 16 || s.M > 50000)) continue;
         if (ns == 1 && tiles < 64) continue;
         ConvArgs q = p;
         q.nsplit = ns; q.ks_per_split = (int)cdiv(ksteps, ns);
@@ -130,7 +137,7 @@ int main(int argc, char** argv) {
         printf("  glds cfg%d %3dx%-3d tiles %5ld: 3-stage %6.1f us %5.1f TFLOP/s | 2-stage %6.1f us %5.1f TFLOP/s\n", cfg, CFG_BM[cfg],
                CFG_BN[cfg], (long)tiles, us3, fl / us3 / 1e6, us2, fl / us2 / 1e6);
       }
-    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(bias)); CK(hipFree(ws));
+    CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(bias)); CK(hipFree(ws)); if (resid) CK(hipFree(resid));
   }
   return 0;
 }
