@@ -130,6 +130,11 @@ int mtlssl_conv2d_force_config(const mtlssl_conv_desc* d, int mode, int cfg);
  * initial value), 2 = Winograd F(4x4,3x3) for every eligible problem. Returns the previous mode; a mode
  * outside 0..2 only queries. Process-wide. */
 int mtlssl_conv2d_set_winograd(int mode);
+/* Test switch (no reference counterpart). 1x1 / stride-1 layers run on the tile engine's pointwise instantiation
+ * (k_conv_mfma_pw / k_conv_glds_pw: no gather arithmetic in the K loop); 0 routes them through the general gather
+ * instantiation instead — same sums in the same order, bit-identical results, 12-20 % slower — so that the suite can
+ * hold one against the other. Returns the previous setting; a value outside 0..1 only queries. Process-wide. */
+int mtlssl_conv2d_set_pointwise(int on);
 /* fp32 matrix engine of the large implicit GEMMs. 0 (default; MTLSSL_FP32_ENGINE unset): v_mfma_f32_32x32x2_f32,
  * exact fp32 products with fp32 accumulation. 1 (MTLSSL_FP32_ENGINE=split): problems with at least 192 tiles of
  * 256 x 256 run on the bf16 matrix datapath with every operand split EXACTLY into three bf16 pieces (hi + mid + lo

@@ -809,13 +809,16 @@ static void small_wgrad_plan(const mtlssl_conv_desc* d, int* nsplit, int* k_per_
   *k_per_split = (int)per;
 }
 
+static std::atomic<int>& pointwise_ref() { static std::atomic<int> v{1}; return v; }   // mtlssl_conv2d_set_pointwise
+
 template <int MODE>
 static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st, int tile_rows = -1) {
   p.tiles_m = tile_rows >= 0 ? tile_rows : (int)cdiv(p.M, CFG_BM[cfg]);
   p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
   if (cfg >= NCFG && (p.a_tab || !glds_ok(p.NG) || (MODE == MODE_WGRAD && !glds_ok(p.M)))) cfg -= NCFG;
-  if (cfg < NCFG && conv_is_pointwise(p)) {     // 1x1 stride-1 layers: the engine's pointwise instantiation
+  const bool pw = conv_is_pointwise(p) && pointwise_ref().load() != 0;
+  if (cfg < NCFG && pw) {     // 1x1 stride-1 layers: the engine's pointwise instantiation
     switch (cfg) {
       case 0: hipLaunchKernelGGL((k_conv_mfma_pw<128, 128, MODE>), grid, dim3(256), 0, st, p); break;
       case 1: hipLaunchKernelGGL((k_conv_mfma_pw<128, 64, MODE>), grid, dim3(256), 0, st, p); break;
@@ -824,7 +827,7 @@ static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st, int ti
     }
     return;
   }
-  if (conv_is_pointwise(p)) {
+  if (pw) {
     switch (cfg) {
       case 4: hipLaunchKernelGGL((k_conv_glds_pw<128, 128, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
       case 5: hipLaunchKernelGGL((k_conv_glds_pw<128, 64, MODE, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
@@ -1408,6 +1411,12 @@ int mtlssl_conv2d_set_fp32_engine(int mode) {
 int mtlssl_conv2d_set_winograd(int mode) {
   const int prev = wino_env();
   if (mode >= 0 && mode <= 2) { wino_mode_ref().store(mode); plans_clear(); }
+  return prev;
+}
+
+int mtlssl_conv2d_set_pointwise(int on) {
+  const int prev = pointwise_ref().load();
+  if (on == 0 || on == 1) pointwise_ref().store(on);
   return prev;
 }
 

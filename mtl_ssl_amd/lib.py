@@ -79,7 +79,8 @@ class _Lib:
             fn.restype = restype
             fn.argtypes = argtypes
             if restype is ctypes.c_int and name not in ("mtlssl_abi_version", "mtlssl_conv2d_tile_config", "mtlssl_conv2d_num_dispatches",
-                                                        "mtlssl_conv2d_set_winograd", "mtlssl_conv2d_set_fp32_engine", "mtlssl_conv2d_filter_xf_variant"):
+                                                        "mtlssl_conv2d_set_winograd", "mtlssl_conv2d_set_fp32_engine", "mtlssl_conv2d_filter_xf_variant",
+                                                        "mtlssl_conv2d_set_pointwise"):
                 setattr(self, name[len("mtlssl_"):], self._checked(fn, name))
             else:
                 setattr(self, name[len("mtlssl_"):], fn)

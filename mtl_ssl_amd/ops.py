@@ -332,6 +332,12 @@ def set_winograd(mode):
     return lib().conv2d_set_winograd(int(mode))
 
 
+def set_pointwise(on):
+    """Test switch: 0 routes 1x1 stride-1 layers through the tile engine's general gather instantiation (bit-identical,
+    slower) instead of the pointwise one. Returns the previous setting (on=-1 only queries)."""
+    return lib().conv2d_set_pointwise(int(on))
+
+
 def set_fp32_engine(mode):
     """0: the native fp32 MFMA engine (default), 1: large implicit GEMMs on the exact split-bf16 engine
     (csrc/conv_split.h; MTLSSL_FP32_ENGINE=split sets the initial value). Returns the previous mode; -1 only queries."""

@@ -161,6 +161,49 @@ def test_every_direct_tile_matches_oracle(ops, case, tile):
             ops.force_conv_config(d, mode, -1)
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 12, 13, 14, 15])
+@pytest.mark.parametrize("case", [
+    (2, 38, 64, 256, 1024),      # the B=2 trunk's block3 bottleneck exit (4 864 rows, 16 K-steps)
+    (3, 19, 23, 64, 160),        # ragged M (1 311 rows) and N (160)
+    (300, 1, 1, 512, 272),       # FC-shaped, N one quad past 256
+    (5, 7, 7, 272, 512),         # wgrad M = C = 272 (ragged rows of the 256-row tile), 245 pixels (ragged last K-step)
+    (4, 9, 13, 1088, 192),       # 68 K-steps: split-K plans
+])
+def test_pointwise_instantiation_is_bit_identical_to_the_general_gather(ops, case, tile):
+    """1x1 stride-1 layers run on k_conv_mfma_pw / k_conv_glds_pw (a lane's address = constant + K-step offset; wgrad
+    lets the buffer range check zero the ragged last K-step). mtlssl_conv2d_set_pointwise(0) sends the same problem
+    through the general gather instantiation: same products, same order — every output bit must agree, in all three
+    modes with their epilogues, for every tile of both engines."""
+    N, H, W, C, K = case
+    g = torch.Generator().manual_seed(1234 + C + K)
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    w = (torch.randn(1, 1, C, K, generator=g) / np.sqrt(C)).cuda()
+    bias, res = torch.randn(K, generator=g).cuda(), torch.randn(N, H, W, K, generator=g).cuda()
+    gy = torch.randn(N, H, W, K, generator=g).cuda()
+    mref, addend = torch.randn(N, H, W, C, generator=g).cuda(), torch.randn(N, H, W, C, generator=g).cuda()
+    scale = (torch.rand(K, generator=g) + 0.5).cuda()
+    d = ops.conv_desc(x.shape, w.shape, 1, 1, "SAME")
+    out = {}
+    try:
+        for mode in (0, 1, 2):
+            assert ops.force_conv_config(d, mode, tile) == tile
+        for on in (1, 0):
+            ops.set_pointwise(on)
+            y = ops.conv2d_fwd(d, x, w, bias, res, ops.EPI_BIAS | ops.EPI_RESIDUAL | ops.EPI_RELU)
+            dx = ops.conv2d_dgrad(d, gy, w, addend, mref, ops.EPI_RESIDUAL | ops.EPI_MASK)
+            dw, db = torch.zeros_like(w), torch.zeros(K, device="cuda")
+            ops.conv2d_wgrad(d, x, gy, dw, out_scale=scale, dbias=db, beta=0.0)
+            out[on] = (y.clone(), dx.clone(), dw.clone(), db.clone())
+    finally:
+        ops.set_pointwise(1)
+        for mode in (0, 1, 2):
+            ops.force_conv_config(d, mode, -1)
+    for a, b, name in zip(out[1], out[0], ("forward", "dgrad", "wgrad", "dbias")):
+        assert torch.equal(a, b), name
+    ref = torch.relu(x.reshape(-1, C).double() @ w.reshape(C, K).double() + bias.double() + res.reshape(-1, K).double())
+    assert relerr(out[1][0].reshape(-1, K).cpu(), ref.float().cpu()) < 1e-5
+
+
 def test_conv_same_padding_matches_reference_known_answer(ops):
     """Known answers of slim/nets/resnet_v1_test.py:72-111 (testConv2DSameEven): x[i,j] = i+j on
     4x4, w[i,j] = i+j on 3x3; SAME stride 1, conv2d_same stride 2 (== subsample of the former)
