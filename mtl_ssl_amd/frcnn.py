@@ -272,9 +272,13 @@ class FasterRCNNMetaArch:
 
     def _wgrad_exec(self):
         """Side stream for the filter gradients of the trunk / RPN backward (nn.WgradStream); inline when
-        MTLSSL_WGRAD_STREAM=0 or on CPU."""
+        MTLSSL_WGRAD_STREAM=0 or on CPU, and by default for a feature extractor whose backward does not take one
+        (MobileNet: a 5-ms step of ~10-us kernels, where the stream's events cost more than the heads' three filter
+        gradients gain — 5.10 vs 4.97 ms; MTLSSL_WGRAD_STREAM=1 forces it on)."""
         import os
-        if self.ps.device.type != "cuda" or os.environ.get("MTLSSL_WGRAD_STREAM", "1") == "0":
+        env = os.environ.get("MTLSSL_WGRAD_STREAM")
+        if self.ps.device.type != "cuda" or env == "0" or (
+                env is None and not getattr(self._feature_extractor, "supports_wgrad_stream", False)):
             return nn.INLINE_WGRAD
         if getattr(self, "_wgrad_stream_obj", None) is None:
             self._wgrad_stream_obj = nn.WgradStream(torch.cuda.Stream(device=self.ps.device),

@@ -128,9 +128,11 @@ class Branches:
         self.couts = [int(o.shape[-1]) for o in outs]
         return ops.concat_channels(outs), acts
 
-    def backward(self, g_cat, acts, residual=None, mask_ref=None, need_input_grad=True):
+    def backward(self, g_cat, acts, residual=None, mask_ref=None, need_input_grad=True, wgrad=nn.INLINE_WGRAD):
         """g_cat: dL/d(concat), already masked by (concat > 0). Returns dL/dx (+ residual), masked by
-        (mask_ref > 0) when given."""
+        (mask_ref > 0) when given. `wgrad`: where the filter gradients run (inline, or an nn.WgradStream the caller
+        joins): the 4 200 / 1 032-RoI problems of this network leave most of the chip idle, and the filter gradients feed
+        nothing but the optimizer."""
         x = acts[0][0]
         # pooling-first chains go first so that a convolution's dgrad epilogue applies the final mask
         order = sorted(range(len(self.chains)), key=lambda i: not isinstance(self.chains[i][0], Pool))
@@ -143,7 +145,8 @@ class Branches:
             last = n == len(order) - 1
             for li in range(len(ch) - 1, -1, -1):
                 l, xin = ch[li], a[li]
-                l.wgrad(xin, gp)
+                if not isinstance(l, Pool):
+                    wgrad.run(l, xin, gp)
                 if li > 0:
                     if isinstance(l, Pool):
                         gp = l.input_grad(xin, a[li + 1], gp)
@@ -185,12 +188,12 @@ class ResBlock:
         mixed, acts = self.br.forward(x, save)
         return self.up.forward(mixed, x, self.relu), ((mixed, acts) if save else None)
 
-    def backward(self, gp, ctx, mask_input=True):
+    def backward(self, gp, ctx, mask_input=True, wgrad=nn.INLINE_WGRAD):
         mixed, acts = ctx
         x = acts[0][0]
-        self.up.wgrad(mixed, gp)
+        wgrad.run(self.up, mixed, gp)
         g_mixed = self.up.dgrad(mixed.shape, gp, mask_ref=mixed)
-        return self.br.backward(g_mixed, acts, residual=gp, mask_ref=x if mask_input else None)
+        return self.br.backward(g_mixed, acts, residual=gp, mask_ref=x if mask_input else None, wgrad=wgrad)
 
 
 class MixedBlock:
@@ -205,8 +208,8 @@ class MixedBlock:
     def forward(self, x, save):
         return self.br.forward(x, save)
 
-    def backward(self, g_cat, acts, mask_input=True, need_input_grad=True):
-        return self.br.backward(g_cat, acts, None, acts[0][0] if mask_input else None, need_input_grad)
+    def backward(self, g_cat, acts, mask_input=True, need_input_grad=True, wgrad=nn.INLINE_WGRAD):
+        return self.br.backward(g_cat, acts, None, acts[0][0] if mask_input else None, need_input_grad, wgrad=wgrad)
 
 
 def block35(ps, s, t, wd):
@@ -273,14 +276,18 @@ class InceptionTower:
         out = self.conv_7b.forward(x)
         return out, ((c7, ctxs, x) if save else None)
 
-    def backward(self, g_out, out, ctx, need_input_grad, masked=False):
+    supports_wgrad_stream = True
+
+    def backward(self, g_out, out, ctx, need_input_grad, masked=False, wgrad=nn.INLINE_WGRAD):
         c7, ctxs, pre7b = ctx
         gp = g_out if masked else ops.relu_bwd(out, g_out)
-        self.conv_7b.wgrad(pre7b, gp)
+        wgrad.run(self.conv_7b, pre7b, gp)
         gp = self.conv_7b.dgrad(pre7b.shape, gp)                # Block8 has no activation: no mask
         for i in range(len(self.blocks) - 1, -1, -1):
-            gp = self.blocks[i].backward(gp, ctxs[i], mask_input=True)
-        return self.mixed_7a.backward(gp, c7, mask_input=False, need_input_grad=need_input_grad)
+            gp = self.blocks[i].backward(gp, ctxs[i], mask_input=True, wgrad=wgrad)
+        g = self.mixed_7a.backward(gp, c7, mask_input=False, need_input_grad=need_input_grad, wgrad=wgrad)
+        wgrad.flush()
+        return g
 
 
 class FasterRCNNInceptionResnetV2FeatureExtractor:
@@ -353,28 +360,31 @@ class FasterRCNNInceptionResnetV2FeatureExtractor:
             c17.append(c)
         return x, ((acts, c5, c35, c6, c17) if save else None)
 
-    def backward_proposal_features(self, gp, ctx):
+    supports_wgrad_stream = True       # backward_proposal_features(..., wgrad=) can run filter gradients on a side stream
+
+    def backward_proposal_features(self, gp, ctx, wgrad=nn.INLINE_WGRAD):
         """gp: dL/d(pre-activation of the RPN feature map) (already ReLU-masked)."""
         if not self.is_training:
             return
         acts, c5, c35, c6, c17 = ctx
         for i in range(len(self.blocks17) - 1, -1, -1):
-            gp = self.blocks17[i].backward(gp, c17[i])
-        gp = self.mixed_6a.backward(gp, c6)
+            gp = self.blocks17[i].backward(gp, c17[i], wgrad=wgrad)
+        gp = self.mixed_6a.backward(gp, c6, wgrad=wgrad)
         for i in range(len(self.blocks35) - 1, -1, -1):
-            gp = self.blocks35[i].backward(gp, c35[i])
-        g = self.mixed_5b.backward(gp, c5, mask_input=False)      # input is a max-pool output
+            gp = self.blocks35[i].backward(gp, c35[i], wgrad=wgrad)
+        g = self.mixed_5b.backward(gp, c5, mask_input=False, wgrad=wgrad)      # input is a max-pool output
         for i in range(len(self.stem) - 1, -1, -1):
             l, xin, y = self.stem[i], acts[i], acts[i + 1]
             if isinstance(l, Pool):
                 g = l.input_grad(xin, y, g)                       # -> dL/d(ReLU conv output)
                 g = ops.relu_bwd(xin, g, out=g)
                 continue
-            l.wgrad(xin, g)
+            wgrad.run(l, xin, g)
             if i == 0:
                 break
             prev_pool = isinstance(self.stem[i - 1], Pool)
             g = l.dgrad(xin.shape, g, mask_ref=None if prev_pool else xin)
+        wgrad.flush()
 
     def box_classifier_tower(self, scope, trainable):
         return InceptionTower(self.ps, scope, trainable and self.is_training, self.weight_decay)
