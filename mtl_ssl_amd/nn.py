@@ -9,6 +9,8 @@ Frozen BatchNorm (the reference always runs BN in inference mode during detector
 models/faster_rcnn_resnet_v1_feature_extractor.py:138,171) is folded: w_eff = w * scale[k],
 y = conv(x, w_eff) + shift[k]; dW = scale[k] * wgrad(x, g).
 """
+import os
+
 import torch
 
 from . import ops
@@ -33,7 +35,7 @@ class WgradStream:
     optimizer; taken out of that chain they fill the CUs the chain leaves idle. The caller joins the stream
     before the optimizer (FasterRCNNMetaArch.backward) and lists it in compute_streams() for the reducer."""
 
-    GROUP = 8          # shape-identical 1x1 layers whose filter gradients go out as ONE grouped launch
+    GROUP = int(os.environ.get("MTLSSL_WGRAD_GROUP_SIZE", "8"))   # shape-identical 1x1 layers whose filter gradients go out as ONE grouped launch
 
     def __init__(self, stream, group=False):
         """group: collect the 1x1 layers' filter gradients and issue GROUP of them per launch
