@@ -26,4 +26,8 @@ torch.cuda.synchronize()
 a1, r1, peak = torch.cuda.memory_allocated(), torch.cuda.memory_reserved(), torch.cuda.max_memory_allocated()
 print("allocated %.2f -> %.2f GB, reserved %.2f -> %.2f GB, peak allocated %.2f GB, loss %.3f" % (
     a0 / 1e9, a1 / 1e9, r0 / 1e9, r1 / 1e9, peak / 1e9, float(sum(v.item() for v in losses.values()))))
-assert a1 <= a0 * 1.01 + 1e6 and r1 <= r0 * 1.05 + 1e6, "memory grows across steps"
+# live tensors must not accumulate; the caching allocator's RESERVE keeps growing for ~250 steps while the detector trains
+# (proposal / refine-window counts, and with them tensor sizes, change; three streams have a pool each) and then stays at
+# ~53 GB for configs[1] (tools/mem_soak.py, profiles/r04_mem_soak.txt) — bounded well inside the part's 288 GB
+assert a1 <= a0 * 1.01 + 1e6, "live memory grows across steps"
+assert r1 < 96e9, "allocator reserve beyond the expected plateau"
