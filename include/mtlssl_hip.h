@@ -29,8 +29,18 @@ typedef void* mtlssl_stream_t; /* hipStream_t */
 #define MTLSSL_ELAUNCH (-2)  /* HIP launch error */
 #define MTLSSL_ECOMM (-3)    /* RCCL unavailable or an RCCL call failed */
 
+/* Bumped whenever a prototype below changes; mtlssl_abi_version() of the loaded library must equal it (the ctypes
+ * loader checks: an older build called through a newer header would receive shifted arguments). */
+#define MTLSSL_ABI_VERSION 6
+
 const char* mtlssl_last_error(void);
 int mtlssl_abi_version(void);
+
+/* y[i] = e^x[i] in float64 by the fixed IEEE operation sequence of csrc/portable_math.h — the exponential behind
+ * every float that decides index work (RPN foreground softmax faster_rcnn_meta_arch.py:1103-1104, the box decoder
+ * box_coders/faster_rcnn_box_coder.py:107-108, the score converters builders/post_processing_builder.py:85-123).
+ * Exported so that tests can check it bit for bit against oracle/portable_math.py. */
+int mtlssl_exp_rn(const double* x, double* y, int64_t n, mtlssl_stream_t stream);
 
 /* ------------------------------------------------------------------ convolution family
  * Replaces slim.conv2d / resnet_utils.conv2d_same (slim/nets/resnet_utils.py:77-122,

@@ -29,7 +29,7 @@ SOURCES = {
 
 def _digest(path, flags):
     h = hashlib.sha256()
-    for f in (path, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_mfma.h"), os.path.join(CSRC, "conv_split.h"),
+    for f in (path, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_mfma.h"), os.path.join(CSRC, "conv_split.h"), os.path.join(CSRC, "portable_math.h"),
               os.path.join(HERE, "..", "include", "mtlssl_hip.h")):
         with open(f, "rb") as fh:
             h.update(fh.read())

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "portable_math.h"
 
 namespace mtlssl {
 
@@ -71,7 +72,7 @@ __device__ __forceinline__ Box decode_box(float ty, float tx, float th, float tw
   float ha = a.y1 - a.y0, wa = a.x1 - a.x0;
   float yca = a.y0 + ha / 2.f, xca = a.x0 + wa / 2.f;
   ty = ty / sy; tx = tx / sx; th = th / sh; tw = tw / sw;
-  float w = expf(tw) * wa, h = expf(th) * ha;
+  float w = expf_rn(tw) * wa, h = expf_rn(th) * ha;   // portable_math.h: bit-identical to oracle/boxes.py decode
   float yc = ty * ha + yca, xc = tx * wa + xca;
   return Box{yc - h / 2.f, xc - w / 2.f, yc + h / 2.f, xc + w / 2.f};
 }
@@ -85,6 +86,11 @@ __device__ __forceinline__ float4 encode_box(Box b, Box a, float sy, float sx, f
   float tx = (xc - xca) / wa, ty = (yc - yca) / ha;
   float tw = logf(w / wa), th = logf(h / ha);
   return make_float4(ty * sy, tx * sx, th * sh, tw * sw);
+}
+
+__global__ void k_exp_rn(const double* x, double* y, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) y[i] = exp_rn(x[i]);
 }
 
 // ------------------------------------------------------------------------------ anchors
@@ -185,9 +191,11 @@ __global__ void k_rpn_decode_score(const float* enc, const float* logits, const 
     Box a = load_box(anchors + (int64_t)i * 4);
     Box d = decode_box(c.x, c.y, c.z, c.w, a, 10.f, 10.f, 5.f, 5.f);
     float2 l = *reinterpret_cast<const float2*>(logits + o * 2);
-    float m = fmaxf(l.x, l.y);
-    float e0 = expf(l.x - m), e1 = expf(l.y - m);
-    float s = e1 / (e0 + e1);
+    // tf.nn.softmax(...)[..., 1] in float64 by portable_math.h's fixed operation sequence, rounded once to fp32:
+    // bit-identical to oracle/portable_math.py softmax_rn, so near-tied scores sort the same way on both sides
+    double m = (double)fmaxf(l.x, l.y);
+    double e0 = exp_rn((double)l.x - m), e1 = exp_rn((double)l.y - m);
+    float s = (float)(e1 / (e0 + e1));
     valid = s > score_thresh;
     Box cl{fmaxf(fminf(d.y0, H), 0.f), fmaxf(fminf(d.x0, W), 0.f), fmaxf(fminf(d.y1, H), 0.f),
            fmaxf(fminf(d.x1, W), 0.f)};
@@ -790,14 +798,15 @@ __global__ void k_score_convert(const float* logits, float* out, int64_t rows, i
   const float* l = logits + r * C;
   float* o = out + r * C;
   if (mode == 2) {
-    for (int c = 0; c < C; ++c) o[c] = 1.f / (1.f + expf(-l[c]));
+    for (int c = 0; c < C; ++c) o[c] = (float)(1.0 / (1.0 + exp_rn(-(double)l[c])));
     return;
   }
+  // float64, exponentials summed in index order, one division, one rounding (oracle/portable_math.py softmax_rn)
   float m = -INFINITY;
   for (int c = 0; c < C; ++c) m = fmaxf(m, l[c]);
-  float sum = 0.f;
-  for (int c = 0; c < C; ++c) sum += expf(l[c] - m);
-  for (int c = 0; c < C; ++c) o[c] = expf(l[c] - m) / sum;
+  double sum = 0.0;
+  for (int c = 0; c < C; ++c) sum += exp_rn((double)l[c] - (double)m);
+  for (int c = 0; c < C; ++c) o[c] = (float)(exp_rn((double)l[c] - (double)m) / sum);
 }
 
 // ------------------------------------------------------------------------------ target assignment
@@ -1208,7 +1217,13 @@ using namespace mtlssl;
 extern "C" {
 
 const char* mtlssl_last_error(void) { return g_err; }
-int mtlssl_abi_version(void) { return 5; }
+int mtlssl_abi_version(void) { return MTLSSL_ABI_VERSION; }
+
+int mtlssl_exp_rn(const double* x, double* y, int64_t n, mtlssl_stream_t stream) {
+  if (n <= 0) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_exp_rn, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), x, y, n);
+  return check_launch("exp_rn");
+}
 
 int mtlssl_anchors_generate(float* out, int gh, int gw, const float* scales, int ns,
                             const float* ars, int nr, float base_h, float base_w, float sy,

@@ -74,6 +74,13 @@ class _Lib:
         import torch  # noqa: F401
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
+        # an older build (MTLSSL_LIB_PATH, tools/ab_lib.sh) called through this header would get shifted arguments
+        want = int(re.search(r"#define\s+MTLSSL_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+        self.cdll.mtlssl_abi_version.restype = ctypes.c_int
+        have = self.cdll.mtlssl_abi_version()
+        if have != want:
+            raise MtlsslError("%s has ABI version %d, include/mtlssl_hip.h declares %d: rebuild it with "
+                              "`python -m mtl_ssl_amd.build`" % (LIB_PATH, have, want))
         for name, (restype, argtypes) in self.protos.items():
             fn = getattr(self.cdll, name)          # AttributeError if the symbol is missing
             fn.restype = restype

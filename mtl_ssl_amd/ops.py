@@ -258,7 +258,12 @@ def mark(name):
 # the same plan on every run and rank; a (problem, mode) that is not in the table is timed on first
 # use on the caller's tensors (scratch outputs). Either way the choice is handed to the library's
 # plan registry (mtlssl_conv2d_force_config) only when it beat the planner's own by > 5 %.
-AUTOTUNE = os.environ.get("MTLSSL_AUTOTUNE", "1") != "0"
+# The on-line tuner is a measurement tool (tools/tune_plans.py, MTLSSL_AUTOTUNE=1): which tile wins a timing race
+# differs between machines, and with it the summation order, the ReLU flips and the near-ties of a step. By default a
+# problem runs on the committed plan table (conv_plans.json) or, when it is not in the table, on the library's planner
+# — the same kernels on every box.
+AUTOTUNE = os.environ.get("MTLSSL_AUTOTUNE", "0") != "0"
+_AUTOTUNE_DEFAULT = AUTOTUNE
 TUNE_RUNS = int(os.environ.get("MTLSSL_TUNE_RUNS", "4"))
 TUNE_MARGIN = float(os.environ.get("MTLSSL_TUNE_MARGIN", "0.05"))   # a candidate must beat the planner's choice by this much
 TUNE_ENGINES = os.environ.get("MTLSSL_TUNE_ENGINES", "1") != "0"     # 0: the autotuner leaves the LDS-DMA tile engine out
@@ -308,7 +313,7 @@ def force_conv_config(d, mode, cfg):
     return lib().conv2d_tile_config(ctypes.byref(d), mode)
 
 
-def reset_tuning(use_plan_db=True, autotune=True):
+def reset_tuning(use_plan_db=True, autotune=None):
     """Forget every measured / pinned plan: each (problem, mode) seen so far goes back to the library's planner, and
     the next call decides again — from conv_plans.json when `use_plan_db`, by timing when `autotune`. Tests that force
     one algorithm (set_winograd(0 / 2)) call reset_tuning(False, False) first: a tile pinned by an earlier test of
@@ -323,7 +328,7 @@ def reset_tuning(use_plan_db=True, autotune=True):
         lib().conv2d_force_config(ctypes.byref(d), mode, -1)
     _tuned.clear()
     _plan_db = None if use_plan_db else {}
-    AUTOTUNE = bool(autotune)
+    AUTOTUNE = _AUTOTUNE_DEFAULT if autotune is None else bool(autotune)
 
 
 def set_winograd(mode):

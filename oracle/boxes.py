@@ -6,6 +6,8 @@ derived from these floats (matches, keep lists) are bit-exact between CPU and GP
 """
 import numpy as np
 
+from .portable_math import expf_rn
+
 F = np.float32
 
 
@@ -168,8 +170,8 @@ def decode(rel_codes, anchors, scale_factors=(10.0, 10.0, 5.0, 5.0)):
         tx = tx / F(scale_factors[1])
         th = th / F(scale_factors[2])
         tw = tw / F(scale_factors[3])
-    w = np.exp(tw).astype(F) * wa
-    h = np.exp(th).astype(F) * ha
+    w = expf_rn(tw) * wa                       # exp in float64 by a fixed operation sequence, rounded once:
+    h = expf_rn(th) * ha                       # bit-identical to the device (oracle/portable_math.py)
     yc = ty * ha + yca
     xc = tx * wa + xca
     return np.stack([yc - h / F(2), xc - w / F(2), yc + h / F(2), xc + w / F(2)],

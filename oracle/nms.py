@@ -9,6 +9,7 @@ this build DEFINES index-ascending order among equal scores (stable sort).
 import numpy as np
 
 from . import boxes as B
+from . import portable_math as PM
 
 F = np.float32
 
@@ -108,10 +109,7 @@ def batch_multiclass_nms(boxes, scores, score_thresh, iou_thresh, max_size_per_c
 
 def softmax_fg(logits2):
     """tf.nn.softmax(x)[..., 1] for 2-way logits (faster_rcnn_meta_arch.py:1103-1104)."""
-    x = np.asarray(logits2, F)
-    m = np.max(x, axis=-1, keepdims=True)
-    e = np.exp((x - m).astype(F)).astype(F)
-    return (e[..., 1] / np.sum(e, axis=-1, dtype=F)).astype(F)
+    return PM.softmax_rn(logits2)[..., 1]
 
 
 def rpn_proposals(rpn_box_encodings, rpn_objectness, anchors, image_hw,
@@ -142,11 +140,9 @@ def postprocess_box_classifier(refined_box_encodings, class_logits_with_backgrou
     dec = B.decode(enc.reshape(-1, 4), tiled).reshape(Bn, N, K, 4)
     lg = lg.reshape(Bn, N, K + 1)
     if score_converter == "SOFTMAX":
-        m = lg.max(-1, keepdims=True)
-        e = np.exp(lg - m)
-        sc = (e / e.sum(-1, keepdims=True)).astype(F)
+        sc = PM.softmax_rn(lg)
     elif score_converter == "SIGMOID":
-        sc = (F(1) / (F(1) + np.exp(-lg))).astype(F)
+        sc = PM.sigmoid_rn(lg)
     else:
         sc = lg
     H, W = image_hw

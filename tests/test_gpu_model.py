@@ -94,7 +94,7 @@ def conv_algorithm(request):
     ops.set_winograd(request.param)
     yield request.param
     ops.set_winograd(1)
-    ops.reset_tuning(use_plan_db=True, autotune=True)
+    ops.reset_tuning(use_plan_db=True)
 
 
 @pytest.mark.parametrize("conv_algorithm", [0, 2], indirect=True, ids=["direct", "winograd"])

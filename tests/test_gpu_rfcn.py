@@ -141,14 +141,16 @@ def test_rfcn_step_matches_oracle(arch):
     for k in ref:
         assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
     grads = model.ps.grads_dict()
-    # gradients: both sides on the DEVICE'S boxes. The free-running oracle above pools at boxes that differ from the
-    # device's in the last bit (exp() in the box decoder), and a box clipped to the image border puts a bilinear sample
-    # exactly on the interpolate / extrapolate switch of crop_and_resize ("knife edge"): one such
-    # sample moves EVERY gradient by ~1e-3, on one box of the pool and not on the next (which conv plans the on-line
-    # tuner picked decides the last bits). Integer work and losses are compared free-running; gradients are not.
-    _, rgrads, _ = Oracle(bench.hyper_params_for_oracle(cfg), values).step(
-        hb, seed=model.seed, step=0, forced=dict(proposal_boxes=pd["proposal_boxes"].cpu().numpy(),
-                                                 num_proposals=pd["num_proposals"].cpu().numpy()))
+    # gradients: the oracle's proposal chain runs on the DEVICE'S RPN floats — identical inputs, so its sampled boxes
+    # are the device's bit for bit (asserted). The free-running oracle above pools at boxes decoded from RPN floats
+    # that differ by ~1e-6, and a box clipped to the image border puts a bilinear sample exactly on the interpolate /
+    # extrapolate switch of crop_and_resize ("knife edge"): one such sample moves EVERY gradient
+    # by ~1e-3. Integer work and losses are compared free-running; gradients on identical boxes.
+    _, rgrads, auxf = Oracle(bench.hyper_params_for_oracle(cfg), values).step(
+        hb, seed=model.seed, step=0, forced=dict(rpn_box_encodings=pd["rpn_box_encodings"].cpu().numpy(),
+                                                 rpn_objectness=pd["rpn_objectness_predictions_with_background"].cpu().numpy()))
+    np.testing.assert_array_equal(pd["proposal_boxes"].cpu().numpy(), auxf["proposal_boxes"])
+    np.testing.assert_array_equal(pd["_det_targets"]["match"].cpu().numpy(), auxf["det_match"])
     l2errs = []
     for name, gv in grads.items():
         r = rgrads.get(name)
@@ -230,9 +232,10 @@ def test_rfcn_refiner_fc_stack_with_dropout_matches_oracle():
     pd = tr._pd
     hb = dict(batch)
     hb["images"] = batch["images"].cpu().numpy()
-    ref, rgrads, _ = Oracle(bench.hyper_params_for_oracle(cfg), values).step(
-        hb, seed=model.seed, step=0, forced=dict(proposal_boxes=pd["proposal_boxes"].cpu().numpy(),
-                                                 num_proposals=pd["num_proposals"].cpu().numpy()))
+    ref, rgrads, auxf = Oracle(bench.hyper_params_for_oracle(cfg), values).step(
+        hb, seed=model.seed, step=0, forced=dict(rpn_box_encodings=pd["rpn_box_encodings"].cpu().numpy(),
+                                                 rpn_objectness=pd["rpn_objectness_predictions_with_background"].cpu().numpy()))
+    np.testing.assert_array_equal(pd["proposal_boxes"].cpu().numpy(), auxf["proposal_boxes"])     # identical RPN floats -> identical boxes
     assert set(got) == set(ref)
     for k in ref:
         assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])

@@ -114,21 +114,23 @@ def test_switch_matches_the_oracle(case):
     hb = dict(batch)
     hb["images"] = batch["images"].cpu().numpy()
     pd = tr._pd
-    # The oracle evaluates the step on the device's own sampled boxes (free-running agreement of the proposal chain is
-    # tests/test_gpu_model.py's subject). Reason: a proposal clipped to the image border has ymax = 1.0 exactly, so the
-    # last row of its crop samples sits at in_y = H - 1 up to the last bit of ymin — and crop_and_resize switches from
-    # "interpolate" to "extrapolate with 0" right there. ymin comes out of exp() in the box decoder, whose last bit
-    # differs between numpy and the device, and one such RoI moves a 32-RoI loss by 1e-3 (seen: image 0, window 2,
-    # proposal 1 of this batch). Identical boxes remove the knife edge from the comparison; it is a property of the
-    # reference's sampling formula, not of either implementation.
-    forced = None if case == "first_stage_only" else dict(proposal_boxes=pd["proposal_boxes"].cpu().numpy(),
-                                                          num_proposals=pd["num_proposals"].cpu().numpy())
+    # The oracle's proposal chain runs on the DEVICE'S RPN floats (free-running agreement of the chain is
+    # tests/test_gpu_model.py's subject): identical inputs, so counts, sampled boxes and detector matches must come out
+    # bit for bit (asserted below). Reason for not comparing free-running here: a proposal clipped to the image border
+    # has ymax = 1.0 exactly, so the last row of its crop samples sits at in_y = H - 1 up to the last bit of ymin — and
+    # crop_and_resize switches from "interpolate" to "extrapolate with 0" right there; two fp32 trunks that agree to 1e-6
+    # put ymin on either side, and one such RoI moves a 32-RoI loss by 1e-3 (seen: image 0, window 2, proposal 1 of
+    # this batch). It is a property of the reference's sampling formula, not of either implementation.
+    forced = None if case == "first_stage_only" else dict(
+        rpn_box_encodings=pd["rpn_box_encodings"].cpu().numpy(),
+        rpn_objectness=pd["rpn_objectness_predictions_with_background"].cpu().numpy())
     ref, rgrads, aux = Oracle(bench.hyper_params_for_oracle(cfg), values).step(hb, seed=model.seed, step=0, forced=forced)
     np.testing.assert_array_equal(pd["_rpn_targets"]["match"].cpu().numpy(), aux["rpn_match"])
     np.testing.assert_array_equal(pd["_rpn_targets"]["sampled"].cpu().numpy(), aux["rpn_sampled"])
     if case != "first_stage_only":
         np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
         np.testing.assert_array_equal(pd["_det_targets"]["match"].cpu().numpy(), aux["det_match"])
+        np.testing.assert_array_equal(pd["proposal_boxes"].cpu().numpy(), aux["proposal_boxes"])
     else:
         assert set(got) == {"first_stage_localization_loss", "first_stage_objectness_loss", "edgemask_loss"}
         assert "refined_box_encodings" not in pd

@@ -6,6 +6,7 @@ import sys
 
 os.environ.setdefault("MTLSSL_TUNE_RUNS", "12")
 os.environ["MTLSSL_PLAN_DB"] = "0"
+os.environ["MTLSSL_AUTOTUNE"] = "1"                   # off by default: the tuner is this tool's
 os.environ["MTLSSL_AUX_STREAM"] = "0"
 import torch  # noqa: E402
 
