@@ -155,7 +155,9 @@ def common_tail(tr, pd, c, B, timed, add):
             B, Nv, int(c.first_stage_max_proposals)))
     ps = model.ps
     n = ps.weights.numel()
-    g0 = ps.grads.clone()
+    # the gradient buffer holds zeros after an optimizer step (the update leaves them behind): time the update on
+    # gradients of a realistic scale instead (the clip branch and the L2 term then do real work)
+    g0 = torch.empty_like(ps.grads).normal_(0.0, 1e-3, generator=torch.Generator(device=ps.grads.device).manual_seed(7))
 
     def opt():
         ps.grads.copy_(g0)
@@ -166,6 +168,8 @@ def common_tail(tr, pd, c, B, timed, add):
     sec = timed(opt) - t_copy
     ps.weights.copy_(w0)
     ps.accum.copy_(a0)
+    ps.grads.zero_()
+    ps.mark_grads_dirty()                 # written by hand: the next step must not trust "the update left zeros"
     add("k_var_sumsq + k_momentum_update (per-variable clip + momentum + L2)", ["k_var_sumsq", "k_momentum_update"],
         n * 24, n * 24, sec, "%d parameters: norm pass reads g (+w), update reads w,g,acc and writes w,acc" % n)
 
@@ -396,6 +400,10 @@ def main():
                     help="extra steps with the forward streams serialised, for roofline.isolated (0 = skip)")
     ap.add_argument("--conv-breakdown", action="store_true",
                     help="time every conv launch (adds ~2%% to the step) and report the per-kernel table")
+    ap.add_argument("--allow-stand-in", action="store_true",
+                    help="N > 1 only: accept a communicator that is not N RCCL ranks (the torch.distributed stand-in of "
+                         "MTLSSL_DIST_BACKEND=gloo, ranks sharing one GPU). Without it such a run is refused: its line "
+                         "must never be mistaken for a scaling point. The line then carries \"stand_in\": true.")
     a = ap.parse_args()
 
     import torch
@@ -404,6 +412,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        # the driver's contract: N > 1 is launched as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: launch N > 1 as `python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`; refusing to print "
+                         "a line whose n_gpus would not be the number of ranks that ran\n" % (a.gpus, world))
+        sys.exit(3)
     if rank == 0:
         ge.build()
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if world > 1 else 0
@@ -421,6 +435,22 @@ def main():
         dist.init_process_group("gloo")
         dist.barrier()
         comm = comm_mod.default_comm(torch.device("cuda", dev_index))
+        # a scaling point is N RCCL ranks on N devices (slim/deployment/model_deploy.py:414-444's clone sum over xGMI).
+        # Anything else — the gloo stand-in, a fallback after a failed RCCL init, ranks sharing a device — runs the same
+        # code path and is useful for debugging, but its line is refused unless asked for explicitly
+        info = comm.info()
+        # ("torch-nccl (fallback)" = RCCL through torch's binding after the library's own dlopen of librccl failed: still RCCL)
+        is_rccl = info["backend"] == "rccl" or "nccl" in str(info["backend"])
+        stand_in = not is_rccl or int(info["ranks"]) != world or torch.cuda.device_count() < world
+        if stand_in and not a.allow_stand_in:
+            if rank == 0:
+                sys.stderr.write("bench.py: --gpus %d needs %d RCCL ranks on %d devices; this run has backend %r, %s ranks in "
+                                 "the communicator, %d visible device(s). Refusing (pass --allow-stand-in to run the "
+                                 "stand-in for debugging; its line is marked \"stand_in\": true)\n"
+                                 % (world, world, world, info["backend"], info["ranks"], torch.cuda.device_count()))
+            comm.close()
+            dist.destroy_process_group()
+            sys.exit(3)
     else:
         torch.cuda.set_device(0)
         if os.environ.get("MTLSSL_COMM_SELFTEST") == "1":    # 1-rank RCCL through the whole reducer (diagnostic)
@@ -553,6 +583,10 @@ def main():
     }
     if dp is not None:
         out["data_parallel"] = dp
+        if world > 1 and (not (dp["backend"] == "rccl" or "nccl" in str(dp["backend"])) or dp["ranks_reported"] != [world] * world
+                          or torch.cuda.device_count() < world):
+            out["stand_in"] = True
+            out["metric"] = "STAND-IN, not a scaling point (%s, %d device(s)): %s" % (dp["backend"], torch.cuda.device_count(), out["metric"])
     step_s = dt / a.steps
     # Executed FLOPs: what the launches of one step multiply on the matrix cores, summed from the plan registry
     # (mtlssl_conv2d_executed_macs) — direct layers 2*M*N*K of the implicit GEMM, Winograd layers the transformed-domain

@@ -63,17 +63,18 @@ def comm_stream_priority():
 
 
 def _dist_agree(failed):
-    """True on every rank iff `failed` is False on every rank (host channel: the initialised torch.distributed group)."""
+    """True on every rank iff `failed` is False on every rank (host channel: the initialised torch.distributed group;
+    all_gather_object works on every backend — a CPU tensor all-reduce would not on an nccl-only group)."""
     import torch.distributed as dist
-    t = torch.tensor([1 if failed else 0], dtype=torch.int32)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return int(t.item()) == 0
+    flags = [None] * dist.get_world_size()
+    dist.all_gather_object(flags, bool(failed))
+    return not any(flags)
 
 
 class RcclComm:
     """One RCCL communicator rank bound to `device` (mtlssl_comm_init). `exchange(id_or_None)` must
     return rank 0's unique id on every rank; the default uses the initialised torch.distributed
-    group (any backend) as the host channel. world == 1 needs no channel at all. `agree(failed) -> bool` is the
+    group (any backend: object collectives only) as the host channel. world == 1 needs no channel at all. `agree(failed) -> bool` is the
     all-ranks AND of "my preconditions hold" over the same channel: the ranks settle it BEFORE the collective
     mtlssl_comm_init, so a rank that cannot load RCCL or see its device makes every rank raise instead of leaving the
     healthy ones blocked inside ncclCommInitRank."""
@@ -93,7 +94,13 @@ class RcclComm:
         except Exception as e:
             pre = e
         if world > 1:
-            if not (agree or _dist_agree)(pre is not None):
+            if agree is None and exchange is not None:
+                # a caller with its own host channel and no agree step: torch.distributed may not even be initialised.
+                # Without a way to settle it across ranks a failed precondition raises here, on this rank, before the
+                # collective init (the other ranks then fail in `exchange` / mtlssl_comm_init on their side).
+                if pre is not None:
+                    raise pre
+            elif not (agree or _dist_agree)(pre is not None):
                 raise RuntimeError("RCCL preconditions failed on at least one rank%s" % (": %r" % pre if pre else ""))
         elif pre is not None:
             raise pre

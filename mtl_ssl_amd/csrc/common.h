@@ -29,6 +29,11 @@ inline int check_launch(const char* what) {
     }                                    \
   } while (0)
 
+// Kernels that ask for more than the 64 KB default of dynamic LDS: hipFuncAttributeMaxDynamicSharedMemorySize is a
+// per-DEVICE property of the function, so it is set once per (device, function) — thread-safe — and its result is
+// checked (a failure would otherwise only surface as a generic launch error later). Returns MTLSSL_OK / MTLSSL_ELAUNCH.
+int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what);
+
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
 inline hipStream_t S(mtlssl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

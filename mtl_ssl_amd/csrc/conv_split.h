@@ -439,11 +439,10 @@ inline bool split_wgrad_plan(int64_t P, int64_t C, int64_t K, int64_t planes, in
 
 template <int MODE, bool BATCH>
 inline void launch_split(ConvArgs& p, dim3 extra, hipStream_t st, int tile_rows = -1) {
-  static std::once_flag once;               // one per instantiation: the kernels ask for more than 64 KB of LDS
-  std::call_once(once, [&] {
-    (void)hipFuncSetAttribute((const void*)k_split256<MODE, BATCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, split_lds_bytes(256));
-    (void)hipFuncSetAttribute((const void*)k_split256<MODE, BATCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, split_lds_bytes(256));
-  });
+  // the kernels ask for more than 64 KB of LDS: per (device, kernel), checked (common.h); a refusal shows up as the
+  // launch error of the call below with the reason in mtlssl_last_error()
+  (void)ensure_dynamic_lds((const void*)k_split256<MODE, BATCH, false>, split_lds_bytes(256), "split engine");
+  (void)ensure_dynamic_lds((const void*)k_split256<MODE, BATCH, true>, split_lds_bytes(256), "split engine");
   p.tiles_m = tile_rows >= 0 ? tile_rows : (int)cdiv(p.M, SPLIT_BM);
   p.tiles_n = (int)cdiv(p.NG, SPLIT_BN);
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);

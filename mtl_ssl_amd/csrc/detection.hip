@@ -10,6 +10,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 #include "portable_math.h"
 
@@ -21,6 +25,28 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> done;      // (device, kernel) -> bytes granted
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error("%s: hipGetDevice failed", what);
+    return MTLSSL_ELAUNCH;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(dev, fn);
+  auto it = done.find(key);
+  if (it != done.end() && it->second >= bytes) return MTLSSL_OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+    return MTLSSL_ELAUNCH;
+  }
+  done[key] = bytes;
+  return MTLSSL_OK;
 }
 
 // ------------------------------------------------------------------------------ box helpers

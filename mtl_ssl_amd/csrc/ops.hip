@@ -1180,15 +1180,9 @@ int mtlssl_roi_crop_pool_bwd_ex(const float* dout, const uint8_t* argmax, int B,
   int nbands = (int)cdiv(H, band_rows);
   band_rows = (int)cdiv(H, nbands);                        // even bands
   size_t lds = roi_bwd_lds_bytes(band_rows, W, PH);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_roi_crop_pool_bwd_lds<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_roi_crop_pool_bwd_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_roi_crop_pool_bwd_lds<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
   int grid = nbands * (C / kRoiSlice) * B;
   auto kern = pk == 1 ? k_roi_crop_pool_bwd_lds<1> : pk == 2 ? k_roi_crop_pool_bwd_lds<2> : k_roi_crop_pool_bwd_lds<0>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds > 96 * 1024 ? lds : 96 * 1024, "roi_crop_pool_bwd_lds")) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kRoiThreads), lds, S(stream), dout, argmax, H, W, C, boxes, box_ind, R, crop, pk, ps,
                      PH, PH, band_rows, nbands, accumulate, amax, dfeat);
   return check_launch("roi_crop_pool_bwd_lds");
@@ -1217,11 +1211,8 @@ int mtlssl_psroi_bwd(const float* dout, int B, int H, int W, int C, const float*
   MTLSSL_REQUIRE(C <= 1024 && bins_y <= kPsBins && bins_x <= kPsBins,
                  "psroi_bwd: at most 1024 score-map channels and 8 bins per side");
   const size_t lds = (size_t)kPsChunk * (bins_y + bins_x + 1) * 4 + (size_t)kPsChunk * bins_y * bins_x * 2;
-  static bool attr_set = false;
-  if (!attr_set) {            // up to 8 x 8 bins: 34 KB of lists + 64 KB of per-bin lists
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_psroi_bwd_gather), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
+  // up to 8 x 8 bins: 34 KB of lists + 64 KB of per-bin lists
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_psroi_bwd_gather), lds, "psroi_bwd")) return rc;
   hipLaunchKernelGGL(k_psroi_bwd_gather, dim3((unsigned)(B * H * W)), dim3(256), lds, S(stream),
                      dout, H, W, C, boxes, box_ind, R, bins_y, bins_x, crop_h / bins_y, crop_w / bins_x, Cc, dfmap);
   return check_launch("psroi_bwd");

@@ -107,6 +107,10 @@ class ParamStore:
         self.weights = torch.from_numpy(host_t).to(self.device)
         self.frozen = torch.from_numpy(host_f).to(self.device)
         self.grads = torch.zeros_like(self.weights)
+        # True only while the buffer is known to hold zeros (a zeroing optimizer launch was its last writer): the next
+        # step then skips its memset. The flag lives with the buffer, not with a Trainer — anyone who writes `grads`
+        # by hand (a benchmark, a test, a second Trainer on the same store) calls mark_grads_dirty()
+        self.grads_clean = False
         self.accum = torch.zeros_like(self.weights)
         # variable table for the per-variable clip: padding belongs to the preceding variable
         offs = [s.offset for s in tr] + [self.n_train]
@@ -159,6 +163,10 @@ class ParamStore:
 
     def state_dict(self):
         return {s.name: self.value(s.name).detach().cpu().numpy().copy() for s in self.specs}
+
+    def mark_grads_dirty(self):
+        """Tell the store that `grads` was written outside Trainer.forward_backward / apply_gradients."""
+        self.grads_clean = False
 
     def grads_dict(self):
         return {s.name: self.grad(s.name).detach().cpu().numpy().copy() for s in self.trainable_specs}

@@ -258,7 +258,6 @@ class Trainer:
         # the momentum update is the gradient buffer's last reader of a step: it leaves zeros behind, which saves the
         # next step's memset launch over every parameter (the first step starts from ParamStore's zero-initialised buffer)
         self.zero_in_update = os.environ.get("MTLSSL_ZERO_IN_UPDATE", "1") != "0" and self.ps.device.type == "cuda"
-        self._grads_clean = False
         # momentum update and shadow-weight fold in one launch: only when no scale vector trains (frozen BatchNorm)
         self.fuse_fold = (os.environ.get("MTLSSL_FUSE_FOLD", "1") != "0"
                           and not any(getattr(l, "bn_trainable", False) for l in model.layers))
@@ -312,9 +311,12 @@ class Trainer:
         m = self.model
         m.step = self.global_step
         self.provide(batch)
-        if not self._grads_clean:            # the momentum update leaves zeros behind (MTLSSL_ZERO_IN_UPDATE, default on)
+        if not self.ps.grads_clean:          # the momentum update leaves zeros behind (MTLSSL_ZERO_IN_UPDATE, default on)
             self.ps.grads.zero_()
-        self._grads_clean = False
+        elif os.environ.get("MTLSSL_CHECK_GRADS_CLEAN") == "1":      # debug / test suite: the skipped memset was safe
+            assert float(self.ps.grads.abs().max().item()) == 0.0, \
+                "gradient buffer written since the last zeroing update without ParamStore.mark_grads_dirty()"
+        self.ps.grads_clean = False
         self.reducer.compute_streams = m.compute_streams()
         self.reducer.compute_streams_fn = m.compute_streams
         self.reducer.begin_step()
@@ -360,7 +362,7 @@ class Trainer:
             ops.sgd_momentum_clip(ps.weights, ps.grads, ps.accum, ps.var_offsets, ps.max_var_size, lr,
                                   self.momentum, self.clip, 1.0, self.var_wd, self.var_mult,
                                   fold=ps if folded else None, zero_grads=self.zero_in_update)
-            self._grads_clean = self.zero_in_update
+            ps.grads_clean = self.zero_in_update
         elif o["kind"] == "rms_prop":
             ops.adaptive_update_clip(1, ps.weights, ps.grads, ps.accum, self.slot1, ps.var_offsets, ps.max_var_size, lr,
                                      o["decay"], o["momentum"], o["epsilon"], self.clip, 1.0, self.var_wd, self.var_mult)

@@ -372,6 +372,7 @@ class Oracle:
             if mtl["refine"]:
                 raise ValueError("hard_example_miner with mtl.refine: need more than 2 values to unpack "
                                  "(faster_rcnn_meta_arch.py:1828-1832)")
+        norm_direct = None
         if forced is not None and "proposal_boxes" in forced:
             boxes_abs = np.asarray(forced["proposal_boxes"], F)
             num = np.asarray(forced["num_proposals"], np.int32)
@@ -382,11 +383,18 @@ class Oracle:
             pb, _, _, pn = N.rpn_proposals(e_np, o_np, anchors, (H, W), hp["nms_score_threshold"],
                                            hp["nms_iou_threshold"], hp["max_proposals"])
             if miner_on:
-                boxes_abs, num = np.asarray(pb, F), np.asarray(pn, np.int32)
+                # no sampling: every proposal goes on. prediction_dict['proposal_boxes'] is the round trip through the
+                # normalised boxes (faster_rcnn_meta_arch.py:693 normalized_to_image_coordinates of :1126-1132's
+                # to_normalized_coordinates), which is not the identity in fp32
+                num = np.asarray(pn, np.int32)
+                norm_direct = np.stack([B.to_normalized(np.asarray(pb[b], F), H, W) for b in range(Bn)])
+                boxes_abs = np.stack([B.to_absolute(norm_direct[b], H, W) for b in range(Bn)])
             else:
                 boxes_abs, num, _ = L.sample_box_classifier_batch(pb, pn, gt_abs, gt_cls_bg, N2,
                                                                   hp["second_stage_balance_fraction"], seed, step)
         boxes_norm = np.stack([B.to_normalized(boxes_abs[b], H, W) for b in range(Bn)])
+        if norm_direct is not None:
+            boxes_norm = norm_direct                       # the crops use the normalised boxes themselves (:1126-1132)
         box_ind = np.repeat(np.arange(Bn), N2)
         rfcn = hp.get("rfcn")
         stop_aux = mtl["stop_gradient_for_aux_tasks"]

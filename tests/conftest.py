@@ -10,6 +10,8 @@ os.environ.setdefault("MTLSSL_POISON_WS", "1")
 # the suite runs on the committed plan table / the library's planner, never on tiles picked by a timing race on
 # the box at hand (mtl_ssl_amd/ops.py AUTOTUNE): the same kernels, hence the same floats, on every machine
 os.environ["MTLSSL_AUTOTUNE"] = "0"
+# a skipped gradient memset is checked (trainer.py: the buffer must really hold zeros)
+os.environ.setdefault("MTLSSL_CHECK_GRADS_CLEAN", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

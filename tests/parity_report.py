@@ -87,3 +87,30 @@ def against_float64(tag, Oracle, hp, values, host_batch, seed, step, boxes, num,
     assert int((e_gpu >= cap).sum()) <= outliers, (tag, sorted(((v[0], n) for n, v in out.items()), reverse=True)[:outliers + 2])
     assert e_gpu.max() < worst, (tag, w_gpu, e_gpu.max())
     return out
+
+
+def oracle_on_device_rpn(Oracle, hp, values, host_batch, seed, step, pd, dtype=None, float_tol=1e-3):
+    """The staged whole-step comparison every model-level test uses (a step is not one continuous function: the
+    proposal chain — sort, greedy NMS, sampling — is discrete, and crop_and_resize switches from "interpolate" to
+    "extrapolate with 0" at in_y = H - 1, where the last crop row of a box clipped to the image border sits up to the
+    last bit of its decoded ymin):
+      (1) the oracle evaluates trunk and RPN on its own (torch-CPU) and its RPN floats must agree with the device's to
+          `float_tol` relative (asserted here) — the float claim up to the chain;
+      (2) the oracle's chain runs ON THE DEVICE'S RPN FLOATS; identical inputs, so proposal counts, sampled boxes and
+          detector matches must come out BIT FOR BIT (asserted here: no tolerance, no fallback);
+      (3) everything downstream (crops, towers, heads, losses, gradients) is then compared by the caller with both
+          sides looking at identical boxes.
+    `pd` is the device's prediction_dict (faster_rcnn_meta_arch.py:593-601, 693-699). -> (losses, grads, aux)."""
+    enc = pd["rpn_box_encodings"].cpu().numpy()
+    obj = pd["rpn_objectness_predictions_with_background"].cpu().numpy()
+    ora = Oracle(hp, values) if dtype is None else Oracle(hp, values, dtype)
+    ref, rgrads, aux = ora.step(host_batch, seed=seed, step=step, forced=dict(rpn_box_encodings=enc, rpn_objectness=obj))
+    for mine, theirs in ((enc, aux["rpn_box_encodings"]), (obj, aux["rpn_objectness"])):
+        assert float(np.abs(mine - theirs).max()) <= float_tol * float(np.abs(theirs).max()), \
+            (float(np.abs(mine - theirs).max()), float(np.abs(theirs).max()))
+    if "proposal_boxes" in pd:
+        np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
+        np.testing.assert_array_equal(pd["proposal_boxes"].cpu().numpy(), aux["proposal_boxes"])
+        if "_det_targets" in pd and "det_match" in aux:
+            np.testing.assert_array_equal(pd["_det_targets"]["match"].cpu().numpy(), aux["det_match"])
+    return ref, rgrads, aux

