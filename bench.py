@@ -375,6 +375,55 @@ def cpu_plumbing_config0(dev, steps=10, H=600, W=800):
             "total_loss_last_step": float(sum(losses.values()))}
 
 
+OTHER_CONFIGS = [
+    # (key, pipeline config, H, W, timed steps, what it is in BASELINE.json)
+    ("configs2_rfcn_resnet101", "rfcn_resnet101_voc_mtl.config", 600, 1024, 15,
+     "configs[2]: R-FCN + ResNet-101 (PS-RoI pooling), 1 GPU, batch 4, 1024x600"),
+    ("configs4_inception_resnet_v2_per_gpu_share", "frcnn_inception_resnet_v2_coco_mtl.config", 800, 1333, 10,
+     "configs[4]: Faster R-CNN + Inception-ResNet-v2, 1333x800 — ONE GPU's share (batch 1) of the 8-GPU global batch 8"),
+    ("configs0_mobilenet_v1_on_gpu", "frcnn_mobilenet_v1_voc_mtl.config", 600, 1024, 40,
+     "configs[0]'s model (Faster R-CNN + MobileNet-v1, VOC07 settings, batch 1) on the GPU path; the configuration itself is "
+     "the CPU plumbing run reported in cpu_baseline_config0"),
+]
+
+
+def other_configs(dev, warmup=4):
+    """Driver-timed side block: the other single-GPU configurations of BASELINE.json through the same Trainer.step, timed
+    with the same barrier-free wall clock (one rank), after the headline region. Not part of `value`."""
+    import torch
+    from mtl_ssl_amd import config, model_builder, ops, synthetic, trainer
+    rows = {}
+    for key, name, H, W, steps, what in OTHER_CONFIGS:
+        try:
+            cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", name)).read())
+            B, K = int(cfg.train_config.batch_size), int(cfg.model.faster_rcnn.num_classes)
+            model = model_builder.build(cfg.model, True, dev, seed=0)
+            tr = trainer.Trainer(model, cfg.train_config, 1)
+            ring = [tr.stage_batch(synthetic.make_batch(B, H, W, K, seed=1234 + 1000 * i, device=dev)) for i in range(4)]
+            for i in range(warmup):
+                tr.step(ring[i % 4])
+            torch.cuda.synchronize()
+            ops.ACCOUNT = ops.FlopAccount()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                losses = tr.step(ring[(warmup + i) % 4])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            account, ops.ACCOUNT = ops.ACCOUNT, None
+            ex = sum(r[1] for r in account.rows.values()) * 2.0 / steps
+            rows[key] = {"what": what, "pipeline_config": "configs/" + name, "per_gpu_batch": B, "image": "%dx%d" % (W, H),
+                         "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt, "images_per_sec": B / dt,
+                         "executed_mfma_tflop_per_step": ex / 1e12,
+                         "executed_over_fp32_mfma_peak": ex / dt / FP32_MFMA_PEAK,
+                         "final_total_loss": float(sum(v.item() for v in losses.values()))}
+            del model, tr, ring
+            torch.cuda.empty_cache()
+        except Exception as e:                       # a side measurement never takes the headline line down
+            ops.ACCOUNT = None
+            rows[key] = {"what": what, "error": repr(e)}
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -400,6 +449,9 @@ def main():
                     help="extra steps with the forward streams serialised, for roofline.isolated (0 = skip)")
     ap.add_argument("--conv-breakdown", action="store_true",
                     help="time every conv launch (adds ~2%% to the step) and report the per-kernel table")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the side block that times BASELINE.json's other single-GPU configurations (R-FCN B=4, one "
+                         "GPU's share of the Inception-ResNet-v2 configuration, MobileNet) after the headline region")
     ap.add_argument("--allow-stand-in", action="store_true",
                     help="N > 1 only: accept a communicator that is not N RCCL ranks (the torch.distributed stand-in of "
                          "MTLSSL_DIST_BACKEND=gloo, ranks sharing one GPU). Without it such a run is refused: its line "
@@ -779,6 +831,8 @@ def main():
                     r["avg_us_random_init"] = hbm_first[r["kernel"]]
         except Exception as e:
             out["hbm_kernels"] = {"error": repr(e)}
+    if world == 1 and comm is None and default_cfg and not a.no_other_configs:
+        out["other_configs"] = other_configs(dev)
     if world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, model, tr, a.height, a.width, seed=1234, steps=a.cpu_steps,

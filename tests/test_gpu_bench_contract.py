@@ -38,3 +38,11 @@ def test_bench_line_contract_single_gpu():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "images/sec" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert d["value"] / cb["value"] > 20
+    # the other single-GPU configurations of BASELINE.json, timed by the same command (side block, not `value`)
+    oc = d["other_configs"]
+    assert set(oc) == {"configs2_rfcn_resnet101", "configs4_inception_resnet_v2_per_gpu_share", "configs0_mobilenet_v1_on_gpu"}
+    for key, row in oc.items():
+        assert "error" not in row, (key, row)
+        assert row["ms_per_step"] > 0 and abs(row["images_per_sec"] - 1e3 * row["per_gpu_batch"] / row["ms_per_step"]) < 1e-6 * row["images_per_sec"]
+        assert 0.05 < row["executed_over_fp32_mfma_peak"] < 1.0 and row["final_total_loss"] == row["final_total_loss"]
+    assert oc["configs2_rfcn_resnet101"]["per_gpu_batch"] == 4 and oc["configs4_inception_resnet_v2_per_gpu_share"]["image"] == "1333x800"

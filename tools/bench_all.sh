@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 S=${1:-20}; shift
 cd $R
-COMMON="--steps $S --warmup 5 --no-cpu-baseline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 $@"
+COMMON="--steps $S --warmup 5 --no-cpu-baseline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 --no-other-configs $@"
 for c in "resnet101 --config $R/configs/frcnn_resnet101_coco_mtl.config" "rfcn --config $R/configs/rfcn_resnet101_voc_mtl.config" \
          "mobilenet --config $R/configs/frcnn_mobilenet_v1_voc_mtl.config" "inception --config $R/configs/frcnn_inception_resnet_v2_coco_mtl.config --height 800 --width 1333"; do
   set -- $c; name=$1; shift

@@ -16,9 +16,9 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --config configs/frcnn_i
 python tools/phase_times.py > $E/phase_times.txt 2>/dev/null
 python tools/phase_times.py --config configs/frcnn_mobilenet_v1_voc_mtl.config --steps 30 >> $E/phase_times.txt 2>/dev/null
 # profile of the timed region's schedule only (no side measurements that switch overlaps off)
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $E/prof -o ev -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 > $E/bench_profiled.json 2> $E/bench_profiled.err)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $E/prof -o ev -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 --no-other-configs > $E/bench_profiled.json 2> $E/bench_profiled.err)
 # the same with the two forward overlaps off: every launch of the roofline kernel alone on the chip (roofline.isolated)
-(cd /tmp && export TMPDIR=/tmp && MTLSSL_CLOSENESS_FWD_SIDE=0 MTLSSL_REFINE_EARLY=0 rocprofv3 --kernel-trace --stats -d $E/prof_ser -o ev -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 > $E/bench_profiled_serialised.json 2> $E/bench_profiled_serialised.err)
+(cd /tmp && export TMPDIR=/tmp && MTLSSL_CLOSENESS_FWD_SIDE=0 MTLSSL_REFINE_EARLY=0 rocprofv3 --kernel-trace --stats -d $E/prof_ser -o ev -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 --no-other-configs > $E/bench_profiled_serialised.json 2> $E/bench_profiled_serialised.err)
 DBS=$(find $E/prof_ser -name "*.db" | head -1)
 python tools/rocprof_summary.py $DBS 45 > $E/kernel_stats_forward_serialised.md
 rm -rf $E/prof_ser
