@@ -4,6 +4,7 @@ re-designed as one process per GPU: weights replicated in HBM, gradients summed 
 RCCL all-reduce of contiguous buckets of the flat gradient buffer on a side stream, then an
 identical per-variable clip + momentum update on every rank.
 """
+import os
 import time
 
 import torch

@@ -376,3 +376,39 @@ def test_sampler_counts_of_the_reference_tests(vec):
         s = A.subsample_indicator(ind, c["num"], A.hash_priority(3, len(ind)))
         assert s.sum() == c["exp"] and not (s & ~ind).any()
     assert A.subsample_indicator(np.zeros(0, bool), 4, A.hash_priority(3, 0)).size == 0
+
+
+def test_portable_exp_is_pinned_and_accurate():
+    """oracle/portable_math.py exp_rn — the exponential both sides use wherever a float decides index work. (1) The
+    operation sequence is pinned by known answers (bit patterns of 18 arguments: a change of a constant, of the
+    polynomial order or of the evaluation order shows up here, and the GPU test test_exp_rn_is_bit_identical_to_the_oracle
+    then ties the device to the same bits); (2) it is within 2 ulp(double) of libm's exp over the whole range, hence its
+    fp32 rounding equals the correctly rounded fp32 exponential except on a ~2^-28 fraction of arguments; (3) special
+    values and cut-offs; (4) the 2-way softmax equals the reference's tf.nn.softmax to fp32 rounding
+    (faster_rcnn_meta_arch.py:1103-1104) and sums to one."""
+    from oracle import portable_math as PM
+    pins = {0.0: "0x1.0000000000000p+0", 1.0: "0x1.5bf0a8b14576ap+1", -1.0: "0x1.78b56362cef38p-2",
+            0.5: "0x1.a61298e1e069cp+0", -0.5: "0x1.368b2fc6f960ap-1", 10.0: "0x1.5829dcf950560p+14",
+            -10.0: "0x1.7cd79b5647c9ap-15", 88.0: "0x1.f1056dc7bf22dp+126", -87.0: "0x1.666d0dad2961dp-126",
+            -103.5: "0x1.9a733e3852834p-150", 0.001: "0x1.0041919b7ee34p+0", -0.001: "0x1.ff7cfe56f1a9ep-1",
+            0.34657359027997264: "0x1.6a09e667f3bccp+0", -0.34657359027997264: "0x1.6a09e667f3bccp-1",
+            709.0: "0x1.d422d2be5dc9bp+1022", -700.0: "0x1.14f2b0fb9307fp-1010", 3.14159: "0x1.7240068789162p+4",
+            -20.25: "0x1.b93de1e27ca3bp-30"}
+    for x, want in pins.items():
+        assert PM.exp_rn(np.float64(x)).item().hex() == want, (x, PM.exp_rn(np.float64(x)).item().hex(), want)
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-40, 40, 400000), rng.uniform(-700, 709, 100000), rng.standard_normal(100000) * 1e-4])
+    got, ref = PM.exp_rn(x), np.exp(x)
+    assert float((np.abs(got - ref) / np.spacing(ref)).max()) <= 2.0
+    xf = rng.uniform(-30, 10, 1000000).astype(np.float32)
+    a, b = PM.expf_rn(xf), np.exp(xf.astype(np.float64)).astype(np.float32)
+    assert int((a != b).sum()) <= 2                            # fp32 rounding of two double results <= 2 ulp(double) apart
+    sp = PM.exp_rn(np.array([np.inf, -np.inf, np.nan, 709.5, -700.5, -0.0]))
+    assert sp[0] == np.inf and sp[1] == 0.0 and np.isnan(sp[2]) and sp[3] == np.inf and sp[4] == 0.0 and sp[5] == 1.0
+    lg = (rng.standard_normal((20000, 2)) * 3).astype(np.float32)
+    sm = PM.softmax_rn(lg)
+    e = np.exp(lg.astype(np.float64) - lg.astype(np.float64).max(-1, keepdims=True))
+    np.testing.assert_allclose(sm, (e / e.sum(-1, keepdims=True)), rtol=1e-7, atol=0)
+    np.testing.assert_allclose(sm.sum(-1), 1.0, atol=2e-7)
+    from oracle import nms as N
+    np.testing.assert_array_equal(N.softmax_fg(lg), sm[:, 1])
