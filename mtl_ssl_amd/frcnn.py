@@ -539,7 +539,7 @@ class FasterRCNNMetaArch:
                 early_win = self._refine_window_predictions(F, boxes_norm)
         cside = None
         if (mtl.closeness and not self._shared_classifier and self._is_training
-                and os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "1") == "1"):
+                and os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "0") == "1"):
             cside = self._aux_stream()
         if cside is not None:
             cur = torch.cuda.current_stream()
@@ -634,7 +634,7 @@ class FasterRCNNMetaArch:
         """Third forward stream: the refiner's window pass next to the second stage's own towers (None on CPU, without
         the auxiliary stream, or with MTLSSL_REFINE_EARLY=0)."""
         import os
-        if self._aux_stream() is None or os.environ.get("MTLSSL_REFINE_EARLY", "1") == "0":
+        if self._aux_stream() is None or os.environ.get("MTLSSL_REFINE_EARLY", "0") != "1":
             return None
         # the filter-gradient stream is idle during the forward pass: reuse it rather than create a fourth compute
         # stream — HIP multiplexes streams onto a few hardware queues (4 by default), and with the data-parallel

@@ -106,7 +106,7 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         flat = boxes_norm.view(B * N2, 4)
         import os
         cside = None
-        if mtl.closeness and self._is_training and os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "1") == "1":
+        if mtl.closeness and self._is_training and os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "0") == "1":
             cside = self._aux_stream()
         if cside is not None:          # the closeness tower (block4 on the whole map) next to the main tower's forward
             cside.wait_stream(torch.cuda.current_stream())

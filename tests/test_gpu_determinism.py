@@ -78,3 +78,32 @@ def test_fused_fold_is_off_when_batch_norm_parameters_train(cfg_name):
     model = model_builder.build(cfg.model, True, "cuda", seed=5)
     assert any(getattr(l, "bn_trainable", False) for l in model.layers)
     assert not trainer.Trainer(model, cfg.train_config, 1).fuse_fold
+
+
+@pytest.mark.parametrize("cfg_name", ["smoke_resnet50_mtl.config", "smoke_rfcn_resnet50_mtl.config"])
+def test_forward_overlap_switches_do_not_change_a_bit(cfg_name, monkeypatch):
+    """MTLSSL_CLOSENESS_FWD_SIDE / MTLSSL_REFINE_EARLY (closeness tower beside the main tower; the refiner's window
+    pass on the third stream) only move launches between streams. Off by default since round 5 (chains of chip-filling
+    GEMMs gain nothing from time-slicing each other: profiles/r05_fwd_overlap_ab.txt); with them on, losses and
+    gradients of a step are bit-identical to the serial schedule."""
+    import __graft_entry__ as g
+    g.build()
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", cfg_name)).read())
+    K = int(cfg.model.faster_rcnn.num_classes)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MTLSSL_CLOSENESS_FWD_SIDE", mode)
+        monkeypatch.setenv("MTLSSL_REFINE_EARLY", mode)
+        model = model_builder.build(cfg.model, True, "cuda", seed=5)
+        tr = trainer.Trainer(model, cfg.train_config, 1)
+        batch = tr.stage_batch(synthetic.make_batch(2, 160, 224, K, seed=21, device="cuda", max_gt=4, num_windows=6))
+        tr.forward_backward(batch)
+        losses = {k: float(v.item()) for k, v in tr.forward_backward(batch).items()}
+        torch.cuda.synchronize()
+        if mode == "1" and "resnet50_mtl" in cfg_name and "rfcn" not in cfg_name:
+            assert "_refine_win" in tr._pd                     # the early window pass really ran
+        res[mode] = (losses, model.ps.grads.clone())
+        del tr, model
+    assert res["0"][0] == res["1"][0]
+    assert torch.equal(res["0"][1], res["1"][1])
