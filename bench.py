@@ -59,6 +59,7 @@ def hyper_params_for_oracle(cfg):
     return dict(
         predictors=predictors, first_stage_only=bool(fr.first_stage_only), hard_example_miner=miner,
         rfcn=rf, stride=int(fr.feature_extractor.first_stage_features_stride),
+        batch_norm_trainable=bool(fr.feature_extractor.batch_norm_trainable),
         first_stage_atrous_rate=int(fr.first_stage_atrous_rate), anchor_stride=int(g.height_stride),
         arch={"faster_rcnn_resnet50": "resnet_v1_50", "faster_rcnn_resnet101": "resnet_v1_101",
               "faster_rcnn_resnet152": "resnet_v1_152", "frcnn_mobilenet_v1": "mobilenet_v1",

@@ -316,13 +316,22 @@ class FasterRCNNMetaArch:
         optimizer launch already wrote them, mtlssl_sgd_momentum_clip_fold)."""
         if self.ps.device.type == "cuda":
             if getattr(self, "_bn_table", None) is None:
-                self._bn_table = ops.BnRefreshTable([l for l in self.layers if getattr(l, "trainable", False)],
-                                                    self.ps.device)
+                # every layer whose gamma / beta train — with resnet's batch_norm_trainable that includes layers whose
+                # FILTERS are frozen (root conv, frozen blocks: slim/nets/resnet_utils.py:203-237)
+                self._bn_table = ops.BnRefreshTable(self.layers, self.ps.device)
+                self._frozen_w_bn = [l for l in self.layers if getattr(l, "bn_trainable", False)
+                                     and not l.w.trainable and getattr(l, "w_eff", None) is not None]
             ops.bn_refresh(self._bn_table)
         else:
             for l in self.layers:
-                if getattr(l, "trainable", False):
+                if getattr(l, "trainable", False) or getattr(l, "bn_trainable", False):
                     l.refold()
+            self._frozen_w_bn = [l for l in self.layers if getattr(l, "bn_trainable", False) and not l.w.trainable
+                                 and getattr(l, "w_eff", None) is not None]
+        for l in self._frozen_w_bn:
+            # a frozen filter under a trained normaliser: its shadow copy is not one of the batched folds (those cover
+            # the trainable filters' flat buffer), so it is re-scaled here — a handful of layers of an unusual config
+            ops.scale_channels(self.ps.value(l.w.name).view(l.w_eff.shape), l.scale, l.w_eff)
         if not folded:
             ops.fold_scales(self.ps)
         if self.ps.filter_cache is not None:

@@ -375,19 +375,24 @@ class Bottleneck:
     """slim/nets/resnet_v1.py:69-130 bottleneck (v1: BN after conv, stride in the 3x3)."""
 
     def __init__(self, ps, scope, cin, depth, depth_bottleneck, stride, rate=1, trainable=True,
-                 weight_decay=0.0):
+                 weight_decay=0.0, bn_trainable=False):
+        """bn_trainable: the unit's BatchNorm gamma / beta are trained (resnet_arg_scope(batch_norm_trainable=True),
+        slim/nets/resnet_utils.py:203-237: a property of the normaliser, independent of `trainable`, which freezes
+        the FILTERS of a block — a frozen block's gamma / beta still train); the statistics stay the moving ones."""
         s = scope + "/bottleneck_v1/"
         self.stride, self.cin, self.depth = stride, cin, depth
         self.shortcut = None
         if depth != cin:
             self.shortcut = ConvBN(ps, s + "shortcut", cin, depth, 1, stride, 1, "SAME", trainable,
-                                   weight_decay, relu=False)
-        self.conv1 = ConvBN(ps, s + "conv1", cin, depth_bottleneck, 1, 1, 1, "SAME", trainable, weight_decay)
+                                   weight_decay, relu=False, bn_trainable=bn_trainable)
+        self.conv1 = ConvBN(ps, s + "conv1", cin, depth_bottleneck, 1, 1, 1, "SAME", trainable, weight_decay,
+                            bn_trainable=bn_trainable)
         self.conv2 = ConvBN(ps, s + "conv2", depth_bottleneck, depth_bottleneck, 3, stride, rate,
-                            "RESNET_SAME", trainable, weight_decay)
+                            "RESNET_SAME", trainable, weight_decay, bn_trainable=bn_trainable)
         self.conv3 = ConvBN(ps, s + "conv3", depth_bottleneck, depth, 1, 1, 1, "SAME", trainable,
-                            weight_decay, gamma_init=0.3, relu=True)
+                            weight_decay, gamma_init=0.3, relu=True, bn_trainable=bn_trainable)
         self.trainable = trainable
+        self.bn_trainable = bn_trainable
 
     def layers(self):
         return [l for l in (self.shortcut, self.conv1, self.conv2, self.conv3) if l is not None]
@@ -403,16 +408,32 @@ class Bottleneck:
         a2 = self.conv2.forward(a1, keep=save)
         out = self.conv3.forward(a2, residual=sc)
         ctx = (x, a1, a2, sc if (self.shortcut is None and self.stride > 1) else None) if save else None
+        if save and self.bn_trainable:
+            # d(gamma) / d(beta) of conv3 and of the shortcut conv need the normalisers' own outputs: out - sc and sc
+            ctx = ctx + (out, sc)
         return out, ctx
 
     def backward(self, gp, ctx, need_input_grad=True, mask_input=True, wgrad=INLINE_WGRAD):
         """gp: dL/d(pre-activation of out). Returns dL/d(pre-activation of x) (masked by x>0 when
         mask_input), or None. `wgrad`: where the filter gradients run (inline, or a WgradStream)."""
-        x, a1, a2, sc_sub = ctx
+        x, a1, a2, sc_sub = ctx[:4]
+        if self.bn_trainable:
+            out, sc = ctx[4], ctx[5]
+            # conv3's normaliser output is out - sc wherever gp != 0 (gp is masked by out > 0, and there out is the
+            # pre-activation sum); elsewhere the product with gp vanishes
+            o3 = ops.axpby(sc, out.clone(), -1.0, 1.0)
+            self.conv3.bn_grad(o3, gp)
+            del o3
+            if self.shortcut is not None:
+                self.shortcut.bn_grad(sc, gp)
         wgrad.run(self.conv3, a2, gp)
         gp2 = self.conv3.dgrad(a2.shape, gp, mask_ref=a2)
+        if self.bn_trainable:
+            self.conv2.bn_grad(a2, gp2)
         wgrad.run(self.conv2, a1, gp2)
         gp1 = self.conv2.dgrad(a1.shape, gp2, mask_ref=a1)
+        if self.bn_trainable:
+            self.conv1.bn_grad(a1, gp1)
         wgrad.run(self.conv1, x, gp1)
         if self.shortcut is not None:
             wgrad.run(self.shortcut, x, gp)
@@ -431,7 +452,8 @@ class BlockStack:
     """resnet_utils.stack_blocks_dense (slim/nets/resnet_utils.py:126-200) for a list of
     (scope, depth, depth_bottleneck, stride-of-last-unit, num_units, trainable)."""
 
-    def __init__(self, ps, prefix, cin, blocks, output_stride=None, current_stride=1, weight_decay=0.0):
+    def __init__(self, ps, prefix, cin, blocks, output_stride=None, current_stride=1, weight_decay=0.0,
+                 bn_trainable=False):
         self.units = []
         rate = 1
         for (scope, base_depth, num_units, stride, trainable) in blocks:
@@ -439,10 +461,11 @@ class BlockStack:
                 ustride = stride if i == num_units - 1 else 1
                 name = "%s/%s/unit_%d" % (prefix, scope, i + 1)
                 if output_stride is not None and current_stride == output_stride:
-                    u = Bottleneck(ps, name, cin, base_depth * 4, base_depth, 1, rate, trainable, weight_decay)
+                    u = Bottleneck(ps, name, cin, base_depth * 4, base_depth, 1, rate, trainable, weight_decay, bn_trainable)
                     rate *= ustride
                 else:
-                    u = Bottleneck(ps, name, cin, base_depth * 4, base_depth, ustride, 1, trainable, weight_decay)
+                    u = Bottleneck(ps, name, cin, base_depth * 4, base_depth, ustride, 1, trainable, weight_decay,
+                                   bn_trainable)
                     current_stride *= ustride
                 u.block = scope
                 self.units.append(u)

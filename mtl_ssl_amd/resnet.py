@@ -17,9 +17,9 @@ class BoxClassifierTower:
     """block4 applied to ROI crops (models/...resnet...:148-185), one weight copy per scope
     (SecondStageFeatureExtractor / ClosenessBoxPredictor / WindowBoxPredictor)."""
 
-    def __init__(self, ps, scope, arch, cin, trainable, weight_decay):
+    def __init__(self, ps, scope, arch, cin, trainable, weight_decay, bn_trainable=False):
         self.stack = nn.BlockStack(ps, "%s/%s" % (scope, arch), cin,
-                                   [("block4", 512, 3, 1, trainable)], None, 1, weight_decay)
+                                   [("block4", 512, 3, 1, trainable)], None, 1, weight_decay, bn_trainable)
         self.trainable = trainable
         self.cout = self.stack.cout
 
@@ -62,9 +62,11 @@ class FasterRCNNResnetV1FeatureExtractor:
                  first_stage_scope="FirstStageFeatureExtractor"):
         if first_stage_features_stride not in (8, 16):
             raise ValueError("`first_stage_features_stride` must be 8 or 16.")
-        if batch_norm_trainable:
-            raise ValueError("batch_norm_trainable=True is not supported: the reference's paper "
-                             "configs never enable it (SURVEY.md appendix C)")
+        # models/faster_rcnn_resnet_v1_feature_extractor.py:131,169 -> resnet_arg_scope(batch_norm_trainable=
+        # is_training and batch_norm_trainable) (slim/nets/resnet_utils.py:203-237): gamma / beta of EVERY BatchNorm of the
+        # extractor become trainable variables — the frozen root conv and frozen blocks included, only their filters are
+        # frozen — while the normaliser keeps its moving statistics (is_training=False, :138, :171)
+        self.bn_trainable = bool(batch_norm_trainable) and bool(is_training)
         self.ps, self.arch, self.is_training, self.weight_decay = ps, architecture, is_training, weight_decay
         n_freeze = int(freeze_layer[-1]) if freeze_layer else 0
         bt = [False] * n_freeze + [bool(is_training)] * (4 - n_freeze)
@@ -74,15 +76,18 @@ class FasterRCNNResnetV1FeatureExtractor:
         # gamma_init only shapes the SYNTHETIC BatchNorm statistics (no checkpoint here): a small
         # gamma stands in for the normalisation a trained BN applies to 0..255 pixel inputs.
         self.conv1 = nn.ConvBN(ps, prefix + "/conv1", 3, 64, 7, 2, 1, "RESNET_SAME", False, weight_decay,
-                               gamma_init=0.015)
+                               gamma_init=0.015, bn_trainable=self.bn_trainable)
         blocks = [("block1", 64, units[0], 2, bt[0]), ("block2", 128, units[1], 2, bt[1]),
                   ("block3", 256, units[2], 2, bt[2])]
         # output_stride / 4 because conv1 and pool1 already contribute 4 (resnet_v1.py:205-209)
-        self.trunk = nn.BlockStack(ps, prefix, 64, blocks, first_stage_features_stride // 4, 1, weight_decay)
+        self.trunk = nn.BlockStack(ps, prefix, 64, blocks, first_stage_features_stride // 4, 1, weight_decay,
+                                   self.bn_trainable)
         self.cout = self.trunk.cout
         self._neg_means = None
-        self.first_trainable = next((i for i, u in enumerate(self.trunk.units) if u.trainable),
-                                    len(self.trunk.units))
+        # the backward pass stops at the first unit with a trainable variable; with trainable normalisers that is the
+        # root convolution itself
+        self.first_trainable = 0 if self.bn_trainable else next(
+            (i for i, u in enumerate(self.trunk.units) if u.trainable), len(self.trunk.units))
 
     def layers(self):
         return [self.conv1] + self.trunk.layers()
@@ -100,9 +105,11 @@ class FasterRCNNResnetV1FeatureExtractor:
                              % (tuple(x.shape),))
         if x.shape[1] < 33 or x.shape[2] < 33:
             raise ValueError("image size must at least be 33 in both height and width.")
-        x = self.conv1.forward(x)
-        x, _ = ops.maxpool_fwd(x, 3, 2, "SAME")
+        y1 = self.conv1.forward(x)
+        x, pads = ops.maxpool_fwd(y1, 3, 2, "SAME")
         ctxs = []
+        if save and self.bn_trainable:
+            self._root_ctx = (y1, x, pads)       # conv1's gamma / beta train: the backward pass reaches the root
         for i, u in enumerate(self.trunk.units):
             x, c = u.forward(x, save and i >= self.first_trainable)
             ctxs.append(c)
@@ -112,9 +119,17 @@ class FasterRCNNResnetV1FeatureExtractor:
         """gp: dL/d(pre-activation of the rpn feature map) (already ReLU-masked)."""
         units = self.trunk.units
         for i in range(len(units) - 1, self.first_trainable - 1, -1):
-            gp = units[i].backward(gp, ctxs[i], need_input_grad=(i > self.first_trainable), wgrad=wgrad)
+            gp = units[i].backward(gp, ctxs[i], need_input_grad=(i > self.first_trainable or self.bn_trainable),
+                                   wgrad=wgrad)
+        if self.bn_trainable:
+            # gp = dL/d(pre-activation of pool1's output) = dL/d(pool1 output) masked by (pooled > 0); through the
+            # 3x3 / 2 max-pool to conv1's output, whose own ReLU mask the normaliser gradient needs
+            y1, pooled, pads = self._root_ctx
+            g1 = ops.maxpool_bwd(y1, pooled, gp, 3, 2, pads)
+            self.conv1.bn_grad(y1, ops.relu_bwd(y1, g1))
+            self._root_ctx = None
         wgrad.flush()
 
     def box_classifier_tower(self, scope, trainable):
         return BoxClassifierTower(self.ps, scope, self.arch, self.cout, trainable and self.is_training,
-                                  self.weight_decay)
+                                  self.weight_decay, self.bn_trainable and trainable)

@@ -77,11 +77,14 @@ class RfcnBoxPredictor:
 class RFCNMetaArch(FasterRCNNMetaArch):
     def __init__(self, ps, is_training, frcnn, mtl, feature_extractor, seed=0):
         super().__init__(ps, is_training, frcnn, mtl, feature_extractor, seed=seed)
-        # the switches below are built for the Faster R-CNN second stage only (no paper configuration combines them
-        # with R-FCN: configs/test/model4?.config)
-        if self._shared_classifier:
-            raise ValueError("RFCNMetaArch: shared_feature 'classifier_feature_maps' is implemented for "
-                             "FasterRCNNMetaArch only")
+        # mtl.shared_feature 'classifier_feature_maps' under R-FCN (rfcn_meta_arch.py:292-300, 346-362) is not what it
+        # is under Faster R-CNN: the closeness predictor reads the MAIN tower's whole-map features (stopped or not) and
+        # has no tower, while the window head keeps a block4 copy of its own under the WindowBoxPredictor scope — run on
+        # the un-stopped shared map, with the gradient stopped at the tower's OUTPUT when stop_gradient_for_aux_tasks
+        # (so that copy's filters only ever see their weight decay)
+        if self._shared_classifier and mtl.window:
+            self.window_tower = self._feature_extractor.box_classifier_tower(self.window_box_predictor_scope, True)
+            self.layers += self.window_tower.layers()
 
     def _make_predictor(self, scope, num_classes, bp_cfg, class_only, slot0=0):
         if not bp_cfg.has("rfcn_box_predictor"):
@@ -106,7 +109,8 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         flat = boxes_norm.view(B * N2, 4)
         import os
         cside = None
-        if mtl.closeness and self._is_training and os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "0") == "1":
+        if (mtl.closeness and self._is_training and not self._shared_classifier
+                and os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "0") == "1"):
             cside = self._aux_stream()
         if cside is not None:          # the closeness tower (block4 on the whole map) next to the main tower's forward
             cside.wait_stream(torch.cuda.current_stream())
@@ -125,6 +129,9 @@ class RFCNMetaArch(FasterRCNNMetaArch):
             if cside is not None:
                 torch.cuda.current_stream().wait_stream(cside)
                 cfeat, cctx, cp = cfeat_s, cctx_s, cp_s
+            elif self._shared_classifier:        # the main tower's map; no tower, no context of its own
+                cfeat, cctx = feat, None
+                cp = self.closeness_predictor.predict(cfeat, flat, box_ind)
             else:
                 cfeat, cctx = self.closeness_tower.forward(F, self._is_training)
                 cp = self.closeness_predictor.predict(cfeat, flat, box_ind)
@@ -135,6 +142,8 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         """block4 (window scope) on the whole map; computed once per step and shared by the
         window loss head and the refine windows (the reference rebuilds the identical ops)."""
         if "_wfeat" not in pd:
+            if self._shared_classifier and bool(self._mtl.stop_gradient_for_aux_tasks):
+                save = False                      # the gradient stops at this tower's output: nothing to keep
             feat, ctx = self.window_tower.forward(pd["rpn_features_to_crop"], save)
             pd["_wfeat"], pd["_wctx"] = feat, ctx
         return pd["_wfeat"]
@@ -202,8 +211,16 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         stop = bool(mtl.stop_gradient_for_aux_tasks)
         held = []          # the aux towers' input gradients (only without stop_gradient_for_aux_tasks)
 
+        shared = self._shared_classifier
+        g_feat_closeness = None
+        if shared and mtl.closeness:
+            # the closeness predictor sits on the main tower's map: its input gradient (if not stopped) joins the main
+            # predictor's BEFORE the main tower's backward, so it runs here, on this stream
+            g_feat_closeness = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None,
+                                                                 pd["_cfeat"], need_feat_grad=not stop)
+
         def aux_backward():
-            if mtl.closeness:
+            if mtl.closeness and not shared:
                 cfeat = pd["_cfeat"]
                 g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat)
                 g_c = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop)
@@ -211,6 +228,13 @@ class RFCNMetaArch(FasterRCNNMetaArch):
                     held.append(g_c)
             if mtl.window:
                 wfeat = pd["_wfeat"]
+                if shared and stop:               # gradient stopped at the window tower's output: the predictor alone trains
+                    self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat,
+                                                   need_feat_grad=False)
+                    for l in self.window_tower.layers():       # their gradient is final: zero (only weight decay acts)
+                        self.ps.grad_ready(l.w if l.trainable else None,
+                                           *((l.gamma, l.beta) if getattr(l, "bn_trainable", False) else ()))
+                    return
                 g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat)
                 g_w = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop)
                 if not stop:
@@ -230,6 +254,8 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         feat = pd["_feat"]
         g_feat = self.box_predictor.backward(pd["_bp"], d_cls,
                                              d["refined_box_encodings"].view(d_cls.shape[0], -1), feat)
+        if g_feat_closeness is not None:
+            ops.axpby(g_feat_closeness, g_feat, 1.0, 1.0)
         g_F = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True)
         ops.axpby(g_F, dF, 1.0, 1.0)
         if side is None:

@@ -38,8 +38,13 @@ class Oracle:
         else:
             y = T.conv2d(x, w, stride, rate, "SAME")
         bn = scope + "/BatchNorm/"
-        y = T.frozen_bn(y, self.v[bn + "gamma"].detach(), self.v[bn + "beta"].detach(),
-                        self.v[bn + "moving_mean"].detach(), self.v[bn + "moving_variance"].detach(), 1e-5)
+        g, b = self.v[bn + "gamma"], self.v[bn + "beta"]
+        if not self.hp.get("batch_norm_trainable", False):
+            g, b = g.detach(), b.detach()
+        # batch_norm_trainable (models/faster_rcnn_resnet_v1_feature_extractor.py:131,169 -> resnet_arg_scope,
+        # slim/nets/resnet_utils.py:203-237): gamma / beta of every BatchNorm are trainable variables, the statistics
+        # stay the moving ones (is_training=False)
+        y = T.frozen_bn(y, g, b, self.v[bn + "moving_mean"].detach(), self.v[bn + "moving_variance"].detach(), 1e-5)
         return torch.relu(y) if relu else y
 
     def bottleneck(self, x, scope, depth, stride, rate):
@@ -425,7 +430,10 @@ class Oracle:
             cls, box_enc = self.rfcn_predict(fmap, "SecondStageBoxPredictor", flat, box_ind, True)
             box_enc = box_enc.reshape(Bn * N2, K, 4)
             if mtl["closeness"]:
-                cmap = self.tower(Fm.detach() if stop_aux else Fm, "ClosenessBoxPredictor")
+                if shared:       # rfcn_meta_arch.py:292-300: the main tower's map (stopped or not), no closeness tower
+                    cmap = fmap.detach() if stop_aux else fmap
+                else:
+                    cmap = self.tower(Fm.detach() if stop_aux else Fm, "ClosenessBoxPredictor")
                 clo, _ = self.rfcn_predict(cmap, "ClosenessBoxPredictor", flat, box_ind, False)
         losses = {}
         # ---- RPN loss
@@ -457,6 +465,15 @@ class Oracle:
                     wt = wt.detach()
                 wf = self.head_input(wt, "WindowBoxPredictor", seed, step)
                 win_logits = self.fc(wf, "WindowBoxPredictor/ClassPredictor")
+            elif shared:
+                # rfcn_meta_arch.py:346-362: under R-FCN the window head keeps a tower of its own in both modes (the
+                # scope is WindowBoxPredictor either way); with classifier_feature_maps the shared map is NOT stopped
+                # going in, and the gradient stops at the tower's OUTPUT when stop_gradient_for_aux_tasks
+                wmap = self.tower(Fm, "WindowBoxPredictor")
+                if stop_aux:
+                    wmap = wmap.detach()
+                win_logits, _ = self.rfcn_predict(wmap, "WindowBoxPredictor", wb.reshape(-1, 4),
+                                                  np.repeat(np.arange(Bn), Wn), False)
             else:
                 wmap = self.tower(Fm.detach() if stop_aux else Fm, "WindowBoxPredictor")
                 win_logits, _ = self.rfcn_predict(wmap, "WindowBoxPredictor", wb.reshape(-1, 4),

@@ -236,3 +236,66 @@ def test_rfcn_refiner_fc_stack_with_dropout_matches_oracle():
     for n in ("MTLClassRefiner/fc1/weights", "MTLClassRefiner/fc2/weights", "MTLClassRefiner/fc3/weights"):
         a, b = grads[n].ravel(), np.asarray(rgrads[n]).ravel()
         assert np.any(b) and np.linalg.norm(a - b) <= 5e-3 * np.linalg.norm(b), (n, np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("stop", ["true", "false"], ids=["stopped", "with_gradient"])
+def test_rfcn_shared_classifier_feature_maps_matches_oracle(stop):
+    """mtl.shared_feature: 'classifier_feature_maps' under RFCNMetaArch (rfcn_meta_arch.py:292-300, 346-362) — NOT what it
+    is under Faster R-CNN: the closeness predictor reads the MAIN tower's whole-map features (no closeness tower); the
+    window head keeps a block4 copy of its own on the un-stopped shared map, and with stop_gradient_for_aux_tasks the
+    gradient stops at that tower's OUTPUT (its filters then receive no gradient at all, the trunk none from it)."""
+    import bench
+    from mtl_ssl_amd import config, model_builder, rfcn, synthetic, trainer
+    from oracle.model import Oracle
+    from tests import parity_report
+    text = open(os.path.join(ROOT, "configs", "smoke_rfcn_resnet50_mtl.config")).read()
+    assert "refine_num_fc_layers: 0  stop_gradient_for_aux_tasks: false" in text and "shared_feature" not in text
+    text = text.replace("refine_num_fc_layers: 0  stop_gradient_for_aux_tasks: false",
+                        "refine_num_fc_layers: 0  stop_gradient_for_aux_tasks: %s  shared_feature: 'classifier_feature_maps'" % stop)
+    cfg = config.parse_pipeline_config(text)
+    assert cfg.model.mtl.shared_feature == "classifier_feature_maps"
+    model = model_builder.build(cfg.model, True, "cuda", seed=3)
+    assert isinstance(model, rfcn.RFCNMetaArch) and model._shared_classifier
+    names = set(model.ps.state_dict())
+    assert not any(n.startswith("ClosenessBoxPredictor/resnet") for n in names)            # no closeness tower
+    assert any(n.startswith("WindowBoxPredictor/resnet_v1_50/block4") for n in names)        # the window head keeps its own
+    assert "ClosenessBoxPredictor/class_predictions/weights" in names
+    tr = trainer.Trainer(model, cfg.train_config, 1)
+    batch = synthetic.make_batch(2, 160, 224, 5, seed=11, device="cuda", max_gt=4, num_windows=6)
+    values = model.ps.state_dict()
+    reports = {}
+    model.ps.grad_ready_hook = lambda sp: reports.__setitem__(sp.name, reports.get(sp.name, 0) + 1)
+    losses = tr.forward_backward(batch)
+    model.ps.grad_ready_hook = None
+    assert reports == {sp.name: 1 for sp in model.ps.trainable_specs}, \
+        [n for n in set(reports) ^ {sp.name for sp in model.ps.trainable_specs}][:5]
+    torch.cuda.synchronize()
+    got = {k: float(v.item()) for k, v in losses.items()}
+    hb = dict(batch)
+    hb["images"] = batch["images"].cpu().numpy()
+    ref, rgrads, _ = parity_report.oracle_on_device_rpn(Oracle, bench.hyper_params_for_oracle(cfg), values, hb, model.seed, 0, tr._pd)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
+    grads = model.ps.grads_dict()
+    l2 = []
+    for n, gv in grads.items():
+        r = rgrads.get(n)
+        if r is None or not np.any(r):
+            assert not np.any(gv), n
+            continue
+        e = float(np.linalg.norm((gv - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-12))
+        assert e < 5e-3, (n, e)
+        l2.append(e)
+    assert len(l2) > 50 and np.median(l2) < 1e-3
+    tower = [n for n in grads if n.startswith("WindowBoxPredictor/resnet_v1_50/block4") and n.endswith("weights")]
+    assert len(tower) == 10
+    if stop == "true":      # the gradient stops at the window tower's output: its filters see nothing, the predictor trains
+        assert not any(np.any(grads[n]) for n in tower)
+        assert np.any(grads["WindowBoxPredictor/class_predictions/weights"])
+    else:
+        assert all(np.any(grads[n]) for n in tower)
+    parity_report.gradients("R-FCN shared classifier_feature_maps (%s) 160x224" % ("stopped" if stop == "true" else "with gradient"),
+                            {k: v for k, v in grads.items() if k in rgrads and np.any(rgrads[k])}, rgrads, got, ref)
+    tr.apply_gradients()
+    assert np.isfinite(model.ps.weights.sum().item())

@@ -38,7 +38,7 @@ model {
     first_stage_only: %(first_only)s
     %(miner)s
     image_resizer { keep_aspect_ratio_resizer { min_dimension: 160 max_dimension: 224 } }
-    feature_extractor { type: 'faster_rcnn_resnet50' first_stage_features_stride: 16 weight_decay: 0.0 }
+    feature_extractor { type: 'faster_rcnn_resnet50' first_stage_features_stride: 16 weight_decay: 0.0 %(fe_extra)s }
     first_stage_anchor_generator { grid_anchor_generator {
       scales: [0.25, 0.5, 1.0] aspect_ratios: [0.5, 1.0, 2.0] height_stride: 16 width_stride: 16 } }
     first_stage_box_predictor_conv_hyperparams { op: CONV
@@ -61,7 +61,7 @@ train_config { batch_size: 2
 """
 
 BASE = dict(refine="true", window="true", closeness="true", refine_layers=0, refine_keep="1.0", stop="true",
-            shared="proposal_feature_maps", win_avg="true", first_only="false", main_extra="", miner="")
+            shared="proposal_feature_maps", win_avg="true", first_only="false", main_extra="", miner="", fe_extra="")
 CASES = {
     "refiner_fc_stack_with_dropout": dict(refine_layers=2, refine_keep="0.7"),
     "predictor_extra_layers_with_dropout": dict(
@@ -75,6 +75,10 @@ CASES = {
     # (faster_rcnn_meta_arch.py:475, :1118); with mtl.refine the reference cannot build its loss (:1828-1832), so off
     "hard_example_miner_both": dict(
         refine="false", miner="hard_example_miner { num_hard_examples: 6 iou_threshold: 0.5 loss_type: BOTH }"),
+    # resnet_arg_scope(batch_norm_trainable=True) (models/faster_rcnn_resnet_v1_feature_extractor.py:131,169;
+    # slim/nets/resnet_utils.py:203-237): gamma / beta of EVERY BatchNorm train — also those of the frozen root conv
+    # and of frozen block1 — on the moving statistics
+    "resnet_batch_norm_trainable": dict(fe_extra="batch_norm_trainable: true"),
     "hard_example_miner_cls_all_survivors": dict(
         refine="false", miner="hard_example_miner { num_hard_examples: 0 iou_threshold: 0.3 loss_type: CLASSIFICATION }"),
 }
@@ -105,6 +109,16 @@ def test_switch_matches_the_oracle(case):
         assert not any("/FC_" in n for n in names)
     if case == "window_predictor_flatten":
         assert tuple(model.ps.value("WindowBoxPredictor/ClassPredictor/weights").shape) == (7 * 7 * 2048, 6)
+    if case == "resnet_batch_norm_trainable":
+        tn = {sp.name for sp in model.ps.trainable_specs}
+        fe = "FirstStageFeatureExtractor/resnet_v1_50/"
+        for n in (fe + "conv1/BatchNorm/gamma", fe + "block1/unit_1/bottleneck_v1/shortcut/BatchNorm/beta",
+                  fe + "block3/unit_2/bottleneck_v1/conv2/BatchNorm/gamma",
+                  "SecondStageFeatureExtractor/resnet_v1_50/block4/unit_3/bottleneck_v1/conv3/BatchNorm/gamma",
+                  "WindowBoxPredictor/resnet_v1_50/block4/unit_1/bottleneck_v1/shortcut/BatchNorm/beta"):
+            assert n in tn, n
+        assert fe + "conv1/weights" not in tn and fe + "block1/unit_1/bottleneck_v1/conv1/weights" not in tn   # filters stay frozen
+        assert not any("moving_" in n for n in tn)
     tr = trainer.Trainer(model, cfg.train_config, 1)
     batch = synthetic.make_batch(2, 160, 224, 5, seed=11, device="cuda", max_gt=4, num_windows=6, with_aux=True)
     values = model.ps.state_dict()
@@ -158,6 +172,20 @@ def test_switch_matches_the_oracle(case):
         assert e < 5e-3, (name, e)
         l2.append(e)
     assert len(l2) > 10 and np.median(l2) < 1e-3
+    if case == "resnet_batch_norm_trainable":
+        assert sum(1 for n in rgrads if "BatchNorm/" in n and n in grads and np.any(rgrads[n])) > 100
+        # a second step after the update: the folded constants AND the shadow copies of the FROZEN filters (root conv,
+        # block1) must follow the moved gamma / beta
+        tr.apply_gradients()
+        values2 = model.ps.state_dict()
+        moved = [n for n in values2 if "block1" in n and "BatchNorm/gamma" in n and not np.array_equal(values2[n], values[n])]
+        assert len(moved) >= 9
+        losses2 = tr.forward_backward(batch)
+        torch.cuda.synchronize()
+        got2 = {k: float(v.item()) for k, v in losses2.items()}
+        ref2, _, _ = parity_report.oracle_on_device_rpn(Oracle, bench.hyper_params_for_oracle(cfg), values2, hb, model.seed, 1, tr._pd)
+        for k in ref2:
+            assert abs(got2[k] - ref2[k]) <= 1e-3 * max(abs(ref2[k]), 1e-3), (k, got2[k], ref2[k])
     parity_report.gradients("switch %s (ResNet-50 160x224)" % case, {k: v for k, v in grads.items() if k in rgrads and np.any(rgrads[k])},
                             rgrads, got, ref)
     # and one optimizer step runs (every variable of the configuration has a slot in the fused update)
