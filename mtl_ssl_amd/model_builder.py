@@ -19,7 +19,19 @@ def _resnet(arch):
     return make
 
 
+def _no_batch_statistics(fe_cfg):
+    """For the MobileNet / Inception-ResNet-v2 extractors `batch_norm_trainable` is not the ResNet extractor's meaning
+    (trainable gamma / beta on moving statistics): it switches slim.batch_norm to TRAINING mode — batch statistics and
+    moving-average updates (models/faster_rcnn_mobilenet_v1_feature_extractor.py:89,127,168;
+    faster_rcnn_inception_resnet_v2_feature_extractor.py:59). Not built (no paper config sets it): a clear error instead
+    of a silently different model."""
+    if bool(fe_cfg.batch_norm_trainable):
+        raise ValueError("feature_extractor.batch_norm_trainable: true means batch-statistics BatchNorm for %s; this build "
+                         "runs its normalisers on the moving statistics only" % fe_cfg.type)
+
+
 def _mobilenet(ps, fe_cfg, is_training):
+    _no_batch_statistics(fe_cfg)
     kwargs = {}
     if fe_cfg.has("weight_decay"):
         kwargs["weight_decay"] = float(fe_cfg.weight_decay)
@@ -28,6 +40,7 @@ def _mobilenet(ps, fe_cfg, is_training):
 
 
 def _inception_resnet_v2(ps, fe_cfg, is_training):
+    _no_batch_statistics(fe_cfg)
     kwargs = {}
     if fe_cfg.has("weight_decay"):
         kwargs["weight_decay"] = float(fe_cfg.weight_decay)

@@ -61,6 +61,41 @@ def test_model_builder_rejects_unknown_types():
         model_builder.build(cfg.model, True, "cpu")
 
 
+def test_batch_norm_trainable_by_extractor_family():
+    """ResNet: gamma / beta of every BatchNorm — frozen root conv and frozen block1 included — become trainable variables
+    on the moving statistics (models/faster_rcnn_resnet_v1_feature_extractor.py:131,169; slim/nets/resnet_utils.py:203-237).
+    MobileNet / Inception-ResNet-v2: the flag means batch-statistics BatchNorm there (…mobilenet…:89,127; …inception…:59):
+    a clear error, never a silently different model."""
+    from mtl_ssl_amd import config, model_builder
+    from mtl_ssl_amd.params import ParamStore
+    text = open(os.path.join(ROOT, "configs", "frcnn_resnet101_coco_mtl.config")).read()
+    assert "type: 'faster_rcnn_resnet101'" in text
+    cfg = config.parse_pipeline_config(text.replace("type: 'faster_rcnn_resnet101'",
+                                                    "type: 'faster_rcnn_resnet101' batch_norm_trainable: true"))
+    fe_cfg = cfg.model.faster_rcnn.feature_extractor
+    ps = ParamStore()
+    fe = model_builder.FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP["faster_rcnn_resnet101"](ps, fe_cfg, True)
+    tower = fe.box_classifier_tower("SecondStageFeatureExtractor", True)
+    by = {sp.name: sp for sp in ps.specs}
+    p = "FirstStageFeatureExtractor/resnet_v1_101/"
+    assert by[p + "conv1/BatchNorm/gamma"].trainable and by[p + "block1/unit_2/bottleneck_v1/conv2/BatchNorm/beta"].trainable
+    assert not by[p + "conv1/weights"].trainable and not by[p + "block1/unit_2/bottleneck_v1/conv2/weights"].trainable
+    assert by[p + "block3/unit_23/bottleneck_v1/conv3/BatchNorm/gamma"].trainable
+    assert by["SecondStageFeatureExtractor/resnet_v1_101/block4/unit_3/bottleneck_v1/conv3/BatchNorm/beta"].trainable
+    assert not any(sp.trainable for sp in ps.specs if "moving_" in sp.name)
+    assert fe.first_trainable == 0 and tower.stack.units[0].bn_trainable
+    ps2 = ParamStore()                                   # inference replica: nothing trains
+    model_builder.FASTER_RCNN_FEATURE_EXTRACTOR_CLASS_MAP["faster_rcnn_resnet101"](ps2, fe_cfg, False)
+    assert not any(sp.trainable for sp in ps2.specs)
+    for name, typ in (("frcnn_mobilenet_v1_voc_mtl.config", "frcnn_mobilenet_v1"),
+                      ("frcnn_inception_resnet_v2_coco_mtl.config", "faster_rcnn_inception_resnet_v2")):
+        t = open(os.path.join(ROOT, "configs", name)).read()
+        assert "type: '%s'" % typ in t, name
+        c = config.parse_pipeline_config(t.replace("type: '%s'" % typ, "type: '%s' batch_norm_trainable: true" % typ))
+        with pytest.raises(ValueError, match="batch-statistics"):
+            model_builder.build(c.model, True, "cpu")
+
+
 def test_param_store_layout_and_reference_names():
     from mtl_ssl_amd import frcnn, model_builder
     from mtl_ssl_amd.params import ParamStore
