@@ -31,7 +31,10 @@ def test_bench_line_contract_single_gpu():
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-6 and 0.2 < ro["frac"] < 1.0
     assert ro["traffic"] is None or ro["traffic"] > 1e8
     iso = ro["isolated"]
-    assert 0.6 < iso["frac"] < 1.0 and iso["frac"] > ro["frac"] and iso["avg_launch_us"] < ro["avg_launch_us"]
+    # since round 5 the forward chains of large GEMMs run one after the other: the launches of the roofline
+    # kernel have the chip to themselves inside the step too, so the in-step rate is the isolated rate up to noise
+    # (rounds 3-4: 0.59 in the step against 0.80 alone)
+    assert 0.6 < iso["frac"] < 1.0 and 0.6 < ro["frac"] < 1.0 and ro["frac"] > 0.9 * iso["frac"]
     assert abs(ro["frac_isolated"] - iso["frac"]) < 1e-9
     ws = d["whole_step"]
     assert 0.3 < ws["executed_over_fp32_mfma_peak"] < 1.0 and ws["executed_mfma_tflop_per_step"] > 5
