@@ -26,13 +26,14 @@ torch.cuda.synchronize()
 a1, r1, peak = torch.cuda.memory_allocated(), torch.cuda.memory_reserved(), torch.cuda.max_memory_allocated()
 print("allocated %.2f -> %.2f GB, reserved %.2f -> %.2f GB, peak allocated %.2f GB, loss %.3f" % (
     a0 / 1e9, a1 / 1e9, r0 / 1e9, r1 / 1e9, peak / 1e9, float(sum(v.item() for v in losses.values()))))
-# live tensors must not accumulate; the caching allocator's RESERVE keeps growing for ~250 steps while the detector trains
-# (proposal / refine-window counts, and with them tensor sizes, change; three streams have a pool each) and then stays at
-# ~53 GB for configs[1] (tools/mem_soak.py, profiles/r04_mem_soak.txt) — bounded well inside the part's 288 GB
+# live tensors must not accumulate. The caching allocator's RESERVE is a function of how far the launch thread runs
+# ahead of the device (every step in flight pins its record_stream'd temporaries): unbounded (rounds 1-4) it reached
+# 52 GB for 9.8 GB live within 40 steps; with Trainer's default of two steps in flight (MTLSSL_MAX_STEPS_IN_FLIGHT) it
+# stays at 24.3 GB at the same step time (profiles/r05_steps_in_flight.txt)
 assert a1 <= a0 * 1.01 + 1e6, "live memory grows across steps"
-# the measured plateau (profiles/r04_mem_soak.txt: 52.6 GB reserved for 10.3 GB live after 1 500 steps) with 30 % margin,
-# and relative to the live bytes so that the check does not depend on the part's HBM size
-PLATEAU_RESERVED, PLATEAU_LIVE = 52.6e9, 10.3e9
+# the measured plateau (profiles/r05_steps_in_flight.txt: 24.3 GB reserved for 9.8 GB live, two steps in flight) with
+# 30 % margin, and relative to the live bytes so that the check does not depend on the part's HBM size
+PLATEAU_RESERVED, PLATEAU_LIVE = 24.3e9, 9.8e9
 assert r1 < 1.3 * PLATEAU_RESERVED, "allocator reserve beyond 1.3x the measured plateau (%.1f GB)" % (r1 / 1e9)
 assert r1 < 1.3 * (PLATEAU_RESERVED / PLATEAU_LIVE) * max(a1, peak), "reserve / live ratio beyond 1.3x the measured one"
 if steps >= 20:
