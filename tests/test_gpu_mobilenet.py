@@ -157,6 +157,7 @@ def test_mobilenet_step_matches_oracle():
     first = tr.step(batch)
     for _ in range(4):
         last = tr.step(batch)
+    assert tr.max_steps_in_flight == 2 and len(tr._step_events) == 2      # the launch thread stays <= 2 steps ahead
     assert np.isfinite(model.ps.weights.sum().item())
     l0 = model._feature_extractor.stages[0]
     ps = model.ps
