@@ -16,7 +16,15 @@ f32 = torch.float32
 i32 = torch.int32
 
 
+# torch.cuda.current_stream() builds a Stream object through five Python frames (~3 us; 340 calls per MobileNet step
+# were a third of that configuration's launch-thread time, tools/lab/host_profile.py); the raw handle is one C call
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -37,7 +45,7 @@ def workspace(nbytes, key="default", device=None):
     that no entry point can get by on what an earlier call left in its workspace."""
     device = device or torch.device("cuda", torch.cuda.current_device())
     # one buffer per (purpose, device, stream): kernels on different streams may run concurrently
-    k = (key, device.index, torch.cuda.current_stream().cuda_stream)
+    k = (key, device.index, _stream())
     buf = _ws_cache.get(k)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

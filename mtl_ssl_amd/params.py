@@ -153,13 +153,23 @@ class ParamStore:
     def _view(self, buf, s):
         return buf[s.offset:s.offset + s.size].view(s.shape)
 
+    # value() / grad() are called a few hundred times per step by the layers: the views are cached per (variable, flat
+    # buffer) — a buffer that is replaced (a restore, a new store) has another address and gets fresh views
+    def _cached_view(self, kind, buf, s):
+        cache = self.__dict__.setdefault("_views", {})
+        key = (kind, s.name, buf.data_ptr())
+        v = cache.get(key)
+        if v is None:
+            v = cache[key] = self._view(buf, s)
+        return v
+
     def value(self, name):
         s = self.by_name[name]
-        return self._view(self.weights if s.trainable else self.frozen, s)
+        return self._cached_view(0, self.weights if s.trainable else self.frozen, s)
 
     def grad(self, name):
         s = self.by_name[name]
-        return self._view(self.grads, s) if s.trainable else None
+        return self._cached_view(1, self.grads, s) if s.trainable else None
 
     def state_dict(self):
         return {s.name: self.value(s.name).detach().cpu().numpy().copy() for s in self.specs}
