@@ -531,11 +531,13 @@ def main():
         info = comm.info()
         # ("torch-nccl (fallback)" = RCCL through torch's binding after the library's own dlopen of librccl failed: still RCCL)
         is_rccl = info["backend"] == "rccl" or "nccl" in str(info["backend"])
-        stand_in = not is_rccl or int(info["ranks"]) != world or torch.cuda.device_count() < world
+        # (no test on torch.cuda.device_count(): a launcher may show every rank ONE device; RCCL itself refuses two ranks
+        # on one device, so an N-rank RCCL communicator already means N devices)
+        stand_in = not is_rccl or int(info["ranks"]) != world
         if stand_in and not a.allow_stand_in:
             if rank == 0:
                 sys.stderr.write("bench.py: --gpus %d needs %d RCCL ranks on %d devices; this run has backend %r, %s ranks in "
-                                 "the communicator, %d visible device(s). Refusing (pass --allow-stand-in to run the "
+                                 "the communicator (%d device(s) visible to this rank). Refusing (pass --allow-stand-in to run the "
                                  "stand-in for debugging; its line is marked \"stand_in\": true)\n"
                                  % (world, world, world, info["backend"], info["ranks"], torch.cuda.device_count()))
             comm.close()
@@ -673,8 +675,7 @@ def main():
     }
     if dp is not None:
         out["data_parallel"] = dp
-        if world > 1 and (not (dp["backend"] == "rccl" or "nccl" in str(dp["backend"])) or dp["ranks_reported"] != [world] * world
-                          or torch.cuda.device_count() < world):
+        if world > 1 and (not (dp["backend"] == "rccl" or "nccl" in str(dp["backend"])) or dp["ranks_reported"] != [world] * world):
             out["stand_in"] = True
             out["metric"] = "STAND-IN, not a scaling point (%s, %d device(s)): %s" % (dp["backend"], torch.cuda.device_count(), out["metric"])
     step_s = dt / a.steps
