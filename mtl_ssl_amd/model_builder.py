@@ -20,11 +20,10 @@ def _resnet(arch):
 
 
 def _no_batch_statistics(fe_cfg):
-    """For the MobileNet / Inception-ResNet-v2 extractors `batch_norm_trainable` is not the ResNet extractor's meaning
-    (trainable gamma / beta on moving statistics): it switches slim.batch_norm to TRAINING mode — batch statistics and
-    moving-average updates (models/faster_rcnn_mobilenet_v1_feature_extractor.py:89,127,168;
-    faster_rcnn_inception_resnet_v2_feature_extractor.py:59). Not built (no paper config sets it): a clear error instead
-    of a silently different model."""
+    """For the MobileNet extractor `batch_norm_trainable` is not the ResNet extractor's meaning (trainable gamma / beta
+    on moving statistics): it switches slim.batch_norm to TRAINING mode — batch statistics and moving-average updates
+    (models/faster_rcnn_mobilenet_v1_feature_extractor.py:89,127,168). Not built (no paper config sets it): a clear
+    error instead of a silently different model."""
     if bool(fe_cfg.batch_norm_trainable):
         raise ValueError("feature_extractor.batch_norm_trainable: true means batch-statistics BatchNorm for %s; this build "
                          "runs its normalisers on the moving statistics only" % fe_cfg.type)
@@ -40,7 +39,10 @@ def _mobilenet(ps, fe_cfg, is_training):
 
 
 def _inception_resnet_v2(ps, fe_cfg, is_training):
-    _no_batch_statistics(fe_cfg)
+    # `batch_norm_trainable` is accepted and IGNORED, exactly like the reference: its Inception-ResNet-v2 extractor
+    # stores the flag (models/faster_rcnn_inception_resnet_v2_feature_extractor.py:59) and never reads it — both of its
+    # arg scopes force slim.batch_norm(is_training=False) (:105-106, :136-137), so a config with the flag builds the
+    # same variables and computes the same losses as one without it.
     kwargs = {}
     if fe_cfg.has("weight_decay"):
         kwargs["weight_decay"] = float(fe_cfg.weight_decay)
