@@ -38,8 +38,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # worst: cap on the per-variable relative L2 between the HIP path and the torch-CPU fp32 oracle (two fp32 evaluations:
-# two sets of ReLU / max-pool branch flips; which elements flip depends on the plans the on-line tuner picks on a given
-# box), set from the largest value observed over the round's runs (profiles/r0*_parity_report.txt: 3.1e-4, 2.2e-4,
+# two sets of ReLU / max-pool branch flips; the on-line tuner is OFF in the suite, so the kernels — and with them which
+# elements flip — are the same on every box), set from the largest value observed over the rounds' runs (profiles/r0*_parity_report.txt: 3.1e-4, 2.2e-4,
 # 3.5e-3, 7.1e-4, 9.1e-4, 1.0e-3 in the order below) with ~3x room;
 # f64: additionally judge every variable against a float64 evaluation of the same graph (<= 1e-3, the claim proper).
 CASES = {
@@ -170,9 +170,11 @@ def test_trained_state_step_matches_the_free_running_oracle():
     step is compared with the oracle FREE-RUNNING — its own trunk, its own RPN floats, its own decode -> sort -> NMS ->
     sampling — with nothing forced. Asserted: the RPN scores are in fact spread; the RPN floats agree to 1e-3; the
     oracle's chain ON THE DEVICE'S RPN FLOATS is bit-exact (counts, sampled boxes, detector matches); anchor targets /
-    sampler bit-exact (they do not depend on the RPN floats); losses 1e-3 and gradients on the device's boxes. How
-    many slots of the FREE-RUNNING oracle coincide is reported (two fp32 trunks differ by ~1e-6, and a greedy NMS
-    over thousands of candidate pairs has O(1) IoU comparisons within that of the 0.7 threshold). faster_rcnn_meta_arch.py:1055-1216, 1670-1793."""
+    sampler bit-exact (they do not depend on the RPN floats); losses 1e-3 and gradients on the device's boxes; and the
+    FREE-RUNNING oracle's sampled boxes coincide with the device's slot for slot in all but at most 4 of the 512 slots
+    (two fp32 trunks differ by ~1e-6, and a greedy NMS over thousands of candidate pairs has O(1) IoU comparisons within
+    that of the 0.7 threshold), with equal detector matches on the agreeing slots and free-running losses within 1e-3.
+    faster_rcnn_meta_arch.py:1055-1216, 1670-1793."""
     import __graft_entry__ as g
     g.build()
     import bench
@@ -221,26 +223,35 @@ def test_trained_state_step_matches_the_free_running_oracle():
     np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), auxf["num_proposals"])
     np.testing.assert_array_equal(mine, auxf["proposal_boxes"])
     np.testing.assert_array_equal(pd["_det_targets"]["match"].cpu().numpy(), auxf["det_match"])
-    # free-running: "the same box" = within 0.02 px: two decodes of RPN floats that agree to ~4e-6 differ by ~1e-3 px,
-    # while two DIFFERENT anchors' decodes that survive NMS against each other are pixels apart. Reported; the bound
-    # below only says that the two runs are looking at the same proposals (a greedy NMS over thousands of candidate
-    # pairs has O(1) IoU comparisons within 1e-6 of the 0.7 threshold).
+    # FREE-RUNNING (nothing forced: the oracle's own trunk / RPN floats through its own chain) — the one assertion that a
+    # trunk or RPN drift INSIDE the 1e-3 float tolerance which reorders proposals cannot pass. "The same box" = within
+    # 0.02 px: two decodes of RPN floats that agree to ~4e-6 differ by ~1e-3 px, while two DIFFERENT anchors' decodes that
+    # survive NMS against each other are pixels apart. A greedy NMS over thousands of candidate pairs has O(1) IoU
+    # comparisons within 1e-6 of the 0.7 threshold, hence "at most 4 slots" and not "none" (every committed lease log,
+    # profiles/r05_gpu_tests_lease*.txt, shows 512 of 512).
     tol = 0.02
     same = np.abs(mine - aux["proposal_boxes"]).max(-1) <= tol           # [B, N2]
     differing = int((~same).sum())
     a, b = aux["proposal_boxes"].reshape(-1, 4), mine.reshape(-1, 4)
     in_set = int((np.abs(a[:, None, :] - b[None, :, :]).max(-1) <= tol).any(1).sum())
-    assert in_set >= 0.9 * same.size, (differing, in_set)
+    assert differing <= 4, (differing, in_set)
+    assert in_set >= same.size - 4, (differing, in_set)
+    np.testing.assert_array_equal(pd["num_proposals"].cpu().numpy(), aux["num_proposals"])
     dm, rm = pd["_det_targets"]["match"].cpu().numpy().reshape(same.shape), aux["det_match"].reshape(same.shape)
+    np.testing.assert_array_equal(dm[same], rm[same])
     free_loss = 0.0
+    for k in ref:
+        free_loss = max(free_loss, abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-3))
     if not differing:
-        np.testing.assert_array_equal(dm, rm)
-        for k in ref:
-            free_loss = max(free_loss, abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-3))
+        # free-running losses: 1e-3 (the two runs crop at boxes that differ in the last bits)
+        assert free_loss <= 1e-3, free_loss
         chain = "every one of the %d slots agrees, det_match bit-exact, losses free-running within %.1e" % (same.size, free_loss)
     else:
+        # a differing slot is one RoI of 512 with another box: each loss is a mean over the RoIs
+        assert free_loss <= 1e-3 + 2.0 * differing / same.size, (free_loss, differing)
         chain = ("%d of %d slots differ (%d of the oracle's boxes found in the device's set): near-threshold NMS / "
-                 "near-tied scores" % (differing, same.size, in_set))
+                 "near-tied scores; det_match equal on the agreeing slots, losses free-running within %.1e" % (
+                     differing, same.size, in_set, free_loss))
     # the float comparison proper (losses 1e-3, gradients) on the device's own boxes (= the forced-RPN run's, bit for bit)
     ref, rgrads, aux = ref_f, rgrads_f, auxf
     worst_loss = 0.0

@@ -128,8 +128,8 @@ def test_switch_matches_the_oracle(case):
     hb = dict(batch)
     hb["images"] = batch["images"].cpu().numpy()
     pd = tr._pd
-    # The oracle's proposal chain runs on the DEVICE'S RPN floats (free-running agreement of the chain is
-    # tests/test_gpu_model.py's subject): identical inputs, so counts, sampled boxes and detector matches must come out
+    # The oracle's proposal chain runs on the DEVICE'S RPN floats (free-running agreement of the chain is asserted by
+    # tests/test_gpu_fullsize_parity.py::test_trained_state_step_matches_the_free_running_oracle): identical inputs, so counts, sampled boxes and detector matches must come out
     # bit for bit (asserted below). Reason for not comparing free-running here: a proposal clipped to the image border
     # has ymax = 1.0 exactly, so the last row of its crop samples sits at in_y = H - 1 up to the last bit of ymin — and
     # crop_and_resize switches from "interpolate" to "extrapolate with 0" right there; two fp32 trunks that agree to 1e-6
