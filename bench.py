@@ -104,12 +104,21 @@ def kernel_time_per_step(default_cfg):
     import re
     if not default_cfg:
         return None
+    try:
+        return _kernel_time_per_step(re)
+    except Exception as e:                          # a committed summary whose first line changed format: a side block
+        return {"error": "%s: %s" % (type(e).__name__, e)}       # like the others, never the whole bench line
+
+
+def _kernel_time_per_step(re):
     out = {}
     for key, suffix in (("overlapped_ms", "resnet101_kernel_stats.md"), ("serialised_ms", "resnet101_kernel_stats_serialised.md")):
         path = _latest_profile(suffix)
         if path is None:
             return None
         m = re.match(r"Total kernel time ([0-9.]+) ms over (\d+) dispatches", open(path).readline())
+        if m is None:
+            return {"error": "unrecognised first line in %s" % os.path.relpath(path, ROOT)}
         bj = path.replace("kernel_stats", "bench_profiled").replace(".md", ".json")
         steps = 12
         if os.path.exists(bj):

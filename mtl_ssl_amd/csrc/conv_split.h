@@ -25,6 +25,7 @@
 // K-steps ahead, one barrier per K-step. Loaders, split-K / batched / grouped variants and the epilogue are the
 // native engine's (conv_mfma.h).
 #pragma once
+#include <atomic>
 #include <mutex>
 
 #include "conv_mfma.h"
@@ -441,8 +442,17 @@ template <int MODE, bool BATCH>
 inline void launch_split(ConvArgs& p, dim3 extra, hipStream_t st, int tile_rows = -1) {
   // the kernels ask for more than 64 KB of LDS: per (device, kernel), checked (common.h); a refusal shows up as the
   // launch error of the call below with the reason in mtlssl_last_error()
-  (void)ensure_dynamic_lds((const void*)k_split256<MODE, BATCH, false>, split_lds_bytes(256), "split engine");
-  (void)ensure_dynamic_lds((const void*)k_split256<MODE, BATCH, true>, split_lds_bytes(256), "split engine");
+  // (per instantiation, a bitmask of the devices already done sits in front of ensure_dynamic_lds' mutex + map: this is a
+  // launch path). A refusal keeps its bit clear and the launch below then fails, which the entry point's check_launch reports.
+  static std::atomic<unsigned long long> done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;
+  if (!(done.load(std::memory_order_acquire) & bit) || !bit) {
+    const int rc0 = ensure_dynamic_lds((const void*)k_split256<MODE, BATCH, false>, split_lds_bytes(256), "split engine");
+    const int rc1 = ensure_dynamic_lds((const void*)k_split256<MODE, BATCH, true>, split_lds_bytes(256), "split engine");
+    if (rc0 == MTLSSL_OK && rc1 == MTLSSL_OK) done.fetch_or(bit, std::memory_order_release);
+  }
   p.tiles_m = tile_rows >= 0 ? tile_rows : (int)cdiv(p.M, SPLIT_BM);
   p.tiles_n = (int)cdiv(p.NG, SPLIT_BN);
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);

@@ -420,12 +420,10 @@ __global__ void __launch_bounds__(256)
     k_psroi_fwd(const float* __restrict__ fmap, int H, int W, int Ctot, const float* __restrict__ boxes,
                 const int32_t* __restrict__ box_ind, int bins_y, int bins_x, int bs_y, int bs_x, int Cc,
                 float* __restrict__ out) {
-  extern __shared__ float s_acc[];                 // [Cc]
+  extern __shared__ float s_part[];                // [bins_y * bins_x][Cc]: one partial per (bin, channel)
   int r = blockIdx.x;
   float4 bx = *reinterpret_cast<const float4*>(boxes + (int64_t)r * 4);
   const float* fb = fmap + (int64_t)box_ind[r] * H * W * Ctot;
-  for (int c = threadIdx.x; c < Cc; c += blockDim.x) s_acc[c] = 0.f;
-  __syncthreads();
   int nb = bins_y * bins_x;
   float step_y = (bx.z - bx.x) / (float)bins_y, step_x = (bx.w - bx.y) / (float)bins_x;
   for (int t = threadIdx.x; t < nb * Cc; t += blockDim.x) {
@@ -453,11 +451,17 @@ __global__ void __launch_bounds__(256)
         acc += top + (bot - top) * yl;
       }
     }
-    atomicAdd(&s_acc[c], acc);                       // LDS atomic; 9 bins per channel
+    s_part[t] = acc;                                 // t = g * Cc + c: its only writer
   }
   __syncthreads();
+  // the bins of a channel are summed in bin order by one thread: a fixed order, so two runs give the same bits (an LDS
+  // float atomic here made the R-FCN step's last bits depend on the wave schedule)
   float inv = 1.f / (float)(nb * bs_y * bs_x);
-  for (int c = threadIdx.x; c < Cc; c += blockDim.x) out[(int64_t)r * Cc + c] = s_acc[c] * inv;
+  for (int c = threadIdx.x; c < Cc; c += blockDim.x) {
+    float s = 0.f;
+    for (int g = 0; g < nb; ++g) s += s_part[g * Cc + c];
+    out[(int64_t)r * Cc + c] = s * inv;
+  }
 }
 // Backward as a gather: one block per score-map pixel, a thread per channel. A channel belongs to one bin of every
 // RoI; the bilinear weights a bin's bs_y x bs_x samples put on pixel (y, x) factor into (sum over the sample rows
@@ -1243,7 +1247,7 @@ int mtlssl_psroi_fwd(const float* fmap, int B, int H, int W, int C, const float*
   MTLSSL_REQUIRE(C % (bins_y * bins_x) == 0, "depth must be divisible by the number of bins");
   if (R == 0) return MTLSSL_OK;
   int Cc = C / (bins_y * bins_x);
-  hipLaunchKernelGGL(k_psroi_fwd, dim3(R), dim3(256), sizeof(float) * Cc, S(stream), fmap, H, W, C, boxes,
+  hipLaunchKernelGGL(k_psroi_fwd, dim3(R), dim3(256), sizeof(float) * Cc * bins_y * bins_x, S(stream), fmap, H, W, C, boxes,
                      box_ind, bins_y, bins_x, crop_h / bins_y, crop_w / bins_x, Cc, out);
   return check_launch("psroi_fwd");
 }
@@ -1304,7 +1308,10 @@ int mtlssl_maxpool_bwd(const float* x, const float* y, const float* dy, float* d
   if (!total) return MTLSSL_OK;
   if (k > stride) {
     int64_t tin = (int64_t)N * H * W * C;
-    if (C % 4 == 0)
+    // the float4 kernel reinterprets all four tensors: 16-byte bases (a view with an odd storage offset takes the scalar one)
+    const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) |
+                        reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    if (C % 4 == 0 && al16)
       hipLaunchKernelGGL(k_maxpool_bwd_gather4, dim3(cdiv(tin / 4, 256)), dim3(256), 0, S(stream), x, y, dy, dx, H, W,
                          C / 4, k, stride, pt, pl, OH, OW, tin / 4);
     else

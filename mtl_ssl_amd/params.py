@@ -107,6 +107,7 @@ class ParamStore:
         self.weights = torch.from_numpy(host_t).to(self.device)
         self.frozen = torch.from_numpy(host_f).to(self.device)
         self.grads = torch.zeros_like(self.weights)
+        self.invalidate_views()
         # True only while the buffer is known to hold zeros (a zeroing optimizer launch was its last writer): the next
         # step then skips its memset. The flag lives with the buffer, not with a Trainer — anyone who writes `grads`
         # by hand (a benchmark, a test, a second Trainer on the same store) calls mark_grads_dirty()
@@ -154,7 +155,13 @@ class ParamStore:
         return buf[s.offset:s.offset + s.size].view(s.shape)
 
     # value() / grad() are called a few hundred times per step by the layers: the views are cached per (variable, flat
-    # buffer) — a buffer that is replaced (a restore, a new store) has another address and gets fresh views
+    # buffer) — a buffer that is replaced (a restore, a new store) has another address and gets fresh views. The returned
+    # tensors are SHARED between all callers: never change a view's metadata in place (resize_, set_, as_strided_).
+    # Whoever assigns weights / grads / frozen / accum afresh calls invalidate_views(), which also drops the stale
+    # entries that would otherwise keep the replaced storage alive.
+    def invalidate_views(self):
+        self.__dict__.pop("_views", None)
+
     def _cached_view(self, kind, buf, s):
         cache = self.__dict__.setdefault("_views", {})
         key = (kind, s.name, buf.data_ptr())
