@@ -134,6 +134,27 @@ def _kernel_time_per_step(re):
     return out
 
 
+def overlap_text(tr):
+    """What runs beside the roofline kernel's launches in the timed region, from the schedule switches actually on
+    (read at call time by frcnn.py)."""
+    beside = []
+    if os.environ.get("MTLSSL_AUX_STREAM", "1") != "0":
+        if os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "0") == "1":
+            beside.append("the closeness tower's forward on the aux stream (MTLSSL_CLOSENESS_FWD_SIDE=1)")
+        if os.environ.get("MTLSSL_REFINE_EARLY", "0") == "1":
+            beside.append("the refiner's window pass on the third stream (MTLSSL_REFINE_EARLY=1)")
+        if getattr(tr, "split_loss", False):
+            beside.append("the early loss terms' small latency-bound kernels (target assignment, samplers, reductions) on the "
+                          "aux stream under the refiner's tower forward (MTLSSL_SPLIT_LOSS, default on)")
+    if not beside:
+        return ("in the timed region every forward chain runs on the main stream (both forward overlaps are off by default "
+                "since round 5): each launch of this kernel has the chip to itself, `isolated` (every side stream off) is the "
+                "same schedule for this kernel")
+    return ("in the timed region the forward chains are serial on the main stream (MTLSSL_CLOSENESS_FWD_SIDE / "
+            "MTLSSL_REFINE_EARLY off by default since round 5); beside this kernel's launches run only: " + "; ".join(beside)
+            + ". `isolated` is the same kernel on the same problems with every side stream off")
+
+
 def pmc_traffic(default_cfg):
     """HBM bytes per launch of the roofline kernel. PMC counters cannot be read from inside the
     process being timed, so this is the committed result of the separate `rocprofv3 --pmc FETCH_SIZE`
@@ -494,6 +515,8 @@ def main():
                     help="skip the stand-alone timing of the HBM-bound kernels (keeps a rocprofv3 trace to the steps)")
     ap.add_argument("--roofline-isolated-steps", type=int, default=4,
                     help="extra steps with the forward streams serialised, for roofline.isolated (0 = skip)")
+    ap.add_argument("--join-steps", type=int, default=6,
+                    help="extra steps with HIP-event pairs around the main stream's joins, for whole_step.main_stream_idle_ms (0 = skip)")
     ap.add_argument("--conv-breakdown", action="store_true",
                     help="time every conv launch (adds ~2%% to the step) and report the per-kernel table")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -708,6 +731,29 @@ def main():
                 "zero-padded widths included; tile-padding rows not), per rank; direct_algorithm = the same layers priced "
                 "as direct convolutions (SURVEY.md §8d counts 4.93 TFLOP/image that way)",
     }
+    if world == 1 and comm is None and a.join_steps > 0:
+        # How long the main stream has no kernel of its own because it waits for a side stream, measured UN-PROFILED:
+        # a HIP-event pair around each join of the step (ops.wait_on; a dozen pairs per step) over a few extra steps.
+        # The launch thread runs a whole step ahead of the device (launch_thread_lead_ms_at_end), so launch gaps are not
+        # host-bound and the joins are where the stream can stall; rocprofv3's own figure (inflated by its per-launch
+        # overhead) is tools/step_timeline.py's "waiting" line in profiles/rNN_resnet101_non_conv_breakdown.md.
+        try:
+            ops.JOIN_TIMER = ops.JoinTimer()
+            t1 = time.perf_counter()
+            for _ in range(a.join_steps):
+                tr.step(next_batch())
+            torch.cuda.synchronize()
+            j_ms = 1e3 * (time.perf_counter() - t1) / a.join_steps
+            jt, ops.JOIN_TIMER = ops.JOIN_TIMER, None
+            js = jt.summary(a.join_steps)
+            out["whole_step"]["main_stream_idle_ms"] = js["total_ms_per_step"]
+            out["whole_step"]["main_stream_joins"] = {
+                "by_join_ms_per_step": js["by_join"], "steps": a.join_steps, "ms_per_step_of_these_steps": round(j_ms, 3),
+                "how": "hipEventElapsedTime between an event recorded on the main stream just before and just after each "
+                       "wait on a side stream / event (mtl_ssl_amd/ops.py wait_on), summed per step; not under a profiler"}
+        except Exception as e:
+            ops.JOIN_TIMER = None
+            out["whole_step"]["main_stream_joins"] = {"error": repr(e)}
     if prof is not None:
         s = prof.summary()
         dom = s.get((ops.ConvProfiler.MODES[dom_key[0]], dom_key[1], dom_key[2]))
@@ -746,11 +792,7 @@ def main():
             iso = ops.PROFILER.summary().get(("fwd", 0, True))
             ops.PROFILER = None
             if iso and iso["seconds"] > 0:
-                out["roofline"]["overlap"] = (
-                    "in the timed region the launches of this kernel run next to other streams' large-tile launches "
-                    "(closeness tower beside the main tower, refiner window pass beside both): achieved / frac / "
-                    "avg_launch_us above are per launch WHILE SHARING the chip; `isolated` is the same kernel on the same "
-                    "problems with every side stream off")
+                out["roofline"]["overlap"] = overlap_text(tr)
                 out["roofline"]["frac_isolated"] = iso["flops"] / iso["seconds"] / FP32_MFMA_PEAK
                 out["roofline"]["isolated"] = {
                     "achieved": iso["flops"] / iso["seconds"] / 1e12, "frac": iso["flops"] / iso["seconds"] / FP32_MFMA_PEAK,

@@ -31,7 +31,7 @@ typedef void* mtlssl_stream_t; /* hipStream_t */
 
 /* Bumped whenever a prototype below changes; mtlssl_abi_version() of the loaded library must equal it (the ctypes
  * loader checks: an older build called through a newer header would receive shifted arguments). */
-#define MTLSSL_ABI_VERSION 6
+#define MTLSSL_ABI_VERSION 7
 
 const char* mtlssl_last_error(void);
 int mtlssl_abi_version(void);
@@ -55,6 +55,13 @@ typedef struct {
   int32_t OH, OW;            /* output [N,OH,OW,K] */
   int32_t stride, dilation;
   int32_t pad_t, pad_l;
+  int32_t ldy;               /* row stride (floats) of the OUTPUT-side tensor: y of the forward, dy of dgrad / wgrad.
+                              * 0 (or K): dense [N,OH,OW,K]. > K: the tensor is the channel slice [c0, c0+K) of a wider
+                              * NHWC map with ldy channels and the y / dy pointer already points at channel c0 — this is
+                              * tf.concat(axis=3) folded into its producers and the consumers of its gradient
+                              * (slim/nets/inception_resnet_v2.py:46,67,88,185-186,213,253: every branch writes its slice
+                              * of the concatenated map; the backward reads its slice of the map's gradient in place).
+                              * ldy % 4 == 0 and a 16-byte aligned pointer are required; residual / mask / dx stay dense. */
 } mtlssl_conv_desc;
 
 #define MTLSSL_EPI_BIAS 1      /* + bias[k] (folded BN shift or conv bias)                  */
@@ -117,6 +124,12 @@ int mtlssl_conv2d_fwd_keep(const mtlssl_conv_desc* d, const float* x, const floa
                            int xf_variant, float* input_xf, int input_variant, mtlssl_stream_t stream);
 int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const float* dy,
                            const float* out_scale, float* dw, float* dbias, float beta,
+                           void* workspace, const float* input_xf, int input_variant, mtlssl_stream_t stream);
+/* The same with the bias gradient scaled per output channel too: dbias[k] = beta*dbias[k] + dbias_scale[k] * sum dy[:,k]
+ * (dbias_scale nullable = 1): a bias that reaches the layer through a folded per-channel factor — the residual scale of
+ * the Inception-ResNet blocks, net += scale * (conv(mixed) + b), slim/nets/inception_resnet_v2.py:47-52. */
+int mtlssl_conv2d_wgrad_ex(const mtlssl_conv_desc* d, const float* x, const float* dy,
+                           const float* out_scale, float* dw, float* dbias, const float* dbias_scale, float beta,
                            void* workspace, const float* input_xf, int input_variant, mtlssl_stream_t stream);
 /* dw[r,s,c,k] (beta=0: overwrite, beta=1: accumulate) = sum_pixels x*dy, optionally scaled
  * per output channel by out_scale[k] (frozen-BN fold) and dbias[k] = sum dy (nullable).
@@ -216,6 +229,15 @@ int mtlssl_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, int
 int mtlssl_maxpool_bwd(const float* x, const float* y, const float* dy, float* dx, int N, int H,
                        int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW,
                        mtlssl_stream_t stream);
+/* The pooling branch of a tf.concat(axis=3) (Mixed_6a / Mixed_7a Branch_2 / Branch_3, slim/nets/inception_resnet_v2.py:
+ * 200-213, 240-253): y (forward) and y / dy (backward) are the channel slice [c0, c0+C) of a wider NHWC map with `ldy`
+ * channels per pixel, the pointers already at channel c0; x / dx are dense. C % 4 == 0, ldy % 4 == 0, 16-byte aligned
+ * pointers, k in {2, 3}; the backward is the overlapping-window gather (k > stride). */
+int mtlssl_maxpool_fwd_strided(const float* x, float* y, int N, int H, int W, int C, int k, int stride,
+                               int pad_t, int pad_l, int OH, int OW, int ldy, mtlssl_stream_t stream);
+int mtlssl_maxpool_bwd_strided(const float* x, const float* y, const float* dy, float* dx, int N, int H,
+                               int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int ldy,
+                               mtlssl_stream_t stream);
 /* tf.reduce_mean over H,W (core/box_predictor.py:469-471) and its gradient. */
 int mtlssl_spatial_mean_fwd(const float* x, float* y, int N, int HW, int C, mtlssl_stream_t s);
 int mtlssl_spatial_mean_bwd(const float* dy, float* dx, int N, int HW, int C, mtlssl_stream_t s);

@@ -32,7 +32,8 @@ namespace mtlssl {
 // trainable BatchNorm beta on every one of its ~370 convolutions, i.e. one launch less per layer and step).
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* ws, int nsplit, int64_t total4, int K,
                                                       const float* scale, float* dw, float beta, int main_blocks,
-                                                      const float* cs_part, int cs_chunks, float* dbias) {
+                                                      const float* cs_part, int cs_chunks, float* dbias,
+                                                      const float* dbias_scale) {
   if ((int)blockIdx.x >= main_blocks) {
     const int lane = threadIdx.x & 63;
     const int k = ((int)blockIdx.x - main_blocks) * 4 + (threadIdx.x >> 6);
@@ -40,6 +41,7 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* ws, int nspli
     float s = 0.f;
     for (int c = lane; c < cs_chunks; c += 64) s += cs_part[(int64_t)c * K + k];
     s = wave_sum(s);
+    if (dbias_scale) s *= dbias_scale[k];
     if (lane == 0) dbias[k] = beta != 0.f ? beta * dbias[k] + s : s;
     return;
   }
@@ -326,7 +328,7 @@ __global__ void k_small_reduce(const float* ws, int nsplit, int64_t total, int K
 // reduction is latency- before it is bandwidth-bound on the B=1/B=2 feature maps. The fold gives one
 // wavefront to each channel (lanes stride over the chunks, butterfly sum): deterministic, no atomics.
 template <typename VT>
-__global__ void __launch_bounds__(256) k_colsum_partial(const float* dy, int rows, int K, int rows_per_chunk,
+__global__ void __launch_bounds__(256) k_colsum_partial(const float* dy, int rows, int K, int ld, int rows_per_chunk,
                                                         int CQ, float* part) {
   constexpr int VW = sizeof(VT) / 4;
   const int KG = (K + VW - 1) / VW, PL = 256 / CQ;
@@ -337,8 +339,8 @@ __global__ void __launch_bounds__(256) k_colsum_partial(const float* dy, int row
   if (g < KG) {
     const float* b = dy + g * VW;
     for (int r = r0 + sub; r < r1; r += 2 * PL) {
-      VT v0 = *reinterpret_cast<const VT*>(b + (int64_t)r * K);
-      VT v1 = r + PL < r1 ? *reinterpret_cast<const VT*>(b + (int64_t)(r + PL) * K) : VT{};
+      VT v0 = *reinterpret_cast<const VT*>(b + (int64_t)r * ld);
+      VT v1 = r + PL < r1 ? *reinterpret_cast<const VT*>(b + (int64_t)(r + PL) * ld) : VT{};
       acc += v0;
       acc += v1;
     }
@@ -353,13 +355,15 @@ __global__ void __launch_bounds__(256) k_colsum_partial(const float* dy, int row
     *reinterpret_cast<VT*>(part + (int64_t)blockIdx.y * K + g * VW) = v;
   }
 }
-__global__ void __launch_bounds__(256) k_colsum_fold(const float* part, int chunks, int K, float* out, float beta) {
+__global__ void __launch_bounds__(256) k_colsum_fold(const float* part, int chunks, int K, float* out, float beta,
+                                                     const float* out_scale) {
   const int lane = threadIdx.x & 63;
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (k >= K) return;
   float s = 0.f;
   for (int c = lane; c < chunks; c += 64) s += part[(int64_t)c * K + k];
   s = wave_sum(s);
+  if (out_scale) s *= out_scale[k];
   if (lane == 0) out[k] = beta != 0.f ? beta * out[k] + s : s;
 }
 constexpr int COLSUM_MAX_PARTS = 2048;
@@ -450,7 +454,16 @@ static ConvArgs make_args(const mtlssl_conv_desc* d) {
   p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.K = d->K; p.R = d->R; p.S = d->S;
   p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.dil = d->dilation; p.pt = d->pad_t;
   p.pl = d->pad_l;
+  p.ldy = d->ldy > 0 ? d->ldy : d->K;
   return p;
+}
+// row stride of the output-side tensor (y / dy) and whether it is the dense [.., K] form
+static inline int desc_ldy(const mtlssl_conv_desc* d) { return d->ldy > 0 ? d->ldy : d->K; }
+static inline bool desc_dense(const mtlssl_conv_desc* d) { return desc_ldy(d) == d->K; }
+// bytes from the y / dy pointer to the end of its last row (buffer range of the strided tensor)
+static inline unsigned ydy_bytes(const mtlssl_conv_desc* d) {
+  const int64_t P = (int64_t)d->N * d->OH * d->OW;
+  return (unsigned)(((P - 1) * desc_ldy(d) + d->K) * 4);
 }
 
 static inline bool cfg_allowed(int c, int kc) { return kc % CFG_BK[c] == 0; }
@@ -461,8 +474,10 @@ static int check_desc(const mtlssl_conv_desc* d) {
                      d->OH > 0 && d->OW > 0 && d->stride > 0 && d->dilation > 0,
                  "conv: non-positive dimension");
   MTLSSL_REQUIRE((int64_t)d->N * d->H * d->W * d->C < (1ll << 30) &&
-                     (int64_t)d->N * d->OH * d->OW * d->K < (1ll << 30),
+                     (int64_t)d->N * d->OH * d->OW * desc_ldy(d) < (1ll << 30),
                  "conv: tensor exceeds 2^30 elements (32-bit buffer offsets)");
+  MTLSSL_REQUIRE(d->ldy == 0 || (d->ldy >= d->K && d->ldy % 4 == 0 && d->K % 4 == 0),
+                 "conv: ldy = %d must be 0 or a multiple of 4 that is >= K = %d (K % 4 == 0)", d->ldy, d->K);
   return MTLSSL_OK;
 }
 
@@ -502,6 +517,8 @@ __global__ void k_splitk_epilogue(ConvArgs p) {
       if (p.epi & MTLSSL_EPI_RELU6) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
       if (p.epi & MTLSSL_EPI_TANH) v[e] = tanhf(v[e]);
     }
+    const int ldy = args_ldy(p);
+    if (ldy != p.NG) o = (o / p.NG) * ldy + col;       // y is a channel slice of a wider map
   } else {
     if (p.epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const floatx4*>(p.residual + o);
     if (p.epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const floatx4*>(p.out + o);
@@ -530,6 +547,8 @@ __global__ void k_splitk_epilogue_scalar(ConvArgs p) {
     if (p.epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
     if (p.epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
     if (p.epi & MTLSSL_EPI_TANH) v = tanhf(v);
+    p.out[(i / p.NG) * args_ldy(p) + col] = v;
+    return;
   } else {
     if (p.epi & MTLSSL_EPI_RESIDUAL) v += p.residual[i];
     if (p.epi & MTLSSL_EPI_ACCUM) v += p.out[i];
@@ -669,6 +688,7 @@ static DescKey desc_key(const mtlssl_conv_desc* d, int mode) {
   DescKey k;
   memset(&k, 0, sizeof(k));
   k.d = *d; k.mode = mode;
+  k.d.ldy = 0;                   // plans do not depend on the row stride of y / dy
   return k;
 }
 struct PlanMemo { Plan plan; double t; };
@@ -853,7 +873,8 @@ static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st, int ti
 template <int MODE>
 static void launch_planned(const Plan& pl, ConvArgs& p, float* ws, hipStream_t st) {
   p.splitk_ws = ws;
-  if (pl.nsplit == 1 && split_engine_takes(pl.cfg, p.M, p.NG, (int64_t)p.R * p.S * (MODE == MODE_FWD ? p.C : p.K))) {
+  if (pl.nsplit == 1 && args_ldy(p) == p.K &&
+      split_engine_takes(pl.cfg, p.M, p.NG, (int64_t)p.R * p.S * (MODE == MODE_FWD ? p.C : p.K))) {
     p.nsplit = 1; p.ks_per_split = 0; p.tile_m0 = 0; p.ws_m0 = 0;     // one launch over every tile, no K-split tail
     launch_split<MODE, false>(p, dim3(1, 1, 1), st);
     return;
@@ -881,7 +902,7 @@ static void launch_planned(const Plan& pl, ConvArgs& p, float* ws, hipStream_t s
   ConvArgs f = q;                       // fold: the tail rows as a matrix of their own
   const int64_t off = (int64_t)q.ws_m0 * p.NG;
   f.M = p.M - q.ws_m0;
-  f.out = p.out + off;
+  f.out = p.out + (MODE == MODE_FWD ? (int64_t)q.ws_m0 * args_ldy(p) : off);
   if (p.residual) f.residual = p.residual + off;
   if (p.mask) f.mask = p.mask + off;
   hipLaunchKernelGGL(k_splitk_epilogue<MODE>, dim3(cdiv((int64_t)f.M * f.NG / 4, 256)), dim3(256), 0, st, f);
@@ -1126,7 +1147,8 @@ static void parity_dgrad(const mtlssl_conv_desc* d, const float* dy, const float
       p.N = d->N; p.H = q.Hs; p.W = q.Ws; p.C = d->C; p.K = d->K; p.R = q.Rs; p.S = q.Ss;
       p.OH = d->OH; p.OW = d->OW; p.stride = 1; p.dil = 1; p.pt = q.a; p.pl = q.b;
       p.a = dy; p.b = wsub; p.out = tmp; p.epi = 0;
-      p.a_bytes = (unsigned)((int64_t)d->N * d->OH * d->OW * d->K * 4);
+      p.ldy = desc_ldy(d);
+      p.a_bytes = ydy_bytes(d);
       p.b_bytes = (unsigned)((int64_t)q.Rs * q.Ss * CK * 4);
       p.M = (int)M; p.NG = d->C;
       launch_planned<MODE_DGRAD>(parity_plan(d, q), p, split, st);
@@ -1231,7 +1253,9 @@ int mtlssl_conv2d_fwd_keep(const mtlssl_conv_desc* d, const float* x, const floa
   p.b_bytes = (unsigned)((int64_t)d->R * d->S * d->C * d->K * 4);
   p.M = d->N * d->OH * d->OW;
   p.NG = d->K;
+  const bool dense = desc_dense(d);
   WinoChoice wc;
+  MTLSSL_REQUIRE(dense || mfma_fwd_ok(d), "conv_fwd: a strided output (ldy = %d) needs C %% 16 == 0 and K >= 16", d->ldy);
   if (workspace && choose_wino(d, MODE_FWD, &wc)) {
     wino_fwd(d, wc.variant, wc.tile, x, w, bias, residual, y, epi, workspace, S(stream),
              (filter_xf && xf_variant == wc.variant) ? filter_xf : nullptr,
@@ -1303,10 +1327,12 @@ int mtlssl_conv2d_dgrad_xf(const mtlssl_conv_desc* d, const float* dy, const flo
   MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "conv_dgrad: residual pointer required");
   ConvArgs p = make_args(d);
   p.a = dy; p.b = w; p.out = dx; p.residual = residual; p.mask = mask_ref; p.epi = epi;
-  p.a_bytes = (unsigned)((int64_t)d->N * d->OH * d->OW * d->K * 4);
+  p.a_bytes = ydy_bytes(d);
   p.b_bytes = (unsigned)((int64_t)d->R * d->S * d->C * d->K * 4);
   p.M = d->N * d->H * d->W;
   p.NG = d->C;
+  MTLSSL_REQUIRE(desc_dense(d) || mfma_dgrad_ok(d),
+                 "conv_dgrad: a strided dy (ldy = %d) needs K %% 16 == 0, C %% 4 == 0 and C >= 16", d->ldy);
   WinoChoice wc;
   if (workspace && choose_wino(d, MODE_DGRAD, &wc)) {
     wino_dgrad(d, wc.variant, wc.tile, dy, w, residual, mask_ref, dx, epi, workspace, S(stream),
@@ -1482,7 +1508,7 @@ int mtlssl_conv2d_wgrad_grouped(const mtlssl_conv_desc* d, int n, const void* x_
   hipStream_t st = S(stream);
   ConvArgs p = make_args(d);
   p.a_bytes = (unsigned)((int64_t)d->N * d->H * d->W * d->C * 4);
-  p.b_bytes = (unsigned)((int64_t)d->N * d->OH * d->OW * d->K * 4);
+  p.b_bytes = ydy_bytes(d);
   p.a_tab = (const float* const*)x_ptrs;
   p.b_tab = (const float* const*)dy_ptrs;
   int cfg, ns, pps;
@@ -1506,12 +1532,27 @@ int mtlssl_conv2d_wgrad(const mtlssl_conv_desc* d, const float* x, const float* 
 int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const float* dy,
                            const float* out_scale, float* dw, float* dbias, float beta,
                            void* workspace, const float* input_xf, int input_variant, mtlssl_stream_t stream) {
+  return mtlssl_conv2d_wgrad_ex(d, x, dy, out_scale, dw, dbias, nullptr, beta, workspace, input_xf, input_variant, stream);
+}
+
+// MTLSSL_FUSE_COLSUM=0: the bias gradient's partial column sums as a launch of their own (A/B switch)
+static bool fuse_colsum() {
+  static const bool on = [] { const char* e = getenv("MTLSSL_FUSE_COLSUM"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+int mtlssl_conv2d_wgrad_ex(const mtlssl_conv_desc* d, const float* x, const float* dy,
+                           const float* out_scale, float* dw, float* dbias, const float* dbias_scale, float beta,
+                           void* workspace, const float* input_xf, int input_variant, mtlssl_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   hipStream_t st = S(stream);
   ConvArgs p = make_args(d);
   p.a = x; p.b = dy;
   p.a_bytes = (unsigned)((int64_t)d->N * d->H * d->W * d->C * 4);
-  p.b_bytes = (unsigned)((int64_t)d->N * d->OH * d->OW * d->K * 4);
+  p.b_bytes = ydy_bytes(d);
+  const int ldy = desc_ldy(d);
+  MTLSSL_REQUIRE(desc_dense(d) || mfma_wgrad_ok(d),
+                 "conv_wgrad: a strided dy (ldy = %d) needs C, K %% 4 == 0 and C, K >= 16", d->ldy);
   int64_t P = (int64_t)d->N * d->OH * d->OW;
   MTLSSL_REQUIRE(workspace != nullptr, "conv_wgrad: workspace required");
   float* ws_main = (float*)((char*)workspace + align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256));
@@ -1523,10 +1564,10 @@ int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const floa
     const int kg = (int)cdiv(d->K, (d->K & 3) ? 1 : 4);
     dim3 grid(cdiv(kg, cp.CQ), cp.chunks);
     if (d->K & 3)
-      hipLaunchKernelGGL(k_colsum_partial<float>, grid, dim3(256), 0, st, dy, (int)P, d->K, cp.per_chunk, cp.CQ,
+      hipLaunchKernelGGL(k_colsum_partial<float>, grid, dim3(256), 0, st, dy, (int)P, d->K, ldy, cp.per_chunk, cp.CQ,
                          (float*)workspace);
     else
-      hipLaunchKernelGGL(k_colsum_partial<floatx4>, grid, dim3(256), 0, st, dy, (int)P, d->K, cp.per_chunk, cp.CQ,
+      hipLaunchKernelGGL(k_colsum_partial<floatx4>, grid, dim3(256), 0, st, dy, (int)P, d->K, ldy, cp.per_chunk, cp.CQ,
                          (float*)workspace);
   };
   WinoChoice wc;
@@ -1534,20 +1575,24 @@ int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const floa
     wino_wgrad(d, wc.variant, wc.tile, x, dy, out_scale, dw, beta, ws_main, st,
                (input_xf && input_variant == wc.variant) ? input_xf : nullptr);
   } else if (mfma_wgrad_ok(d)) {
-    if (dbias) colsum_partial();
     int cfg, ns, pps;
     wgrad_plan(d, &cfg, &ns, &pps);
-    const bool split = fp32_engine() == 1 && (cfg == 0 || cfg == 3) &&
+    const bool split = fp32_engine() == 1 && (cfg == 0 || cfg == 3) && desc_dense(d) &&
                        split_wgrad_plan(P, d->C, d->K, d->R * d->S, &ns, &pps);
+    // bias gradient: the GEMM's own blocks of tile row 0 / tap 0 leave [split][K] column sums of dy in the column-sum
+    // region of the workspace (conv_mfma.h: cs_part) — no launch of its own; the split engine keeps the partial kernel
+    const bool ride = dbias && !split && fuse_colsum() && ns <= COLSUM_MAX_PARTS;
+    if (dbias && !ride) colsum_partial();
     p.out = ws_main;
     p.M = d->C; p.NG = d->K; p.nsplit = ns; p.pix_per_split = pps;
+    p.cs_part = ride ? (float*)workspace : nullptr;
     if (split) launch_split<MODE_WGRAD, false>(p, dim3(1, d->R * d->S, ns), st);
     else launch_mfma<MODE_WGRAD>(cfg, p, dim3(1, d->R * d->S, ns), st);
     int64_t total4 = (int64_t)d->R * d->S * d->C * d->K / 4;
     const int main_blocks = (int)cdiv(total4 * 4, 256);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(main_blocks + (dbias ? (int)cdiv(d->K, 4) : 0)), dim3(256), 0, st,
                        (const float*)ws_main, ns, total4, d->K, out_scale, dw, beta, main_blocks,
-                       (const float*)workspace, cp.chunks, dbias);
+                       (const float*)workspace, ride ? ns : cp.chunks, dbias, dbias_scale);
     colsum_folded = dbias != nullptr;
   } else if (is_pointwise(d)) {
     int ns, kps;
@@ -1571,7 +1616,7 @@ int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const floa
   if (dbias && !colsum_folded) {
     colsum_partial();
     hipLaunchKernelGGL(k_colsum_fold, dim3(cdiv(d->K, 4)), dim3(256), 0, st, (const float*)workspace, cp.chunks, d->K,
-                       dbias, beta);
+                       dbias, beta, dbias_scale);
   }
   return check_launch("conv2d_wgrad");
 }

@@ -45,6 +45,10 @@ struct ConvArgs {
   int pix_per_split;     // wgrad
   int tile_m0;           // first tile row covered by this launch (tail launches start past 0)
   int ws_m0;             // first GEMM row held by the split-K workspace of this launch
+  int ldy;               // row stride (floats) of the output-side tensor (fwd: y = out, dgrad: dy = a, wgrad: dy = b);
+                         // 0 = K, dense. > K: a channel slice of a wider NHWC map (mtlssl_conv_desc.ldy)
+  float* cs_part;        // wgrad: != nullptr -> the blocks of tile row 0 / tap 0 also sum their dy tile's columns and
+                         // store [split][K] partials here (the bias gradient riding on the filter gradient's GEMM)
   int64_t a_bs, b_bs, o_bs;   // batched launches: element strides between the planes of a / b / out
   // grouped wgrad (n problems of one descriptor in one launch): per-problem operand pointers, blockIdx.z =
   // problem * nsplit + split; the partial tiles land in the workspace in that order
@@ -53,6 +57,7 @@ struct ConvArgs {
 };
 
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+__host__ __device__ __forceinline__ int args_ldy(const ConvArgs& p) { return p.ldy ? p.ldy : p.K; }
 
 __device__ __forceinline__ floatx4 bufload4(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset,
                                             unsigned soffset) {
@@ -87,6 +92,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
       return;
     }
   const int ldo = p.NG;
+  // final forward stores go out with the y row stride (a channel slice of a concatenated map); split-K partials, the
+  // wgrad partial tiles and the dense residual / mask / dx operands keep the GEMM width
+  const int ldf = MODE == MODE_FWD ? args_ldy(p) : p.NG;
   float* outp = p.out;
   if constexpr (MODE == MODE_WGRAD)
     outp += ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (int64_t)p.M * p.NG;
@@ -138,6 +146,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
             continue;
           }
           const int64_t o = (int64_t)row * ldo + col;
+          const int64_t of = MODE == MODE_FWD ? (int64_t)row * ldf + col : o;
           if constexpr (MODE == MODE_FWD) {
             v += bv;
             if (p.epi & MTLSSL_EPI_RESIDUAL) v += PREFETCH_RES ? res_cur[k] : *reinterpret_cast<const floatx4*>(p.residual + o);
@@ -156,7 +165,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
               for (int q = 0; q < 4; ++q) v[q] = act_mask(v[q], mk[q], p.epi);
             }
           }
-          *reinterpret_cast<floatx4*>(outp + o) = v;
+          *reinterpret_cast<floatx4*>(outp + of) = v;
         }
         if constexpr (PREFETCH_RES) {
 #pragma unroll
@@ -180,6 +189,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
         const int row = m0 + wr * (BM / WR) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
         if (row >= p.M || !col_ok) continue;
         const int64_t o = (int64_t)row * ldo + col;
+        const int64_t of = MODE == MODE_FWD ? (int64_t)row * ldf + col : o;
         float v = acc[i][j][e];
         if (raw) {
           outp[(int64_t)(row - p.ws_m0) * ldo + col] = v;
@@ -196,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
           if (p.epi & MTLSSL_EPI_ACCUM) v += outp[o];
           if (p.epi & MASK_ANY) v = act_mask(v, p.mask[o], p.epi);
         }
-        outp[o] = v;
+        outp[of] = v;
       }
     }
   }
@@ -253,6 +263,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
       p.b = p.b_tab[grp];
     }
   }
+  const int ldy = args_ldy(p);     // row stride of dy (the A operand of dgrad, the B operand of wgrad)
   // ---- K-loop extent
   int rs_fixed = 0, pix0 = 0, pix1 = 0, ksteps, ks_begin = 0;
   if constexpr (MODE == MODE_FWD) {
@@ -272,7 +283,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
   unsigned a_rec = p.a_bytes, b_rec = p.b_bytes;
   if constexpr (PW && MODE == MODE_WGRAD) {
     a_rec = min(a_rec, (unsigned)(max(pix1, 0) * p.C) * 4u);
-    b_rec = min(b_rec, (unsigned)(max(pix1, 0) * p.K) * 4u);
+    b_rec = min(b_rec, (unsigned)(max(pix1, 0) * ldy) * 4u);
   }
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, a_rec, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, b_rec, 0x00020000);
@@ -301,7 +312,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int m = m0 + (tid / KQ) + RP * i;
-      const int ld = MODE == MODE_FWD ? p.C : p.K;
+      const int ld = MODE == MODE_FWD ? p.C : ldy;
       a_voff[i] = m < p.M ? (unsigned)(m * ld + kq4) * 4u : OOB;
     }
   } else if constexpr (A_KC) {
@@ -321,7 +332,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
         a_x[i] = iw + p.pl;
         a_y[i] = (t % p.H) + p.pt;
         a_n[i] = t / p.H;
-        a_base[i] = ((a_n[i] * p.OH + a_y[i]) * p.OW + a_x[i]) * p.K + kq4;   // stride-1 form
+        a_base[i] = ((a_n[i] * p.OH + a_y[i]) * p.OW + a_x[i]) * ldy + kq4;   // stride-1 form
       }
     }
   }
@@ -340,7 +351,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
       int u = tid + NT * i;
       int col = n0 + (u % (BN / 4)) * 4;
       if constexpr (PW)
-        b_base[i] = col < p.NG ? (unsigned)((pix0 + u / (BN / 4)) * p.K + col) * 4u : OOB;
+        b_base[i] = col < p.NG ? (unsigned)((pix0 + u / (BN / 4)) * ldy + col) * 4u : OOB;
       else
         b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
     }
@@ -388,7 +399,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     floatx4 (&rb)[B_LD] = rB[decltype(SET)::value];
     if constexpr (PW && MODE == MODE_WGRAD) {
       // the K-step's rows start ks*BKT pixels further on; a saturating add keeps the out-of-range marker out of range
-      const unsigned sa = (unsigned)(ks * BKT * p.C) * 4u, sb = (unsigned)(ks * BKT * p.K) * 4u;
+      const unsigned sa = (unsigned)(ks * BKT * p.C) * 4u, sb = (unsigned)(ks * BKT * ldy) * 4u;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) ra[i] = bufload4(rsrc_a, __builtin_elementwise_add_sat(a_voff[i], sa), 0);
 #pragma unroll
@@ -435,7 +446,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
       const int dy = t_r * p.dil, dx = t_s * p.dil;
       next_tap();
       if (p.stride == 1) {
-        int tapoff = k0 - (dy * p.OW + dx) * p.K;
+        int tapoff = k0 - (dy * p.OW + dx) * ldy;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
           int oh = a_y[i] - dy, ow = a_x[i] - dx;
@@ -449,7 +460,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
           bool ok = a_ok[i] && ny >= 0 && nx >= 0 && (ny % p.stride == 0) && (nx % p.stride == 0);
           int oh = ny / p.stride, ow = nx / p.stride;
           ok = ok && oh < p.OH && ow < p.OW;
-          int off = ((a_n[i] * p.OH + oh) * p.OW + ow) * p.K + k0 + kq4;
+          int off = ((a_n[i] * p.OH + oh) * p.OW + ow) * ldy + k0 + kq4;
           ra[i] = bufload4(rsrc_a, ok ? (unsigned)off * 4u : OOB, 0);
         }
       }
@@ -478,16 +489,31 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
       for (int i = 0; i < B_LD; ++i) {
         int u = tid + NT * i;
         int pix = pix0 + ks * BKT + u / (BN / 4);
-        rb[i] = bufload4(rsrc_b, (pix < pix1 && b_base[i] != OOB) ? b_base[i] + (unsigned)(pix * p.K) * 4u : OOB, 0);
+        rb[i] = bufload4(rsrc_b, (pix < pix1 && b_base[i] != OOB) ? b_base[i] + (unsigned)(pix * ldy) * 4u : OOB, 0);
       }
     }
   };
 
+  // wgrad with a bias gradient riding along (p.cs_part): the blocks of tile row 0 / tap 0 see every dy element of their
+  // pixel range and column tile exactly once — each B float4 on its way to LDS is also added to a per-thread column sum
+  // (a block-uniform branch; every tile passes through store_tile exactly once; rows past the range arrive as zeros)
+  bool do_cs = false;
+  floatx4 cs[B_LD];
+  if constexpr (MODE == MODE_WGRAD && !BATCH) {
+    do_cs = p.cs_part != nullptr && tile_m == 0 && rs_fixed == 0 && p.a_tab == nullptr;
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) cs[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
   auto store_tile = [&](int buf, auto SET) {
     floatx4 (&ra)[A_LD] = rA[decltype(SET)::value];
     floatx4 (&rb)[B_LD] = rB[decltype(SET)::value];
     float* a = sA + buf * (BKT * LDA);
     float* b = sB + buf * (BKT * LDB);
+    if constexpr (MODE == MODE_WGRAD && !BATCH)
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) cs[i] += rb[i];
+      }
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       if constexpr (A_KC) {
@@ -576,6 +602,24 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     if (it + 1 < nk) kstep(it + 1, Set0{}, Set1{});
   }
 
+  if constexpr (MODE == MODE_WGRAD && !BATCH) {
+    if (do_cs) {
+      // unit u = tid + NT * i of the [BKT][BN / 4] tile image: BKT threads hold partial sums of one column quad; they
+      // meet in LDS (free after the last K-step's barrier) and one thread adds them in row order — a fixed order
+      floatx4* red = reinterpret_cast<floatx4*>(smem);
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) red[tid + NT * i] = cs[i];
+      __syncthreads();
+      if (tid < BN / 4) {
+        floatx4 t = red[tid];
+#pragma unroll
+        for (int r = 1; r < BKT; ++r) t += red[r * (BN / 4) + tid];
+        const int col = n0 + tid * 4;
+        if (col < p.NG) *reinterpret_cast<floatx4*>(p.cs_part + (int64_t)blockIdx.z * p.NG + col) = t;
+      }
+      __syncthreads();
+    }
+  }
   conv_epilogue<BM, BN, MODE, NW>(p, acc, smem, m0, n0);
 }
 
@@ -654,10 +698,11 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
     }
   }
 
+  const int ldy = args_ldy(p);                       // row stride of dy (A of dgrad, B of wgrad)
   unsigned a_rec = p.a_bytes, b_rec = p.b_bytes;     // pointwise wgrad: see conv_mfma_body
   if constexpr (PWISE && MODE == MODE_WGRAD) {
     a_rec = min(a_rec, (unsigned)(max(pix1, 0) * p.C) * 4u);
-    b_rec = min(b_rec, (unsigned)(max(pix1, 0) * p.K) * 4u);
+    b_rec = min(b_rec, (unsigned)(max(pix1, 0) * ldy) * 4u);
   }
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, a_rec, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, b_rec, 0x00020000);
@@ -679,7 +724,7 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
     for (int i = 0; i < PA; ++i) {
       const int row = kc_row(wid * PA + i);
       const int m = m0 + row;
-      a_voff[i] = m < p.M ? (unsigned)(m * (MODE == MODE_FWD ? p.C : p.K) + kc_quad4(row)) * 4u : OOB;
+      a_voff[i] = m < p.M ? (unsigned)(m * (MODE == MODE_FWD ? p.C : ldy) + kc_quad4(row)) * 4u : OOB;
     }
   } else if constexpr (A_KC) {
 #pragma unroll
@@ -700,7 +745,7 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
         a_x[i] = iw + p.pl;
         a_y[i] = (t % p.H) + p.pt;
         a_n[i] = t / p.H;
-        a_base[i] = ((a_n[i] * p.OH + a_y[i]) * p.OW + a_x[i]) * p.K + a_q4[i];   // stride-1 form
+        a_base[i] = ((a_n[i] * p.OH + a_y[i]) * p.OW + a_x[i]) * ldy + a_q4[i];   // stride-1 form
       }
     }
   }
@@ -716,7 +761,7 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
     } else {
       int col = n0 + (pos % (BN / 4)) * 4;
       if constexpr (PWISE)
-        b_base[i] = col < p.NG ? (unsigned)((pix0 + pos / (BN / 4)) * p.K + col) * 4u : OOB;
+        b_base[i] = col < p.NG ? (unsigned)((pix0 + pos / (BN / 4)) * ldy + col) * 4u : OOB;
       else
         b_base[i] = col < p.NG ? (unsigned)col * 4u : OOB;
     }
@@ -728,7 +773,7 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
     float* sa = smem + st * STAGE + wid * (PA * 256);
     float* sb = smem + st * STAGE + A_FL + wid * (PB * 256);
     if constexpr (PWISE && MODE == MODE_WGRAD) {
-      const unsigned sa_off = (unsigned)(ks * BKT * p.C) * 4u, sb_off = (unsigned)(ks * BKT * p.K) * 4u;
+      const unsigned sa_off = (unsigned)(ks * BKT * p.C) * 4u, sb_off = (unsigned)(ks * BKT * ldy) * 4u;
 #pragma unroll
       for (int i = 0; i < PA; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + i * 256), 16, __builtin_elementwise_add_sat(a_voff[i], sa_off), 0, 0, 0);
@@ -771,7 +816,7 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
       int r = rs / p.S, s = rs - r * p.S;
       int dy = r * p.dil, dx = s * p.dil;
       if (p.stride == 1) {
-        int tapoff = k0 - (dy * p.OW + dx) * p.K;
+        int tapoff = k0 - (dy * p.OW + dx) * ldy;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
           int oh = a_y[i] - dy, ow = a_x[i] - dx;
@@ -786,7 +831,7 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
           bool ok = a_ok[i] && ny >= 0 && nx >= 0 && (ny % p.stride == 0) && (nx % p.stride == 0);
           int oh = ny / p.stride, ow = nx / p.stride;
           ok = ok && oh < p.OH && ow < p.OW;
-          int off = ((a_n[i] * p.OH + oh) * p.OW + ow) * p.K + k0 + a_q4[i];
+          int off = ((a_n[i] * p.OH + oh) * p.OW + ow) * ldy + k0 + a_q4[i];
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + i * 256), 16,
                                                    ok ? (unsigned)off * 4u : OOB, 0, 0, 0);
         }
@@ -823,7 +868,7 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
         int pix = pix0 + ks * BKT + pos / (BN / 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             rsrc_b, (lds_ptr_t)(sb + i * 256), 16,
-            (pix < pix1 && b_base[i] != OOB) ? b_base[i] + (unsigned)(pix * p.K) * 4u : OOB, 0, 0, 0);
+            (pix < pix1 && b_base[i] != OOB) ? b_base[i] + (unsigned)(pix * ldy) * 4u : OOB, 0, 0, 0);
       }
     }
   };
@@ -861,6 +906,11 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
+  // wgrad with a bias gradient riding along: see conv_mfma_body. Here the dy tile is already in LDS as [k][BN]: thread
+  // t < BN adds column t of every stage image of the blocks of tile row 0 / tap 0 (k order: a fixed order).
+  bool do_cs = false;
+  float csum = 0.f;
+  if constexpr (MODE == MODE_WGRAD && !BATCH) do_cs = p.cs_part != nullptr && tile_m == 0 && rs_fixed == 0;
   int cur = 0, nxt = NSTAGE - 1;                 // stage being multiplied / stage the next DMA targets
   for (int it = 0; it < nk; ++it) {
     const bool more = it + NSTAGE - 1 < nk;
@@ -868,6 +918,11 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
       if (more) issue_tile(ks_begin + it + NSTAGE - 1, nxt);
     const float* a = smem + cur * STAGE;
     const float* b = a + A_FL;
+    if constexpr (MODE == MODE_WGRAD && !BATCH)
+      if (do_cs && tid < BN) {
+#pragma unroll
+        for (int k = 0; k < BKT; ++k) csum += b[k * BN + tid];
+      }
     // fragments in groups of 4 MFMA k-steps; group g+1 is requested behind the first MFMAs of group g, so
     // only the first group's LDS latency is exposed (once per K-step)
     float fa[TM][BKT / 2], fb[TN][BKT / 2];
@@ -941,6 +996,8 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
     cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
+  if constexpr (MODE == MODE_WGRAD && !BATCH)
+    if (do_cs && tid < BN && n0 + tid < p.NG) p.cs_part[(int64_t)blockIdx.z * p.NG + n0 + tid] = csum;
   conv_epilogue<BM, BN, MODE, NW>(p, acc, smem, m0, n0);
 }
 

@@ -690,7 +690,7 @@ __global__ void k_maxpool_fwd(const float* x, float* y, int H, int W, int C4, in
 template <int K>
 __global__ void __launch_bounds__(256)
     k_maxpool_fwd_k(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C4, int stride, int pt, int pl,
-                    int OH, int OW, int64_t total) {
+                    int OH, int OW, int64_t total, int ldy4) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= total) return;
   int c4 = i % C4;
@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(256)
   for (int d = 0; d < K * K; ++d) {
     if (ok[d]) { m.x = fmaxf(m.x, v[d].x); m.y = fmaxf(m.y, v[d].y); m.z = fmaxf(m.z, v[d].z); m.w = fmaxf(m.w, v[d].w); }
   }
-  reinterpret_cast<float4*>(y)[i] = m;
+  reinterpret_cast<float4*>(y)[(i / C4) * ldy4 + c4] = m;      // ldy4: row stride of y in float4 (C4 when dense)
 }
 // Gradient goes to the first maximum in window order (TF MaxPoolGrad semantics). Non-overlapping windows
 // (k <= stride) scatter into a zeroed dx; overlapping ones (3x3/2) use the gather below.
@@ -781,7 +781,7 @@ __global__ void k_maxpool_bwd_gather(const float* __restrict__ x, const float* _
 __global__ void __launch_bounds__(256)
     k_maxpool_bwd_gather4(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                           float* __restrict__ dx, int H, int W, int C4, int k, int stride, int pt, int pl, int OH, int OW,
-                          int64_t total) {
+                          int64_t total, int ldy4) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int c4 = i % C4;
@@ -797,7 +797,7 @@ __global__ void __launch_bounds__(256)
   const int oy1 = min((iy + pt) / stride, OH - 1), ox1 = min((ix + pl) / stride, OW - 1);
   for (int oy = oy0; oy <= oy1; ++oy) {
     for (int ox = ox0; ox <= ox1; ++ox) {
-      const int64_t o = (((int64_t)n * OH + oy) * OW + ox) * C4 + c4;
+      const int64_t o = (((int64_t)n * OH + oy) * OW + ox) * ldy4 + c4;     // y / dy row stride (float4)
       const float4 m = reinterpret_cast<const float4*>(y)[o];
       bool f0 = v.x == m.x, f1 = v.y == m.y, f2 = v.z == m.z, f3 = v.w == m.w;
       if (!(f0 | f1 | f2 | f3)) continue;
@@ -1292,10 +1292,10 @@ int mtlssl_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, int
   if (!total) return MTLSSL_OK;
   if (k == 3)
     hipLaunchKernelGGL(k_maxpool_fwd_k<3>, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W, C / 4, stride, pt,
-                       pl, OH, OW, total);
+                       pl, OH, OW, total, C / 4);
   else if (k == 2)
     hipLaunchKernelGGL(k_maxpool_fwd_k<2>, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W, C / 4, stride, pt,
-                       pl, OH, OW, total);
+                       pl, OH, OW, total, C / 4);
   else
     hipLaunchKernelGGL(k_maxpool_fwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W,
                        C / 4, k, stride, pt, pl, OH, OW, total);
@@ -1313,7 +1313,7 @@ int mtlssl_maxpool_bwd(const float* x, const float* y, const float* dy, float* d
                         reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
     if (C % 4 == 0 && al16)
       hipLaunchKernelGGL(k_maxpool_bwd_gather4, dim3(cdiv(tin / 4, 256)), dim3(256), 0, S(stream), x, y, dy, dx, H, W,
-                         C / 4, k, stride, pt, pl, OH, OW, tin / 4);
+                         C / 4, k, stride, pt, pl, OH, OW, tin / 4, C / 4);
     else
       hipLaunchKernelGGL(k_maxpool_bwd_gather, dim3(cdiv(tin, 256)), dim3(256), 0, S(stream), x, y, dy, dx, H, W, C, k,
                          stride, pt, pl, OH, OW, tin);
@@ -1324,6 +1324,32 @@ int mtlssl_maxpool_bwd(const float* x, const float* y, const float* dy, float* d
   hipLaunchKernelGGL(k_maxpool_bwd, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, dy, dx, H,
                      W, C, k, stride, pt, pl, OH, OW, total);
   return check_launch("maxpool_bwd");
+}
+int mtlssl_maxpool_fwd_strided(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pt,
+                               int pl, int OH, int OW, int ldy, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(C % 4 == 0 && ldy % 4 == 0 && ldy >= C && (k == 2 || k == 3), "maxpool_fwd_strided: C, ldy %% 4, k in {2, 3}");
+  MTLSSL_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "maxpool_fwd_strided: 16-byte alignment");
+  int64_t total = (int64_t)N * OH * OW * C / 4;
+  if (!total) return MTLSSL_OK;
+  if (k == 3)
+    hipLaunchKernelGGL(k_maxpool_fwd_k<3>, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W, C / 4, stride, pt,
+                       pl, OH, OW, total, ldy / 4);
+  else
+    hipLaunchKernelGGL(k_maxpool_fwd_k<2>, dim3(cdiv(total, 256)), dim3(256), 0, S(stream), x, y, H, W, C / 4, stride, pt,
+                       pl, OH, OW, total, ldy / 4);
+  return check_launch("maxpool_fwd_strided");
+}
+int mtlssl_maxpool_bwd_strided(const float* x, const float* y, const float* dy, float* dx, int N, int H, int W, int C,
+                               int k, int stride, int pt, int pl, int OH, int OW, int ldy, mtlssl_stream_t stream) {
+  MTLSSL_REQUIRE(C % 4 == 0 && ldy % 4 == 0 && ldy >= C && k > stride,
+                 "maxpool_bwd_strided: C, ldy %% 4 and overlapping windows (k > stride)");
+  MTLSSL_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) |
+                   reinterpret_cast<uintptr_t>(dx)) & 15) == 0, "maxpool_bwd_strided: 16-byte alignment");
+  int64_t tin = (int64_t)N * H * W * C;
+  if (!tin) return MTLSSL_OK;
+  hipLaunchKernelGGL(k_maxpool_bwd_gather4, dim3(cdiv(tin / 4, 256)), dim3(256), 0, S(stream), x, y, dy, dx, H, W,
+                     C / 4, k, stride, pt, pl, OH, OW, tin / 4, ldy / 4);
+  return check_launch("maxpool_bwd_strided");
 }
 int mtlssl_spatial_mean_fwd(const float* x, float* y, int N, int HW, int C, mtlssl_stream_t stream) {
   if (!N) return MTLSSL_OK;

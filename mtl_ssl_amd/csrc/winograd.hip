@@ -191,12 +191,12 @@ __global__ void __launch_bounds__(256) k_wino_filter_batched(const float* const*
 // zero outside the map). The patch is streamed a column at a time, the column-transformed P x I block is
 // held in registers, then rows are transformed and stored plane by plane.
 template <typename S, typename VT>
-__global__ void __launch_bounds__(256) k_wino_input(const float* in, float* V, WinoGeom g, int C) {
+__global__ void __launch_bounds__(256) k_wino_input(const float* in, float* V, WinoGeom g, int C, int ld) {
   constexpr int P = S::P, I = S::I;
   const TileIdx ix = tile_index<VT>(g, C);
   if (!ix.ok) return;
   const int y0 = S::O * ix.ty - 1, x0 = S::O * ix.tx - 1;
-  const float* base = in + ((int64_t)ix.n * g.H * g.W) * C + ix.c;
+  const float* base = in + ((int64_t)ix.n * g.H * g.W) * ld + ix.c;     // ld: row stride of `in` (>= C: a channel slice)
   VT tmp[P][I];
 #pragma unroll
   for (int j = 0; j < I; ++j) {
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) k_wino_input(const float* in, float* V, W
     for (int i = 0; i < I; ++i) {
       const int y = y0 + i;
       const bool ok = okx && (unsigned)y < (unsigned)g.H;
-      col[i] = ok ? *reinterpret_cast<const VT*>(base + ((int64_t)y * g.W + x) * C) : VT{};
+      col[i] = ok ? *reinterpret_cast<const VT*>(base + ((int64_t)y * g.W + x) * ld) : VT{};
     }
     xform<S, XF_BT, P, I>(col, o);
 #pragma unroll
@@ -227,11 +227,11 @@ __global__ void __launch_bounds__(256) k_wino_input(const float* in, float* V, W
 // Output-gradient transform for the filter gradient: dM[xi][t][k] = (A dY A^T)[xi] of the O x O
 // tile of dY (zero outside the map).
 template <typename S, typename VT>
-__global__ void __launch_bounds__(256) k_wino_dy(const float* dy, float* dM, WinoGeom g, int K) {
+__global__ void __launch_bounds__(256) k_wino_dy(const float* dy, float* dM, WinoGeom g, int K, int ld) {
   constexpr int P = S::P, O = S::O;
   const TileIdx ix = tile_index<VT>(g, K);
   if (!ix.ok) return;
-  const float* base = dy + ((int64_t)ix.n * g.H * g.W) * K + ix.c;
+  const float* base = dy + ((int64_t)ix.n * g.H * g.W) * ld + ix.c;    // ld: row stride of dy
   VT tmp[P][O];
 #pragma unroll
   for (int j = 0; j < O; ++j) {
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) k_wino_dy(const float* dy, float* dM, Win
     for (int i = 0; i < O; ++i) {
       const int y = O * ix.ty + i;
       const bool ok = y < g.H && x < g.W;
-      col[i] = ok ? *reinterpret_cast<const VT*>(base + ((int64_t)y * g.W + x) * K) : VT{};
+      col[i] = ok ? *reinterpret_cast<const VT*>(base + ((int64_t)y * g.W + x) * ld) : VT{};
     }
     xform<S, XF_A, P, O>(col, o);
 #pragma unroll
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) k_wino_dy(const float* dy, float* dM, Win
 // Output transform Y = A^T m A of Mb[xi][t][k] + the epilogue of the direct kernel (forward:
 // bias / residual / ReLU / ReLU6 / tanh; dgrad: residual / accumulate / activation mask).
 template <typename S, int MODE, typename VT>
-__global__ void __launch_bounds__(256) k_wino_output(const float* Mb, float* out, WinoGeom g, int K,
+__global__ void __launch_bounds__(256) k_wino_output(const float* Mb, float* out, WinoGeom g, int K, int ldo,
                                                      const float* bias, const float* residual,
                                                      const float* mask, int epi) {
   constexpr int P = S::P, O = S::O;
@@ -292,7 +292,9 @@ __global__ void __launch_bounds__(256) k_wino_output(const float* Mb, float* out
     for (int v_ = 0; v_ < O; ++v_) {
       const int ox = O * ix.tx + v_;
       if (ox >= g.W) continue;
-      const int64_t off = (((int64_t)ix.n * g.H + oy) * g.W + ox) * K + ix.c;
+      const int64_t pix = ((int64_t)ix.n * g.H + oy) * g.W + ox;
+      const int64_t off = pix * K + ix.c;               // residual / mask / accumulate operands are dense
+      const int64_t offo = pix * ldo + ix.c;            // ldo: row stride of `out` (forward: y may be a channel slice)
       VT v = o[v_];
       if constexpr (MODE == MODE_FWD) {
         v += bv;
@@ -300,10 +302,10 @@ __global__ void __launch_bounds__(256) k_wino_output(const float* Mb, float* out
         v = act_fwd(v, epi);
       } else {
         if (epi & MTLSSL_EPI_RESIDUAL) v += *reinterpret_cast<const VT*>(residual + off);
-        if (epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const VT*>(out + off);
+        if (epi & MTLSSL_EPI_ACCUM) v += *reinterpret_cast<const VT*>(out + offo);
         if (epi & MASK_ANY) v = mask_bwd(v, *reinterpret_cast<const VT*>(mask + off), epi);
       }
-      *reinterpret_cast<VT*>(out + off) = v;
+      *reinterpret_cast<VT*>(out + offo) = v;
     }
   }
 }
@@ -381,37 +383,40 @@ void run_filter(const float* w, float* U, int64_t CK, int flip, hipStream_t st) 
   hipLaunchKernelGGL((k_wino_filter<S, float>), dim3(cdiv(CK, 256)), dim3(256), 0, st, w, U, CK, flip);
 }
 template <typename S>
-void run_input(const float* in, float* V, const WinoGeom& g, int C, hipStream_t st) {
+void run_input(const float* in, float* V, const WinoGeom& g, int C, hipStream_t st, int ld = 0) {
+  if (ld <= 0) ld = C;
   if constexpr (can_vec<S>()) {
     if (wide(g.T, C)) {
-      hipLaunchKernelGGL((k_wino_input<S, floatx4>), dim3(cdiv(g.T * C / 4, 256)), dim3(256), 0, st, in, V, g, C);
+      hipLaunchKernelGGL((k_wino_input<S, floatx4>), dim3(cdiv(g.T * C / 4, 256)), dim3(256), 0, st, in, V, g, C, ld);
       return;
     }
   }
-  hipLaunchKernelGGL((k_wino_input<S, float>), dim3(cdiv(g.T * C, 256)), dim3(256), 0, st, in, V, g, C);
+  hipLaunchKernelGGL((k_wino_input<S, float>), dim3(cdiv(g.T * C, 256)), dim3(256), 0, st, in, V, g, C, ld);
 }
 template <typename S>
-void run_dy(const float* dy, float* dM, const WinoGeom& g, int K, hipStream_t st) {
+void run_dy(const float* dy, float* dM, const WinoGeom& g, int K, hipStream_t st, int ld = 0) {
+  if (ld <= 0) ld = K;
   if constexpr (can_vec<S>()) {
     if (wide(g.T, K)) {
-      hipLaunchKernelGGL((k_wino_dy<S, floatx4>), dim3(cdiv(g.T * K / 4, 256)), dim3(256), 0, st, dy, dM, g, K);
+      hipLaunchKernelGGL((k_wino_dy<S, floatx4>), dim3(cdiv(g.T * K / 4, 256)), dim3(256), 0, st, dy, dM, g, K, ld);
       return;
     }
   }
-  hipLaunchKernelGGL((k_wino_dy<S, float>), dim3(cdiv(g.T * K, 256)), dim3(256), 0, st, dy, dM, g, K);
+  hipLaunchKernelGGL((k_wino_dy<S, float>), dim3(cdiv(g.T * K, 256)), dim3(256), 0, st, dy, dM, g, K, ld);
 }
 template <typename S, int MODE>
 void run_output(const float* Mb, float* out, const WinoGeom& g, int K, const float* bias, const float* residual,
-                const float* mask, int epi, hipStream_t st) {
+                const float* mask, int epi, hipStream_t st, int ldo = 0) {
+  if (ldo <= 0) ldo = K;
   if constexpr (can_vec<S>()) {
     if (wide(g.T, K)) {
       hipLaunchKernelGGL((k_wino_output<S, MODE, floatx4>), dim3(cdiv(g.T * K / 4, 256)), dim3(256), 0, st, Mb, out,
-                         g, K, bias, residual, mask, epi);
+                         g, K, ldo, bias, residual, mask, epi);
       return;
     }
   }
-  hipLaunchKernelGGL((k_wino_output<S, MODE, float>), dim3(cdiv(g.T * K, 256)), dim3(256), 0, st, Mb, out, g, K, bias,
-                     residual, mask, epi);
+  hipLaunchKernelGGL((k_wino_output<S, MODE, float>), dim3(cdiv(g.T * K, 256)), dim3(256), 0, st, Mb, out, g, K, ldo,
+                     bias, residual, mask, epi);
 }
 template <typename S>
 void run_wgrad_out(const float* dU, int ns, int64_t CK, int K, const float* scale, float* dw, float beta,
@@ -558,7 +563,7 @@ void fwd(const mtlssl_conv_desc* d, int tile, const float* x, const float* w, co
   p.a_bytes = (unsigned)(g.T * d->C * 4); p.b_bytes = (unsigned)(CK * 4);
   p.a_bs = g.T * d->C; p.b_bs = CK; p.o_bs = g.T * d->K;
   launch_gemm<MODE_FWD>(tile, p, PL, 1, st);
-  run_output<S, MODE_FWD>(Mb, y, g, d->K, bias, residual, nullptr, epi, st);
+  run_output<S, MODE_FWD>(Mb, y, g, d->K, bias, residual, nullptr, epi, st, d->ldy);
 }
 
 template <typename S>
@@ -572,7 +577,7 @@ void dgrad(const mtlssl_conv_desc* d, int tile, const float* dy, const float* w,
   float* Mb = (float*)((char*)V + align_up((int64_t)PL * g.T * d->K * 4, 256));   // [P^2][T][C]
   if (U_pre) U = const_cast<float*>(U_pre);
   else run_filter<S>(w, U, CK, 1, st);
-  run_input<S>(dy, V, g, d->K, st);
+  run_input<S>(dy, V, g, d->K, st, d->ldy);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = U; p.out = Mb;
   p.M = (int)g.T; p.NG = d->C;
@@ -596,7 +601,7 @@ void wgrad(const mtlssl_conv_desc* d, int tile, const float* x, const float* dy,
   const bool split = fp32_engine() == 1 && (tile == 0 || tile == 3) && split_wgrad_plan(g.T, d->C, d->K, PL, &ns, &pps);
   if (V_pre) V = const_cast<float*>(V_pre);        // kept by the forward call of the same layer
   else run_input<S>(x, V, g, d->C, st);
-  run_dy<S>(dy, dM, g, d->K, st);
+  run_dy<S>(dy, dM, g, d->K, st, d->ldy);
   ConvArgs p = gemm_args(g.T, d->C, d->K);
   p.a = V; p.b = dM; p.out = dU;
   p.M = d->C; p.NG = d->K; p.nsplit = ns; p.pix_per_split = pps;

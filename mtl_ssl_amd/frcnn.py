@@ -455,7 +455,7 @@ class FasterRCNNMetaArch:
                 aux = aux_forward()
         pd = self._predict_from_features(x, F, trunk_ctx)
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            ops.wait_on(side, "predict: aux heads")
         else:
             aux = aux_forward()
         pd.update(aux)
@@ -571,7 +571,7 @@ class FasterRCNNMetaArch:
             if self._shared_classifier:          # :701-706, 713-714: the predictor reads the main tower's features
                 cfeat, cctx = feat, None
             elif cside is not None:
-                torch.cuda.current_stream().wait_stream(cside)
+                ops.wait_on(cside, "second stage: closeness tower")
                 cfeat, cctx = cfeat_s, cctx_s
             else:
                 # stop_gradient_for_aux_tasks only decides whether d(crops) is propagated (:668-673)
@@ -667,7 +667,7 @@ class FasterRCNNMetaArch:
         win = None
         if mtl.window:
             if "_refine_win" in pd:               # issued early on the third stream (_predict_second_stage)
-                torch.cuda.current_stream().wait_stream(self._refine_stream())
+                ops.wait_on(self._refine_stream(), "refine: early window pass")
                 win = pd.pop("_refine_win")
                 win.record_stream(torch.cuda.current_stream())
             else:
@@ -978,7 +978,7 @@ class FasterRCNNMetaArch:
         if gw_shared is not None:
             ops.roi_crop_pool_bwd(gw_shared, pd["_wargmax"], F.shape, pd["_wboxes"], pd["_wbox_ind"], *crop_args, dfeat=dF)
         if early is not None:
-            cur.wait_stream(early)
+            ops.wait_on(early, "backward: aux towers released early", cur)
             for gx, am, bx, bi in pending:
                 gx.record_stream(cur)         # made on the second stream, consumed and released on this one
                 ops.roi_crop_pool_bwd(gx, am, F.shape, bx, bi, *crop_args, dfeat=dF)
@@ -1032,6 +1032,6 @@ class FasterRCNNMetaArch:
         else:
             self._feature_extractor.backward_proposal_features(gpF, pd["_trunk_ctx"])
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            ops.wait_on(side, "backward end: aux stream")
         if wg.stream is not None:
-            torch.cuda.current_stream().wait_stream(wg.stream)
+            ops.wait_on(wg.stream, "backward end: filter-gradient stream")

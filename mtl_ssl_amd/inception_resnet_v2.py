@@ -37,12 +37,19 @@ class Pool:
     def refold(self):
         pass
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: the pooling branch's channel slice of a concatenated map (max pooling only), or None."""
         if self.kind == "max":
-            y, self.pads = ops.maxpool_fwd(x, self.k, self.stride, self.padding)
+            y, self.pads = ops.maxpool_fwd(x, self.k, self.stride, self.padding, out=out)
         else:
+            assert out is None
             y, self.pads = ops.avgpool_fwd(x, self.k, self.stride, self.padding)
         return y
+
+    def out_shape(self, x_shape):
+        N, H, W, C = x_shape
+        _, _, OH, OW = ops.pool_geometry(H, W, self.k, self.stride, self.padding)
+        return (N, OH, OW, C)
 
     def wgrad(self, x, g):
         pass
@@ -67,7 +74,6 @@ class ResidualUp:
     def prepare(self):
         ps, dev = self.ps, self.ps.device
         self.scale_vec = torch.full((self.cout,), float(self.scale), dtype=torch.float32, device=dev)
-        self.db_tmp = torch.zeros((self.cout,), dtype=torch.float32, device=dev)
         if self.w.trainable:       # refreshed by the batched fold (ops.fold_scales) after each update
             self.w_eff = ps.register_fold(self.w, self.scale_vec)
             self.b_eff = ps.register_fold(self.b, self.scale_vec)
@@ -94,12 +100,9 @@ class ResidualUp:
     def wgrad(self, mixed, gp):
         if not self.trainable:
             return
+        # b enters as scale * b (b_eff): its gradient is the column sum of gp times the same folded factor
         ops.conv2d_wgrad(self.desc(mixed.shape), mixed, gp, self.ps.grad(self.w.name), out_scale=self.scale_vec,
-                         dbias=self.db_tmp, beta=1.0)
-        # conv2d_wgrad accumulated the unscaled column sum on top of db_tmp's previous content:
-        # keep db_tmp zeroed between uses instead of a separate beta for the bias
-        ops.axpby(self.db_tmp, self.ps.grad(self.b.name), self.scale, 1.0)
-        self.db_tmp.zero_()
+                         dbias=self.ps.grad(self.b.name), beta=1.0, dbias_scale=self.scale_vec)
         self.ps.grad_ready(self.w, self.b)
 
     def dgrad(self, mixed_shape, gp, mask_ref):
@@ -108,25 +111,49 @@ class ResidualUp:
 
 
 class Branches:
-    """Parallel chains on one input, concatenated on the channel axis."""
+    """Parallel chains on one input, concatenated on the channel axis. tf.concat(axis=3) is folded into its producers and
+    into the consumers of its gradient (inception_resnet_v2.py:46,67,88,185-186,213,253): the last layer of every chain
+    writes straight into its channel slice of the concatenated map (conv epilogue / pooling store with the map's row
+    stride), and the backward hands every chain a VIEW of its slice of the map's gradient, which the chain's dgrad,
+    filter-gradient, bias-gradient and pooling-gradient kernels read in place — no copy in either direction."""
 
     def __init__(self, chains):
         self.chains = chains
-        self.couts = None
+        cin = next(int(ch[0].w.shape[2]) for ch in chains if not isinstance(ch[0], Pool))
+        self.couts = []
+        for ch in chains:
+            c = cin
+            for l in ch:
+                c = c if isinstance(l, Pool) else int(l.w.shape[-1])
+            self.couts.append(c)
+        self.ccat = sum(self.couts)
+        self.offs = [sum(self.couts[:i]) for i in range(len(self.couts))]
+        for ch in chains:
+            if not isinstance(ch[-1], Pool):
+                ch[-1].ldy = self.ccat
 
     def layers(self):
         return [l for ch in self.chains for l in ch]
 
     def forward(self, x, save):
-        outs, acts = [], []
-        for ch in self.chains:
+        acts = []
+        for ch in self.chains:                       # everything but the last layer of each chain
             a = [x]
-            for l in ch:
+            for l in ch[:-1]:
                 a.append(l.forward(a[-1]))
-            outs.append(a[-1])
-            acts.append(a if save else None)
-        self.couts = [int(o.shape[-1]) for o in outs]
-        return ops.concat_channels(outs), acts
+            acts.append(a)
+        l0, x0 = self.chains[0][-1], acts[0][-1]
+        if isinstance(l0, Pool):
+            N, OH, OW, _ = l0.out_shape(x0.shape)
+        else:
+            d = l0.desc(x0.shape)
+            N, OH, OW = d.N, d.OH, d.OW
+        cat = torch.empty((N, OH, OW, self.ccat), dtype=torch.float32, device=x.device)
+        for ch, a, off, c in zip(self.chains, acts, self.offs, self.couts):
+            view = cat[..., off:off + c]
+            ch[-1].forward(a[-1], out=view)
+            a.append(view)
+        return cat, (acts if save else [None] * len(acts))
 
     def backward(self, g_cat, acts, residual=None, mask_ref=None, need_input_grad=True, wgrad=nn.INLINE_WGRAD):
         """g_cat: dL/d(concat), already masked by (concat > 0). Returns dL/dx (+ residual), masked by
@@ -137,11 +164,10 @@ class Branches:
         # pooling-first chains go first so that a convolution's dgrad epilogue applies the final mask
         order = sorted(range(len(self.chains)), key=lambda i: not isinstance(self.chains[i][0], Pool))
         assert not isinstance(self.chains[order[-1]][0], Pool)
-        offs = [sum(self.couts[:i]) for i in range(len(self.couts))]
         dx = None
         for n, ci in enumerate(order):
             ch, a = self.chains[ci], acts[ci]
-            gp = ops.slice_channels(g_cat, offs[ci], self.couts[ci])
+            gp = g_cat[..., self.offs[ci]:self.offs[ci] + self.couts[ci]]       # read in place (row stride = ccat)
             last = n == len(order) - 1
             for li in range(len(ch) - 1, -1, -1):
                 l, xin = ch[li], a[li]

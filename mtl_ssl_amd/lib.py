@@ -17,7 +17,7 @@ class ConvDesc(ctypes.Structure):
     """mtlssl_conv_desc."""
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("N", "H", "W", "C", "K", "R", "S", "OH", "OW", "stride", "dilation",
-                 "pad_t", "pad_l")]
+                 "pad_t", "pad_l", "ldy")]
 
 
 _SCALARS = {

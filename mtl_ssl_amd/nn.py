@@ -134,6 +134,9 @@ class ConvBN:
         self._desc = {}
         self._kept = {}          # x.data_ptr() -> (Winograd-transformed x, variant), between forward(keep=True) and wgrad
         self.w_eff = None
+        # > 0: this layer's output is a channel slice of a concatenated map with `ldy` channels (set by the owner of the
+        # concat before the first call): forward(out=view) writes it in place, dgrad / wgrad read dy views in place
+        self.ldy = 0
 
     def prepare(self):
         ps = self.ps
@@ -164,17 +167,18 @@ class ConvBN:
     def desc(self, shape):
         d = self._desc.get(tuple(shape))
         if d is None:
-            d = ops.conv_desc(shape, self.w.shape, self.stride, self.dilation, self.padding)
+            d = ops.conv_desc(shape, self.w.shape, self.stride, self.dilation, self.padding, ldy=self.ldy)
             self._desc[tuple(shape)] = d
         return d
 
-    def forward(self, x, residual=None, relu=None, keep=False):
+    def forward(self, x, residual=None, relu=None, keep=False, out=None):
         """keep: this forward will be followed by wgrad(x, .) of the same x (training with saved activations) —
-        a Winograd layer then keeps its transformed input for the filter gradient."""
+        a Winograd layer then keeps its transformed input for the filter gradient.
+        out: where to write (required when self.ldy is set: the layer's slice of the concatenated map)."""
         act = self.act if relu is None else ("relu" if relu else None)
         epi = ops.EPI_BIAS | {None: 0, "relu": ops.EPI_RELU, "relu6": ops.EPI_RELU6}[act] \
             | (ops.EPI_RESIDUAL if residual is not None else 0)
-        return ops.conv2d_fwd(self.desc(x.shape), x, self.w_eff, self.shift, residual, epi,
+        return ops.conv2d_fwd(self.desc(x.shape), x, self.w_eff, self.shift, residual, epi, out=out,
                               xf_cache=self.ps.filter_cache,
                               keep_input_xf=self._keep_slot() if (keep and self.trainable and self.k == 3) else None)
 

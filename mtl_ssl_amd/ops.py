@@ -33,6 +33,17 @@ def _chk(t, dtype=f32):
     return t
 
 
+def _chk_y(d, t):
+    """The output-side tensor of a convolution (y / dy): dense, or — d.ldy set — the channel slice [..., c0:c0+K] of a
+    contiguous NHWC map with d.ldy channels (a torch view: its data_ptr() is the slice's first element)."""
+    if not d.ldy:
+        return _chk(t)
+    assert t.is_cuda and t.dtype == f32 and t.dim() == 4 and t.shape[-1] == d.K and t.stride(-1) == 1 \
+        and t.stride(-2) == d.ldy and t.stride(-3) == d.ldy * t.shape[-2] and t.data_ptr() % 16 == 0, \
+        (tuple(t.shape), t.stride(), d.ldy)
+    return t
+
+
 _ws_cache = {}
 
 
@@ -64,8 +75,10 @@ def same_pad(in_size, k, stride, dilation=1):
     return total // 2, out
 
 
-def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding="SAME"):
-    """padding: 'SAME' | 'VALID' | 'RESNET_SAME' (slim/nets/resnet_utils.py:77-122 conv2d_same)."""
+def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding="SAME", ldy=0):
+    """padding: 'SAME' | 'VALID' | 'RESNET_SAME' (slim/nets/resnet_utils.py:77-122 conv2d_same).
+    ldy: row stride (floats) of the output-side tensor — y of the forward, dy of dgrad / wgrad — when it is a channel
+    slice of a wider NHWC map (tf.concat(axis=3) folded into its producers / the consumers of its gradient); 0 = dense."""
     N, H, W, C = x_shape
     R, S, C2, K = w_shape
     assert C == C2, (x_shape, w_shape)
@@ -83,7 +96,7 @@ def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding="SAME"):
         OW = (W - ((S - 1) * dilation + 1)) // stride + 1
     else:
         raise ValueError(padding)
-    return ConvDesc(N, H, W, C, K, R, S, OH, OW, stride, dilation, pt, pl)
+    return ConvDesc(N, H, W, C, K, R, S, OH, OW, stride, dilation, pt, pl, int(ldy) if int(ldy) != K else 0)
 
 
 def desc_is_pointwise(d):
@@ -256,6 +269,44 @@ class FlopAccount:
 ACCOUNT = None         # a FlopAccount while bench.py counts executed FLOPs
 
 
+class JoinTimer:
+    """HIP-event pairs around the points where the step's MAIN stream waits for a side stream (bench.py's
+    whole_step.main_stream_idle_ms): `wait_on` records one event just before and one just after the wait on the waiting
+    stream, so their distance is the time that stream had nothing of its own to run at that join — measured un-profiled,
+    a handful of event pairs per step. Off by default (JOIN_TIMER is None)."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def summary(self, steps):
+        """{"total_ms_per_step", "by_join": {tag: ms_per_step}} — after torch.cuda.synchronize()."""
+        by = {}
+        for tag, a, b in self.pairs:
+            by[tag] = by.get(tag, 0.0) + a.elapsed_time(b)
+        steps = max(int(steps), 1)
+        return {"total_ms_per_step": round(sum(by.values()) / steps, 3),
+                "by_join": {k: round(v / steps, 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1])}}
+
+
+JOIN_TIMER = None
+
+
+def wait_on(other, tag, cur=None):
+    """The current (or given) stream waits for everything enqueued on stream `other` (or for event `other`)."""
+    cur = cur if cur is not None else torch.cuda.current_stream()
+    jt = JOIN_TIMER
+    if jt is not None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(cur)
+    if isinstance(other, torch.cuda.Event):
+        cur.wait_event(other)
+    else:
+        cur.wait_stream(other)
+    if jt is not None:
+        b.record(cur)
+        jt.pairs.append((tag, a, b))
+
+
 def mark(name):
     if PHASE_HOOK is not None:
         PHASE_HOOK(name)
@@ -422,7 +473,7 @@ class FilterXfCache:
             e["event"].record(cur)
             self.entries[key] = e
         elif cur.cuda_stream not in e["waited"]:
-            cur.wait_event(e["event"])
+            wait_on(e["event"], "filter_cache_refresh", cur)
             e["waited"].add(cur.cuda_stream)
         return e["U"], variant
 
@@ -475,6 +526,9 @@ def _shared_input_variant(d):
 def conv2d_fwd(d, x, w, bias=None, residual=None, epilogue=0, out=None, xf_cache=None, keep_input_xf=None):
     """keep_input_xf: a dict (owned by the layer) that receives {x.data_ptr(): (V, variant)} when the forward
     and the filter gradient of this problem share a Winograd input transform; conv2d_wgrad takes it back."""
+    if d.ldy:
+        assert out is not None, "a strided forward writes into the caller's concatenated map"
+        _chk_y(d, out)
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
     if PROFILER is None:
         def run():
@@ -509,7 +563,7 @@ def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None, x
             tmp = workspace(4 * d.N * d.H * d.W * d.C, "tune_out", dy.device)
             nb_ = lib().conv2d_workspace_bytes(ctypes.byref(d), 1)
             ws_ = workspace(nb_, "splitk", dy.device) if nb_ else None
-            lib().conv2d_dgrad(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref), ptr(tmp),
+            lib().conv2d_dgrad(ctypes.byref(d), ptr(_chk_y(d, dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref), ptr(tmp),
                                epilogue & ~EPI_ACCUM, ptr(ws_), _stream())
         _autotune(d, 1, run)
     t0 = PROFILER.begin(d, 1) if PROFILER is not None else None
@@ -518,21 +572,22 @@ def conv2d_dgrad(d, dy, w, residual=None, mask_ref=None, epilogue=0, out=None, x
     nb = lib().conv2d_workspace_bytes(ctypes.byref(d), 1)
     ws = workspace(nb, "splitk", dy.device) if nb else None
     U, variant = xf_cache.get(d, 1, w) if (xf_cache is not None and d.R == 3 and d.S == 3) else (None, -1)
-    lib().conv2d_dgrad_xf(ctypes.byref(d), ptr(_chk(dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref),
+    lib().conv2d_dgrad_xf(ctypes.byref(d), ptr(_chk_y(d, dy)), ptr(_chk(w)), ptr(residual), ptr(mask_ref),
                           ptr(dx), epilogue, ptr(ws), ptr(U), variant, _stream())
     if t0 is not None:
         PROFILER.end(d, 1, t0)
     return dx
 
 
-def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0, input_xf=None):
-    """input_xf: (V, variant) kept by this layer's conv2d_fwd(keep_input_xf=...) for the same x, or None."""
+def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0, input_xf=None, dbias_scale=None):
+    """input_xf: (V, variant) kept by this layer's conv2d_fwd(keep_input_xf=...) for the same x, or None.
+    dbias_scale: per-channel factor on the bias gradient (a bias that enters through a folded factor), or None."""
     if PROFILER is None:
         def run():                                    # scratch filter gradient, beta = 0
             tmp = workspace(4 * d.R * d.S * d.C * d.K, "tune_out", x.device)
             nb_ = lib().conv2d_wgrad_workspace_bytes(ctypes.byref(d))
             ws_ = workspace(nb_, "wgrad", x.device)
-            lib().conv2d_wgrad(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(dy)), ptr(out_scale), ptr(tmp), None, 0.0,
+            lib().conv2d_wgrad(ctypes.byref(d), ptr(_chk(x)), ptr(_chk_y(d, dy)), ptr(out_scale), ptr(tmp), None, 0.0,
                                ptr(ws_), _stream())
         _autotune(d, 2, run)
     nbytes = lib().conv2d_wgrad_workspace_bytes(ctypes.byref(d))
@@ -543,8 +598,8 @@ def conv2d_wgrad(d, x, dy, dw, out_scale=None, dbias=None, beta=0.0, input_xf=No
     V, vvar = input_xf if input_xf is not None else (None, -1)
     if V is not None:
         V.record_stream(torch.cuda.current_stream())     # made on the forward's stream, read on this one
-    lib().conv2d_wgrad_xf(ctypes.byref(d), ptr(_chk(x)), ptr(_chk(dy)), ptr(out_scale), ptr(dw),
-                          ptr(dbias), float(beta), ptr(ws), ptr(V), vvar, _stream())
+    lib().conv2d_wgrad_ex(ctypes.byref(d), ptr(_chk(x)), ptr(_chk_y(d, dy)), ptr(out_scale), ptr(dw),
+                          ptr(dbias), ptr(dbias_scale), float(beta), ptr(ws), ptr(V), vvar, _stream())
     if t0 is not None:
         PROFILER.end(d, 2, t0)
     return dw
@@ -620,22 +675,47 @@ def bn_param_grads(y, g, gamma, beta_param, dgamma, dbeta, beta=0.0):
     return dgamma, dbeta
 
 
-def maxpool_fwd(x, k, stride, padding="VALID"):
-    N, H, W, C = x.shape
+def pool_geometry(H, W, k, stride, padding):
+    """-> (pad_t, pad_l, OH, OW) of a k x k / stride pooling window under TF 'SAME' / 'VALID'."""
     if padding == "SAME":
         pt, OH = same_pad(H, k, stride)
         pl, OW = same_pad(W, k, stride)
     else:
         pt = pl = 0
         OH, OW = (H - k) // stride + 1, (W - k) // stride + 1
+    return pt, pl, OH, OW
+
+
+def _slice_ld(t, C):
+    """Row stride of the channel slice `t` = big[..., c0:c0+C] of a contiguous NHWC map (a torch view)."""
+    assert t.is_cuda and t.dtype == f32 and t.dim() == 4 and t.shape[-1] == C and t.stride(-1) == 1 \
+        and t.stride(-3) == t.stride(-2) * t.shape[-2], (tuple(t.shape), t.stride())
+    return int(t.stride(-2))
+
+
+def maxpool_fwd(x, k, stride, padding="VALID", out=None):
+    """out: a channel-slice view of a wider NHWC map to pool into (the pooling branch of a tf.concat), or None."""
+    N, H, W, C = x.shape
+    pt, pl, OH, OW = pool_geometry(H, W, k, stride, padding)
+    if out is not None:
+        assert tuple(out.shape) == (N, OH, OW, C), (tuple(out.shape), (N, OH, OW, C))
+        lib().maxpool_fwd_strided(ptr(_chk(x)), ptr(out), N, H, W, C, k, stride, pt, pl, OH, OW, _slice_ld(out, C), _stream())
+        return out, (pt, pl)
     y = torch.empty((N, OH, OW, C), dtype=f32, device=x.device)
     lib().maxpool_fwd(ptr(_chk(x)), ptr(y), N, H, W, C, k, stride, pt, pl, OH, OW, _stream())
     return y, (pt, pl)
 
 
 def maxpool_bwd(x, y, dy, k, stride, pads):
+    """y / dy: dense, or channel-slice views (same geometry) of wider NHWC maps."""
     N, H, W, C = x.shape
     dx = torch.empty_like(x)
+    if not (y.is_contiguous() and dy.is_contiguous()):
+        ld = _slice_ld(y, C)
+        assert _slice_ld(dy, C) == ld, (ld, dy.stride())
+        lib().maxpool_bwd_strided(ptr(x), ptr(y), ptr(dy), ptr(dx), N, H, W, C, k, stride, pads[0], pads[1],
+                                  y.shape[1], y.shape[2], ld, _stream())
+        return dx
     lib().maxpool_bwd(ptr(x), ptr(y), ptr(_chk(dy)), ptr(dx), N, H, W, C, k, stride, pads[0],
                       pads[1], y.shape[1], y.shape[2], _stream())
     return dx

@@ -127,7 +127,7 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         }
         if mtl.closeness:
             if cside is not None:
-                torch.cuda.current_stream().wait_stream(cside)
+                ops.wait_on(cside, "second stage: closeness tower")
                 cfeat, cctx, cp = cfeat_s, cctx_s, cp_s
             elif self._shared_classifier:        # the main tower's map; no tower, no context of its own
                 cfeat, cctx = feat, None
@@ -261,7 +261,7 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         if side is None:
             aux_backward()
         elif not stop:
-            cur.wait_stream(side)
+            ops.wait_on(side, "backward: aux stream", cur)
         for g in held:
             g.record_stream(cur)            # produced on the second stream, consumed (and then released) on this one
             ops.axpby(g, dF, 1.0, 1.0)

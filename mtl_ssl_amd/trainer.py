@@ -165,7 +165,7 @@ class GradientReducer:
             if self.timing:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(cur)
-            cur.wait_stream(self.stream)
+            ops.wait_on(self.stream, "all-reduce of the gradient buckets", cur)
             if self.timing:
                 e1.record(cur)
                 self._ev_wait.append((e0, e1))
@@ -337,7 +337,7 @@ class Trainer:
             with torch.cuda.stream(side):
                 m.loss(pd, loss_scale=1.0 / self.world, part="early")
             pd = m.predict_with_mtl_results(pd)
-            cur.wait_stream(side)
+            ops.wait_on(side, "losses: early part on the aux stream", cur)
             losses = m.loss(pd, loss_scale=1.0 / self.world, part="late")
         else:
             if mtl.refine:

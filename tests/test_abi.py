@@ -60,6 +60,11 @@ def test_committed_pmc_traffic_was_taken_from_the_current_roofline_kernel():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     from pmc_summary import kernel_source_sha16
-    d = json.load(open(os.path.join(root, "profiles", "r04_pmc_traffic.json")))
+    sys.path.insert(0, root)
+    import bench
+    path = bench._latest_profile("pmc_traffic.json")          # the file bench.py's roofline.traffic is read from
+    assert path is not None, "no profiles/rNN_pmc_traffic.json committed"
+    d = json.load(open(path))
     assert d.get("kernel_source_sha16") == kernel_source_sha16(), \
-        "profiles/r04_pmc_traffic.json is stale: regenerate it with tools/pmc_bench.sh + tools/pmc_summary.py"
+        "%s is stale: regenerate it with tools/config_evidence.sh <tag> pmc (or tools/pmc_bench.sh + tools/pmc_summary.py)" \
+        % os.path.relpath(path, root)

@@ -204,6 +204,91 @@ def test_pointwise_instantiation_is_bit_identical_to_the_general_gather(ops, cas
     assert relerr(out[1][0].reshape(-1, K).cpu(), ref.float().cpu()) < 1e-5
 
 
+STRIDED_CASES = [
+    # N, H, W, C, K, R, stride, dil, padding, algorithm (0 direct / 2 Winograd where eligible), channels of the wide map, c0
+    (1, 35, 37, 320, 32, 1, 1, 1, "SAME", 0, 128, 0),           # block35 Branch_0 1x1 -> slice [0, 32) of 128
+    (1, 35, 37, 32, 32, 3, 1, 1, "SAME", 0, 128, 32),           # block35 Branch_1 3x3, direct
+    (1, 35, 37, 48, 64, 3, 1, 1, "SAME", 2, 128, 64),           # block35 Branch_2 3x3, Winograd (output transform / dy transforms)
+    (2, 17, 19, 160, 192, (7, 1), 1, 1, "SAME", 0, 384, 192),   # block17 7x1
+    (2, 17, 19, 1088, 192, 1, 1, 1, "SAME", 0, 384, 0),         # block17 Branch_0: 68 K-steps (split-K plans)
+    (3, 8, 8, 224, 256, (3, 1), 1, 1, "SAME", 0, 448, 192),     # block8 3x1
+    (2, 33, 33, 320, 384, 3, 2, 1, "SAME", 0, 1088, 0),         # Mixed_6a 3x3/2: dgrad by input parity
+    (8, 17, 17, 256, 288, 3, 2, 1, "VALID", 0, 2080, 384),      # Mixed_7a 3x3/2 VALID
+    (2, 17, 17, 48, 64, 5, 1, 1, "SAME", 0, 320, 96),           # Mixed_5b 5x5
+    (512, 7, 7, 512, 512, 1, 1, 1, "SAME", 0, 1024, 512),       # main launch + K-split tail launch + fold
+]
+
+
+@pytest.mark.parametrize("case", STRIDED_CASES)
+def test_strided_output_side_is_bit_identical_to_dense(ops, case):
+    """tf.concat(axis=3) folded into its producers and the consumers of its gradient (mtlssl_conv_desc.ldy): a forward
+    that writes its channel slice of a wider NHWC map, and dgrad / wgrad / bias-gradient passes that read dy as a channel
+    slice of a wider map, give the bits of the dense calls — same kernels, same plans, only the row stride differs — and
+    the forward touches nothing outside its slice. Every algorithm family the Inception-ResNet-v2 branches end in."""
+    N, H, W, C, K, R, stride, dil, padding, alg, CC, c0 = case
+    R, S = R if isinstance(R, tuple) else (R, R)
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    w = (torch.randn(R, S, C, K, generator=g) / np.sqrt(R * S * C)).cuda()
+    bias = torch.randn(K, generator=g).cuda()
+    prev = ops.set_winograd(alg if alg else 0)
+    ops.reset_tuning(False, False)
+    try:
+        dd = ops.conv_desc(x.shape, w.shape, stride, dil, padding)
+        ds = ops.conv_desc(x.shape, w.shape, stride, dil, padding, ldy=CC)
+        assert ds.ldy == CC and dd.ldy == 0
+        import ctypes
+        for mode in (0, 1, 2):       # the row stride is not part of the plan
+            assert ops.lib().conv2d_tile_config(ctypes.byref(dd), mode) == ops.lib().conv2d_tile_config(ctypes.byref(ds), mode)
+        if alg == 2:
+            assert ops.plan_code_algorithm(ops.lib().conv2d_tile_config(ctypes.byref(dd), 0)) > 0
+        y = ops.conv2d_fwd(dd, x, w, bias, None, ops.EPI_BIAS | ops.EPI_RELU)
+        cat = torch.full((dd.N, dd.OH, dd.OW, CC), float("nan"), device="cuda")
+        ops.conv2d_fwd(ds, x, w, bias, None, ops.EPI_BIAS | ops.EPI_RELU, out=cat[..., c0:c0 + K])
+        assert torch.equal(cat[..., c0:c0 + K], y), "forward"
+        rest = torch.cat([cat[..., :c0], cat[..., c0 + K:]], -1)
+        assert bool(torch.isnan(rest).all()), "the forward wrote outside its slice"
+        gcat = torch.randn(dd.N, dd.OH, dd.OW, CC, generator=g).cuda()
+        gy = gcat[..., c0:c0 + K].contiguous()
+        gv = gcat[..., c0:c0 + K]
+        mref, addend = torch.randn(N, H, W, C, generator=g).cuda(), torch.randn(N, H, W, C, generator=g).cuda()
+        dx = ops.conv2d_dgrad(dd, gy, w, addend, mref, ops.EPI_RESIDUAL | ops.EPI_MASK)
+        dxs = ops.conv2d_dgrad(ds, gv, w, addend, mref, ops.EPI_RESIDUAL | ops.EPI_MASK)
+        assert torch.equal(dx, dxs), "dgrad"
+        scale = (torch.rand(K, generator=g) + 0.5).cuda()
+        dw, db = torch.zeros_like(w), torch.zeros(K, device="cuda")
+        ops.conv2d_wgrad(dd, x, gy, dw, out_scale=scale, dbias=db, beta=0.0)
+        dws, dbs = torch.ones_like(w), torch.ones(K, device="cuda")
+        ops.conv2d_wgrad(ds, x, gv, dws, out_scale=scale, dbias=dbs, beta=0.0, dbias_scale=None)
+        assert torch.equal(dw, dws), "wgrad"
+        assert torch.equal(db, dbs), "dbias"
+        assert relerr(db, gy.double().sum((0, 1, 2)).float()) < 1e-5
+        # the bias gradient with a folded per-channel factor, accumulated (the Inception residual `up` convolution)
+        db2 = torch.ones(K, device="cuda")
+        ops.conv2d_wgrad(dd, x, gy, dw, out_scale=scale, dbias=db2, beta=1.0, dbias_scale=scale)
+        assert relerr(db2, 1.0 + (scale.double() * gy.double().sum((0, 1, 2))).float()) < 1e-5
+    finally:
+        ops.set_winograd(prev)
+        ops.reset_tuning()
+
+
+def test_strided_maxpool_branch_is_bit_identical_to_dense(ops):
+    """The pooling branch of Mixed_6a / Mixed_7a writes its slice of the concatenated map and its backward reads y / dy
+    slices of the wider maps in place."""
+    g = torch.Generator().manual_seed(5)
+    for pad, shape, CC, c0 in (("SAME", (2, 33, 35, 320), 1088, 768), ("VALID", (8, 17, 17, 1088), 2080, 992)):
+        x = torch.randint(0, 4, shape, generator=g).float().cuda()          # ties everywhere
+        y, pads = ops.maxpool_fwd(x, 3, 2, pad)
+        cat = torch.full(tuple(y.shape[:3]) + (CC,), float("nan"), device="cuda")
+        yv, pads2 = ops.maxpool_fwd(x, 3, 2, pad, out=cat[..., c0:c0 + shape[3]])
+        assert pads == pads2 and torch.equal(yv, y)
+        assert bool(torch.isnan(torch.cat([cat[..., :c0], cat[..., c0 + shape[3]:]], -1)).all())
+        gcat = torch.randn(tuple(y.shape[:3]) + (CC,), generator=g).cuda()
+        gv = gcat[..., c0:c0 + shape[3]]
+        dx = ops.maxpool_bwd(x, y, gv.contiguous(), 3, 2, pads)
+        assert torch.equal(dx, ops.maxpool_bwd(x, yv, gv, 3, 2, pads))
+
+
 def test_conv_same_padding_matches_reference_known_answer(ops):
     """Known answers of slim/nets/resnet_v1_test.py:72-111 (testConv2DSameEven): x[i,j] = i+j on
     4x4, w[i,j] = i+j on 3x3; SAME stride 1, conv2d_same stride 2 (== subsample of the former)
