@@ -398,6 +398,11 @@ def cpu_baseline(cfg, model, tr, H, W, seed, steps=3, batch=1, threads_max=128):
     values = model.ps.state_dict()                       # the sweep's updates are not part of the sample
     dt, losses = run(steps, {})
     return {"value": batch / dt, "unit": "images/sec", "cores": cores, "host_cores": host_cores, "kind": "port",
+            "batch": batch, "gpu_leg_batch": int(cfg.train_config.batch_size),
+            "batch_note": "the CPU leg steps on %d image(s) per step, the GPU leg on %d; the unit (images/sec) is per image, "
+                          "and the oracle's per-image work does not depend on the batch (per-image proposal chain, "
+                          "sampling and refine; convolutions linear in B) — `--cpu-batch %d` times the identical batch"
+                          % (batch, int(cfg.train_config.batch_size), int(cfg.train_config.batch_size)),
             "thread_sweep_s_per_step": {str(k): round(v, 2) for k, v in sweep.items()},
             "sample": "CPU oracle (torch-CPU fp32 + numpy; this build's restatement of the step, not TensorFlow): %d full "
                       "training steps (fwd + losses + bwd + clip + momentum update) on %d synthetic %dx%d image(s), "
@@ -484,6 +489,29 @@ def other_configs(dev, warmup=4):
                          "executed_mfma_tflop_per_step": ex / 1e12,
                          "executed_over_fp32_mfma_peak": ex / dt / FP32_MFMA_PEAK,
                          "final_total_loss": float(sum(v.item() for v in losses.values()))}
+            # this configuration's own dominant convolution kernel against its roofline: HIP events around every conv
+            # call of three more steps (on the launching stream), the (mode, plan, pointwise) class with the largest
+            # summed time; direct-algorithm FLOPs of those calls over their launch time
+            try:
+                ops.PROFILER = ops.ConvProfiler(None)
+                for i in range(3):
+                    tr.step(ring[i % 4])
+                torch.cuda.synchronize()
+                summ = {k: v for k, v in ops.PROFILER.summary().items() if k[1] >= 0 and v["seconds"] > 0}
+                ops.PROFILER = None
+                if summ:
+                    best = max(summ, key=lambda k: summ[k]["seconds"])
+                    r = summ[best]
+                    dk = (ops.ConvProfiler.MODES.index(best[0]), best[1], best[2])
+                    rows[key]["roofline"] = {
+                        "bound": "mfma", "kernel": plan_kernel_name(dk), "achieved": r["flops"] / r["seconds"] / 1e12,
+                        "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": r["flops"] / r["seconds"] / FP32_MFMA_PEAK,
+                        "launches": r["dispatches"], "avg_launch_us": 1e6 * r["seconds"] / max(r["dispatches"], 1),
+                        "share_of_conv_time": r["seconds"] / sum(v["seconds"] for v in summ.values()), "traffic": None,
+                        "note": "in-step (three streams), 3 extra steps; FLOPs priced as direct convolutions of the calls that ran this kernel"}
+            except Exception as e:
+                ops.PROFILER = None
+                rows[key]["roofline"] = {"error": repr(e)}
             del model, tr, ring
             torch.cuda.empty_cache()
         except Exception as e:                       # a side measurement never takes the headline line down
@@ -498,6 +526,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)      # >= 50 timed steps after >= 10 warm-up
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=1,
+                    help="images per CPU-oracle step (1 keeps the default run within minutes; the per-GPU batch times the identical batch)")
     ap.add_argument("--cpu-threads-max", type=int, default=128,
                     help="largest thread count of the CPU baseline's sweep (0 = up to every host core)")
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches cycled through the steps")
@@ -927,7 +957,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, model, tr, a.height, a.width, seed=1234, steps=a.cpu_steps,
-                                               threads_max=a.cpu_threads_max)
+                                               batch=a.cpu_batch, threads_max=a.cpu_threads_max)
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
         if default_cfg and a.cpu_config0_steps > 0:

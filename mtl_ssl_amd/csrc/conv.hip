@@ -746,6 +746,81 @@ static int64_t padded_fwd_bytes(const mtlssl_conv_desc* d) {
   const int64_t Cp = align_up(d->C, BK), M = (int64_t)d->N * d->H * d->W;
   return align_up(M * Cp * 4, 256) + align_up(Cp * d->K * 4, 256);
 }
+// Pointwise wgrad whose output width K is not a multiple of 4 (R-FCN's 189-wide position-sensitive class map,
+// core/box_predictor.py:215-337: 21 classes x 9 bins): dy [P, K] is copied into a zero-padded [P, Kp] image (Kp = K
+// rounded up to 4) and the padded problem runs on the MFMA engine; the fold drops the padding columns again. Replaces the
+// scalar tile kernel (229 us per head on R-FCN's 9 728-row maps = 16 TFLOP/s; 3 heads per step).
+static bool padded_wgrad_ok(const mtlssl_conv_desc* d) {
+  return is_pointwise(d) && (d->K & 3) != 0 && d->K >= 13 && d->C % 4 == 0 && d->C >= 16 && desc_dense(d);
+}
+static mtlssl_conv_desc padded_wgrad_desc(const mtlssl_conv_desc* d) {
+  mtlssl_conv_desc q = *d;
+  q.K = (int)align_up(d->K, 4);
+  q.ldy = 0;
+  return q;
+}
+// fold of the padded problem's partial tiles ws[split][C][Kp] into dw[C][K] (+ scale, beta); the blocks past
+// `main_blocks` fold the bias gradient from the [split][Kp] column sums the GEMM left (cs_part), like k_wgrad_reduce
+__global__ void __launch_bounds__(256) k_wgrad_reduce_unpad(const float* ws, int nsplit, int C, int Kp, int K,
+                                                            const float* scale, float* dw, float beta, int main_blocks,
+                                                            const float* cs_part, float* dbias, const float* dbias_scale) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int k = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += cs_part[(int64_t)z * Kp + k];
+    if (dbias_scale) s *= dbias_scale[k];
+    dbias[k] = beta != 0.f ? beta * dbias[k] + s : s;
+    return;
+  }
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)C * K) return;
+  const int c = (int)(i / K), k = (int)(i - (int64_t)c * K);
+  const int64_t plane = (int64_t)C * Kp;
+  float s = 0.f;
+  for (int z = 0; z < nsplit; ++z) s += ws[(int64_t)z * plane + (int64_t)c * Kp + k];
+  if (scale) s *= scale[k];
+  dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+}
+// Thin pointwise forward (K <= 8 outputs per pixel: the edge-mask head's 1024 -> 2, core/mask_predictor.py:105-119): one
+// wavefront per pixel row, lanes stride the channels with 16-byte loads, butterfly sums. The 64x64 scalar tile kernel
+// ran this on 76 blocks (164 us for 20 MB of input).
+__global__ void __launch_bounds__(256) k_pw_thin_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, const float* __restrict__ residual,
+                                                     float* __restrict__ y, int M, int C, int K, int epi) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* xr = x + (int64_t)m * C;
+  for (int c = lane * 4; c < C; c += 256) {
+    const floatx4 xv = *reinterpret_cast<const floatx4*>(xr + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* wr = w + (int64_t)(c + j) * K;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < K) acc[k] = fmaf(xv[j], wr[k], acc[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane < K) {
+    float v = acc[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v = lane == k ? acc[k] : v;
+    const int64_t o = (int64_t)m * K + lane;
+    if (epi & MTLSSL_EPI_BIAS) v += bias[lane];
+    if (epi & MTLSSL_EPI_RESIDUAL) v += residual[o];
+    if (epi & MTLSSL_EPI_RELU) v = fmaxf(v, 0.f);
+    if (epi & MTLSSL_EPI_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+    if (epi & MTLSSL_EPI_TANH) v = tanhf(v);
+    y[o] = v;
+  }
+}
+static bool thin_fwd_ok(const mtlssl_conv_desc* d) {
+  return is_pointwise(d) && d->K <= 8 && d->C % 4 == 0 && desc_dense(d);
+}
 __global__ void __launch_bounds__(256) k_pad_rows(const float* src, int64_t rows, int K, int Kp, float* dst) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * Kp) return;
@@ -838,6 +913,37 @@ static void launch_mfma(int cfg, ConvArgs& p, dim3 extra, hipStream_t st, int ti
   dim3 grid(p.tiles_m * p.tiles_n, extra.y, extra.z);
   if (cfg >= NCFG && (p.a_tab || !glds_ok(p.NG) || (MODE == MODE_WGRAD && !glds_ok(p.M)))) cfg -= NCFG;
   const bool pw = conv_is_pointwise(p) && pointwise_ref().load() != 0;
+  if constexpr (MODE == MODE_WGRAD) {
+    if (p.cs_part) {          // the bias gradient's column sums ride on this launch: the CS instantiations
+      if (cfg < NCFG && pw) {
+        switch (cfg) {
+          case 0: hipLaunchKernelGGL((k_conv_mfma_pw_cs<128, 128>), grid, dim3(256), 0, st, p); break;
+          case 1: hipLaunchKernelGGL((k_conv_mfma_pw_cs<128, 64>), grid, dim3(256), 0, st, p); break;
+          case 2: hipLaunchKernelGGL((k_conv_mfma_pw_cs<64, 64>), grid, dim3(256), 0, st, p); break;
+          default: hipLaunchKernelGGL((k_conv_mfma_pw_cs<256, 128>), grid, dim3(512), 0, st, p); break;
+        }
+      } else if (pw) {
+        switch (cfg) {
+          case 4: hipLaunchKernelGGL((k_conv_glds_pw_cs<128, 128, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+          case 5: hipLaunchKernelGGL((k_conv_glds_pw_cs<128, 64, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+          case 6: hipLaunchKernelGGL((k_conv_glds_pw_cs<64, 64, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+          default: hipLaunchKernelGGL((k_conv_glds_pw_cs<256, 128, 16, GLDS_STAGES>), grid, dim3(512), 0, st, p); break;
+        }
+      } else {
+        switch (cfg) {
+          case 0: hipLaunchKernelGGL((k_conv_mfma_cs<128, 128, 16>), grid, dim3(256), 0, st, p); break;
+          case 1: hipLaunchKernelGGL((k_conv_mfma_cs<128, 64, 16>), grid, dim3(256), 0, st, p); break;
+          case 2: hipLaunchKernelGGL((k_conv_mfma_cs<64, 64, 16>), grid, dim3(256), 0, st, p); break;
+          case 3: hipLaunchKernelGGL((k_conv_mfma_cs<256, 128, 16>), grid, dim3(512), 0, st, p); break;
+          case 4: hipLaunchKernelGGL((k_conv_glds_cs<128, 128, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+          case 5: hipLaunchKernelGGL((k_conv_glds_cs<128, 64, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+          case 6: hipLaunchKernelGGL((k_conv_glds_cs<64, 64, 16, GLDS_STAGES>), grid, dim3(256), 0, st, p); break;
+          default: hipLaunchKernelGGL((k_conv_glds_cs<256, 128, 16, GLDS_STAGES>), grid, dim3(512), 0, st, p); break;
+        }
+      }
+      return;
+    }
+  }
   if (cfg < NCFG && pw) {     // 1x1 stride-1 layers: the engine's pointwise instantiation
     switch (cfg) {
       case 0: hipLaunchKernelGGL((k_conv_mfma_pw<128, 128, MODE>), grid, dim3(256), 0, st, p); break;
@@ -1282,6 +1388,8 @@ int mtlssl_conv2d_fwd_keep(const mtlssl_conv_desc* d, const float* x, const floa
     pq.NG = q.K;
     Plan pl = plan_dir(&q, MODE_FWD);
     launch_planned<MODE_FWD>(pl, pq, (float*)ws_conv, S(stream));
+  } else if (thin_fwd_ok(d)) {
+    hipLaunchKernelGGL(k_pw_thin_fwd, dim3(cdiv(p.M, 4)), dim3(256), 0, S(stream), x, w, bias, residual, y, p.M, d->C, d->K, epi);
   } else if (is_pointwise(d)) {
     GemmArgs g{x, w, y, bias, residual, nullptr, p.M, d->K, d->C, epi, 0};
     hipLaunchKernelGGL(k_gemm_small<GM_FWD>, dim3(cdiv(g.N, 64), cdiv(g.M, 64)), dim3(256), 0, S(stream), g);
@@ -1411,6 +1519,7 @@ int64_t mtlssl_conv2d_executed_macs(const mtlssl_conv_desc* d, int mode, int on_
     else valu = direct;
   } else {
     if (mfma_wgrad_ok(d)) mfma = direct;
+    else if (padded_wgrad_ok(d)) mfma = P_out * d->C * align_up(d->K, 4);
     else valu = direct;
   }
   return on_mfma ? mfma : valu;
@@ -1457,6 +1566,11 @@ int mtlssl_conv2d_num_dispatches(const mtlssl_conv_desc* d, int mode) {
 int64_t mtlssl_conv2d_wgrad_workspace_bytes(const mtlssl_conv_desc* d) {
   if (!d) return 256;
   int64_t bias_part = align_up((int64_t)COLSUM_MAX_PARTS * d->K * 4, 256);
+  if (!mfma_wgrad_ok(d) && padded_wgrad_ok(d)) {
+    const mtlssl_conv_desc q = padded_wgrad_desc(d);
+    return bias_part + align_up((int64_t)d->N * d->OH * d->OW * q.K * 4, 256) + (mtlssl_conv2d_wgrad_workspace_bytes(&q) -
+                                                                                   align_up((int64_t)COLSUM_MAX_PARTS * q.K * 4, 256));
+  }
   if (!mfma_wgrad_ok(d)) {
     if (is_stem3(d)) return bias_part + align_up((int64_t)STEM_MAX_CHUNKS * 27 * d->K * 4, 256);
     if (!is_pointwise(d)) return bias_part;
@@ -1594,6 +1708,25 @@ int mtlssl_conv2d_wgrad_ex(const mtlssl_conv_desc* d, const float* x, const floa
                        (const float*)ws_main, ns, total4, d->K, out_scale, dw, beta, main_blocks,
                        (const float*)workspace, ride ? ns : cp.chunks, dbias, dbias_scale);
     colsum_folded = dbias != nullptr;
+  } else if (padded_wgrad_ok(d)) {
+    const mtlssl_conv_desc q = padded_wgrad_desc(d);
+    float* dy_pad = ws_main;
+    float* ws_q = (float*)((char*)ws_main + align_up(P * q.K * 4, 256));
+    hipLaunchKernelGGL(k_pad_rows, dim3(cdiv(P * q.K, 256)), dim3(256), 0, st, dy, P, d->K, q.K, dy_pad);
+    int cfg, ns, pps;
+    wgrad_plan(&q, &cfg, &ns, &pps);
+    ConvArgs pq = make_args(&q);
+    pq.a = x; pq.b = dy_pad; pq.out = ws_q;
+    pq.a_bytes = p.a_bytes; pq.b_bytes = (unsigned)(P * q.K * 4);
+    pq.M = q.C; pq.NG = q.K; pq.nsplit = ns; pq.pix_per_split = pps;
+    const bool ride = dbias && fuse_colsum() && (int64_t)ns * q.K <= (int64_t)COLSUM_MAX_PARTS * d->K;
+    pq.cs_part = ride ? (float*)workspace : nullptr;
+    launch_mfma<MODE_WGRAD>(cfg, pq, dim3(1, 1, ns), st);
+    const int main_blocks = (int)cdiv((int64_t)d->C * d->K, 256);
+    hipLaunchKernelGGL(k_wgrad_reduce_unpad, dim3(main_blocks + (ride ? (int)cdiv(d->K, 256) : 0)), dim3(256), 0, st,
+                       (const float*)ws_q, ns, d->C, q.K, d->K, out_scale, dw, beta, main_blocks, (const float*)workspace,
+                       dbias, dbias_scale);
+    colsum_folded = ride;
   } else if (is_pointwise(d)) {
     int ns, kps;
     small_wgrad_plan(d, &ns, &kps);

@@ -218,7 +218,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
 // constant plus the K-step's offset — the buffer load's SCALAR offset in forward / dgrad, one saturating add in wgrad —
 // so the K loop carries no tap / bounds / division arithmetic at all (two thirds of the executed FLOPs of config[1] are
 // 1x1 layers and Winograd-domain GEMM stacks, which are pointwise by construction).
-template <int BM, int BN, int MODE, int BKT, bool BATCH, bool PW = false>
+// CS (wgrad only): the bias gradient's column sums of dy ride on the GEMM (p.cs_part) — an instantiation of its own, so
+// that the plain filter-gradient kernels do not carry its accumulators (8 VGPRs: an occupancy step on the large tiles).
+template <int BM, int BN, int MODE, int BKT, bool BATCH, bool PW = false, bool CS = false>
 __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
   // 4 wavefronts (2x2) per block; the 256-row tile has 8 (4x2) so that a wave's tile stays 64x64
   constexpr int NW = BM > 128 ? 8 : 4, NT = 64 * NW, WR = NW / 2;
@@ -497,9 +499,10 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
   // wgrad with a bias gradient riding along (p.cs_part): the blocks of tile row 0 / tap 0 see every dy element of their
   // pixel range and column tile exactly once — each B float4 on its way to LDS is also added to a per-thread column sum
   // (a block-uniform branch; every tile passes through store_tile exactly once; rows past the range arrive as zeros)
+  static_assert(!CS || (MODE == MODE_WGRAD && !BATCH), "column sums ride on the plain wgrad launch only");
   bool do_cs = false;
-  floatx4 cs[B_LD];
-  if constexpr (MODE == MODE_WGRAD && !BATCH) {
+  floatx4 cs[CS ? B_LD : 1];
+  if constexpr (CS) {
     do_cs = p.cs_part != nullptr && tile_m == 0 && rs_fixed == 0 && p.a_tab == nullptr;
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) cs[i] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -509,7 +512,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     floatx4 (&rb)[B_LD] = rB[decltype(SET)::value];
     float* a = sA + buf * (BKT * LDA);
     float* b = sB + buf * (BKT * LDB);
-    if constexpr (MODE == MODE_WGRAD && !BATCH)
+    if constexpr (CS)
       if (do_cs) {
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) cs[i] += rb[i];
@@ -602,7 +605,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     if (it + 1 < nk) kstep(it + 1, Set0{}, Set1{});
   }
 
-  if constexpr (MODE == MODE_WGRAD && !BATCH) {
+  if constexpr (CS) {
     if (do_cs) {
       // unit u = tid + NT * i of the [BKT][BN / 4] tile image: BKT threads hold partial sums of one column quad; they
       // meet in LDS (free after the last K-step's barrier) and one thread adds them in row order — a fixed order
@@ -639,7 +642,7 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
 // k in a different order — same fp32 products, not bit-identical to the register-staged engine.
 // NSTAGE LDS stages of BKT x (BM + BN) floats; tile it+NSTAGE-1 is in flight while tile it is multiplied;
 // one raw s_barrier per K-step behind a counted s_waitcnt vmcnt (never a drain while a tile is in flight).
-template <int BM, int BN, int MODE, int BKT, int NSTAGE, bool BATCH, bool PWISE = false>
+template <int BM, int BN, int MODE, int BKT, int NSTAGE, bool BATCH, bool PWISE = false, bool CS = false>
 __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
   constexpr int NW = BM > 128 ? 8 : 4, WR = NW / 2;
   constexpr int TM = BM / (32 * WR), TN = BN / 64;   // 32x32 MFMA tiles per wave in m / n
@@ -910,7 +913,8 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
   // t < BN adds column t of every stage image of the blocks of tile row 0 / tap 0 (k order: a fixed order).
   bool do_cs = false;
   float csum = 0.f;
-  if constexpr (MODE == MODE_WGRAD && !BATCH) do_cs = p.cs_part != nullptr && tile_m == 0 && rs_fixed == 0;
+  static_assert(!CS || (MODE == MODE_WGRAD && !BATCH), "column sums ride on the plain wgrad launch only");
+  if constexpr (CS) do_cs = p.cs_part != nullptr && tile_m == 0 && rs_fixed == 0;
   int cur = 0, nxt = NSTAGE - 1;                 // stage being multiplied / stage the next DMA targets
   for (int it = 0; it < nk; ++it) {
     const bool more = it + NSTAGE - 1 < nk;
@@ -918,7 +922,7 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
       if (more) issue_tile(ks_begin + it + NSTAGE - 1, nxt);
     const float* a = smem + cur * STAGE;
     const float* b = a + A_FL;
-    if constexpr (MODE == MODE_WGRAD && !BATCH)
+    if constexpr (CS)
       if (do_cs && tid < BN) {
 #pragma unroll
         for (int k = 0; k < BKT; ++k) csum += b[k * BN + tid];
@@ -996,7 +1000,7 @@ __device__ __forceinline__ void conv_glds_body(ConvArgs p) {
     cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
-  if constexpr (MODE == MODE_WGRAD && !BATCH)
+  if constexpr (CS)
     if (do_cs && tid < BN && n0 + tid < p.NG) p.cs_part[(int64_t)blockIdx.z * p.NG + n0 + tid] = csum;
   conv_epilogue<BM, BN, MODE, NW>(p, acc, smem, m0, n0);
 }
@@ -1020,6 +1024,17 @@ __global__ void __launch_bounds__(BM > 128 ? 512 : 256, (glds_waves<BM, BN, BKT,
 k_conv_glds_pw(ConvArgs p) {
   conv_glds_body<BM, BN, MODE, BKT, NSTAGE, false, true>(p);
 }
+// wgrad with the bias gradient's column sums riding along (ConvArgs.cs_part)
+template <int BM, int BN, int BKT, int NSTAGE>
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (glds_waves<BM, BN, BKT, NSTAGE>()))
+k_conv_glds_cs(ConvArgs p) {
+  conv_glds_body<BM, BN, MODE_WGRAD, BKT, NSTAGE, false, false, true>(p);
+}
+template <int BM, int BN, int BKT, int NSTAGE>
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (glds_waves<BM, BN, BKT, NSTAGE>()))
+k_conv_glds_pw_cs(ConvArgs p) {
+  conv_glds_body<BM, BN, MODE_WGRAD, BKT, NSTAGE, false, true, true>(p);
+}
 template <int BM, int BN, int MODE, int BKT, int NSTAGE>
 __global__ void __launch_bounds__(BM > 128 ? 512 : 256, (glds_waves<BM, BN, BKT, NSTAGE>()))
 k_wino_glds(ConvArgs p) {
@@ -1036,6 +1051,16 @@ template <int BM, int BN, int MODE>
 __global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN >= 128 * 128 ? 3 : 4))
 k_conv_mfma_pw(ConvArgs p) {
   conv_mfma_body<BM, BN, MODE, 16, false, true>(p);
+}
+template <int BM, int BN, int BKT>
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN >= 128 * 128 ? (BKT > 16 ? 2 : 3) : 4))
+k_conv_mfma_cs(ConvArgs p) {
+  conv_mfma_body<BM, BN, MODE_WGRAD, BKT, false, false, true>(p);
+}
+template <int BM, int BN>
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN >= 128 * 128 ? 3 : 4))
+k_conv_mfma_pw_cs(ConvArgs p) {
+  conv_mfma_body<BM, BN, MODE_WGRAD, 16, false, true, true>(p);
 }
 // a problem the pointwise kernels take: 1x1, stride 1, dilation 1, no padding, same map in and out
 inline bool conv_is_pointwise(const ConvArgs& p) {

@@ -477,25 +477,42 @@ class FilterXfCache:
             e["waited"].add(cur.cuda_stream)
         return e["U"], variant
 
+    # Entries are refreshed in chunks of consecutive entries of one variant (dict order = order of first use in a step:
+    # the trunk's forward layers first, then the towers, then the dgrad forms in backward order), at most this many bytes
+    # of transformed filters per launch, each chunk with an event of its own: the first Winograd layer of the next forward
+    # waits for the first small launch, not for the transform of every filter of the model (1.3 GB at configs[1] — a
+    # 0.7-ms stall of the main stream per step, measured with ops.JoinTimer)
+    CHUNK_BYTES = int(float(os.environ.get("MTLSSL_XF_REFRESH_CHUNK_MB", "48")) * (1 << 20))
+
     def _tables(self):
-        """Device pointer tables per Winograd variant, rebuilt only when the set of entries changed."""
+        """Device pointer tables per chunk, rebuilt only when the set of entries changed."""
         if getattr(self, "_tab_n", -1) != len(self.entries):
-            self._tab = {}
-            for variant in sorted({e["variant"] for e in self.entries.values()}):
-                es = [e for e in self.entries.values() if e["variant"] == variant]
+            chunks, cur, cur_bytes = [], [], 0
+            for e in self.entries.values():
+                nb = e["U"].numel() * 4
+                if cur and (cur[0]["variant"] != e["variant"] or (cur_bytes + nb > self.CHUNK_BYTES > 0)):
+                    chunks.append(cur)
+                    cur, cur_bytes = [], 0
+                cur.append(e)
+                cur_bytes += nb
+            if cur:
+                chunks.append(cur)
+            self._tab = []
+            for es in chunks:
                 dev = es[0]["U"].device
-                self._tab[variant] = dict(
+                self._tab.append(dict(
+                    variant=es[0]["variant"], entries=es,
                     n=len(es), max_ck=max(e["d"].C * e["d"].K for e in es),
                     w=torch.tensor([e["w"].data_ptr() for e in es], dtype=torch.int64, device=dev),
                     u=torch.tensor([e["U"].data_ptr() for e in es], dtype=torch.int64, device=dev),
                     ck=torch.tensor([e["d"].C * e["d"].K for e in es], dtype=torch.int64, device=dev),
-                    flip=torch.tensor([int(e["mode"] == 1) for e in es], dtype=i32, device=dev))
+                    flip=torch.tensor([int(e["mode"] == 1) for e in es], dtype=i32, device=dev)))
             self._tab_n = len(self.entries)
         return self._tab
 
     def refresh(self, stream=None):
-        """Recompute every entry from the current weights in one launch per Winograd variant — on `stream` (behind
-        everything enqueued on the current stream so far) or on the current stream."""
+        """Recompute every entry from the current weights, one launch per chunk — on `stream` (behind everything
+        enqueued on the current stream so far) or on the current stream."""
         if not self.entries:
             return
         cur = torch.cuda.current_stream()
@@ -503,13 +520,13 @@ class FilterXfCache:
         tabs = self._tables()          # (host->device copies of a rebuild happen before the fork below)
         if stream is not None:
             stream.wait_stream(cur)
-        for variant, t in tabs.items():
-            lib().conv2d_transform_filters(variant, t["n"], ptr(t["w"]), ptr(t["u"]), ptr(t["ck"]), ptr(t["flip"]),
+        for t in tabs:
+            lib().conv2d_transform_filters(t["variant"], t["n"], ptr(t["w"]), ptr(t["u"]), ptr(t["ck"]), ptr(t["flip"]),
                                            t["max_ck"], run_on.cuda_stream)
-        ev = torch.cuda.Event()
-        ev.record(run_on)
-        for e in self.entries.values():
-            e["event"], e["waited"] = ev, {run_on.cuda_stream}
+            ev = torch.cuda.Event()
+            ev.record(run_on)
+            for e in t["entries"]:
+                e["event"], e["waited"] = ev, {run_on.cuda_stream}
 
 
 KEEP_INPUT_XF = os.environ.get("MTLSSL_KEEP_INPUT_XF", "1") != "0"
@@ -1099,17 +1116,20 @@ def reduce_sum(x, scale=1.0, out=None):
 def sgd_momentum_clip(weights, grads, accum, var_offsets, max_var_size, lr, momentum, clip_norm,
                       grad_scale=1.0, var_weight_decay=None, var_grad_mult=None, fold=None, zero_grads=False):
     """fold: a ParamStore whose shadow weights (ops.fold_scales) the same launch refreshes — only when no scale vector
-    depends on a variable being updated (every BatchNorm frozen). zero_grads: the launch leaves zeros in `grads`."""
+    depends on a variable being updated (every BatchNorm frozen) — or the triple (eff, fold_ptrs, fold_len) of such a
+    store, sliced like weights / var_offsets (a per-bucket update: var_offsets relative to the slice's first element).
+    zero_grads: the launch leaves zeros in `grads`."""
     nv = var_offsets.numel() - 1
     norms = workspace(lib().sgd_workspace_bytes(max(nv, 1), int(max_var_size)), "norms", weights.device)
-    has_fold = fold is not None and fold.eff is not None
-    if has_fold or zero_grads:
+    if fold is not None and not isinstance(fold, tuple):
+        fold = (fold.eff, fold.fold_ptrs, fold.fold_len) if fold.eff is not None else None
+    if fold is not None or zero_grads:
+        eff, fptr, flen = fold if fold is not None else (None, None, None)
         lib().sgd_momentum_clip_fold(ptr(_chk(weights)), ptr(_chk(grads)), ptr(_chk(accum)),
                                      ptr(_chk(var_offsets, i32)), nv, weights.numel(), int(max_var_size),
                                      float(lr), float(momentum), float(clip_norm), float(grad_scale),
                                      ptr(var_weight_decay), ptr(var_grad_mult), ptr(norms),
-                                     ptr(fold.eff) if has_fold else None, ptr(fold.fold_ptrs) if has_fold else None,
-                                     ptr(fold.fold_len) if has_fold else None, 1 if zero_grads else 0, _stream())
+                                     ptr(eff), ptr(fptr), ptr(flen), 1 if zero_grads else 0, _stream())
         return
     lib().sgd_momentum_clip(ptr(_chk(weights)), ptr(_chk(grads)), ptr(_chk(accum)),
                             ptr(_chk(var_offsets, i32)), nv, weights.numel(), int(max_var_size),

@@ -107,6 +107,7 @@ class GradientReducer:
         self.launch_order = []             # bucket ids in the order they were issued (diagnostics/tests)
         self.timing = False                # bench: HIP events around every bucket and around the final wait
         self._ev_buckets, self._ev_wait = [], []
+        self._bucket_events = {}
         if self.active:
             ps.grad_ready_hook = self.mark_ready
 
@@ -116,6 +117,7 @@ class GradientReducer:
         self.done = [False] * len(self.buckets)
         self.seen = set()
         self.launch_order = []
+        self._bucket_events = {}
 
     def mark_ready(self, spec):
         if not self.active or not self.pending or spec.name in self.seen:
@@ -147,6 +149,9 @@ class GradientReducer:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(self.stream)
         self.comm.allreduce(g[s:e], stream=self.stream)
+        done = torch.cuda.Event()                    # this bucket's sum is in HBM once the event has passed
+        done.record(self.stream)
+        self._bucket_events[b] = done
         if self.timing:
             e1.record(self.stream)
             self._ev_buckets.append((e0, e1, (e - s) * 4))
@@ -171,6 +176,34 @@ class GradientReducer:
                 self._ev_wait.append((e0, e1))
         self.pending = []
 
+    def finish_by_bucket(self):
+        """finish() one bucket at a time: issues whatever has not been reduced yet, then yields the bucket ids in the
+        order their all-reduces were issued, each AFTER making the compute stream wait for that bucket's all-reduce only —
+        so the caller can clip + update bucket b while the all-reduces of the later buckets are still on the wire, and
+        only the last bucket's reduce and its slice of the update are exposed at the end of the step (the clone-gradient
+        sum followed by apply_gradients, slim/deployment/model_deploy.py:414-444 and slim/learning.py:282-301, per
+        bucket: the per-variable clip makes the update separable per variable)."""
+        if not self.active:
+            return
+        if not self.done:
+            self.begin_step()
+        for b in range(len(self.buckets)):
+            if not self.done[b]:
+                self._launch(b)
+        cur = torch.cuda.current_stream() if self.stream is not None else None
+        for n, b in enumerate(list(self.launch_order)):
+            if cur is not None:
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
+                ops.wait_on(self._bucket_events[b], "all-reduce of gradient bucket (last issued)" if n + 1 == len(self.launch_order)
+                            else "all-reduce of gradient bucket (earlier ones)", cur)
+                if self.timing:
+                    e1.record(cur)
+                    self._ev_wait.append((e0, e1))
+            yield b
+        self.pending = []
+
     def all_reduce(self):
         """Non-overlapped form: reduce every bucket now."""
         self.begin_step()
@@ -186,6 +219,24 @@ class GradientReducer:
         return {"allreduce_ms_per_step": busy / steps, "exposed_ms_per_step": exposed / steps,
                 "hidden_ms_per_step": max(busy - exposed, 0.0) / steps, "bytes_per_step": nbytes // steps,
                 "buckets": len(self.buckets)}
+
+
+def bucket_update_tables(ps, buckets):
+    """Per bucket (start, end) of the flat gradient buffer: (first variable, one past the last variable, offsets of those
+    variables RELATIVE to the bucket start + the bucket length [host list], largest variable extent) — what the fused
+    clip + momentum launch needs to run on the bucket's slice alone. Buckets are variable-aligned and consecutive, so the
+    variable ranges partition the trainable variables in order."""
+    offs = [sp.offset for sp in ps.trainable_specs] + [ps.n_train]
+    tabs, v = [], 0
+    for s, e in buckets:
+        assert offs[v] == s, (offs[v], s)
+        v0 = v
+        while v < len(offs) - 1 and offs[v] < e:
+            v += 1
+        rel = [o - s for o in offs[v0:v]] + [e - s]
+        tabs.append((v0, v, rel, max(b - a for a, b in zip(rel[:-1], rel[1:]))))
+    assert v == len(offs) - 1
+    return tabs
 
 
 def filter_variable_names(names, filter_regex_list, invert=False):
@@ -261,9 +312,19 @@ class Trainer:
         self.zero_in_update = os.environ.get("MTLSSL_ZERO_IN_UPDATE", "1") != "0" and self.ps.device.type == "cuda"
         self.max_steps_in_flight = int(os.environ.get("MTLSSL_MAX_STEPS_IN_FLIGHT", "2"))     # 0: unbounded (rounds 1-4)
         self._step_events = []
-        # momentum update and shadow-weight fold in one launch: only when no scale vector trains (frozen BatchNorm)
+        # momentum update and shadow-weight fold in one launch: only when no SCALE vector trains — frozen BatchNorm, or a
+        # normaliser without gamma whose beta alone trains (Inception-ResNet-v2's slim.batch_norm(scale=False): the folded
+        # scale is 1/sqrt(var + eps), a constant; beta only moves the shift, which bn_refresh recomputes)
         self.fuse_fold = (os.environ.get("MTLSSL_FUSE_FOLD", "1") != "0"
-                          and not any(getattr(l, "bn_trainable", False) for l in model.layers))
+                          and not any(getattr(l, "bn_trainable", False) and getattr(l, "gamma", None) is not None
+                                      for l in model.layers))
+        # with a communicator the clip + momentum update runs per gradient bucket, right behind that bucket's all-reduce
+        # (GradientReducer.finish_by_bucket): the step no longer ends with "last all-reduce -> norms over all 78 M
+        # parameters -> update over all of them" in series. Same arithmetic per variable: bit-identical weights.
+        self.bucket_update = (os.environ.get("MTLSSL_BUCKET_UPDATE", "1") != "0" and self.reducer.active
+                              and self.opt["kind"] == "momentum")
+        self._bucket_tabs = None
+        self.update_order = []             # bucket ids in the order their slices were updated (diagnostics / tests)
         own = os.environ.get("MTLSSL_STEP_STREAM", "auto")
         use = (self.reducer.active if own == "auto" else own == "1") and self.ps.device.type == "cuda"
         self.step_stream = torch.cuda.Stream(device=self.ps.device) if use else None
@@ -353,11 +414,24 @@ class Trainer:
         """trainer.py:379-427: cross-replica sum, gradient multipliers / frozen variables, per-variable
         clip_by_norm, momentum update."""
         self.reducer.compute_streams = self.model.compute_streams()
-        self.reducer.finish()
         lr = self.lr_fn(self.global_step)
         ps = self.ps
         o = self.opt
         folded = False
+        if self.bucket_update:
+            folded = self.fuse_fold and ps.device.type == "cuda" and ps.eff is not None
+            self.update_order = []
+            for b in self.reducer.finish_by_bucket():
+                self._update_bucket(b, lr, folded)
+                self.update_order.append(b)
+            ps.grads_clean = self.zero_in_update
+            if self.ema is not None:
+                ops.axpby(ps.weights, self.ema, 1.0 - self.ema_decay, self.ema_decay)
+            self.model.refold(folded=folded)
+            ops.mark("update")
+            self.global_step += 1
+            return
+        self.reducer.finish()
         if o["kind"] == "momentum":
             # with every BatchNorm frozen the scale vectors are constants: the update launch refreshes the shadow
             # weights itself and the separate fold (a second pass over all 78 M parameters) is skipped
@@ -379,6 +453,20 @@ class Trainer:
         self.model.refold(folded=folded)
         ops.mark("update")
         self.global_step += 1
+
+    def _update_bucket(self, b, lr, folded):
+        """clip_by_norm + momentum (+ shadow-weight fold, + zeroing of the gradients) on the variables of bucket b only."""
+        ps = self.ps
+        if self._bucket_tabs is None:
+            self._bucket_tabs = [(v0, v1, torch.tensor(rel, dtype=torch.int32, device=ps.device), mx)
+                                 for v0, v1, rel, mx in bucket_update_tables(ps, self.reducer.buckets)]
+        s, e = self.reducer.buckets[b]
+        v0, v1, rel, mx = self._bucket_tabs[b]
+        fold = (ps.eff[s:e], ps.fold_ptrs[v0:v1], ps.fold_len[v0:v1]) if folded else None
+        ops.sgd_momentum_clip(ps.weights[s:e], ps.grads[s:e], ps.accum[s:e], rel, mx, lr, self.momentum, self.clip, 1.0,
+                              None if self.var_wd is None else self.var_wd[v0:v1],
+                              None if self.var_mult is None else self.var_mult[v0:v1],
+                              fold=fold, zero_grads=self.zero_in_update)
 
     def step(self, batch):
         """One training step. With a communicator the step runs on a stream of its own instead of the legacy

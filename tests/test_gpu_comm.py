@@ -104,6 +104,37 @@ def test_trainer_reduces_through_rccl_with_overlap(comm):
     assert s["exposed_ms_per_step"] >= 0 and s["hidden_ms_per_step"] >= 0
 
 
+def test_per_bucket_update_is_bit_identical_to_the_monolithic_update(comm, monkeypatch):
+    """With a communicator the clip + momentum update runs bucket by bucket, each behind its own bucket's all-reduce
+    (Trainer._update_bucket / GradientReducer.finish_by_bucket) instead of once over all variables after the last
+    all-reduce. Per-variable clip_by_norm (slim/learning.py:282-301) makes the update separable per variable: three steps
+    of both forms from the same state give the same weights, momentum and shadow weights BIT FOR BIT; the buckets are
+    updated in the order their all-reduces were issued, every bucket once; the gradient buffer is left zeroed."""
+    from mtl_ssl_amd import config, model_builder, synthetic, trainer
+    cfg = config.parse_pipeline_config(open(os.path.join(ROOT, "configs", "smoke_resnet50_mtl.config")).read())
+    batch = synthetic.make_batch(2, 160, 224, 5, seed=100, device="cuda", max_gt=4, num_windows=6)
+    state = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MTLSSL_BUCKET_UPDATE", mode)
+        m = model_builder.build(cfg.model, True, "cuda", seed=3)
+        t = trainer.Trainer(m, cfg.train_config, 1, comm=comm, reduce_always=True)
+        t.reducer = trainer.GradientReducer(m.ps, comm, bucket_bytes=1 << 20, always=True)     # many buckets
+        assert t.bucket_update == (mode == "1") and len(t.reducer.buckets) > 4
+        orders = []
+        for _ in range(3):
+            t.step(batch)
+            orders.append((list(t.update_order), list(t.reducer.launch_order)))
+        torch.cuda.synchronize()
+        assert float(m.ps.grads.abs().max()) == 0.0 and m.ps.grads_clean
+        state[mode] = (m.ps.weights.clone(), m.ps.accum.clone(), m.ps.eff.clone(), orders, len(t.reducer.buckets))
+    wb, ab, eb, orders, nb = state["1"]
+    wm, am, em, _, _ = state["0"]
+    assert torch.equal(wb, wm) and torch.equal(ab, am) and torch.equal(eb, em)
+    for upd, issued in orders:
+        assert upd == issued and sorted(upd) == list(range(nb))
+        assert upd[0] > upd[-1]                       # tower / head buckets (high offsets) first, the trunk's last
+
+
 def test_gradient_multipliers_and_frozen_variables_in_the_fused_update():
     """object_detection/trainer.py:389-410 as per-variable entries of the optimizer launch."""
     from mtl_ssl_amd import ops

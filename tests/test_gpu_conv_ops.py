@@ -64,6 +64,12 @@ CONV_CASES = [
     (2, 11, 11, 32, 64, 3, 2, 1, "VALID"),
     # 784 tiles of 128x128 on 768 resident slots: main launch + K-split tail launch + fold (fwd and dgrad)
     (512, 7, 7, 512, 512, 1, 1, 1, "SAME"),
+    # R-FCN's position-sensitive class map (21 classes x 9 bins): wgrad zero-padded to K = 192 for the MFMA engine
+    (2, 38, 64, 1024, 189, 1, 1, 1, "SAME"),
+    (3, 9, 11, 64, 13, 1, 1, 1, "SAME"),         # the smallest padded wgrad (K = 13 -> 16), ragged everything
+    # the edge-mask head (1024 -> 2): thin pointwise forward, one wavefront per pixel
+    (2, 38, 64, 1024, 2, 1, 1, 1, "SAME"),
+    (1, 5, 7, 100, 7, 1, 1, 1, "SAME"),          # thin forward, C not a multiple of 256, K = 7
 ]
 
 

@@ -383,6 +383,43 @@ def _dp_worker(rank, world, port, out):
         ps.grad_ready(ps.by_name[n])                           # a repeated report is ignored
     early = list(red.launch_order)
     red.finish()
+    res["overlap"] = ps.grads.clone().numpy()
+    res["order"] = list(red.launch_order)
+    # per-bucket form (the optimizer runs bucket by bucket behind each bucket's all-reduce): the same reports, then the
+    # generator yields every bucket exactly once, in issue order, and a bucket's slice holds the cross-replica SUM at
+    # the moment it is yielded — while it is being "updated" the later buckets may still be on the wire
+    ps.grads.copy_(g)
+    red.begin_step()
+    for n in reversed(names[2:]):
+        ps.grad_ready(ps.by_name[n])
+    yielded, summed_at_yield = [], []
+    expect = torch.arange(ps.n_train, dtype=torch.float32) * (1 + 2) / 2
+    for b in red.finish_by_bucket():
+        s0, e0 = red.buckets[b]
+        yielded.append(b)
+        summed_at_yield.append(bool(torch.allclose(ps.grads[s0:e0], expect[s0:e0], rtol=1e-6)))
+        ps.grads[s0:e0].zero_()                                  # the update consumes (and zeroes) its slice
+    res["by_bucket"] = (yielded, list(red.launch_order), summed_at_yield, float(ps.grads.abs().max()))
+    # the per-bucket tables partition the variables in order; a per-variable clip + momentum update applied bucket by
+    # bucket (in ANY order) gives the bits of the update applied to all variables at once
+    tabs = trainer.bucket_update_tables(ps, red.buckets)
+    res["tabs_cover"] = [(v0, v1) for v0, v1, _, _ in tabs]
+    from oracle import optimizer as OO
+    rng = np.random.RandomState(7)
+    vals = {sp.name: rng.randn(*sp.shape).astype(np.float32) for sp in ps.trainable_specs}
+    grads = {k: (rng.randn(*v.shape) * 3).astype(np.float32) for k, v in vals.items()}
+    acc = {k: rng.randn(*v.shape).astype(np.float32) for k, v in vals.items()}
+    mono_v, mono_a = {k: v.copy() for k, v in vals.items()}, {k: v.copy() for k, v in acc.items()}
+    OO.momentum_update(mono_v, grads, mono_a, 0.01, 0.9, 10.0)
+    bk_v, bk_a = {k: v.copy() for k, v in vals.items()}, {k: v.copy() for k, v in acc.items()}
+    for b in reversed(range(len(tabs))):
+        v0, v1, rel, mx = tabs[b]
+        nm = [sp.name for sp in ps.trainable_specs[v0:v1]]
+        assert rel[0] == 0 and rel[-1] == red.buckets[b][1] - red.buckets[b][0] and mx == max(np.diff(rel))
+        sub_v, sub_a = {k: bk_v[k] for k in nm}, {k: bk_a[k] for k in nm}
+        OO.momentum_update(sub_v, {k: grads[k] for k in nm}, sub_a, 0.01, 0.9, 10.0)
+        bk_v.update(sub_v); bk_a.update(sub_a)
+    res["bucket_update_identical"] = all(np.array_equal(mono_v[k], bk_v[k]) and np.array_equal(mono_a[k], bk_a[k]) for k in vals)
     # the step loop's collective failure verdict: rank 1 alone sees a problem, both ranks learn of it
     res["verdict"] = trainer.collective_verdict(GlooComm(), 2 if rank == 1 else 0, "cpu")
     res["verdict_ok"] = trainer.collective_verdict(GlooComm(), 0, "cpu")
@@ -409,9 +446,7 @@ def _dp_worker(rank, world, port, out):
     # RcclComm's precondition agreement (before the collective mtlssl_comm_init): one rank that cannot load RCCL or see
     # its device makes EVERY rank raise, nobody is left inside ncclCommInitRank; and the wrapper reports its group's backend
     res["agree"] = (C._dist_agree(rank == 1), C._dist_agree(False), fb.backend, GlooComm().backend)
-    res["overlap"] = ps.grads.clone().numpy()
     res["early"] = early
-    res["order"] = list(red.launch_order)
     res["nb"] = len(red.buckets)
     out[rank] = res
     dist.destroy_process_group()
@@ -434,6 +469,12 @@ def test_data_parallel_gradient_sum_gloo_world2():
     # every bucket exactly once overall
     assert len(out[0]["early"]) >= 1 and out[0]["early"] == sorted(out[0]["early"], reverse=True)
     assert sorted(out[0]["order"]) == list(range(out[0]["nb"]))
+    for r in (0, 1):
+        yielded, issued, summed, left = out[r]["by_bucket"]
+        assert yielded == issued and sorted(yielded) == list(range(out[r]["nb"])) and all(summed) and left == 0.0
+        cover = out[r]["tabs_cover"]
+        assert cover[0][0] == 0 and cover[-1][1] == 6 and all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+        assert out[r]["bucket_update_identical"]
     # trainer.collective_verdict: a failure seen by one rank stops every rank (none is left waiting in an all-reduce)
     assert out[0]["verdict"] == 2 and out[1]["verdict"] == 2 and out[0]["verdict_ok"] == 0 and out[1]["verdict_ok"] == 0
     # comm.default_comm: one rank's RCCL init failure moves BOTH ranks to the torch.distributed fallback
