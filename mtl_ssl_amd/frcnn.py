@@ -33,6 +33,16 @@ def _l2_from_hyperparams(hp):
     return 0.0
 
 
+
+def side_stream_priority():
+    """HIP priority of the step's side streams (aux towers / losses, filter gradients). MTLSSL_SIDE_STREAM_PRIORITY:
+    0 (default) = the same as the main stream; a positive value = LOWER than the main stream where the runtime has such a
+    level (hipDeviceGetStreamPriorityRange; torch clamps to the range), so that the dispatcher serves the main stream's
+    chain first and the side streams fill what it leaves. A/B: profiles/r06_stream_priority_ab.txt."""
+    import os
+    return int(os.environ.get("MTLSSL_SIDE_STREAM_PRIORITY", "0"))
+
+
 class MaskRCNNBoxPredictor:
     """core/box_predictor.py:339-611: RoI features -> (spatial mean | flatten) -> optional FC_i_depth layers, each
     followed by dropout when use_dropout -> FC heads. The depth of the extra layers is
@@ -267,7 +277,7 @@ class FasterRCNNMetaArch:
         if self.ps.device.type != "cuda" or os.environ.get("MTLSSL_AUX_STREAM", "1") == "0":
             return None
         if getattr(self, "_aux_stream_obj", None) is None:
-            self._aux_stream_obj = torch.cuda.Stream(device=self.ps.device)
+            self._aux_stream_obj = torch.cuda.Stream(device=self.ps.device, priority=side_stream_priority())
         return self._aux_stream_obj
 
     def _wgrad_exec(self):
@@ -281,7 +291,7 @@ class FasterRCNNMetaArch:
                 env is None and not getattr(self._feature_extractor, "supports_wgrad_stream", False)):
             return nn.INLINE_WGRAD
         if getattr(self, "_wgrad_stream_obj", None) is None:
-            self._wgrad_stream_obj = nn.WgradStream(torch.cuda.Stream(device=self.ps.device),
+            self._wgrad_stream_obj = nn.WgradStream(torch.cuda.Stream(device=self.ps.device, priority=side_stream_priority()),
                                                     group=os.environ.get("MTLSSL_WGRAD_GROUP", "0") == "1")
         return self._wgrad_stream_obj
 

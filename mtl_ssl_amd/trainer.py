@@ -327,7 +327,9 @@ class Trainer:
         self.update_order = []             # bucket ids in the order their slices were updated (diagnostics / tests)
         own = os.environ.get("MTLSSL_STEP_STREAM", "auto")
         use = (self.reducer.active if own == "auto" else own == "1") and self.ps.device.type == "cuda"
-        self.step_stream = torch.cuda.Stream(device=self.ps.device) if use else None
+        # MTLSSL_STEP_STREAM_PRIORITY: HIP priority of the step's own (main) stream when it has one (-1 = above the side streams)
+        self.step_stream = (torch.cuda.Stream(device=self.ps.device, priority=int(os.environ.get("MTLSSL_STEP_STREAM_PRIORITY", "0")))
+                            if use else None)
         # builders/optimizer_builder.py:105-111: tf.contrib.opt.MovingAverageOptimizer keeps an exponential
         # moving average of every variable beside it (the trainer's plain Saver stores both); decay as given.
         self.ema = None
