@@ -622,7 +622,13 @@ static bool tail_split_enabled() {
 }
 // The split-K fold kernel: a launch plus its traffic. Partials of a few tens of MB are still in the L2 / MALL when the
 // fold reads them (measured 5-6 us for 4 x 5 MB, tools/lab/mid_lab.hip); larger ones stream at the HBM rate the fold reaches.
-static inline double fold_time_us(double bytes) { return 3.0 + bytes / (bytes < 48.0e6 ? 7.0e6 : 3.0e6); }
+// cost of the fold launch behind a K-split: launch + traffic. MTLSSL_FOLD_BASE_US overrides the launch term (A/B switch:
+// on a dependent chain of small launches the fold costs its launch gap as well, which favours fewer splits)
+static inline double fold_base_us() {
+  static const double v = [] { const char* e = getenv("MTLSSL_FOLD_BASE_US"); return e ? atof(e) : 3.0; }();
+  return v;
+}
+static inline double fold_time_us(double bytes) { return fold_base_us() + bytes / (bytes < 48.0e6 ? 7.0e6 : 3.0e6); }
 // kc = reduction channels per filter tap (C for fwd, K for dgrad), taps = R*S.
 static Plan plan_gemm(int64_t M, int64_t NG, int taps, int kc, int tuned, double* t_out = nullptr, bool pw = false) {
   const int* resident = CFG_RESIDENT;
