@@ -14,7 +14,7 @@ CFG[resnet101]="--config $R/configs/frcnn_resnet101_coco_mtl.config"
 CFG[rfcn]="--config $R/configs/rfcn_resnet101_voc_mtl.config"
 CFG[mobilenet]="--config $R/configs/frcnn_mobilenet_v1_voc_mtl.config"
 CFG[inception]="--config $R/configs/frcnn_inception_resnet_v2_coco_mtl.config --height 800 --width 1333"
-COMMON="--steps 8 --warmup 4 --no-cpu-baseline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 --no-other-configs --no-roofline"
+COMMON="--steps 8 --warmup 4 --no-cpu-baseline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 --no-other-configs --no-roofline --join-steps 0"
 for name in ${CFGS:-resnet101 rfcn mobilenet inception}; do
   args="${CFG[$name]}"
   (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $E/prof_$name -o ev -- python $R/bench.py $COMMON $args > $E/${TAG}_${name}_bench_profiled.json 2> $E/${name}.err)
@@ -29,7 +29,7 @@ for name in ${CFGS:-resnet101 rfcn mobilenet inception}; do
   rm -rf $E/profs_$name
   if [ -n "$PMC" ]; then
     OUT=$E/pmc_$name; rm -rf $OUT; mkdir -p $OUT
-    CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 --no-other-configs $args"
+    CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-hbm-kernels --split-engine-steps 0 --class-steps 0 --roofline-isolated-steps 0 --no-other-configs --join-steps 0 $args"
     (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 \
       --kernel-trace --output-format csv -d $OUT/sq -o sq -- $CMD > $OUT/sq.log 2>&1
      timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
