@@ -159,7 +159,7 @@ def pmc_traffic(default_cfg):
     """HBM bytes per launch of the roofline kernel. PMC counters cannot be read from inside the
     process being timed, so this is the committed result of the separate `rocprofv3 --pmc FETCH_SIZE`
     / `--pmc WRITE_SIZE` passes over this same command (tools/pmc_bench.sh -> tools/pmc_summary.py ->
-    profiles/r04_pmc_traffic.json); null when that file is absent or the config is not the default."""
+    profiles/rNN_pmc_traffic.json of the latest round); null when that file is absent or the config is not the default."""
     path = _latest_profile("pmc_traffic.json")
     if not default_cfg or path is None:
         return None
@@ -198,7 +198,7 @@ def plan_kernel_name(key):
 
 def pmc_hbm_counters():
     """{kernel name fragment: {"fetch_bytes", "write_bytes"} per launch} from the separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes over tools/hbm_kernels.py (tools/pmc_hbm.sh -> profiles/r04_hbm_kernels_pmc.json);
+    FETCH_SIZE / WRITE_SIZE passes over tools/hbm_kernels.py (tools/pmc_hbm.sh -> profiles/rNN_hbm_kernels_pmc.json of the latest round);
     empty when the file is absent."""
     path = _latest_profile("hbm_kernels_pmc.json")
     return json.load(open(path))["kernels"] if path else {}
@@ -829,7 +829,8 @@ def main():
                     "avg_launch_us": 1e6 * iso["seconds"] / iso["dispatches"], "launches": iso["dispatches"],
                     "steps": a.roofline_isolated_steps, "ms_per_step_of_that_schedule": iso_ms,
                     "how": "MTLSSL_AUX_STREAM=0 MTLSSL_WGRAD_STREAM=0 (the fully serialised schedule) for these steps, after the "
-                           "timed region; rocprofv3 of a whole run in that mode: profiles/r05_resnet101_kernel_stats_serialised.md"}
+                           "timed region; rocprofv3 of a whole run in that mode: %s" % os.path.relpath(
+                               _latest_profile("resnet101_kernel_stats_serialised.md") or "profiles/", ROOT)}
         except Exception as e:
             ops.PROFILER = None
             out["roofline"]["isolated"] = {"error": repr(e)}
@@ -934,10 +935,10 @@ def main():
                 "note": "per step; main_ms / side_ms = wall time of the calls issued to the step's main stream / to the "
                         "auxiliary and filter-gradient streams (a Winograd call = its transforms + its GEMM stack); "
                         "non_conv_main_stream_ms = step time minus the main stream's conv calls (RoI crop, proposal "
-                        "chain, losses, optimizer, waits on side streams). Calls on different streams overlap (forward: main "
-                        "tower / closeness tower / refiner pass side by side; backward: dgrad chain / aux towers / filter "
-                        "gradients), so rows do not add up to the step and a row's TFLOP/s is the rate of calls that share "
-                        "the chip; kernel-level rows: profiles/r05_resnet101_kernel_stats.md",
+                        "chain, losses, optimizer, waits on side streams). Calls on different streams overlap (forward: serial "
+                        "on the main stream unless MTLSSL_CLOSENESS_FWD_SIDE / MTLSSL_REFINE_EARLY are set; backward: dgrad chain / "
+                        "aux towers / filter gradients side by side), so rows do not add up to the step and a row's TFLOP/s is the rate of calls that share "
+                        "the chip; kernel-level rows: %s" % os.path.relpath(_latest_profile("resnet101_kernel_stats.md") or "profiles/", ROOT),
             }
         except Exception as e:
             ops.PROFILER = None
