@@ -9,7 +9,8 @@ trainable beta, ReLU, xavier weights, L2 on weights and on the residual convs' b
 layer trains (the extractor has no freeze_layer handling in `_extract_proposal_features`).
 
 Gradient convention (as in nn.py): `gp` is dL/d(pre-activation); ReLU masks are applied in the
-dgrad epilogue of the consuming convolution; tf.concat and its gradient are channel-slice copies.
+dgrad epilogue of the consuming convolution; tf.concat is never materialised by a copy: every branch writes its channel
+slice of the concatenated map in place and the backward reads its slice of the map's gradient in place (`Branches`).
 """
 import torch
 

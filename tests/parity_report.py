@@ -37,7 +37,7 @@ def gradients(tag, grads, ref, losses=None, ref_losses=None):
 
 
 def against_float64(tag, Oracle, hp, values, host_batch, seed, step, boxes, num, grads, cap=1e-3, outliers=12, worst=1e-2,
-                    feat=None, d_feat=None, median_cap=3e-4):
+                    feat=None, d_feat=None, median_cap=3e-4, g32=None):
     """The gradient claim against the better yardstick: the same graph evaluated by the oracle in float64 AND in
     float32 on the DEVICE'S sampled boxes (`boxes` [B,N2,4] absolute, `num` [B]; forcing them takes the proposal chain
     and the crop knife edge at the image border — a sample at in_y = H-1 up to the last bit of a decoded box — out of
@@ -51,7 +51,8 @@ def against_float64(tag, Oracle, hp, values, host_batch, seed, step, boxes, num,
         without those (at most 6; observed 1) elements the map's gradient agrees with float64 to 1e-4.
     Returns {name: (hip_vs_f64, fp32_oracle_vs_f64)}."""
     forced = dict(proposal_boxes=np.asarray(boxes), num_proposals=np.asarray(num))
-    _, g32, a32 = Oracle(hp, values).step(host_batch, seed=seed, step=step, forced=forced)
+    if g32 is None:          # (a caller that already holds the fp32 oracle's gradients on these boxes passes them in)
+        _, g32, a32 = Oracle(hp, values).step(host_batch, seed=seed, step=step, forced=forced)
     _, g64, a64 = Oracle(hp, values, np.float64).step(host_batch, seed=seed, step=step, forced=forced)
     rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
     out = {}

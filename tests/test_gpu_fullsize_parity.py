@@ -284,7 +284,8 @@ def test_trained_state_step_matches_the_free_running_oracle():
     if os.environ.get("MTLSSL_SKIP_F64_TRAINED") != "1":
         f64 = parity_report.against_float64(tag, Oracle, hp, values, hb, model.seed, step_no, mine,
                                             pd["num_proposals"].cpu().numpy(), grads, cap=1e-3, outliers=8, worst=5e-3,
-                                            median_cap=6e-4)        # observed 2.5e-4 (the fp32 oracle's own: 1.5e-4)
+                                            median_cap=6e-4,        # observed 2.5e-4 (the fp32 oracle's own: 1.5e-4)
+                                            g32=rgrads)             # the forced-RPN fp32 run above: the same boxes, bit for bit
         # (no flip location at the trunk output here: with crop 14 -> 2x2 max-pool and three towers behind it, the map's
         # gradient also carries the towers' ReLU flips and the pooling's arg-max ties, which are not flips AT that map —
         # 1.6e-3 of its norm on this state; the MobileNet case, crop 7 and no pooling, is where that check applies)
