@@ -375,13 +375,18 @@ def cpu_baseline(cfg, model, tr, H, W, seed, steps=3, batch=1, threads_max=128):
     hp = hyper_params_for_oracle(cfg)
     b = synthetic.make_batch(batch, H, W, K, seed=seed, device="cpu")
     b["images"] = b["images"].numpy()
+    b1 = b                                       # the thread sweep steps on ONE image (it only ranks thread counts)
+    if batch > 1:
+        b1 = synthetic.make_batch(1, H, W, K, seed=seed, device="cpu")
+        b1["images"] = b1["images"].numpy()
     values = model.ps.state_dict()
     wd = {s.name: s.weight_decay for s in model.ps.trainable_specs if s.weight_decay}
 
-    def run(n_steps, accum):
+    def run(n_steps, accum, bb=None):
+        bb = b if bb is None else bb
         t0 = time.time()
         for step in range(n_steps):
-            losses, grads, _ = Oracle(hp, values).step(b, seed=model.seed, step=step)
+            losses, grads, _ = Oracle(hp, values).step(bb, seed=model.seed, step=step)
             oopt.momentum_update(values, grads, accum, tr.lr_fn(step), tr.momentum, tr.clip, wd)
         return (time.time() - t0) / n_steps, losses
 
@@ -392,21 +397,21 @@ def cpu_baseline(cfg, model, tr, H, W, seed, steps=3, batch=1, threads_max=128):
     sweep = {}
     for n in sorted({min(32, cap), min(64, cap), min(128, cap), cap if threads_max == 0 else min(128, cap)}):
         torch.set_num_threads(n)
-        sweep[n] = run(1, {})[0]
+        sweep[n] = run(1, {}, b1)[0]
     cores = min(sweep, key=sweep.get)
     torch.set_num_threads(cores)
     values = model.ps.state_dict()                       # the sweep's updates are not part of the sample
     dt, losses = run(steps, {})
     return {"value": batch / dt, "unit": "images/sec", "cores": cores, "host_cores": host_cores, "kind": "port",
             "batch": batch, "gpu_leg_batch": int(cfg.train_config.batch_size),
-            "batch_note": "the CPU leg steps on %d image(s) per step, the GPU leg on %d; the unit (images/sec) is per image, "
-                          "and the oracle's per-image work does not depend on the batch (per-image proposal chain, "
-                          "sampling and refine; convolutions linear in B) — `--cpu-batch %d` times the identical batch"
-                          % (batch, int(cfg.train_config.batch_size), int(cfg.train_config.batch_size)),
-            "thread_sweep_s_per_step": {str(k): round(v, 2) for k, v in sweep.items()},
+            "batch_note": ("the CPU leg and the GPU leg step on the same synthetic batch shape (%d images per step)" % batch
+                           if batch == int(cfg.train_config.batch_size) else
+                           "the CPU leg steps on %d image(s) per step, the GPU leg on %d; the unit (images/sec) is per image"
+                           % (batch, int(cfg.train_config.batch_size))),
+            "thread_sweep_s_per_step_one_image": {str(k): round(v, 2) for k, v in sweep.items()},
             "sample": "CPU oracle (torch-CPU fp32 + numpy; this build's restatement of the step, not TensorFlow): %d full "
                       "training steps (fwd + losses + bwd + clip + momentum update) on %d synthetic %dx%d image(s), "
-                      "%.1f s/step on %d torch threads — the fastest of a one-step sweep over %s threads (host has %d "
+                      "%.1f s/step on %d torch threads — the fastest of a one-step, one-image sweep over %s threads (host has %d "
                       "cores)" % (steps, batch, W, H, dt, cores, "/".join(str(k) for k in sorted(sweep)), host_cores),
             "total_loss_last_step": float(sum(losses.values()))}
 
@@ -525,9 +530,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)      # >= 50 timed steps after >= 10 warm-up
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--cpu-batch", type=int, default=1,
-                    help="images per CPU-oracle step (1 keeps the default run within minutes; the per-GPU batch times the identical batch)")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=0,
+                    help="images per CPU-oracle step (0 = the configuration's per-GPU batch: the GPU leg's own batch shape)")
     ap.add_argument("--cpu-threads-max", type=int, default=128,
                     help="largest thread count of the CPU baseline's sweep (0 = up to every host core)")
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches cycled through the steps")
@@ -958,7 +963,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, model, tr, a.height, a.width, seed=1234, steps=a.cpu_steps,
-                                               batch=a.cpu_batch, threads_max=a.cpu_threads_max)
+                                               batch=a.cpu_batch or B, threads_max=a.cpu_threads_max)
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
         if default_cfg and a.cpu_config0_steps > 0:
