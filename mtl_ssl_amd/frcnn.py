@@ -7,6 +7,8 @@ Differences that are deliberate: refine runs per image (Q
 uses counter-hash priorities instead of tf.random_shuffle (Q6); target assignment treats every
 groundtruth box as a normal box (Q1, the reference's effective behaviour).
 """
+import os
+
 import torch
 
 from . import nn, ops
@@ -39,7 +41,6 @@ def side_stream_priority():
     0 (default) = the same as the main stream; a positive value = LOWER than the main stream where the runtime has such a
     level (hipDeviceGetStreamPriorityRange; torch clamps to the range), so that the dispatcher serves the main stream's
     chain first and the side streams fill what it leaves. A/B: profiles/r06_stream_priority_ab.txt."""
-    import os
     return int(os.environ.get("MTLSSL_SIDE_STREAM_PRIORITY", "0"))
 
 
@@ -273,7 +274,6 @@ class FasterRCNNMetaArch:
     def _aux_stream(self):
         """Second compute stream for work that is independent of the main path (None on CPU or when
         MTLSSL_AUX_STREAM=0)."""
-        import os
         if self.ps.device.type != "cuda" or os.environ.get("MTLSSL_AUX_STREAM", "1") == "0":
             return None
         if getattr(self, "_aux_stream_obj", None) is None:
@@ -285,7 +285,6 @@ class FasterRCNNMetaArch:
         MTLSSL_WGRAD_STREAM=0 or on CPU, and by default for a feature extractor whose backward does not take one
         (MobileNet: a 5-ms step of ~10-us kernels, where the stream's events cost more than the heads' three filter
         gradients gain — 5.10 vs 4.97 ms; MTLSSL_WGRAD_STREAM=1 forces it on)."""
-        import os
         env = os.environ.get("MTLSSL_WGRAD_STREAM")
         if self.ps.device.type != "cuda" or env == "0" or (
                 env is None and not getattr(self._feature_extractor, "supports_wgrad_stream", False)):
@@ -316,7 +315,6 @@ class FasterRCNNMetaArch:
         ops.fold_scales(self.ps)
         # transformed filters of the Winograd layers are kept per optimizer step (ops.FilterXfCache); the frozen
         # layers' shadow filters were just re-created, so start from an empty cache
-        import os
         on = self.ps.device.type == "cuda" and os.environ.get("MTLSSL_FILTER_CACHE", "1") != "0"
         self.ps.filter_cache = ops.FilterXfCache() if on else None
 
@@ -545,7 +543,6 @@ class FasterRCNNMetaArch:
         box_ind = self._box_ind(B, N2, F.device)
         flat = boxes_norm.view(B * N2, 4)
         crops, argmax = self._crop(F, flat, box_ind, True)
-        import os
         early_win = None
         if (self._is_training and mtl.refine and mtl.window and self._shared_classifier is False
                 and self._refine_stream() is not None):
@@ -652,7 +649,6 @@ class FasterRCNNMetaArch:
     def _refine_stream(self):
         """Third forward stream: the refiner's window pass next to the second stage's own towers (None on CPU, without
         the auxiliary stream, or with MTLSSL_REFINE_EARLY=0)."""
-        import os
         if self._aux_stream() is None or os.environ.get("MTLSSL_REFINE_EARLY", "0") != "1":
             return None
         # the filter-gradient stream is idle during the forward pass: reuse it rather than create a fourth compute
@@ -924,7 +920,7 @@ class FasterRCNNMetaArch:
                 self.ps.grad_ready_hook = hook
         crop_args = (int(c.initial_crop_size), int(c.maxpool_kernel_size), int(c.maxpool_stride))
 
-        def aux_backward(collect=None):
+        def aux_backward(collect=None, which=("closeness", "window")):
             """collect: a list that receives (crop gradient, arg-max, boxes, box indices) instead of the RoI-crop
             backward being issued here (the caller adds them to dF later, on the stream that owns dF)."""
             if shared:
@@ -934,18 +930,24 @@ class FasterRCNNMetaArch:
                                                    need_feat_grad=False)
                 return
             todo = []
-            if mtl.closeness:
+            # MTLSSL_AUX_TOWER_WGRAD_STREAM=1: the aux towers' filter gradients on the filter-gradient stream as well (they
+            # feed nothing but the optimizer), which leaves the aux stream the two dgrad chains only
+            awg = {}
+            if (os.environ.get("MTLSSL_AUX_TOWER_WGRAD_STREAM", "0") == "1"
+                    and getattr(self.closeness_tower if mtl.closeness else self.window_tower, "supports_wgrad_stream", False)):
+                awg = dict(wgrad=self._wgrad_exec())
+            if mtl.closeness and "closeness" in which:
                 cfeat = pd["_cfeat"]
                 g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat.shape,
                                                       mask_ref=cfeat, mask6=m6)
-                gc = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop, masked=True)
+                gc = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop, masked=True, **awg)
                 if not stop:
                     todo.append((gc, pd["_argmax"], pd["proposal_boxes_normalized"].view(-1, 4), pd["_box_ind"]))
-            if mtl.window:
+            if mtl.window and "window" in which:
                 wfeat = pd["_wfeat"]
                 g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat.shape,
                                                    mask_ref=wfeat, mask6=m6)
-                gw = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop, masked=True)
+                gw = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop, masked=True, **awg)
                 if not stop:
                     todo.append((gw, pd["_wargmax"], pd["_wboxes"], pd["_wbox_ind"]))
             if collect is not None:
@@ -966,15 +968,22 @@ class FasterRCNNMetaArch:
             early.wait_stream(cur)
             with torch.cuda.stream(early):
                 aux_backward(collect=pending)
-        import os
         side0 = None
         if (stop and not shared and (mtl.closeness or mtl.window)
                 and os.environ.get("MTLSSL_AUX_RELEASE", "start") == "start"):
             side0 = self._aux_stream()
             if side0 is not None:
+                # MTLSSL_WINDOW_BWD=third: the window tower's backward on the filter-gradient stream instead of behind the
+                # closeness tower's on the aux stream (A/B: profiles/r06_window_bwd_third_ab.txt)
+                third = getattr(self._wgrad_exec(), "stream", None) if (
+                    os.environ.get("MTLSSL_WINDOW_BWD", "aux") == "third" and mtl.closeness and mtl.window) else None
                 side0.wait_stream(cur)
                 with torch.cuda.stream(side0):
-                    aux_backward()
+                    aux_backward(which=("closeness", "window") if third is None else ("closeness",))
+                if third is not None:
+                    third.wait_stream(cur)
+                    with torch.cuda.stream(third):
+                        aux_backward(which=("window",))
         if (getattr(self.tower, "supports_wgrad_stream", False) and not shared
                 and os.environ.get("MTLSSL_TOWER_WGRAD_STREAM", "1") == "1"):
             # the main tower's filter gradients feed nothing but the optimizer: on the third stream (joined at the end

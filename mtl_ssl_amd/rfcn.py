@@ -219,14 +219,24 @@ class RFCNMetaArch(FasterRCNNMetaArch):
             g_feat_closeness = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None,
                                                                  pd["_cfeat"], need_feat_grad=not stop)
 
-        def aux_backward():
-            if mtl.closeness and not shared:
+        def aux_backward(which=("closeness", "window")):
+            import os
+            awg = {}
+            # The aux towers' filter gradients go to the filter-gradient stream (joined at the end of backward): the aux stream
+            # then carries the two towers' dgrad chains only, whose input gradients the main stream is waiting for (3.5 ms per
+            # step at that join, `whole_step.main_stream_joins`). Same-box A/B, three passes: 35.12 -> 34.79 ms/step
+            # (profiles/r06_rfcn_tower_wgrad_ab.txt); the main tower's own filter gradients there as well: no gain (35.16).
+            # MTLSSL_AUX_TOWER_WGRAD_STREAM=0 keeps them on the aux stream. (Faster R-CNN's aux towers — stop_gradient, nobody
+            # waits for them — lose with it: +1.8 ms on configs[1], +5.8 on configs[4]; off by default there.)
+            if os.environ.get("MTLSSL_AUX_TOWER_WGRAD_STREAM", "1") == "1" and getattr(self.tower, "supports_wgrad_stream", False):
+                awg = dict(wgrad=self._wgrad_exec())
+            if mtl.closeness and not shared and "closeness" in which:
                 cfeat = pd["_cfeat"]
                 g = self.closeness_predictor.backward(pd["_cp"], d["closeness_predictions"], None, cfeat)
-                g_c = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop)
+                g_c = self.closeness_tower.backward(g, cfeat, pd["_cctx"], need_input_grad=not stop, **awg)
                 if not stop:
                     held.append(g_c)
-            if mtl.window:
+            if mtl.window and "window" in which:
                 wfeat = pd["_wfeat"]
                 if shared and stop:               # gradient stopped at the window tower's output: the predictor alone trains
                     self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat,
@@ -236,7 +246,7 @@ class RFCNMetaArch(FasterRCNNMetaArch):
                                            *((l.gamma, l.beta) if getattr(l, "bn_trainable", False) else ()))
                     return
                 g = self.window_predictor.backward(pd["_wp"], d["window_class_predictions"], None, wfeat)
-                g_w = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop)
+                g_w = self.window_tower.backward(g, wfeat, pd["_wctx"], need_input_grad=not stop, **awg)
                 if not stop:
                     held.append(g_w)
 
@@ -247,21 +257,46 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         # stream once the second one has been joined — before the RPN / trunk backward, which needs the sum.
         cur = torch.cuda.current_stream()
         side = self._aux_stream() if (mtl.closeness or mtl.window) else None
+        import os
+        # MTLSSL_RFCN_WINDOW_BWD: where the window tower's backward runs when both aux towers have one — "aux" (default:
+        # behind the closeness tower's on the aux stream), "main" (on this stream, behind the main tower's) or "third" (on
+        # the filter-gradient stream). A/B: profiles/r06_rfcn_window_bwd_ab.txt.
+        wplace = os.environ.get("MTLSSL_RFCN_WINDOW_BWD", "aux")
+        third = None
+        if side is None or shared or not (mtl.closeness and mtl.window):
+            wplace = "aux"
         if side is not None:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                aux_backward()
+                aux_backward(("closeness", "window") if wplace == "aux" else ("closeness",))
+            if wplace == "third":
+                third = getattr(self._wgrad_exec(), "stream", None)
+                if third is None:
+                    wplace = "main"
+                else:
+                    third.wait_stream(cur)
+                    with torch.cuda.stream(third):
+                        aux_backward(("window",))
         feat = pd["_feat"]
         g_feat = self.box_predictor.backward(pd["_bp"], d_cls,
                                              d["refined_box_encodings"].view(d_cls.shape[0], -1), feat)
         if g_feat_closeness is not None:
             ops.axpby(g_feat_closeness, g_feat, 1.0, 1.0)
-        g_F = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True)
+        if os.environ.get("MTLSSL_RFCN_TOWER_WGRAD_STREAM", "0") == "1" and getattr(self.tower, "supports_wgrad_stream", False):
+            # the main tower's filter gradients on the filter-gradient stream (joined at the end of backward)
+            g_F = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True, wgrad=self._wgrad_exec())
+        else:
+            g_F = self.tower.backward(g_feat, feat, pd["_tower_ctx"], need_input_grad=True)
         ops.axpby(g_F, dF, 1.0, 1.0)
         if side is None:
             aux_backward()
-        elif not stop:
-            ops.wait_on(side, "backward: aux stream", cur)
+        else:
+            if wplace == "main":
+                aux_backward(("window",))
+            if not stop:
+                ops.wait_on(side, "backward: aux stream", cur)
+                if third is not None:
+                    ops.wait_on(third, "backward: window tower on the third stream", cur)
         for g in held:
             g.record_stream(cur)            # produced on the second stream, consumed (and then released) on this one
             ops.axpby(g, dF, 1.0, 1.0)
