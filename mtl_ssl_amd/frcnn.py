@@ -968,18 +968,19 @@ class FasterRCNNMetaArch:
             early.wait_stream(cur)
             with torch.cuda.stream(early):
                 aux_backward(collect=pending)
-        side0 = None
+        side0, window_on_main = None, False
         if (stop and not shared and (mtl.closeness or mtl.window)
                 and os.environ.get("MTLSSL_AUX_RELEASE", "start") == "start"):
             side0 = self._aux_stream()
             if side0 is not None:
                 # MTLSSL_WINDOW_BWD=third: the window tower's backward on the filter-gradient stream instead of behind the
                 # closeness tower's on the aux stream (A/B: profiles/r06_window_bwd_third_ab.txt)
-                third = getattr(self._wgrad_exec(), "stream", None) if (
-                    os.environ.get("MTLSSL_WINDOW_BWD", "aux") == "third" and mtl.closeness and mtl.window) else None
+                wplace = os.environ.get("MTLSSL_WINDOW_BWD", "aux") if (mtl.closeness and mtl.window) else "aux"
+                third = getattr(self._wgrad_exec(), "stream", None) if wplace == "third" else None
+                window_on_main = wplace == "main"
                 side0.wait_stream(cur)
                 with torch.cuda.stream(side0):
-                    aux_backward(which=("closeness", "window") if third is None else ("closeness",))
+                    aux_backward(which=("closeness", "window") if (third is None and not window_on_main) else ("closeness",))
                 if third is not None:
                     third.wait_stream(cur)
                     with torch.cuda.stream(third):
@@ -996,6 +997,8 @@ class FasterRCNNMetaArch:
                               pd["_box_ind"], *crop_args, dfeat=dF, accumulate=False)
         if gw_shared is not None:
             ops.roi_crop_pool_bwd(gw_shared, pd["_wargmax"], F.shape, pd["_wboxes"], pd["_wbox_ind"], *crop_args, dfeat=dF)
+        if window_on_main:              # MTLSSL_WINDOW_BWD=main: the (small) window tower's backward behind the main tower's
+            aux_backward(which=("window",))
         if early is not None:
             ops.wait_on(early, "backward: aux towers released early", cur)
             for gx, am, bx, bi in pending:
