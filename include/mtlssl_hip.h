@@ -125,6 +125,24 @@ int mtlssl_conv2d_fwd_keep(const mtlssl_conv_desc* d, const float* x, const floa
 int mtlssl_conv2d_wgrad_xf(const mtlssl_conv_desc* d, const float* x, const float* dy,
                            const float* out_scale, float* dw, float* dbias, float beta,
                            void* workspace, const float* input_xf, int input_variant, mtlssl_stream_t stream);
+/* n pointwise (1x1, stride 1) forward convolutions that read the SAME input x in ONE launch (blockIdx.y = problem): the
+ * branch-first 1x1 layers of an Inception-ResNet block (slim/nets/inception_resnet_v2.py:36-44, 57-65, 78-86, 165-184,
+ * 226-248 — Branch_0 / Branch_1 / Branch_2 `Conv2d_0a_1x1` all take `net`), or conv1 + shortcut of a ResNet unit
+ * (slim/nets/resnet_v1.py:102-112). Each problem keeps its own filter [1,1,C,K_i], bias, output pointer, output row
+ * stride (ldy_i: 0 = dense, else the channel count of the concatenated map it writes a slice of) and epilogue flags
+ * (BIAS / RELU / RELU6 / TANH; no residual); they share N, H, W, C of `d` (d->K is ignored). `entries` is a HOST array
+ * of n <= MTLSSL_CONV_GROUP_MAX records (they travel as kernel arguments: no device table, no copy); max_k / sum_k =
+ * largest / summed K_i (the library picks the tile for the summed problem and sizes the grid for the widest one). Requirements: C % 16 == 0, every K_i % 4 == 0 and >= 16, 16-byte aligned pointers. Results
+ * are those of n mtlssl_conv2d_fwd calls without a K split. */
+#define MTLSSL_CONV_GROUP_MAX 4
+typedef struct {
+  const float* w;            /* [1,1,C,K] */
+  float* y;                  /* [N,H,W,K] with row stride ldy (or K) */
+  const float* bias;         /* [K] or NULL */
+  int32_t K, ldy, epilogue, reserved;
+} mtlssl_conv_group_entry;
+int mtlssl_conv2d_fwd_grouped(const mtlssl_conv_desc* d, const float* x, int n, const mtlssl_conv_group_entry* entries,
+                              int max_k, int sum_k, mtlssl_stream_t stream);
 /* The same with the bias gradient scaled per output channel too: dbias[k] = beta*dbias[k] + dbias_scale[k] * sum dy[:,k]
  * (dbias_scale nullable = 1): a bias that reaches the layer through a folded per-channel factor — the residual scale of
  * the Inception-ResNet blocks, net += scale * (conv(mixed) + b), slim/nets/inception_resnet_v2.py:47-52. */

@@ -1427,6 +1427,56 @@ int mtlssl_conv2d_fwd_keep(const mtlssl_conv_desc* d, const float* x, const floa
   return check_launch("conv2d_fwd");
 }
 
+// MTLSSL_GROUPED_FWD_CFG: pin the tile of the grouped pointwise forward (0 128x128, 1 128x64, 2 64x64, 3 256x128)
+static int grouped_fwd_cfg_env() {
+  static const int v = [] { const char* e = getenv("MTLSSL_GROUPED_FWD_CFG"); return e ? atoi(e) : -1; }();
+  return v;
+}
+int mtlssl_conv2d_fwd_grouped(const mtlssl_conv_desc* d, const float* x, int n, const mtlssl_conv_group_entry* entries,
+                              int max_k, int sum_k, mtlssl_stream_t stream) {
+  if (n <= 0) return MTLSSL_OK;
+  if (int rc = check_desc(d)) return rc;
+  MTLSSL_REQUIRE(is_pointwise(d) && d->dilation == 1, "fwd_grouped: pointwise problems only (1x1, stride 1, no padding)");
+  MTLSSL_REQUIRE(d->C % BK == 0, "fwd_grouped: C = %d must be a multiple of %d", d->C, BK);
+  MTLSSL_REQUIRE(x && entries && n <= MTLSSL_CONV_GROUP_MAX && max_k >= 16 && sum_k >= max_k, "fwd_grouped: bad arguments");
+  ConvArgs p = make_args(d);
+  GroupArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  p.a = x;
+  for (int i = 0; i < n; ++i) {
+    const mtlssl_conv_group_entry& e = entries[i];
+    MTLSSL_REQUIRE(e.w && e.y && e.K >= 16 && e.K % 4 == 0 && e.K <= max_k && (e.ldy == 0 || (e.ldy >= e.K && e.ldy % 4 == 0)) &&
+                       !(e.epilogue & (MTLSSL_EPI_RESIDUAL | MASK_ANY | MTLSSL_EPI_ACCUM)) && (!(e.epilogue & MTLSSL_EPI_BIAS) || e.bias),
+                   "fwd_grouped: problem %d: K = %d, ldy = %d, epilogue = %d", i, e.K, e.ldy, e.epilogue);
+    ga.e[i] = e;
+  }
+  p.a_bytes = (unsigned)((int64_t)d->N * d->H * d->W * d->C * 4);
+  p.M = d->N * d->H * d->W;
+  p.NG = max_k; p.K = max_k; p.ldy = 0;
+  p.nsplit = 1; p.ks_per_split = 0; p.tile_m0 = 0; p.ws_m0 = 0;
+  // the tile the planner would give the summed problem, without a K split (the group fills the chip instead)
+  int cfg = grouped_fwd_cfg_env();
+  if (cfg < 0 || cfg >= NCFG) {
+    double best = 1e30;
+    cfg = 2;
+    for (int c = 0; c < NCFG; ++c) {
+      const int64_t tiles = cdiv(p.M, CFG_BM[c]) * cdiv(sum_k, CFG_BN[c]);
+      const double t = tile_time_us(c, tiles, d->C / CFG_BK[c], true);
+      if (t < best) { best = t; cfg = c; }
+    }
+  }
+  p.tiles_m = (int)cdiv(p.M, CFG_BM[cfg]);
+  p.tiles_n = (int)cdiv(max_k, CFG_BN[cfg]);
+  dim3 grid(p.tiles_m * p.tiles_n, n, 1);
+  switch (cfg) {
+    case 0: hipLaunchKernelGGL((k_conv_mfma_pw_grp<128, 128>), grid, dim3(256), 0, S(stream), p, ga); break;
+    case 1: hipLaunchKernelGGL((k_conv_mfma_pw_grp<128, 64>), grid, dim3(256), 0, S(stream), p, ga); break;
+    case 2: hipLaunchKernelGGL((k_conv_mfma_pw_grp<64, 64>), grid, dim3(256), 0, S(stream), p, ga); break;
+    default: hipLaunchKernelGGL((k_conv_mfma_pw_grp<256, 128>), grid, dim3(512), 0, S(stream), p, ga); break;
+  }
+  return check_launch("conv2d_fwd_grouped");
+}
+
 int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float* w,
                         const float* residual, const float* mask_ref, float* dx, int epi,
                         void* workspace, mtlssl_stream_t stream) {

@@ -1062,6 +1062,25 @@ __global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN 
 k_conv_mfma_pw_cs(ConvArgs p) {
   conv_mfma_body<BM, BN, MODE_WGRAD, 16, false, true, true>(p);
 }
+// Grouped pointwise forward (mtlssl_conv2d_fwd_grouped): blockIdx.y selects one of up to four problems on the same input;
+// the problem brings its own filter, output (+ row stride), bias, width and epilogue. A kernel of its own with the records
+// as a SECOND argument: inside ConvArgs (dynamic index, or even a select chain on the by-value struct) they sent the
+// argument struct to scratch and cost every pointwise forward kernel an occupancy step (measured: +30 % step time).
+// The grid is sized for the widest problem: blocks past this problem's tiles leave at once.
+struct GroupArgs { mtlssl_conv_group_entry e[MTLSSL_CONV_GROUP_MAX]; };
+template <int BM, int BN>
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN >= 128 * 128 ? 3 : 4))
+k_conv_mfma_pw_grp(ConvArgs p, GroupArgs g) {
+  static_assert(MTLSSL_CONV_GROUP_MAX == 4, "the select chain below covers four problems");
+  const int gy = blockIdx.y;                       // wave-uniform: scalar selects
+  const mtlssl_conv_group_entry e = gy == 0 ? g.e[0] : gy == 1 ? g.e[1] : gy == 2 ? g.e[2] : g.e[3];
+  p.b = e.w; p.out = e.y; p.bias = e.bias;
+  p.NG = e.K; p.K = e.K; p.ldy = e.ldy; p.epi = e.epilogue;
+  p.b_bytes = (unsigned)(p.C * e.K) * 4u;
+  p.tiles_n = (e.K + BN - 1) / BN;
+  if ((int)blockIdx.x >= p.tiles_m * p.tiles_n) return;
+  conv_mfma_body<BM, BN, MODE_FWD, 16, false, true>(p);
+}
 // a problem the pointwise kernels take: 1x1, stride 1, dilation 1, no padding, same map in and out
 inline bool conv_is_pointwise(const ConvArgs& p) {
   return p.R == 1 && p.S == 1 && p.stride == 1 && p.dil == 1 && p.pt == 0 && p.pl == 0 && p.OH == p.H && p.OW == p.W;

@@ -136,24 +136,53 @@ class Branches:
     def layers(self):
         return [l for ch in self.chains for l in ch]
 
+    def _out_shape(self, x_shape):
+        """(N, OH, OW) of the concatenated map for an input of `x_shape`: shapes walked through chain 0, no launch."""
+        s = tuple(x_shape)
+        for l in self.chains[0]:
+            if isinstance(l, Pool):
+                s = l.out_shape(s)
+            else:
+                d = l.desc(s)
+                s = (d.N, d.OH, d.OW, d.K)
+        return s[:3]
+
+    def _groupable(self, l, x):
+        """A branch-first layer that can join the block's grouped pointwise launch: 1x1 / stride 1 on x, widths the MFMA
+        engine takes (ops.conv2d_fwd_grouped)."""
+        if not isinstance(l, nn.ConvBN) or not x.is_cuda:
+            return False
+        d = l.desc(x.shape)
+        return (ops.desc_is_pointwise(d) and d.C % 16 == 0 and d.K % 4 == 0 and d.K >= 16
+                and d.N * d.H * d.W <= ops.GROUPED_FWD_MAX_ROWS)
+
     def forward(self, x, save):
-        acts = []
-        for ch in self.chains:                       # everything but the last layer of each chain
-            a = [x]
-            for l in ch[:-1]:
-                a.append(l.forward(a[-1]))
-            acts.append(a)
-        l0, x0 = self.chains[0][-1], acts[0][-1]
-        if isinstance(l0, Pool):
-            N, OH, OW, _ = l0.out_shape(x0.shape)
-        else:
-            d = l0.desc(x0.shape)
-            N, OH, OW = d.N, d.OH, d.OW
+        N, OH, OW = self._out_shape(x.shape)
         cat = torch.empty((N, OH, OW, self.ccat), dtype=torch.float32, device=x.device)
-        for ch, a, off, c in zip(self.chains, acts, self.offs, self.couts):
-            view = cat[..., off:off + c]
-            ch[-1].forward(a[-1], out=view)
-            a.append(view)
+        views = [cat[..., off:off + c] for off, c in zip(self.offs, self.couts)]
+        acts = [[x] for _ in self.chains]
+        # The branch-first 1x1 layers all read the block input (inception_resnet_v2.py:36-44, 57-65, 78-86, 165-184,
+        # 226-248): ONE grouped launch (blockIdx.y = branch) instead of two to four under-filled ones — the input panel
+        # is shared through L2 and no branch needs a K split to fill the chip. A single-layer branch writes its slice of
+        # the concatenated map straight from that launch.
+        first = [ci for ci, ch in enumerate(self.chains) if self._groupable(ch[0], x)] if ops.GROUPED_FWD else []
+        if len(first) >= 2:
+            probs = []
+            for ci in first:
+                l = self.chains[ci][0]
+                epi = ops.EPI_BIAS | {None: 0, "relu": ops.EPI_RELU, "relu6": ops.EPI_RELU6}[l.act]
+                probs.append((l.desc(x.shape), l.w_eff, l.shift, epi, views[ci] if len(self.chains[ci]) == 1 else None))
+            for ci, y in zip(first, ops.conv2d_fwd_grouped(x, probs)):
+                acts[ci].append(y)
+        for ci, ch in enumerate(self.chains):
+            a = acts[ci]
+            for li in range(len(a) - 1, len(ch)):        # the layers the grouped launch did not run
+                l = ch[li]
+                if li == len(ch) - 1:
+                    l.forward(a[-1], out=views[ci])
+                    a.append(views[ci])
+                else:
+                    a.append(l.forward(a[-1]))
         return cat, (acts if save else [None] * len(acts))
 
     def backward(self, g_cat, acts, residual=None, mask_ref=None, need_input_grad=True, wgrad=nn.INLINE_WGRAD):

@@ -654,6 +654,54 @@ def conv2d_wgrad_grouped(d, xs, dys, dws, scales=None, beta=0.0):
                                ptr(_ptr_table(dws, dev)), float(beta), ptr(ws), _stream())
 
 
+GROUPED_FWD = os.environ.get("MTLSSL_GROUPED_FWD", "1") != "0"
+# problems with more rows than this fill the chip on their own and keep their tuned plans (the grouped launch runs the
+# register-staged engine without a K split). Same-box A/B on configs[4] (profiles/r06_grouped_fwd_ab.txt): separate
+# launches 108.2 ms/step, grouped up to 5 000 rows 107.9, up to 17 000 rows 107.5, every block 107.5
+GROUPED_FWD_MAX_ROWS = int(os.environ.get("MTLSSL_GROUPED_FWD_MAX_ROWS", "20000"))
+
+
+class _GroupEntry(ctypes.Structure):
+    """mtlssl_conv_group_entry."""
+    _fields_ = [("w", ctypes.c_void_p), ("y", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("K", ctypes.c_int32),
+                ("ldy", ctypes.c_int32), ("epilogue", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def conv2d_fwd_grouped(x, problems):
+    """n pointwise forward convolutions on the same input in one launch (mtlssl_conv2d_fwd_grouped).
+    problems: list of (desc, w, bias, epilogue, out) — desc of each problem on x (pointwise: 1x1 / stride 1; its ldy set when
+    `out` is a channel-slice view), out a tensor / view to write, or None for a fresh dense tensor. -> list of outputs."""
+    d0 = problems[0][0]
+    outs = []
+    for d, w, bias, epi, out in problems:
+        assert desc_is_pointwise(d) and (d.N, d.H, d.W, d.C) == (d0.N, d0.H, d0.W, d0.C) and d.C % 16 == 0 \
+            and d.K % 4 == 0 and d.K >= 16 and not (epi & EPI_RESIDUAL), (d.C, d.K, epi)
+        if out is None:
+            assert not d.ldy
+            out = torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
+        else:
+            _chk_y(d, out)
+        _chk(w)
+        outs.append(out)
+    ks = [d.K for d, _, _, _, _ in problems]
+    # the per-problem records travel as kernel arguments (a HOST array of 3 pointers + 4 int32 each): no device table
+    assert len(problems) <= 4, len(problems)
+    tab = (_GroupEntry * len(problems))()
+    for i, ((d, w, bias, epi, _), out) in enumerate(zip(problems, outs)):
+        tab[i] = _GroupEntry(w.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else 0, d.K, int(d.ldy),
+                             int(epi), 0)
+    dsum = None
+    if ACCOUNT is not None or PROFILER is not None:     # booked as ONE problem of the summed width: the same products
+        dsum = ConvDesc(d0.N, d0.H, d0.W, d0.C, sum(ks), 1, 1, d0.OH, d0.OW, 1, 1, 0, 0, 0)
+    t0 = PROFILER.begin(dsum, 0) if PROFILER is not None else None
+    if ACCOUNT is not None:
+        ACCOUNT.add(dsum, 0)
+    lib().conv2d_fwd_grouped(ctypes.byref(d0), ptr(_chk(x)), len(problems), ctypes.addressof(tab), max(ks), sum(ks), _stream())
+    if t0 is not None:
+        PROFILER.end(dsum, 0, t0)
+    return outs
+
+
 def depthwise_fwd(d, x, w, bias=None, epilogue=0):
     y = torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
     t0 = _hbm_begin("depthwise_fwd")

@@ -278,6 +278,54 @@ def test_strided_output_side_is_bit_identical_to_dense(ops, case):
         ops.reset_tuning()
 
 
+@pytest.mark.parametrize("shape,ks,cat", [
+    ((1, 50, 84, 1088), (192, 128), (384, 0)),        # block17: Branch_0 writes its slice of the 384-wide map, Branch_1 dense
+    ((1, 37, 41, 320), (32, 32, 32), (128, 0)),       # block35: three 32-wide problems (half a tile each), ragged M
+    ((16, 8, 8, 2080), (192, 192), (448, 0)),         # block8 on RoI crops: 130 K-steps
+    ((8, 17, 17, 1088), (256, 256, 256), None),       # Mixed_7a: three dense problems
+    ((2, 19, 23, 192), (96, 48, 64), (320, 0)),       # Mixed_5b: widths 96 / 48 / 64 -> a different tile count per problem
+])
+def test_grouped_pointwise_forward_matches_separate_calls(ops, shape, ks, cat):
+    """mtlssl_conv2d_fwd_grouped: the branch-first 1x1 layers of an Inception-ResNet block (same input, own filter / bias
+    / output / row stride / epilogue per problem) in one launch. Against n separate mtlssl_conv2d_fwd calls (which may
+    split K: another summation order, hence a tolerance) and against float64; the first problem writes a channel slice
+    of a wider map and nothing outside it."""
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(C + sum(ks))
+    x = torch.randn(shape, generator=g).cuda()
+    ws = [(torch.randn(1, 1, C, k, generator=g) / np.sqrt(C)).cuda() for k in ks]
+    bs = [torch.randn(k, generator=g).cuda() for k in ks]
+    epis = [ops.EPI_BIAS | ops.EPI_RELU, ops.EPI_BIAS, ops.EPI_BIAS | ops.EPI_RELU6][:len(ks)]
+    epis += [ops.EPI_BIAS | ops.EPI_RELU] * (len(ks) - len(epis))
+    wide = None
+    probs, refs = [], []
+    for i, k in enumerate(ks):
+        out, ldy = None, 0
+        if i == 0 and cat is not None:
+            wide = torch.full((N, H, W, cat[0]), float("nan"), device="cuda")
+            out, ldy = wide[..., cat[1]:cat[1] + k], cat[0]
+        d = ops.conv_desc(shape, ws[i].shape, 1, 1, "SAME", ldy=ldy)
+        probs.append((d, ws[i], bs[i], epis[i], out))
+        refs.append(ops.conv2d_fwd(ops.conv_desc(shape, ws[i].shape, 1, 1, "SAME"), x, ws[i], bs[i], None, epis[i]))
+    outs = ops.conv2d_fwd_grouped(x, probs)
+    torch.cuda.synchronize()
+    for i, (y, r) in enumerate(zip(outs, refs)):
+        assert tuple(y.shape) == tuple(r.shape)
+        assert relerr(y, r) < 1e-5, (i, relerr(y, r))
+        v = x.reshape(-1, C).double() @ ws[i].reshape(C, -1).double() + bs[i].double()
+        if epis[i] & ops.EPI_RELU:
+            v = v.clamp(min=0)
+        if epis[i] & ops.EPI_RELU6:
+            v = v.clamp(min=0, max=6)
+        assert relerr(y.reshape(-1, ks[i]).cpu(), v.float().cpu()) < 1e-5
+    if wide is not None:
+        rest = torch.cat([wide[..., :cat[1]], wide[..., cat[1] + ks[0]:]], -1)
+        assert bool(torch.isnan(rest).all()), "the grouped forward wrote outside its slice"
+    again = ops.conv2d_fwd_grouped(x, [(d, w, b, e, None if o is None else o) for (d, w, b, e, o) in probs])
+    for y, z in zip(outs, again):
+        assert torch.equal(y, z)                      # no K split, no atomics: the same bits every time
+
+
 def test_strided_maxpool_branch_is_bit_identical_to_dense(ops):
     """The pooling branch of Mixed_6a / Mixed_7a writes its slice of the concatenated map and its backward reads y / dy
     slices of the wider maps in place."""
