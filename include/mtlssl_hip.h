@@ -31,7 +31,7 @@ typedef void* mtlssl_stream_t; /* hipStream_t */
 
 /* Bumped whenever a prototype below changes; mtlssl_abi_version() of the loaded library must equal it (the ctypes
  * loader checks: an older build called through a newer header would receive shifted arguments). */
-#define MTLSSL_ABI_VERSION 7
+#define MTLSSL_ABI_VERSION 8
 
 const char* mtlssl_last_error(void);
 int mtlssl_abi_version(void);
@@ -143,6 +143,24 @@ typedef struct {
 } mtlssl_conv_group_entry;
 int mtlssl_conv2d_fwd_grouped(const mtlssl_conv_desc* d, const float* x, int n, const mtlssl_conv_group_entry* entries,
                               int max_k, int sum_k, mtlssl_stream_t stream);
+/* Input gradient of n pointwise (1x1, stride 1) convolutions that read the SAME input, in ONE launch and ONE accumulator
+ * pass: dx = sum_i dy_i . w_i^T (+ residual, masked) — the branch-first 1x1 layers of an Inception-ResNet block
+ * (slim/nets/inception_resnet_v2.py:36-44, 57-65, 78-86: Branch_0 / Branch_1 / Branch_2 `Conv2d_0a_1x1` all take `net`, so
+ * tf.gradients adds their input gradients), or conv1 + shortcut of a ResNet unit (slim/nets/resnet_v1.py:102-112). The
+ * reduction walks the segments in the order given: segment i brings its own dy [N,H,W,K_i] (row stride ldy_i: 0 = dense,
+ * else the channel count of the concatenated map's gradient it is a slice of) and filter [1,1,C,K_i]; they share N, H, W, C
+ * of `d` (d->K, d->ldy ignored). `entries` is a HOST array of n <= MTLSSL_CONV_GROUP_MAX records (kernel arguments: no device
+ * table). epilogue: RESIDUAL / MASK / MASK6 as in mtlssl_conv2d_dgrad (no ACCUM). Requirements: C % 4 == 0, C >= 16, every
+ * K_i % 16 == 0, 16-byte aligned pointers. Equal to n mtlssl_conv2d_dgrad calls chained with ACCUM up to the order of the
+ * fp32 sum (one accumulator over sum K_i instead of n rounded partial results). */
+typedef struct {
+  const float* dy;           /* [N,H,W,K] with row stride ldy (or K) */
+  const float* w;            /* [1,1,C,K] */
+  int32_t K, ldy;
+} mtlssl_conv_seg_entry;
+int mtlssl_conv2d_dgrad_segmented(const mtlssl_conv_desc* d, int n, const mtlssl_conv_seg_entry* entries,
+                                  const float* residual, const float* mask_ref, float* dx, int epilogue,
+                                  mtlssl_stream_t stream);
 /* The same with the bias gradient scaled per output channel too: dbias[k] = beta*dbias[k] + dbias_scale[k] * sum dy[:,k]
  * (dbias_scale nullable = 1): a bias that reaches the layer through a folded per-channel factor — the residual scale of
  * the Inception-ResNet blocks, net += scale * (conv(mixed) + b), slim/nets/inception_resnet_v2.py:47-52. */

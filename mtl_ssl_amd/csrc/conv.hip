@@ -1477,6 +1477,66 @@ int mtlssl_conv2d_fwd_grouped(const mtlssl_conv_desc* d, const float* x, int n, 
   return check_launch("conv2d_fwd_grouped");
 }
 
+// MTLSSL_SEG_DGRAD_CFG: pin the tile of the segmented pointwise dgrad (0 128x128, 1 128x64, 2 64x64, 3 256x128)
+static int seg_dgrad_cfg_env() {
+  static const int v = [] { const char* e = getenv("MTLSSL_SEG_DGRAD_CFG"); return e ? atoi(e) : -1; }();
+  return v;
+}
+int mtlssl_conv2d_dgrad_segmented(const mtlssl_conv_desc* d, int n, const mtlssl_conv_seg_entry* entries,
+                                  const float* residual, const float* mask_ref, float* dx, int epi,
+                                  mtlssl_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  MTLSSL_REQUIRE(is_pointwise(d) && d->dilation == 1, "dgrad_segmented: pointwise problems only (1x1, stride 1, no padding)");
+  MTLSSL_REQUIRE(entries && dx && n >= 1 && n <= MTLSSL_CONV_GROUP_MAX, "dgrad_segmented: bad arguments (n = %d)", n);
+  MTLSSL_REQUIRE(d->C % 4 == 0 && d->C >= 16, "dgrad_segmented: C = %d must be a multiple of 4 and >= 16", d->C);
+  MTLSSL_REQUIRE(!(epi & MASK_ANY) || mask_ref, "dgrad_segmented: mask_ref pointer required");
+  MTLSSL_REQUIRE(!(epi & MTLSSL_EPI_RESIDUAL) || residual, "dgrad_segmented: residual pointer required");
+  MTLSSL_REQUIRE(!(epi & ~(MTLSSL_EPI_RESIDUAL | MASK_ANY)), "dgrad_segmented: epilogue = %d (RESIDUAL / MASK / MASK6 only)", epi);
+  const int64_t M = (int64_t)d->N * d->H * d->W;
+  SegArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  int sum_k = 0;
+  for (int i = 0; i < n; ++i) {
+    const mtlssl_conv_seg_entry& e = entries[i];
+    MTLSSL_REQUIRE(e.dy && e.w && e.K >= BK && e.K % BK == 0 && (e.ldy == 0 || (e.ldy >= e.K && e.ldy % 4 == 0)),
+                   "dgrad_segmented: segment %d: K = %d, ldy = %d", i, e.K, e.ldy);
+    MTLSSL_REQUIRE(((M - 1) * (e.ldy ? e.ldy : e.K) + e.K) * 4 < (int64_t)1 << 32, "dgrad_segmented: segment %d exceeds 4 GiB", i);
+    sa.e[i] = e;
+    sum_k += e.K;
+  }
+  mtlssl_conv_desc q = *d;
+  q.K = sum_k; q.ldy = 0;
+  ConvArgs p = make_args(&q);
+  p.a = entries[0].dy; p.b = entries[0].w; p.out = dx; p.residual = residual; p.mask = mask_ref; p.epi = epi;
+  p.a_bytes = 0; p.b_bytes = 0;                  // the kernel builds its descriptors per segment
+  p.M = (int)M;
+  p.NG = d->C;
+  p.nsplit = 1; p.ks_per_split = 0; p.tile_m0 = 0; p.ws_m0 = 0;
+  int cfg = seg_dgrad_cfg_env();
+  if (cfg < 0 || cfg >= NCFG) {
+    // 128x64 or 64x64: the short reductions of these problems (sum K = 96 ... 384) make the epilogue — residual and mask
+    // reads, the dx store — a large share of a tile's life, and the smaller tiles keep more of them in flight (same-box
+    // A/B on configs[4], profiles/r06_seg_dgrad_ab.txt: 128x64 106.4-106.6 ms/step, 64x64 106.8, 128x128 107.0-107.6)
+    double best = 1e30;
+    cfg = 2;
+    for (int c = 1; c <= 2; ++c) {
+      const int64_t tiles = cdiv(p.M, CFG_BM[c]) * cdiv(p.NG, CFG_BN[c]);
+      const double t = tile_time_us(c, tiles, sum_k / CFG_BK[c], true);
+      if (t < best) { best = t; cfg = c; }
+    }
+  }
+  p.tiles_m = (int)cdiv(p.M, CFG_BM[cfg]);
+  p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
+  dim3 grid(p.tiles_m * p.tiles_n, 1, 1);
+  switch (cfg) {
+    case 0: hipLaunchKernelGGL((k_conv_mfma_pw_seg<128, 128>), grid, dim3(256), 0, S(stream), p, sa); break;
+    case 1: hipLaunchKernelGGL((k_conv_mfma_pw_seg<128, 64>), grid, dim3(256), 0, S(stream), p, sa); break;
+    case 2: hipLaunchKernelGGL((k_conv_mfma_pw_seg<64, 64>), grid, dim3(256), 0, S(stream), p, sa); break;
+    default: hipLaunchKernelGGL((k_conv_mfma_pw_seg<256, 128>), grid, dim3(512), 0, S(stream), p, sa); break;
+  }
+  return check_launch("conv2d_dgrad_segmented");
+}
+
 int mtlssl_conv2d_dgrad(const mtlssl_conv_desc* d, const float* dy, const float* w,
                         const float* residual, const float* mask_ref, float* dx, int epi,
                         void* workspace, mtlssl_stream_t stream) {

@@ -220,8 +220,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, floatx16 (&acc)
 // 1x1 layers and Winograd-domain GEMM stacks, which are pointwise by construction).
 // CS (wgrad only): the bias gradient's column sums of dy ride on the GEMM (p.cs_part) — an instantiation of its own, so
 // that the plain filter-gradient kernels do not carry its accumulators (8 VGPRs: an occupancy step on the large tiles).
-template <int BM, int BN, int MODE, int BKT, bool BATCH, bool PW = false, bool CS = false>
-__device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
+// SEG (pointwise dgrad only): the reduction runs over up to four SEGMENTS, each with its own dy tensor (+ row stride), width
+// and filter — dx = sum_s dy_s . w_s^T in ONE accumulator pass (mtlssl_conv2d_dgrad_segmented). The K loop walks the
+// segments in order; at a boundary (wave-uniform, once per segment) the buffer descriptors and the per-lane row offsets
+// are re-based, inside a segment the loads are the pointwise ones. The records are the kernel's second argument (`sg`).
+struct SegArgs { mtlssl_conv_seg_entry e[MTLSSL_CONV_GROUP_MAX]; };
+template <int BM, int BN, int MODE, int BKT, bool BATCH, bool PW = false, bool CS = false, bool SEG = false>
+__device__ __forceinline__ void conv_mfma_body(ConvArgs p, const SegArgs sg = SegArgs{}) {
+  static_assert(!SEG || (PW && MODE == MODE_DGRAD && !BATCH), "segments: pointwise dgrad only");
   // 4 wavefronts (2x2) per block; the 256-row tile has 8 (4x2) so that a wave's tile stays 64x64
   constexpr int NW = BM > 128 ? 8 : 4, NT = 64 * NW, WR = NW / 2;
   constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -287,8 +293,8 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     a_rec = min(a_rec, (unsigned)(max(pix1, 0) * p.C) * 4u);
     b_rec = min(b_rec, (unsigned)(max(pix1, 0) * ldy) * 4u);
   }
-  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, a_rec, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, b_rec, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, a_rec, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, b_rec, 0x00020000);
   if constexpr (MODE != MODE_WGRAD) {
     if (p.nsplit > 1) {          // split-K: this block covers K-steps [ks_begin, ksteps)
       ks_begin = blockIdx.z * p.ks_per_split;
@@ -359,6 +365,40 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
     }
   }
 
+  // segment cursor (SEG): K-steps [seg_ks0, ...) belong to the current segment; segment s begins at K-step seg_b[s]
+  // (INT_MAX for the unused records: K = 0). Static record indices only: a dynamic index sends the by-value records to
+  // scratch.
+  int seg_ks0 = 0;
+  int seg_b[MTLSSL_CONV_GROUP_MAX] = {0, 0, 0, 0};
+  auto seg_setup = [&](auto SI) {
+    constexpr int s = decltype(SI)::value;
+    const int e_K = sg.e[s].K;
+    const int ld = sg.e[s].ldy ? sg.e[s].ldy : e_K;
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.e[s].dy), 0, (unsigned)((p.M - 1) * ld + e_K) * 4u, 0x00020000);
+    rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.e[s].w), 0, (unsigned)(p.NG * e_K) * 4u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int m = m0 + (tid / KQ) + RP * i;
+      a_voff[i] = m < p.M ? (unsigned)(m * ld + kq4) * 4u : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int row = n0 + (tid / KQ) + RP * i;
+      b_base[i] = row < p.NG ? (unsigned)(row * e_K + kq4) * 4u : OOB;
+    }
+    seg_ks0 = seg_b[s];
+  };
+  if constexpr (SEG) {
+    static_assert(MTLSSL_CONV_GROUP_MAX == 4, "the boundary ladder in load_tile covers four segments");
+    int at = 0;
+#pragma unroll
+    for (int s = 0; s < MTLSSL_CONV_GROUP_MAX; ++s) {
+      seg_b[s] = sg.e[s].K > 0 ? at : 0x7fffffff;
+      at += sg.e[s].K / BKT;
+    }
+    seg_setup(std::integral_constant<int, 0>{});
+  }
+
   // Tap state of the next K-step to be loaded: load_tile is only ever called for consecutive K-steps, so the filter tap
   // (r, s) and the channel offset advance by carry instead of two integer divisions per K-step; the wgrad gather keeps
   // each A row's output pixel (n, oh, ow) the same way.
@@ -407,7 +447,12 @@ __device__ __forceinline__ void conv_mfma_body(ConvArgs p) {
 #pragma unroll
       for (int i = 0; i < B_LD; ++i) rb[i] = bufload4(rsrc_b, __builtin_elementwise_add_sat(b_base[i], sb), 0);
     } else if constexpr (PW) {
-      const unsigned ka = (unsigned)(ks * BKT) * 4u;
+      if constexpr (SEG) {           // load_tile sees consecutive K-steps from 0: each boundary is met exactly once
+        if (ks == seg_b[1]) seg_setup(std::integral_constant<int, 1>{});
+        else if (ks == seg_b[2]) seg_setup(std::integral_constant<int, 2>{});
+        else if (ks == seg_b[3]) seg_setup(std::integral_constant<int, 3>{});
+      }
+      const unsigned ka = (unsigned)((SEG ? ks - seg_ks0 : ks) * BKT) * 4u;
 #pragma unroll
       for (int i = 0; i < A_LD; ++i) ra[i] = bufload4(rsrc_a, a_voff[i], ka);
       const unsigned so = MODE == MODE_FWD ? (unsigned)(ks * BKT * p.K) * 4u : ka;
@@ -1080,6 +1125,14 @@ k_conv_mfma_pw_grp(ConvArgs p, GroupArgs g) {
   p.tiles_n = (e.K + BN - 1) / BN;
   if ((int)blockIdx.x >= p.tiles_m * p.tiles_n) return;
   conv_mfma_body<BM, BN, MODE_FWD, 16, false, true>(p);
+}
+// Segmented pointwise dgrad (mtlssl_conv2d_dgrad_segmented): the branch-first 1x1 layers of an Inception-ResNet block all
+// feed the block input's gradient; one GEMM whose reduction walks the branches' (dy, filter) pairs replaces one launch per
+// branch and the read-modify-write of dx of every launch after the first. Records as a second argument (see above).
+template <int BM, int BN>
+__global__ void __launch_bounds__(BM > 128 ? 512 : 256, (BM > 128 ? 2 : BM * BN >= 128 * 128 ? 3 : 4))
+k_conv_mfma_pw_seg(ConvArgs p, SegArgs g) {
+  conv_mfma_body<BM, BN, MODE_DGRAD, 16, false, true, false, true>(p, g);
 }
 // a problem the pointwise kernels take: 1x1, stride 1, dilation 1, no padding, same map in and out
 inline bool conv_is_pointwise(const ConvArgs& p) {

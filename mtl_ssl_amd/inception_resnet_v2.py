@@ -185,12 +185,46 @@ class Branches:
                     a.append(l.forward(a[-1]))
         return cat, (acts if save else [None] * len(acts))
 
+    def _segmentable(self, x):
+        """Every chain starts with a 1x1 / stride-1 convolution on x of a width the segmented dgrad takes
+        (ops.conv2d_dgrad_segmented): block35 / block17 / block8."""
+        if not (ops.SEG_DGRAD and x.is_cuda and len(self.chains) <= 4):
+            return False
+        for ch in self.chains:
+            if not isinstance(ch[0], nn.ConvBN):
+                return False
+            d = ch[0].desc(x.shape)
+            if not (ops.desc_is_pointwise(d) and d.K % 16 == 0 and d.C % 4 == 0 and d.C >= 16):
+                return False
+        return x.shape[0] * x.shape[1] * x.shape[2] <= ops.SEG_DGRAD_MAX_ROWS
+
     def backward(self, g_cat, acts, residual=None, mask_ref=None, need_input_grad=True, wgrad=nn.INLINE_WGRAD):
         """g_cat: dL/d(concat), already masked by (concat > 0). Returns dL/dx (+ residual), masked by
         (mask_ref > 0) when given. `wgrad`: where the filter gradients run (inline, or an nn.WgradStream the caller
         joins): the 4 200 / 1 032-RoI problems of this network leave most of the chip idle, and the filter gradients feed
         nothing but the optimizer."""
         x = acts[0][0]
+        if self._segmentable(x):
+            # The branch-first 1x1 layers all read the block input, so its gradient is the SUM of their input gradients
+            # (inception_resnet_v2.py:36-44, 57-65, 78-86): one GEMM whose reduction walks the branches' (dy, filter)
+            # pairs — one launch and one pass over dx instead of a launch per branch that re-reads and re-writes it.
+            segs = []
+            for ci, ch in enumerate(self.chains):
+                a = acts[ci]
+                gp = g_cat[..., self.offs[ci]:self.offs[ci] + self.couts[ci]]
+                for li in range(len(ch) - 1, 0, -1):
+                    l, xin = ch[li], a[li]
+                    if isinstance(l, Pool):
+                        gp = l.input_grad(xin, a[li + 1], gp)
+                    else:
+                        wgrad.run(l, xin, gp)
+                        gp = l.dgrad(xin.shape, gp, mask_ref=None if isinstance(ch[li - 1], Pool) else xin)
+                wgrad.run(ch[0], x, gp)
+                segs.append((ch[0].desc(x.shape), gp, ch[0].w_eff))
+            if not need_input_grad:
+                return None
+            epi = (ops.EPI_RESIDUAL if residual is not None else 0) | (ops.EPI_MASK if mask_ref is not None else 0)
+            return ops.conv2d_dgrad_segmented(segs, residual, mask_ref, epi)
         # pooling-first chains go first so that a convolution's dgrad epilogue applies the final mask
         order = sorted(range(len(self.chains)), key=lambda i: not isinstance(self.chains[i][0], Pool))
         assert not isinstance(self.chains[order[-1]][0], Pool)

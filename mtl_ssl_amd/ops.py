@@ -702,6 +702,40 @@ def conv2d_fwd_grouped(x, problems):
     return outs
 
 
+SEG_DGRAD = os.environ.get("MTLSSL_SEG_DGRAD", "1") != "0"
+SEG_DGRAD_MAX_ROWS = int(os.environ.get("MTLSSL_SEG_DGRAD_MAX_ROWS", "1000000000"))
+
+
+class _SegEntry(ctypes.Structure):
+    """mtlssl_conv_seg_entry."""
+    _fields_ = [("dy", ctypes.c_void_p), ("w", ctypes.c_void_p), ("K", ctypes.c_int32), ("ldy", ctypes.c_int32)]
+
+
+def conv2d_dgrad_segmented(segments, residual=None, mask_ref=None, epilogue=0):
+    """Input gradient of n pointwise convolutions on the same input in one launch and one accumulator pass
+    (mtlssl_conv2d_dgrad_segmented): dx = sum_i dy_i . w_i^T (+ residual, masked).
+    segments: list of (desc, dy, w) — desc of each problem on the shared input (pointwise; its ldy set when dy is a
+    channel-slice view). -> dx."""
+    d0 = segments[0][0]
+    assert 1 <= len(segments) <= 4, len(segments)
+    tab = (_SegEntry * len(segments))()
+    for i, (d, dy, w) in enumerate(segments):
+        assert desc_is_pointwise(d) and (d.N, d.H, d.W, d.C) == (d0.N, d0.H, d0.W, d0.C) and d.K % 16 == 0, (d.C, d.K)
+        tab[i] = _SegEntry(_chk_y(d, dy).data_ptr(), _chk(w).data_ptr(), d.K, int(d.ldy))
+    dx = torch.empty((d0.N, d0.H, d0.W, d0.C), dtype=f32, device=segments[0][1].device)
+    dsum = None
+    if ACCOUNT is not None or PROFILER is not None:     # booked as ONE problem of the summed width: the same products
+        dsum = ConvDesc(d0.N, d0.H, d0.W, d0.C, sum(d.K for d, _, _ in segments), 1, 1, d0.OH, d0.OW, 1, 1, 0, 0, 0)
+    t0 = PROFILER.begin(dsum, 1) if PROFILER is not None else None
+    if ACCOUNT is not None:
+        ACCOUNT.add(dsum, 1)
+    lib().conv2d_dgrad_segmented(ctypes.byref(d0), len(segments), ctypes.addressof(tab), ptr(residual), ptr(mask_ref), ptr(dx),
+                                 int(epilogue), _stream())
+    if t0 is not None:
+        PROFILER.end(dsum, 1, t0)
+    return dx
+
+
 def depthwise_fwd(d, x, w, bias=None, epilogue=0):
     y = torch.empty((d.N, d.OH, d.OW, d.K), dtype=f32, device=x.device)
     t0 = _hbm_begin("depthwise_fwd")

@@ -43,12 +43,17 @@ class RfcnBoxPredictor:
         return [l for l in (self.reduce, self.loc, self.cls) if l is not None]
 
     def predict(self, feat, boxes_flat, box_ind):
+        """boxes_flat: the [n,4] normalised boxes, or a callable that returns them — called after the score maps have been
+        issued and before the first pooling (the maps do not depend on the boxes: a caller whose proposal chain runs on
+        another stream joins it there)."""
         net = self.reduce.forward(feat)
         cls_map = self.cls.forward(net)
+        loc_map = self.loc.forward(net) if self.loc is not None else None
+        if callable(boxes_flat):
+            boxes_flat = boxes_flat()
         out = {"net": net, "cls_map_shape": tuple(cls_map.shape), "boxes": boxes_flat, "box_ind": box_ind,
                "class": ops.psroi_fwd(cls_map, boxes_flat, box_ind, self.crop, self.bins)}
-        if self.loc is not None:
-            loc_map = self.loc.forward(net)
+        if loc_map is not None:
             out["loc_map_shape"] = tuple(loc_map.shape)
             out["box"] = ops.psroi_fwd(loc_map, boxes_flat, box_ind, self.crop, self.bins)
         return out
@@ -99,26 +104,60 @@ class RFCNMetaArch(FasterRCNNMetaArch):
         B, H, W, _ = pd["image_shape"]
         F = pd["rpn_features_to_crop"]
         gt = self._format_groundtruth_data(H, W) if self._is_training else None
-        props, _scores, nprop = ops.rpn_proposals(
-            pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"],
-            H, W, c.first_stage_nms_score_threshold, c.first_stage_nms_iou_threshold,
-            int(c.first_stage_max_proposals))
-        N2 = self.max_num_proposals
-        boxes_abs, boxes_norm, num = self._second_stage_proposals(props, nprop, gt, H, W)
-        box_ind = self._box_ind(B, N2, F.device)
-        flat = boxes_norm.view(B * N2, 4)
         import os
+        N2 = self.max_num_proposals
+
+        def proposal_chain():
+            props, _scores, nprop = ops.rpn_proposals(
+                pd["rpn_box_encodings"], pd["rpn_objectness_predictions_with_background"], pd["anchors"],
+                H, W, c.first_stage_nms_score_threshold, c.first_stage_nms_iou_threshold,
+                int(c.first_stage_max_proposals))
+            return self._second_stage_proposals(props, nprop, gt, H, W)
+
+        # block4 runs on the WHOLE map here: the main tower and its score maps do not depend on the proposals, only the
+        # position-sensitive pooling does. The decode -> NMS -> sampling chain (a string of latency-bound kernels, a
+        # one-wavefront greedy scan among them) therefore goes to the filter-gradient stream, idle during the forward pass,
+        # and is joined right before the first pooling — MTLSSL_RFCN_PROPOSALS_SIDE=1. OFF by default: a measured null
+        # (34.93 / 34.91 / 34.97 ms per step against 34.80 / 34.91 / 35.05 on this stream, profiles/r06_rfcn_chain_side_ab.txt):
+        # the window tower's forward on the aux stream already fills the chip under the chain.
+        pside = None
+        if self._is_training and self._aux_stream() is not None and os.environ.get("MTLSSL_RFCN_PROPOSALS_SIDE", "0") == "1":
+            pside = getattr(self._wgrad_exec(), "stream", None)
+        cur = torch.cuda.current_stream() if pside is not None else None
+        if pside is not None:
+            pside.wait_stream(cur)
+            with torch.cuda.stream(pside):
+                chain_out = proposal_chain()
+        else:
+            chain_out = proposal_chain()
+        joined = {}
+
+        def flat_boxes():
+            """The sampled boxes as the poolings take them; joins the proposal chain on first use."""
+            if "flat" not in joined:
+                if pside is not None:
+                    ops.wait_on(pside, "second stage: proposal chain", cur)
+                    for t in chain_out:                      # made on that stream, used (and released) on this one and on
+                        t.record_stream(cur)                 # the aux stream (loss terms)
+                        t.record_stream(self._aux_stream())
+                joined["flat"] = chain_out[1].view(B * N2, 4)
+            return joined["flat"]
+
+        box_ind = self._box_ind(B, N2, F.device)
         cside = None
         if (mtl.closeness and self._is_training and not self._shared_classifier
                 and os.environ.get("MTLSSL_CLOSENESS_FWD_SIDE", "0") == "1"):
             cside = self._aux_stream()
         if cside is not None:          # the closeness tower (block4 on the whole map) next to the main tower's forward
+            flat_boxes()               # its pooling runs over there: join the proposal chain on this stream first
             cside.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cside):
                 cfeat_s, cctx_s = self.closeness_tower.forward(F, self._is_training)
-                cp_s = self.closeness_predictor.predict(cfeat_s, flat, box_ind)
+                cp_s = self.closeness_predictor.predict(cfeat_s, flat_boxes(), box_ind)
         feat, tower_ctx = self.tower.forward(F, self._is_training)
-        bp = self.box_predictor.predict(feat, flat, box_ind)
+        bp = self.box_predictor.predict(feat, flat_boxes, box_ind)
+        flat = flat_boxes()
+        boxes_abs, boxes_norm, num = chain_out
         out = {
             "refined_box_encodings": bp["box"].view(B * N2, self.num_classes, 4),
             "class_predictions_with_background": bp["class"],

@@ -1,11 +1,15 @@
 """GPU parity: convolution family (fp32 MFMA implicit GEMM), ROI crop/pool, resize, pooling,
 losses and the optimizer, each against the torch-CPU fp32 oracle (autograd for backward).
 Tolerance 1e-3 relative fp32 (BASELINE.json north_star); in practice ~1e-6."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import ops_torch as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -324,6 +328,69 @@ def test_grouped_pointwise_forward_matches_separate_calls(ops, shape, ks, cat):
     again = ops.conv2d_fwd_grouped(x, [(d, w, b, e, None if o is None else o) for (d, w, b, e, o) in probs])
     for y, z in zip(outs, again):
         assert torch.equal(y, z)                      # no K split, no atomics: the same bits every time
+
+
+@pytest.mark.parametrize("shape,ks,cat,cfg", [
+    ((1, 50, 84, 1088), (192, 128), (384, 0), None),         # block17: Branch_0's dy is a slice of the 384-wide map's gradient
+    ((4, 25, 42, 320), (32, 32, 32), (128, 0), None),        # block35: three segments of two K-steps each
+    ((16, 8, 8, 2080), (192, 192), (448, 0), None),          # block8 on 8x8 crops
+    ((3, 9, 11, 64), (16, 48, 32, 16), (96, 16), None),      # four segments, ragged rows (297) and a one-K-step segment
+    ((16, 8, 8, 2080), (192, 192), None, 0), ((16, 8, 8, 2080), (192, 192), (448, 0), 1),
+    ((16, 8, 8, 2080), (192, 192), (448, 0), 3),             # every tile of the engine
+])
+def test_segmented_pointwise_dgrad_matches_chained_calls(ops, shape, ks, cat, cfg, monkeypatch):
+    """mtlssl_conv2d_dgrad_segmented: the input gradient of the branch-first 1x1 layers of an Inception-ResNet block (same
+    input; own dy / row stride / filter per branch) as ONE GEMM whose reduction walks the branches. Against the chain of
+    mtlssl_conv2d_dgrad calls it replaces (first call writes dx + residual, the others accumulate, the last one masks:
+    another summation order, hence a tolerance) and against float64; with and without residual / mask."""
+    if cfg is not None:
+        import subprocess
+        import sys
+        # the tile pin is read once per process: run this case in a child with the variable set
+        env = dict(os.environ, MTLSSL_SEG_DGRAD_CFG=str(cfg))
+        code = ("import sys; sys.path.insert(0, %r); import tests.test_gpu_conv_ops as t; from mtl_ssl_amd import ops; "
+                "t._segmented_dgrad_case(ops, %r, %r, %r)" % (ROOT, shape, ks, cat))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
+    _segmented_dgrad_case(ops, shape, ks, cat)
+
+
+def _segmented_dgrad_case(ops, shape, ks, cat):
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(C + sum(ks))
+    ws = [(torch.randn(1, 1, C, k, generator=g) / np.sqrt(k)).cuda() for k in ks]
+    x = torch.randn(shape, generator=g).cuda()              # mask reference
+    res = torch.randn(shape, generator=g).cuda()
+    wide = torch.randn((N, H, W, cat[0]), generator=g).cuda() if cat is not None else None
+    segs, dys = [], []
+    for i, k in enumerate(ks):
+        if i == 0 and cat is not None:
+            dy, ldy = wide[..., cat[1]:cat[1] + k], cat[0]
+        else:
+            dy, ldy = torch.randn((N, H, W, k), generator=g).cuda(), 0
+        segs.append((ops.conv_desc(shape, ws[i].shape, 1, 1, "SAME", ldy=ldy), dy, ws[i]))
+        dys.append(dy)
+    v = sum(dy.reshape(-1, k).double() @ w.reshape(C, k).double().t() for dy, w, k in zip(dys, ws, ks))
+    for use_res, use_mask in ((True, True), (False, False), (True, False), (False, True)):
+        epi = (ops.EPI_RESIDUAL if use_res else 0) | (ops.EPI_MASK if use_mask else 0)
+        dx = ops.conv2d_dgrad_segmented(segs, res if use_res else None, x if use_mask else None, epi)
+        # the chain of calls it replaces
+        ref = None
+        for i, (d, dy, w) in enumerate(segs):
+            last = i == len(segs) - 1
+            e = ((ops.EPI_RESIDUAL if (use_res and i == 0) else 0) | (ops.EPI_ACCUM if i > 0 else 0)
+                 | (ops.EPI_MASK if (use_mask and last) else 0))
+            ref = ops.conv2d_dgrad(d, dy, w, res if (use_res and i == 0) else None, x if (use_mask and last) else None, e,
+                                   out=ref)
+        torch.cuda.synchronize()
+        assert tuple(dx.shape) == tuple(shape)
+        assert relerr(dx, ref) < 1e-5, (use_res, use_mask, relerr(dx, ref))
+        want = v + (res.reshape(-1, C).double() if use_res else 0)
+        if use_mask:
+            want = want * (x.reshape(-1, C) > 0)
+        assert relerr(dx.reshape(-1, C).cpu(), want.float().cpu()) < 1e-5
+        assert torch.equal(dx, ops.conv2d_dgrad_segmented(segs, res if use_res else None, x if use_mask else None, epi))
 
 
 def test_strided_maxpool_branch_is_bit_identical_to_dense(ops):
