@@ -1517,13 +1517,9 @@ int mtlssl_conv2d_dgrad_segmented(const mtlssl_conv_desc* d, int n, const mtlssl
     // 128x64 or 64x64: the short reductions of these problems (sum K = 96 ... 384) make the epilogue — residual and mask
     // reads, the dx store — a large share of a tile's life, and the smaller tiles keep more of them in flight (same-box
     // A/B on configs[4], profiles/r06_seg_dgrad_ab.txt: 128x64 106.4-106.6 ms/step, 64x64 106.8, 128x128 107.0-107.6)
-    double best = 1e30;
-    cfg = 2;
-    for (int c = 1; c <= 2; ++c) {
-      const int64_t tiles = cdiv(p.M, CFG_BM[c]) * cdiv(p.NG, CFG_BN[c]);
-      const double t = tile_time_us(c, tiles, sum_k / CFG_BK[c], true);
-      if (t < best) { best = t; cfg = c; }
-    }
+    // 128x64 as soon as it gives every CU two tiles, else 64x64 (the time model picked 64x64 for most of these: 106.6 /
+    // 106.9 ms per step where the pinned 128x64 ran 106.4 / 106.6)
+    cfg = cdiv(p.M, CFG_BM[1]) * cdiv(p.NG, CFG_BN[1]) >= 512 ? 1 : 2;
   }
   p.tiles_m = (int)cdiv(p.M, CFG_BM[cfg]);
   p.tiles_n = (int)cdiv(p.NG, CFG_BN[cfg]);
