@@ -563,6 +563,9 @@ def main():
                          "must never be mistaken for a scaling point. The line then carries \"stand_in\": true.")
     a = ap.parse_args()
 
+    # the host driver only supports dmabuf IPC (RCCL / device-memory sharing across processes): set before the HIP runtime
+    # comes up — torch.cuda.device_count() below already initialises it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
