@@ -334,6 +334,7 @@ def test_grouped_pointwise_forward_matches_separate_calls(ops, shape, ks, cat):
     ((1, 50, 84, 1088), (192, 128), (384, 0), None),         # block17: Branch_0's dy is a slice of the 384-wide map's gradient
     ((4, 25, 42, 320), (32, 32, 32), (128, 0), None),        # block35: three segments of two K-steps each
     ((16, 8, 8, 2080), (192, 192), (448, 0), None),          # block8 on 8x8 crops
+    ((256, 8, 8, 2080), (192, 192), (448, 0), None),         # the same at configs[4]'s full size: 16 384 rows (256 RoIs)
     ((3, 9, 11, 64), (16, 48, 32, 16), (96, 16), None),      # four segments, ragged rows (297) and a one-K-step segment
     ((16, 8, 8, 2080), (192, 192), None, 0), ((16, 8, 8, 2080), (192, 192), (448, 0), 1),
     ((16, 8, 8, 2080), (192, 192), (448, 0), 3),             # every tile of the engine
